@@ -1,0 +1,97 @@
+"""Seeded parity cases shared by the golden generator, the oracle tests (CPU)
+and the HIP parity tests (GPU).  Inputs are regenerated from the seed with
+hashgan_amd.synth; only expected outputs live in tests/golden/.
+
+Shapes follow BASELINE.json `configs` / SURVEY.md section 8 (C1..C5), on query
+subsets where the unmodified reference needs 16 B per (query, db) pair.
+"""
+import os
+import numpy as np
+from hashgan_amd import synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# name -> dict(Q, N, b, R, C, kind, seed, [flip], [q_take])
+CASES = {
+    # --- BASELINE configs (query subsets of the big ones) -------------------
+    "c1_cifar_full":   dict(Q=1000, N=54000, b=32, R=54000, C=10, kind="cifar", seed=0xC1, flip=0.25),
+    "c2_q64":          dict(Q=10000, q_take=64, N=1000000, b=64, R=5000, C=10, kind="planted", seed=0xC2, flip=0.30),
+    "c3_nus_q64":      dict(Q=2100, q_take=64, N=190000, b=48, R=5000, C=81, kind="multihot", seed=0xC3, flip=0.20),
+    "c4_n10m_q8":      dict(Q=10000, q_take=8, N=10000000, b=64, R=5000, C=10, kind="iid", seed=0xC4),
+    "c5_b128_q32":     dict(Q=10000, q_take=32, N=1000000, b=128, R=5000, C=10, kind="planted", seed=0xC5, flip=0.35),
+    # --- edge cases ----------------------------------------------------------
+    "e_r_eq_n":        dict(Q=70, N=3000, b=32, R=3000, C=10, kind="planted", seed=0xE1, flip=0.25),
+    "e_r_1":           dict(Q=70, N=3000, b=32, R=1, C=10, kind="planted", seed=0xE2, flip=0.25),
+    "e_b1":            dict(Q=33, N=2500, b=1, R=500, C=4, kind="planted", seed=0xE3, flip=0.10),
+    "e_b8":            dict(Q=64, N=4096, b=8, R=1000, C=10, kind="planted", seed=0xE4, flip=0.20),
+    "e_b65_pad":       dict(Q=65, N=5001, b=65, R=777, C=10, kind="planted", seed=0xE5, flip=0.30),
+    "e_b100":          dict(Q=129, N=7777, b=100, R=2000, C=81, kind="multihot", seed=0xE6, flip=0.25),
+    "e_dups_alleq":    dict(Q=10, N=2000, b=16, R=300, C=5, kind="alleq", seed=0xE7),
+    "e_q1_n1":         dict(Q=1, N=1, b=64, R=1, C=3, kind="iid", seed=0xE8),
+    "e_some_skipped":  dict(Q=40, N=1500, b=24, R=20, C=50, kind="iid", seed=0xE9),
+    "e_all_skipped":   dict(Q=5, N=300, b=16, R=10, C=10, kind="disjoint", seed=0xEA),
+    "e_ragged":        dict(Q=191, N=10007, b=48, R=4999, C=10, kind="planted", seed=0xEB, flip=0.30),
+    "e_big_r":         dict(Q=16, N=200000, b=64, R=150000, C=10, kind="planted", seed=0xEC, flip=0.30),
+}
+
+SMALL = [k for k in CASES if k.startswith("e_") and k != "e_big_r"]
+
+
+def _cifar_labels():
+    z = np.load(os.path.join(GOLDEN_DIR, "cifar10_labels.npz"))
+    def onehot(cls):
+        lab = np.zeros((cls.shape[0], 10), dtype=np.int8)
+        lab[np.arange(cls.shape[0]), cls] = 1
+        return lab
+    return onehot(z["database_cls"]), onehot(z["test_cls"])
+
+
+def build_case(name):
+    """-> dict(qbits, dbbits uint8 {0,1}; qlab, dblab int8 {0,1}; R, b, spec)."""
+    c = CASES[name]
+    Q, N, b, C, seed, kind = c["Q"], c["N"], c["b"], c["C"], c["seed"], c["kind"]
+    if kind == "cifar":
+        dblab, qlab = _cifar_labels()
+        dbbits = synth.planted_codes(seed, dblab, b, c["flip"])
+        qbits = synth.planted_codes(seed, qlab, b, c["flip"])       # same prototypes, own noise below
+        qbits = qbits ^ (synth.random_bits(seed + 17, Q, b) & synth.random_bits(seed + 18, Q, b) & synth.random_bits(seed + 19, Q, b))
+    elif kind == "planted":
+        dblab, _ = synth.onehot_labels(seed * 3 + 1, N, C)
+        qlab, _ = synth.onehot_labels(seed * 3 + 2, Q, C)
+        dbbits = synth.planted_codes(seed, dblab, b, c["flip"])
+        qbits = synth.planted_codes(seed, qlab, b, c["flip"]) ^ (
+            synth.random_bits(seed + 17, Q, b) & synth.random_bits(seed + 18, Q, b))
+    elif kind == "multihot":
+        dblab = synth.multihot_labels(seed * 3 + 1, N, C)
+        qlab = synth.multihot_labels(seed * 3 + 2, Q, C)
+        dbbits = synth.planted_codes(seed, dblab, b, c["flip"])
+        qbits = synth.planted_codes(seed, qlab, b, c["flip"]) ^ (
+            synth.random_bits(seed + 17, Q, b) & synth.random_bits(seed + 18, Q, b))
+    elif kind == "iid":
+        dblab, _ = synth.onehot_labels(seed * 3 + 1, N, C)
+        qlab, _ = synth.onehot_labels(seed * 3 + 2, Q, C)
+        dbbits = synth.random_bits(seed, N, b)
+        qbits = synth.random_bits(seed + 7, Q, b)
+    elif kind == "alleq":          # every database code identical: one giant tie group
+        dblab, _ = synth.onehot_labels(seed * 3 + 1, N, C)
+        qlab, _ = synth.onehot_labels(seed * 3 + 2, Q, C)
+        dbbits = np.repeat(synth.random_bits(seed, 1, b), N, axis=0)
+        qbits = synth.random_bits(seed + 7, Q, b)
+    elif kind == "disjoint":       # queries use classes the database never has
+        dcls = (synth.splitmix64(seed, N) % np.uint64(C // 2)).astype(np.int64)
+        qcls = (synth.splitmix64(seed + 1, Q) % np.uint64(C // 2)).astype(np.int64) + C // 2
+        dblab = np.zeros((N, C), np.int8); dblab[np.arange(N), dcls] = 1
+        qlab = np.zeros((Q, C), np.int8); qlab[np.arange(Q), qcls] = 1
+        dbbits = synth.random_bits(seed, N, b)
+        qbits = synth.random_bits(seed + 7, Q, b)
+    else:
+        raise KeyError(kind)
+    take = c.get("q_take", Q)
+    return dict(qbits=np.ascontiguousarray(qbits[:take]), dbbits=dbbits,
+                qlab=np.ascontiguousarray(qlab[:take]), dblab=dblab,
+                R=c["R"], b=b, spec=c, name=name)
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return {k: z[k] for k in z.files}
