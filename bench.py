@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Benchmark of the retrieval-evaluation hot path (BASELINE.json metric:
+queries/sec at Q=10k, N=1M, b=64, R=5000 -- config C2 -- on MI355X).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5|c1]
+
+One step = one full pass of the path over the query batch with codes and labels
+already resident in HBM: distance histogram -> threshold plan -> select ->
+order -> label match -> AP (all HIP) -> per-query AP to the host -> mean.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the database is
+sharded, every rank holds `N` rows of it (weak scaling in database size), the
+shards exchange histograms and match bits over RCCL (see hashgan_amd/sharded.py).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VALU_PEAK_TLANEOPS = 78.6     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0         # HBM3E spec (6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (case in tests/cases.py whose seeds/shape we reuse, Q, golden anchor)
+    "c2": dict(Q=10000, N=1000000, b=64, R=5000, C=10, kind="planted", seed=0xC2, flip=0.30, golden="c2_q64"),
+    "c5": dict(Q=10000, N=1000000, b=128, R=5000, C=10, kind="planted", seed=0xC5, flip=0.35, golden="c5_b128_q32"),
+    "c3": dict(Q=2100, N=190000, b=48, R=5000, C=81, kind="multihot", seed=0xC3, flip=0.20, golden="c3_nus_q64"),
+    "c1": dict(Q=1000, N=54000, b=32, R=54000, C=10, kind="cifar", seed=0xC1, flip=0.25, golden="c1_cifar_full"),
+}
+
+
+def build_inputs(spec):
+    from tests import cases
+    s = {k: v for k, v in spec.items() if k != "golden"}
+    cases.CASES["_bench"] = s
+    try:
+        return cases.build_case("_bench")
+    finally:
+        del cases.CASES["_bench"]
+
+
+def cpu_baseline(c, spec, budget_queries=48):
+    """metric.py:12-24 as written (float32 np.dot -> np.argsort(-ips,1) -> Python
+    loop; oracle.reference_as_written) on a bounded query sample, host cores."""
+    from oracle import hamming_map as O
+    nq = min(budget_queries, c["qbits"].shape[0])
+    dbf = c["dbbits"].astype(np.float32) * 2 - 1
+    qf = c["qbits"][:nq].astype(np.float32) * 2 - 1
+    dl, ql = c["dblab"].astype(np.int64), c["qlab"][:nq].astype(np.int64)
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        O.reference_as_written(dbf, dl, qf, ql, c["R"])
+    dt = time.perf_counter() - t0
+    return {"value": nq / dt, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d of %d queries x full N=%d database, float32 +-1 features, "
+                      "np.dot (BLAS, all cores) + np.argsort + per-query loop (1 core): %.1f s"
+                      % (nq, c["qbits"].shape[0], c["dbbits"].shape[0], dt)}
+
+
+def kernel_rooflines(timing, steps, spec, geo_bytes):
+    """Per-kernel average launch time -> VALU and HBM fractions of the dominant one."""
+    Q, N, b = spec["Q"], spec["N"], spec["b"]
+    NW = (b + 31) // 32
+    pairs = Q * N
+    out = {}
+    for name, (ms, cnt) in timing.items():
+        out[name] = {"avg_ms": ms / max(cnt, 1), "launches": cnt}
+    dom = max(out, key=lambda k: out[k]["avg_ms"] * out[k]["launches"])
+    t = out[dom]["avg_ms"] * 1e-3
+    laneops = pairs * 2 * NW                      # one v_xor_b32 + one v_bcnt_u32_b32 per 32-bit word per pair
+    alg_bytes = geo_bytes.get(dom, 0)
+    roof = {"bound": "valu", "kernel": dom, "achieved": laneops / t / 1e12, "peak": VALU_PEAK_TLANEOPS,
+            "unit": "Tlaneop/s", "frac": laneops / t / 1e12 / VALU_PEAK_TLANEOPS, "traffic": None,
+            "avg_launch_ms": out[dom]["avg_ms"],
+            "hbm": {"algorithmic_bytes": alg_bytes, "achieved": alg_bytes / t / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": alg_bytes / t / 1e9 / HBM_PEAK_GBS}}
+    return roof, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--target-units", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+
+    spec = WORKLOADS[args.workload]
+    from hashgan_amd import _native, metric
+    c = build_inputs(spec)
+    Q, N, R, b = c["qbits"].shape[0], c["dbbits"].shape[0], c["R"], c["b"]
+    qw, ql = metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"])
+    dw, dl = metric.pack_codes(c["dbbits"]), metric.pack_labels(c["dblab"])
+
+    if world > 1:
+        from bench_sharded import run_sharded
+        return run_sharded(args, spec, c, (qw, ql, dw, dl), rank, local_rank, world)
+
+    ctx = _native.Context(0)
+    if args.target_units:
+        ctx.set_option("target_units", args.target_units)
+    ctx.set_database(dw, dl, b, spec["C"])           # inputs resident in HBM before the timed region
+    ctx.set_queries(qw, ql)
+
+    def step():
+        a, r = ctx.map(R)
+        return metric.mean_over_hits(a, r), a
+
+    for _ in range(args.warmup):
+        m, a = step()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m, a = step()
+    dt = time.perf_counter() - t0
+    timing = ctx.timing_read()
+    ctx.timing_enable(False)
+
+    # parity flag: the first queries are a golden case of the unmodified reference
+    from tests import cases
+    g = cases.load_golden(spec["golden"])
+    k = g["ap"].shape[0]
+    parity = bool(np.array_equal(a[:k], g["ap"], equal_nan=True))
+
+    NW = (b + 31) // 32
+    NB = b + 1
+    Qpad = (Q + 63) // 64 * 64
+    code_bytes = (Q + N) * NW * 4
+    geo_bytes = {  # algorithmic (compulsory) HBM bytes per launch, DESIGN.md section 5
+        "k_hist": code_bytes + NB * Qpad * 4,
+        "k_select": code_bytes + Q * R * 4,
+    }
+    roof, per_kernel = kernel_rooflines(timing, args.steps, spec, geo_bytes)
+    ms = dt / args.steps * 1e3
+    out = {
+        "metric": "queries/sec (mAP@R of Q queries vs N-code database, Hamming ranking)",
+        "value": Q / (dt / args.steps), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 (xor+popcount), int counters, f64 AP", "data": "synthetic",
+        "config": {"workload": "%s: Q=%d N=%d b=%d R=%d C=%d, planted codes" % (args.workload.upper(), Q, N, b, R, spec["C"]),
+                   "parallelism": "1 GPU"},
+        "map": float(m), "parity_vs_reference_golden": parity,
+        "pairs_per_sec": Q * N / (dt / args.steps),
+        "roofline": roof,
+        "kernels": {k_: {"avg_ms": round(v["avg_ms"], 5), "launches": v["launches"]} for k_, v in per_kernel.items()},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(c, spec)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

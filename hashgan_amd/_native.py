@@ -1,0 +1,240 @@
+"""ctypes binding of libhashgan_amd.so (the C ABI in include/hashgan_amd.h).
+
+There is no CPU implementation behind this module: if the library is missing,
+fails to load, or finds no GPU, the error propagates (HashganNativeError).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+HG_OK, HG_ERR_ARG, HG_ERR_HIP, HG_ERR_STATE, HG_ERR_NOMEM = 0, -1, -2, -3, -4
+IDX_NONE = 0xFFFFFFFF
+
+
+class HashganNativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hashgan_amd native error %d: %s" % (code, msg))
+        self.code = code
+
+
+_p = C.c_void_p
+_i64 = C.c_int64
+# name -> (argtypes); every function returns int except hg_last_error
+_SIGNATURES = {
+    "hg_version": [],
+    "hg_device_count": [C.POINTER(C.c_int)],
+    "hg_init": [C.c_int, C.POINTER(_p)],
+    "hg_destroy": [_p],
+    "hg_pack_sign_f32": [_p, _i64, C.c_int, _p],
+    "hg_set_database": [_p, _p, _p, _i64, C.c_int, C.c_int, _i64, _i64],
+    "hg_set_queries": [_p, _p, _p, _i64],
+    "hg_hist": [_p],
+    "hg_hist_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
+    "hg_plan": [_p, _i64, _p, C.c_int, C.c_int],
+    "hg_select": [_p],
+    "hg_match": [_p],
+    "hg_match_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
+    "hg_merge_match": [_p, _p, C.c_int],
+    "hg_ap": [_p],
+    "hg_topr_buffers": [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_i64)],
+    "hg_merge_topr": [_p, _p, _p, C.c_int],
+    "hg_topr": [_p, _i64],
+    "hg_map": [_p, _i64, _p, _p],
+    "hg_get_topr": [_p, _p, _p],
+    "hg_get_match": [_p, _p],
+    "hg_get_ap": [_p, _p, _p],
+    "hg_get_hist": [_p, _p],
+    "hg_set_option": [_p, C.c_char_p, _i64],
+    "hg_timing_enable": [_p, C.c_int],
+    "hg_timing_reset": [_p],
+    "hg_timing_read": [_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_int)],
+}
+EXPORTS = sorted(list(_SIGNATURES) + ["hg_last_error"])
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """dlopen the library (no GPU needed for this step) and bind every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise HashganNativeError(HG_ERR_STATE, "%s not built -- run `python -m hashgan_amd.build` "
+                                 "(or __graft_entry__.build())" % path)
+    lib = C.CDLL(path)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.hg_last_error.argtypes = []
+    lib.hg_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != HG_OK:
+        raise HashganNativeError(rc, load().hg_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_p) if a is not None else None
+
+
+def _carray(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+class Context:
+    """One GPU context (hg_ctx).  Thin, 1:1 with the C ABI."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = _p()
+        check(self._lib.hg_init(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.Q = self.N = self.R = self.b = self.C = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs ---------------------------------------------------------------
+    def set_database(self, codes_u64, labels_u64, b, C_, idx_base=0, n_total=None):
+        codes = _carray(codes_u64, np.uint64)
+        labels = _carray(labels_u64, np.uint64)
+        N = codes.shape[0]
+        n_total = N if n_total is None else int(n_total)
+        check(self._lib.hg_set_database(self._h, _ptr(codes), _ptr(labels), N, int(b), int(C_), int(idx_base), n_total))
+        self.N, self.b, self.C = N, int(b), int(C_)
+
+    def set_queries(self, codes_u64, labels_u64):
+        codes = _carray(codes_u64, np.uint64)
+        labels = _carray(labels_u64, np.uint64)
+        check(self._lib.hg_set_queries(self._h, _ptr(codes), _ptr(labels), codes.shape[0]))
+        self.Q = codes.shape[0]
+
+    # -- stages -----------------------------------------------------------------
+    def hist(self):
+        check(self._lib.hg_hist(self._h))
+
+    def hist_buffer(self):
+        p, n = _p(), _i64()
+        check(self._lib.hg_hist_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def plan(self, R, dev_hist_all=None, G=1, rank=0):
+        check(self._lib.hg_plan(self._h, int(R), _p(dev_hist_all) if dev_hist_all else None, int(G), int(rank)))
+        self.R = int(R)
+
+    def select(self):
+        check(self._lib.hg_select(self._h))
+
+    def match(self):
+        check(self._lib.hg_match(self._h))
+
+    def match_buffer(self):
+        p, n = _p(), _i64()
+        check(self._lib.hg_match_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def merge_match(self, dev_bits_all, G):
+        check(self._lib.hg_merge_match(self._h, _p(dev_bits_all), int(G)))
+
+    def ap(self):
+        check(self._lib.hg_ap(self._h))
+
+    def topr_buffers(self):
+        a, b, n = _p(), _p(), _i64()
+        check(self._lib.hg_topr_buffers(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+    def merge_topr(self, dev_idx_all, dev_dist_all, G):
+        check(self._lib.hg_merge_topr(self._h, _p(dev_idx_all), _p(dev_dist_all), int(G)))
+
+    # -- one-shot ---------------------------------------------------------------
+    def topr(self, R):
+        check(self._lib.hg_topr(self._h, int(R)))
+        self.R = int(R)
+
+    def map(self, R):
+        ap = np.empty(self.Q, dtype=np.float64)
+        rel = np.empty(self.Q, dtype=np.int64)
+        check(self._lib.hg_map(self._h, int(R), _ptr(ap), _ptr(rel)))
+        self.R = int(R)
+        return ap, rel
+
+    # -- results ----------------------------------------------------------------
+    def get_topr(self):
+        idx = np.empty((self.Q, self.R), dtype=np.uint32)
+        dist = np.empty((self.Q, self.R), dtype=np.uint8)
+        check(self._lib.hg_get_topr(self._h, _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def get_match(self):
+        m = np.empty((self.Q, self.R), dtype=np.uint8)
+        check(self._lib.hg_get_match(self._h, _ptr(m)))
+        return m
+
+    def get_ap(self):
+        ap = np.empty(self.Q, dtype=np.float64)
+        rel = np.empty(self.Q, dtype=np.int64)
+        check(self._lib.hg_get_ap(self._h, _ptr(ap), _ptr(rel)))
+        return ap, rel
+
+    def get_hist(self):
+        h = np.empty((self.b + 1, self.Q), dtype=np.uint32)
+        check(self._lib.hg_get_hist(self._h, _ptr(h)))
+        return h
+
+    # -- tuning / timing ----------------------------------------------------------
+    def set_option(self, key, value):
+        check(self._lib.hg_set_option(self._h, key.encode(), int(value)))
+
+    def timing_enable(self, on=True):
+        check(self._lib.hg_timing_enable(self._h, 1 if on else 0))
+
+    def timing_reset(self):
+        check(self._lib.hg_timing_reset(self._h))
+
+    def timing_read(self):
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        cnt = (_i64 * cap)()
+        n = C.c_int()
+        check(self._lib.hg_timing_read(self._h, cap, names, ms, cnt, C.byref(n)))
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+
+def device_count():
+    n = C.c_int()
+    check(load().hg_device_count(C.byref(n)))
+    return n.value
+
+
+def pack_sign_f32(x):
+    """float32 [n, b] -> uint64 [n, ceil(b/64)], bit = (x > 0) (hg_pack_sign_f32)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, b = x.shape
+    out = np.empty((n, (b + 63) // 64), dtype=np.uint64)
+    check(load().hg_pack_sign_f32(_ptr(x), n, b, _ptr(out)))
+    return out

@@ -1,0 +1,653 @@
+// Host side of libhashgan_amd.so: device context, buffers, launch geometry and
+// the C ABI declared in include/hashgan_amd.h.  No torch, no CPU compute path:
+// every entry point either runs the HIP kernels of hg_kernels.hpp or fails.
+#include "hg_kernels.hpp"
+#include "../../include/hashgan_amd.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hg;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HG_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? HG_ERR_NOMEM : HG_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                          \
+    } while (0)
+
+#define HG_TRY(expr)                \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != HG_OK) return rc_; \
+    } while (0)
+
+// A device buffer that only ever grows.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return HG_OK;
+        if (p) { HG_HIP(hipFree(p)); p = nullptr; cap = 0; }
+        HG_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return HG_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_PREFIX, KI_SELECT, KI_ORDER,
+                KI_MATCH, KI_AP, KI_MERGE, KI_FILL, KI_COUNT };
+const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_prefix",
+                                            "k_select", "k_order", "k_match", "k_ap", "k_merge", "k_fill"};
+
+enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
+
+// Flatten NumPy's pairwise-summation tree for a chunk of n elements (n <= 8192):
+// numpy/_core/src/umath/loops_utils.h.src, pairwise_sum: n <= 128 is a leaf,
+// otherwise split at n/2 rounded down to a multiple of 8.
+void build_shape(int n, ApShape& sh) {
+    memset(&sh, 0, sizeof sh);
+    sh.n = n;
+    struct Rec {
+        ApShape& s;
+        void go(int off, int len) {
+            if (len <= AP_LEAF) {
+                s.leaf_start[s.n_leaves] = (unsigned short)off;
+                s.leaf_len[s.n_leaves] = (unsigned short)len;
+                s.prog[s.n_prog++] = (short)s.n_leaves++;
+            } else {
+                int n2 = len / 2;
+                n2 -= n2 % 8;
+                go(off, n2);
+                go(off + n2, len - n2);
+                s.prog[s.n_prog++] = -1;
+            }
+        }
+    } rec{sh};
+    if (n > 0) rec.go(0, n);
+}
+
+}  // namespace
+
+struct hg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    unsigned stage = ST_NONE;
+
+    // problem
+    i64 N = 0, Q = 0, R = 0, n_total = 0;
+    int b = 0, C = 0, NW = 0, NB = 0, LW = 0;
+    u32 idx_base = 0;
+    int G = 1, rank = 0;
+    Geo geo{};
+    i64 RW = 0;
+
+    // options
+    i64 target_units = 16384;
+    i64 min_segment = 256;
+
+    // device state
+    DevBuf db, dblab, qc, qlab;
+    DevBuf hist, hown, posbase, seglt, segtie;
+    DevBuf t, cnt_lt, quota, tie_before, n_lt, err;
+    DevBuf scr, out_idx, out_dist, mbits, shapes, ap, rel;
+    i64 shapes_for_R = -1;
+
+    // timing
+    bool timing = false;
+    double t_ms[KI_COUNT] = {0};
+    i64 t_n[KI_COUNT] = {0};
+    struct Pending { int id; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+
+    int use() { HG_HIP(hipSetDevice(device)); return HG_OK; }
+
+    hipEvent_t get_event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void t_begin(int id) {
+        if (!timing) return;
+        Pending p{id, get_event(), get_event()};
+        (void)hipEventRecord(p.a, stream);
+        pending.push_back(p);
+    }
+    void t_end() {
+        if (!timing) return;
+        (void)hipEventRecord(pending.back().b, stream);
+    }
+    void t_collect() {   // after a stream sync
+        for (auto& p : pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { t_ms[p.id] += ms; t_n[p.id] += 1; }
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+    int sync() {
+        HG_HIP(hipStreamSynchronize(stream));
+        t_collect();
+        return HG_OK;
+    }
+    int check_launch(const char* what) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(HG_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+        return HG_OK;
+    }
+};
+
+namespace {
+
+int grid_for(i64 n, int per_block = 256) { return (int)((n + per_block - 1) / per_block); }
+
+// Segment geometry of the pair passes: ~target_units wavefront-sized units.
+void make_geometry(hg_ctx* c) {
+    Geo& g = c->geo;
+    g.Q = (int)c->Q;
+    g.nQT = (int)((c->Q + 63) / 64);
+    g.Qpad = g.nQT * 64;
+    g.NW = c->NW; g.NB = c->NB; g.LW = c->LW;
+    g.N = c->N; g.R = c->R; g.idx_base = c->idx_base;
+    i64 S = (c->target_units + g.nQT - 1) / g.nQT;
+    const i64 maxS = (c->N + c->min_segment - 1) / c->min_segment;
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    i64 L = (c->N + S - 1) / S;
+    L = (L + 15) / 16 * 16;
+    if (L < 16) L = 16;
+    S = (c->N + L - 1) / L;
+    if (S < 1) S = 1;
+    g.S = (int)S; g.L = L;
+    g.nUnits = (i64)g.S * g.nQT;
+    g.wpb = WPB;
+    g.nBlk = (int)((g.nUnits + WPB - 1) / WPB);
+}
+
+int padded_grid(int nBlk) { return (nBlk + 7) / 8 * 8; }
+
+template <int NW> int launch_hist_t(hg_ctx* c) {
+    Geo g = c->geo;
+    // LDS: one u32 histogram column per lane: wpb * NB * 64 * 4 bytes (<= 160 KiB per workgroup)
+    int wpb = WPB;
+    while (wpb > 1 && (size_t)wpb * g.NB * 256 > 160u * 1024u) wpb >>= 1;
+    g.wpb = wpb;
+    g.nBlk = (int)((g.nUnits + wpb - 1) / wpb);
+    const size_t lds = (size_t)wpb * g.NB * 256;
+    if (lds > 64 * 1024)
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    c->t_begin(KI_HIST);
+    hipLaunchKernelGGL(k_hist<NW>, dim3(padded_grid(g.nBlk)), dim3(64 * wpb), lds, c->stream,
+                       c->qc.as<u32>(), c->db.as<u32>(), c->hist.as<u32>(), g);
+    c->t_end();
+    return c->check_launch("k_hist");
+}
+
+template <int NW> int launch_select_t(hg_ctx* c) {
+    const Geo& g = c->geo;
+    SelectArgs a{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(),
+                 c->seglt.as<u32>(), c->segtie.as<u32>()};
+    c->t_begin(KI_SELECT);
+    hipLaunchKernelGGL(k_select<NW>, dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream,
+                       c->qc.as<u32>(), c->db.as<u32>(), a, c->scr.as<u32>(), c->out_idx.as<u32>(), c->out_dist.as<u8>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_select"));
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    c->t_begin(KI_ORDER);
+    hipLaunchKernelGGL(k_order<NW>, dim3(grid_for(g.Q, WPB)), dim3(256), (size_t)WPB * g.NB * 4, c->stream,
+                       c->qc.as<u32>(), c->db.as<u32>(), c->scr.as<u32>(), c->n_lt.as<u32>(), c->t.as<int>(),
+                       c->posbase.as<u32>(), c->out_idx.as<u32>(), c->out_dist.as<u8>(), nbits, g);
+    c->t_end();
+    return c->check_launch("k_order");
+}
+
+#define HG_DISPATCH_NW(fn, c)                                   \
+    switch ((c)->NW) {                                          \
+        case 1: return fn<1>(c);                                \
+        case 2: return fn<2>(c);                                \
+        case 3: return fn<3>(c);                                \
+        case 4: return fn<4>(c);                                \
+        case 5: return fn<5>(c);                                \
+        case 6: return fn<6>(c);                                \
+        case 7: return fn<7>(c);                                \
+        case 8: return fn<8>(c);                                \
+        default: return fail(HG_ERR_ARG, "unsupported code length: %d words", (c)->NW); \
+    }
+
+int launch_hist(hg_ctx* c) { HG_DISPATCH_NW(launch_hist_t, c) }
+int launch_select(hg_ctx* c) { HG_DISPATCH_NW(launch_select_t, c) }
+
+int need(hg_ctx* c, unsigned st, const char* who, const char* what) {
+    if (!c) return fail(HG_ERR_ARG, "%s: null context", who);
+    if ((c->stage & st) != st) return fail(HG_ERR_STATE, "%s called before %s", who, what);
+    return c->use();
+}
+
+// Upload packed uint64 codes as dense uint32 [n][NW] (NW = ceil(b/32)): when NW is
+// odd the unused high half of the last uint64 word is dropped by a strided copy.
+int upload_codes(hg_ctx* c, DevBuf& dst, const uint64_t* host, i64 n, int W, int NW) {
+    HG_TRY(dst.reserve((size_t)(n > 0 ? n : 1) * NW * 4 + 64 * 4));  // +64 words: scalar loads may read past a ragged tail
+    if (n == 0) return HG_OK;
+    if (NW == 2 * W) {
+        HG_HIP(hipMemcpyAsync(dst.p, host, (size_t)n * NW * 4, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HG_HIP(hipMemcpy2DAsync(dst.p, (size_t)NW * 4, host, (size_t)W * 8, (size_t)NW * 4, (size_t)n,
+                                hipMemcpyHostToDevice, c->stream));
+    }
+    return HG_OK;
+}
+
+}  // namespace
+
+// =============================================================================
+extern "C" {
+
+const char* hg_last_error(void) { return g_err.c_str(); }
+int hg_version(void) { return 100; }
+
+int hg_device_count(int* count) {
+    if (!count) return fail(HG_ERR_ARG, "hg_device_count: null pointer");
+    HG_HIP(hipGetDeviceCount(count));
+    return HG_OK;
+}
+
+int hg_init(int device, hg_ctx** out) {
+    if (!out) return fail(HG_ERR_ARG, "hg_init: null pointer");
+    *out = nullptr;
+    int n = 0;
+    HG_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(HG_ERR_ARG, "hg_init: device %d out of range (%d visible)", device, n);
+    HG_HIP(hipSetDevice(device));
+    hg_ctx* c = new hg_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(HG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    *out = c;
+    return HG_OK;
+}
+
+int hg_destroy(hg_ctx* c) {
+    if (!c) return HG_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->t_collect();
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
+                     &c->t, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->scr, &c->out_idx,
+                     &c->out_dist, &c->mbits, &c->shapes, &c->ap, &c->rel};
+    for (auto* d : all) d->release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return HG_OK;
+}
+
+int hg_pack_sign_f32(const float* x, int64_t n, int b, uint64_t* out) {
+    if (!x || !out || n < 0 || b < 1) return fail(HG_ERR_ARG, "hg_pack_sign_f32: bad argument");
+    const int W = (b + 63) / 64;
+    for (int64_t i = 0; i < n; ++i) {
+        const float* row = x + i * b;
+        for (int w = 0; w < W; ++w) {
+            uint64_t v = 0;
+            const int hi = b - w * 64 < 64 ? b - w * 64 : 64;
+            for (int j = 0; j < hi; ++j) v |= (uint64_t)(row[w * 64 + j] > 0.0f) << j;
+            out[i * W + w] = v;
+        }
+    }
+    return HG_OK;
+}
+
+int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int64_t N, int b, int C,
+                    int64_t idx_base, int64_t n_total) {
+    if (!c) return fail(HG_ERR_ARG, "hg_set_database: null context");
+    if (N < 1 || !codes || !labels) return fail(HG_ERR_ARG, "hg_set_database: need N >= 1 and data");
+    if (b < 1 || b > HG_MAX_BITS) return fail(HG_ERR_ARG, "hg_set_database: b=%d outside 1..%d", b, HG_MAX_BITS);
+    if (C < 1) return fail(HG_ERR_ARG, "hg_set_database: C=%d", C);
+    if (idx_base < 0 || n_total < N || idx_base + N > n_total || n_total >= 0xFFFFFFFFll)
+        return fail(HG_ERR_ARG, "hg_set_database: shard [%lld, %lld) does not fit a database of %lld rows (< 2^32 - 1)",
+                    (long long)idx_base, (long long)(idx_base + N), (long long)n_total);
+    HG_TRY(c->use());
+    c->N = N; c->b = b; c->C = C; c->n_total = n_total;
+    c->NW = (b + 31) / 32; c->NB = b + 1; c->LW = (C + 63) / 64;
+    c->idx_base = (u32)idx_base;
+    HG_TRY(upload_codes(c, c->db, codes, N, (b + 63) / 64, c->NW));
+    HG_TRY(c->dblab.reserve((size_t)(N > 0 ? N : 1) * c->LW * 8));
+    if (N) HG_HIP(hipMemcpyAsync(c->dblab.p, labels, (size_t)N * c->LW * 8, hipMemcpyHostToDevice, c->stream));
+    HG_TRY(c->sync());
+    c->stage = ST_DB;   // queries must be (re)set after the database: b, C may have changed
+    return HG_OK;
+}
+
+int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int64_t Q) {
+    HG_TRY(need(c, ST_DB, "hg_set_queries", "hg_set_database"));
+    if (Q < 1 || !codes || !labels) return fail(HG_ERR_ARG, "hg_set_queries: need Q >= 1 and data");
+    if (Q > 0x7FFFFFC0ll) return fail(HG_ERR_ARG, "hg_set_queries: Q too large");
+    c->Q = Q;
+    HG_TRY(upload_codes(c, c->qc, codes, Q, (c->b + 63) / 64, c->NW));
+    HG_TRY(c->qlab.reserve((size_t)Q * c->LW * 8));
+    HG_HIP(hipMemcpyAsync(c->qlab.p, labels, (size_t)Q * c->LW * 8, hipMemcpyHostToDevice, c->stream));
+    HG_TRY(c->sync());
+    c->stage = ST_DB | ST_Q;
+    return HG_OK;
+}
+
+static int do_hist(hg_ctx* c) {
+    make_geometry(c);
+    const Geo& g = c->geo;
+    const size_t plane = (size_t)g.NB * g.Qpad * 4;
+    HG_TRY(c->hist.reserve(plane * g.S));
+    HG_TRY(c->hown.reserve(plane));
+    HG_TRY(launch_hist(c));
+    c->t_begin(KI_HIST_REDUCE);
+    hipLaunchKernelGGL(k_hist_reduce, dim3(grid_for((i64)g.NB * g.Qpad)), dim3(256), 0, c->stream,
+                       c->hist.as<u32>(), c->hown.as<u32>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_hist_reduce"));
+    c->stage = ST_DB | ST_Q | ST_HIST;
+    return HG_OK;
+}
+
+int hg_hist(hg_ctx* c) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_hist", "hg_set_database + hg_set_queries"));
+    HG_TRY(do_hist(c));
+    return c->sync();
+}
+
+int hg_hist_buffer(hg_ctx* c, void** dev_ptr, int64_t* nbytes) {
+    HG_TRY(need(c, ST_HIST, "hg_hist_buffer", "hg_hist"));
+    if (dev_ptr) *dev_ptr = c->hown.p;
+    if (nbytes) *nbytes = (int64_t)c->geo.NB * c->geo.Qpad * 4;
+    return HG_OK;
+}
+
+static int do_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
+    if (G < 1 || rank < 0 || rank >= G) return fail(HG_ERR_ARG, "hg_plan: rank %d of %d", rank, G);
+    if (G > 1 && !dev_hist_all) return fail(HG_ERR_ARG, "hg_plan: G > 1 needs the gathered histograms");
+    if (R < 1 || R > c->n_total)
+        return fail(HG_ERR_ARG, "hg_plan: R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->n_total);
+    c->R = R; c->G = G; c->rank = rank;
+    c->geo.R = R;
+    c->RW = (R + 63) / 64;
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(c->posbase.reserve((size_t)g.NB * qb));
+    HG_TRY(c->t.reserve(qb)); HG_TRY(c->cnt_lt.reserve(qb)); HG_TRY(c->quota.reserve(qb));
+    HG_TRY(c->tie_before.reserve(qb)); HG_TRY(c->n_lt.reserve(qb)); HG_TRY(c->err.reserve(4));
+    HG_TRY(c->seglt.reserve((size_t)g.S * qb)); HG_TRY(c->segtie.reserve((size_t)g.S * qb));
+    HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+    Plan pl{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->n_lt.as<u32>(),
+            c->posbase.as<u32>(), c->err.as<int>()};
+    c->t_begin(KI_PLAN);
+    hipLaunchKernelGGL(k_plan, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(),
+                       (const u32*)dev_hist_all, G, rank, pl, g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_plan"));
+    c->t_begin(KI_SEG_COUNTS);
+    hipLaunchKernelGGL(k_seg_counts, dim3(grid_for((i64)g.S * g.Qpad)), dim3(256), 0, c->stream, c->hist.as<u32>(),
+                       c->t.as<int>(), c->seglt.as<u32>(), c->segtie.as<u32>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_seg_counts"));
+    c->t_begin(KI_SEG_PREFIX);
+    hipLaunchKernelGGL(k_seg_prefix, dim3(grid_for(g.Qpad)), dim3(256), 0, c->stream, c->seglt.as<u32>(),
+                       c->segtie.as<u32>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_seg_prefix"));
+    c->stage = ST_DB | ST_Q | ST_HIST | ST_PLAN;
+    return HG_OK;
+}
+
+// The plan kernel flags R > (rows in the gathered histograms); read it back with the results.
+static int check_plan_flag(hg_ctx* c) {
+    int err = 0;
+    HG_HIP(hipMemcpyAsync(&err, c->err.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HG_TRY(c->sync());
+    if (err) {
+        c->stage = ST_DB | ST_Q | ST_HIST;
+        return fail(HG_ERR_ARG, "R=%lld exceeds the rows present in the gathered histograms", (long long)c->R);
+    }
+    return HG_OK;
+}
+
+int hg_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
+    HG_TRY(need(c, ST_HIST, "hg_plan", "hg_hist"));
+    HG_TRY(do_plan(c, R, dev_hist_all, G, rank));
+    return check_plan_flag(c);
+}
+
+static int do_select(hg_ctx* c) {
+    const Geo& g = c->geo;
+    const size_t slots = (size_t)g.Q * g.R;
+    HG_TRY(c->scr.reserve(slots * 4));
+    HG_TRY(c->out_idx.reserve(slots * 4));
+    HG_TRY(c->out_dist.reserve(slots));
+    if (c->G > 1) {  // slots of other shards stay IDX_NONE / 0xFF
+        HG_HIP(hipMemsetAsync(c->out_idx.p, 0xFF, slots * 4, c->stream));
+        HG_HIP(hipMemsetAsync(c->out_dist.p, 0xFF, slots, c->stream));
+    }
+    HG_TRY(launch_select(c));
+    c->stage = ST_DB | ST_Q | ST_HIST | ST_PLAN | ST_SELECT;
+    return HG_OK;
+}
+
+int hg_select(hg_ctx* c) {
+    HG_TRY(need(c, ST_PLAN, "hg_select", "hg_plan"));
+    HG_TRY(do_select(c));
+    return c->sync();
+}
+
+static int do_match(hg_ctx* c) {
+    const Geo& g = c->geo;
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    const i64 nKB = (g.R + 255) / 256;
+    const i64 blocks = nKB * g.Q;
+    if (blocks > 0x7FFFFFFFll) return fail(HG_ERR_ARG, "hg_match: Q*R too large for one launch");
+    c->t_begin(KI_MATCH);
+    hipLaunchKernelGGL(k_match, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->out_idx.as<u32>(),
+                       c->dblab.as<u64>(), c->qlab.as<u64>(), c->mbits.as<u64>(), c->RW, (int)nKB, g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_match"));
+    c->stage |= ST_MATCH;
+    c->stage &= ~(unsigned)ST_AP;
+    return HG_OK;
+}
+
+int hg_match(hg_ctx* c) {
+    HG_TRY(need(c, ST_SELECT, "hg_match", "hg_select"));
+    HG_TRY(do_match(c));
+    return c->sync();
+}
+
+int hg_match_buffer(hg_ctx* c, void** dev_ptr, int64_t* nbytes) {
+    HG_TRY(need(c, ST_MATCH, "hg_match_buffer", "hg_match"));
+    if (dev_ptr) *dev_ptr = c->mbits.p;
+    if (nbytes) *nbytes = (int64_t)c->geo.Q * c->RW * 8;
+    return HG_OK;
+}
+
+int hg_merge_match(hg_ctx* c, const uint64_t* dev_bits_all, int G) {
+    HG_TRY(need(c, ST_MATCH, "hg_merge_match", "hg_match"));
+    if (!dev_bits_all || G < 1) return fail(HG_ERR_ARG, "hg_merge_match: bad argument");
+    const i64 n = (i64)c->geo.Q * c->RW;
+    c->t_begin(KI_MERGE);
+    hipLaunchKernelGGL(k_or_bits, dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dev_bits_all, c->mbits.as<u64>(), n, G);
+    c->t_end();
+    HG_TRY(c->check_launch("k_or_bits"));
+    return c->sync();
+}
+
+static int do_ap(hg_ctx* c) {
+    const Geo& g = c->geo;
+    if (c->shapes_for_R != g.R) {
+        std::vector<ApShape> sh(2);
+        build_shape(g.R >= AP_CHUNK ? AP_CHUNK : (int)g.R, sh[0]);
+        build_shape((int)(g.R % AP_CHUNK), sh[1]);
+        HG_TRY(c->shapes.reserve(sizeof(ApShape) * 2));
+        HG_HIP(hipMemcpyAsync(c->shapes.p, sh.data(), sizeof(ApShape) * 2, hipMemcpyHostToDevice, c->stream));
+        HG_HIP(hipStreamSynchronize(c->stream));   // sh goes out of scope
+        c->shapes_for_R = g.R;
+    }
+    HG_TRY(c->ap.reserve((size_t)g.Q * 8));
+    HG_TRY(c->rel.reserve((size_t)g.Q * 4));
+    c->t_begin(KI_AP);
+    hipLaunchKernelGGL(k_ap, dim3(g.Q), dim3(AP_THREADS), 0, c->stream, c->mbits.as<u64>(), c->RW, g.R,
+                       c->shapes.as<ApShape>(), c->ap.as<double>(), c->rel.as<u32>());
+    c->t_end();
+    HG_TRY(c->check_launch("k_ap"));
+    c->stage |= ST_AP;
+    return HG_OK;
+}
+
+int hg_ap(hg_ctx* c) {
+    HG_TRY(need(c, ST_MATCH, "hg_ap", "hg_match"));
+    HG_TRY(do_ap(c));
+    return c->sync();
+}
+
+int hg_topr_buffers(hg_ctx* c, void** dev_idx, void** dev_dist, int64_t* n_slots) {
+    HG_TRY(need(c, ST_SELECT, "hg_topr_buffers", "hg_select"));
+    if (dev_idx) *dev_idx = c->out_idx.p;
+    if (dev_dist) *dev_dist = c->out_dist.p;
+    if (n_slots) *n_slots = (int64_t)c->geo.Q * c->geo.R;
+    return HG_OK;
+}
+
+int hg_merge_topr(hg_ctx* c, const uint32_t* dev_idx_all, const uint8_t* dev_dist_all, int G) {
+    HG_TRY(need(c, ST_SELECT, "hg_merge_topr", "hg_select"));
+    if (!dev_idx_all || !dev_dist_all || G < 1) return fail(HG_ERR_ARG, "hg_merge_topr: bad argument");
+    const i64 n = (i64)c->geo.Q * c->geo.R;
+    c->t_begin(KI_MERGE);
+    hipLaunchKernelGGL(k_min_topr, dim3(grid_for(n)), dim3(256), 0, c->stream, (const u32*)dev_idx_all,
+                       (const u8*)dev_dist_all, c->out_idx.as<u32>(), c->out_dist.as<u8>(), n, G);
+    c->t_end();
+    HG_TRY(c->check_launch("k_min_topr"));
+    return c->sync();
+}
+
+// One-shot forms enqueue every stage back to back and synchronise once.
+int hg_topr(hg_ctx* c, int64_t R) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_topr", "hg_set_database + hg_set_queries"));
+    HG_TRY(do_hist(c));
+    HG_TRY(do_plan(c, R, nullptr, 1, 0));
+    HG_TRY(do_select(c));
+    return check_plan_flag(c);
+}
+
+int hg_map(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_map", "hg_set_database + hg_set_queries"));
+    HG_TRY(do_hist(c));
+    HG_TRY(do_plan(c, R, nullptr, 1, 0));
+    HG_TRY(do_select(c));
+    HG_TRY(do_match(c));
+    HG_TRY(do_ap(c));
+    HG_TRY(check_plan_flag(c));
+    return hg_get_ap(c, host_ap, host_rel);
+}
+
+int hg_get_topr(hg_ctx* c, uint32_t* host_idx, uint8_t* host_dist) {
+    HG_TRY(need(c, ST_SELECT, "hg_get_topr", "hg_select"));
+    const size_t slots = (size_t)c->geo.Q * c->geo.R;
+    if (host_idx) HG_HIP(hipMemcpyAsync(host_idx, c->out_idx.p, slots * 4, hipMemcpyDeviceToHost, c->stream));
+    if (host_dist) HG_HIP(hipMemcpyAsync(host_dist, c->out_dist.p, slots, hipMemcpyDeviceToHost, c->stream));
+    return c->sync();
+}
+
+int hg_get_match(hg_ctx* c, uint8_t* host_imatch) {
+    HG_TRY(need(c, ST_MATCH, "hg_get_match", "hg_match"));
+    if (!host_imatch) return fail(HG_ERR_ARG, "hg_get_match: null pointer");
+    const i64 Q = c->geo.Q, R = c->geo.R, RW = c->RW;
+    std::vector<u64> bits((size_t)Q * RW);
+    HG_HIP(hipMemcpyAsync(bits.data(), c->mbits.p, bits.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HG_TRY(c->sync());
+    for (i64 q = 0; q < Q; ++q)
+        for (i64 k = 0; k < R; ++k) host_imatch[q * R + k] = (u8)((bits[q * RW + (k >> 6)] >> (k & 63)) & 1ull);
+    return HG_OK;
+}
+
+int hg_get_ap(hg_ctx* c, double* host_ap, int64_t* host_rel) {
+    HG_TRY(need(c, ST_AP, "hg_get_ap", "hg_ap"));
+    const i64 Q = c->geo.Q;
+    if (host_ap) HG_HIP(hipMemcpyAsync(host_ap, c->ap.p, (size_t)Q * 8, hipMemcpyDeviceToHost, c->stream));
+    std::vector<u32> rel;
+    if (host_rel) {
+        rel.resize((size_t)Q);
+        HG_HIP(hipMemcpyAsync(rel.data(), c->rel.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HG_TRY(c->sync());
+    if (host_rel) for (i64 q = 0; q < Q; ++q) host_rel[q] = rel[(size_t)q];
+    return HG_OK;
+}
+
+int hg_get_hist(hg_ctx* c, uint32_t* host_hist) {
+    HG_TRY(need(c, ST_HIST, "hg_get_hist", "hg_hist"));
+    if (!host_hist) return fail(HG_ERR_ARG, "hg_get_hist: null pointer");
+    const Geo& g = c->geo;
+    HG_HIP(hipMemcpy2DAsync(host_hist, (size_t)g.Q * 4, c->hown.p, (size_t)g.Qpad * 4, (size_t)g.Q * 4, (size_t)g.NB,
+                            hipMemcpyDeviceToHost, c->stream));
+    return c->sync();
+}
+
+int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return fail(HG_ERR_ARG, "hg_set_option: null argument");
+    if (!strcmp(key, "target_units")) {
+        if (value < 1) return fail(HG_ERR_ARG, "target_units must be >= 1");
+        c->target_units = value;
+    } else if (!strcmp(key, "min_segment")) {
+        if (value < 16) return fail(HG_ERR_ARG, "min_segment must be >= 16");
+        c->min_segment = value;
+    } else {
+        return fail(HG_ERR_ARG, "hg_set_option: unknown key '%s'", key);
+    }
+    return HG_OK;
+}
+
+int hg_timing_enable(hg_ctx* c, int on) {
+    if (!c) return fail(HG_ERR_ARG, "hg_timing_enable: null context");
+    c->timing = on != 0;
+    return HG_OK;
+}
+
+int hg_timing_reset(hg_ctx* c) {
+    if (!c) return fail(HG_ERR_ARG, "hg_timing_reset: null context");
+    for (int i = 0; i < KI_COUNT; ++i) { c->t_ms[i] = 0; c->t_n[i] = 0; }
+    return HG_OK;
+}
+
+int hg_timing_read(hg_ctx* c, int cap, const char** names, double* total_ms, int64_t* launches, int* n) {
+    if (!c || !n) return fail(HG_ERR_ARG, "hg_timing_read: null argument");
+    int k = 0;
+    for (int i = 0; i < KI_COUNT && k < cap; ++i) {
+        if (!c->t_n[i]) continue;
+        if (names) names[k] = kKernelNames[i];
+        if (total_ms) total_ms[k] = c->t_ms[i];
+        if (launches) launches[k] = c->t_n[i];
+        ++k;
+    }
+    *n = k;
+    return HG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+/*
+ * hashgan_amd -- C ABI of the MI355X-native retrieval-evaluation path.
+ *
+ * The reference has no FFI: its boundary for this path is the Python call
+ *     MAPs(R).get_maps_by_feature(database, query)      lib/metric.py:4-24
+ * made from evaluate()                                   main.py:161-164.
+ * hashgan_amd/metric.py keeps that call surface; everything below is what that
+ * Python binds through ctypes.  Conventions:
+ *   - extern "C", plain pointers and sizes, no C++/torch types;
+ *   - every function returns 0 (HG_OK) or a negative HG_ERR_* code and never
+ *     throws; hg_last_error() gives the message of the calling thread's last
+ *     failure;
+ *   - "host" pointers are caller-owned host memory, "dev" pointers are device
+ *     addresses (hipMalloc'ed by the caller or by torch) on the context's GPU;
+ *   - a context owns one GPU stream; every call is complete (stream
+ *     synchronised) when it returns; a context is not thread safe.
+ *
+ * Data layout (pinned by tests/test_pack.py):
+ *   codes   uint64 [n][W], W = ceil(b/64); bit j of a code is bit (j % 64) of
+ *           word j / 64; bit value = (feature[j] > 0); pad bits are zero.
+ *   labels  uint64 [n][LW], LW = ceil(C/64), bit c set <=> label[c] != 0.
+ *   ranked lists: position k of query q is element [q*R + k].
+ *
+ * Canonical order: Hamming distance ascending, then database
+ * index ascending -- what np.argsort(-ips, 1) (metric.py:14) yields for +-1
+ * codes once ties are broken by index.
+ */
+#ifndef HASHGAN_AMD_H
+#define HASHGAN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HG_OK 0
+#define HG_ERR_ARG (-1)    /* bad argument (R > N, b out of range, null pointer ...) */
+#define HG_ERR_HIP (-2)    /* a HIP runtime call or kernel failed */
+#define HG_ERR_STATE (-3)  /* call sequence violated (e.g. hg_select before hg_plan) */
+#define HG_ERR_NOMEM (-4)  /* device allocation failed */
+
+#define HG_MAX_BITS 256        /* longest supported code */
+#define HG_IDX_NONE 0xFFFFFFFFu /* ranked-list slot owned by another shard */
+
+typedef struct hg_ctx hg_ctx;
+
+const char* hg_last_error(void);
+int hg_version(void);
+int hg_device_count(int* count);
+
+/* One context per (process, GPU).  Replaces nothing in the reference (it runs
+ * the metric on the host); it is the handle the Python MAPs object keeps. */
+int hg_init(int device, hg_ctx** out);
+int hg_destroy(hg_ctx* ctx);
+
+/* Binarise-and-pack, host side: bit j = (x[i*b + j] > 0).  This is the sign()
+ * the reference never applies (its tanh features go straight into np.dot,
+ * lib/architecture.py:147 -> metric.py:13); for +-1 features it is exact. */
+int hg_pack_sign_f32(const float* host_x, int64_t n, int b, uint64_t* host_out);
+
+/* database.output / database.label of metric.py:13,19 as packed codes/labels.
+ * idx_base is the global index of this shard's row 0, n_total the size of the
+ * whole (all-shard) database; single GPU: idx_base = 0, n_total = N. */
+int hg_set_database(hg_ctx* ctx, const uint64_t* host_codes, const uint64_t* host_labels,
+                    int64_t N, int b, int C, int64_t idx_base, int64_t n_total);
+/* query.output / query.label of metric.py:13,17. Same b and C as the database. */
+int hg_set_queries(hg_ctx* ctx, const uint64_t* host_codes, const uint64_t* host_labels, int64_t Q);
+
+/* ---- staged pipeline (what multi-GPU orchestration drives) ------------------
+ * hg_hist    metric.py:13   XOR+popcount of every (query, db row) pair, reduced
+ *                           to per-query distance histograms of this shard.
+ * hg_plan    metric.py:14   per query: threshold distance t (the R-th smallest
+ *                           over ALL shards), tie quota, output offsets.
+ *                           dev_hist_all = G shard histograms, each laid out as
+ *                           hg_hist_buffer describes, shard-rank order; pass
+ *                           NULL, G = 1, rank = 0 on a single GPU.
+ * hg_select  metric.py:14 + [0:R] at :19   second pass over the pairs: emits the
+ *                           shard's members of the global top-R into their
+ *                           global rank positions, canonical order.
+ * hg_match   metric.py:17-19  label match of every ranked slot -> bit rows.
+ * hg_merge_match            OR of G shards' bit rows (after an all-gather).
+ * hg_ap      metric.py:20-23  per-query AP in float64, same rounding and
+ *                           summation order as NumPy (pairwise, 8192 chunks).
+ */
+int hg_hist(hg_ctx* ctx);
+int hg_hist_buffer(hg_ctx* ctx, void** dev_ptr, int64_t* nbytes);  /* uint32 [b+1][Qpad] */
+int hg_plan(hg_ctx* ctx, int64_t R, const uint32_t* dev_hist_all, int G, int rank);
+int hg_select(hg_ctx* ctx);
+int hg_match(hg_ctx* ctx);
+int hg_match_buffer(hg_ctx* ctx, void** dev_ptr, int64_t* nbytes); /* uint64 [Q][ceil(R/64)] */
+int hg_merge_match(hg_ctx* ctx, const uint64_t* dev_bits_all, int G);
+int hg_ap(hg_ctx* ctx);
+
+/* Ranked lists in global-position space: uint32 idx [Q][R] (HG_IDX_NONE where a
+ * slot belongs to another shard), uint8 dist [Q][R] (0xFF there). */
+int hg_topr_buffers(hg_ctx* ctx, void** dev_idx, void** dev_dist, int64_t* n_slots);
+/* Element-wise merge of G shards' ranked lists after an all-gather (min picks
+ * the one owner of every slot). dev_idx_all: [G][Q][R], dev_dist_all likewise. */
+int hg_merge_topr(hg_ctx* ctx, const uint32_t* dev_idx_all, const uint8_t* dev_dist_all, int G);
+
+/* ---- one-shot forms ---------------------------------------------------------- */
+int hg_topr(hg_ctx* ctx, int64_t R);                       /* hist + plan + select, one shard */
+int hg_map(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel); /* ... + match + ap + download */
+
+/* ---- results to the host ----------------------------------------------------- */
+int hg_get_topr(hg_ctx* ctx, uint32_t* host_idx, uint8_t* host_dist);   /* [Q][R] each */
+int hg_get_match(hg_ctx* ctx, uint8_t* host_imatch);                    /* [Q][R] of 0/1 */
+int hg_get_ap(hg_ctx* ctx, double* host_ap, int64_t* host_rel);         /* [Q]; ap = NaN where rel == 0 */
+int hg_get_hist(hg_ctx* ctx, uint32_t* host_hist);                      /* [b+1][Q] of this shard */
+
+/* ---- tuning and measurement -------------------------------------------------- */
+/* key: "target_units" (waves the pair passes are split into), "min_segment". */
+int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
+/* HIP-event timing of every kernel launched on the context's stream. */
+int hg_timing_enable(hg_ctx* ctx, int on);
+int hg_timing_reset(hg_ctx* ctx);
+/* Fills up to cap entries; name[i] points to static strings. Returns count via *n. */
+int hg_timing_read(hg_ctx* ctx, int cap, const char** names, double* total_ms, int64_t* launches, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HASHGAN_AMD_H */

@@ -1,0 +1,153 @@
+"""HIP path vs oracle vs golden fixtures, through the C ABI (needs an MI355X).
+
+Stage by stage, so a failure names the kernel:
+  hist   -> per-query distance histograms           (k_hist, k_hist_reduce)
+  topr   -> ranked idx / dist lists, canonical order (k_plan .. k_order)
+  match  -> label-match bits                          (k_match)
+  ap     -> float64 AP, bit-exact                     (k_ap)
+"""
+import warnings
+import numpy as np
+import pytest
+from tests import cases
+from oracle import hamming_map as O
+from hashgan_amd import _native, metric
+
+pytestmark = pytest.mark.gpu
+
+STAGED = cases.SMALL + ["e_big_r", "c3_nus_q64"]
+BIG = ["c2_q64", "c5_b128_q32", "c4_n10m_q8"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def _load(ctx, c):
+    ctx.set_database(metric.pack_codes(c["dbbits"]), metric.pack_labels(c["dblab"]), c["b"], c["dblab"].shape[1])
+    ctx.set_queries(metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"]))
+
+
+def _first_diff(a, b):
+    bad = np.argwhere(a != b)
+    return "first mismatch at %s: got %s want %s (%d mismatches)" % (bad[0], a[tuple(bad[0])], b[tuple(bad[0])], len(bad))
+
+
+def _oracle(c):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return O.map_from_codes(c["qbits"], c["dbbits"], c["qlab"], c["dblab"], c["R"])
+
+
+@pytest.mark.parametrize("name", STAGED)
+def test_stages_match_oracle(name, ctx, case_cache):
+    c = case_cache(name)
+    g = cases.load_golden(name)
+    m_ref, ap_ref, imatch_ref, idx_ref, dist_ref = _oracle(c)
+    _load(ctx, c)
+    # hist
+    ctx.hist()
+    h = ctx.get_hist()                                              # [b+1][Q]
+    D = O.hamming_matrix(O.pack_bits(c["qbits"]), O.pack_bits(c["dbbits"]))
+    h_ref = np.stack([np.bincount(D[i], minlength=c["b"] + 1) for i in range(D.shape[0])], axis=1)
+    assert np.array_equal(h, h_ref), "hist: " + _first_diff(h, h_ref)
+    # plan + select
+    ctx.plan(c["R"])
+    ctx.select()
+    idx, dist = ctx.get_topr()
+    assert np.array_equal(dist, dist_ref), "dist: " + _first_diff(dist.astype(np.int64), dist_ref)
+    assert np.array_equal(idx, idx_ref), "idx: " + _first_diff(idx.astype(np.int64), idx_ref)
+    # match
+    ctx.match()
+    m = ctx.get_match()
+    assert np.array_equal(m.astype(bool), imatch_ref), "match: " + _first_diff(m.astype(bool), imatch_ref)
+    # ap
+    ctx.ap()
+    ap, rel = ctx.get_ap()
+    assert np.array_equal(rel, imatch_ref.sum(1))
+    assert np.array_equal(ap, ap_ref, equal_nan=True), "ap: " + _first_diff(ap, ap_ref)
+    assert np.array_equal(ap, g["ap"], equal_nan=True), "ap vs golden"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mm = metric.mean_over_hits(ap, rel)
+    assert (np.isnan(mm) and np.isnan(g["map"])) or mm == g["map"]
+
+
+@pytest.mark.parametrize("name", BIG)
+def test_big_cases_match_golden(name, ctx, case_cache):
+    c = case_cache(name)
+    g = cases.load_golden(name)
+    _load(ctx, c)
+    ap, rel = ctx.map(c["R"])
+    assert np.array_equal(ap, g["ap"], equal_nan=True), "ap vs golden: " + _first_diff(ap, g["ap"])
+    assert metric.mean_over_hits(ap, rel) == g["map"]
+    # ranked lists against the oracle on the first queries
+    nq = min(8, c["qbits"].shape[0])
+    idx_ref, dist_ref = O.topr_from_codes(c["qbits"][:nq], c["dbbits"], c["R"])
+    idx, dist = ctx.get_topr()
+    assert np.array_equal(idx[:nq], idx_ref) and np.array_equal(dist[:nq], dist_ref)
+
+
+def test_c1_cifar_full_golden(ctx, case_cache):
+    """BASELINE config C1 at full size (Q=1000, N=54000, b=32, R=N) against the
+    unmodified reference's per-query AP and mAP."""
+    c = case_cache("c1_cifar_full")
+    g = cases.load_golden("c1_cifar_full")
+    _load(ctx, c)
+    ap, rel = ctx.map(c["R"])
+    assert np.array_equal(ap, g["ap"], equal_nan=True), _first_diff(ap, g["ap"])
+    assert metric.mean_over_hits(ap, rel) == g["map"]
+
+
+def test_python_surface_matches_golden(case_cache):
+    """MAPs(R).get_maps_by_feature(database, query) and MAP(...) -- the drop-in calls."""
+    import types
+    from hashgan_amd import MAPs, MAP, calc_map
+    for name in ["e_ragged", "e_b100", "e_some_skipped"]:
+        c = case_cache(name)
+        g = cases.load_golden(name)
+        database = types.SimpleNamespace(output=c["dbbits"].astype(np.float32) * 2 - 1, label=c["dblab"].astype(np.int64))
+        query = types.SimpleNamespace(output=c["qbits"].astype(np.float32) * 2 - 1, label=c["qlab"].astype(np.int64))
+        assert MAPs(c["R"]).get_maps_by_feature(database, query) == g["map"]
+        assert MAP(c["qbits"], c["dbbits"], c["qlab"], c["dblab"], c["R"]) == g["map"]
+        assert calc_map is MAP
+    c = case_cache("e_all_skipped")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert np.isnan(MAP(c["qbits"], c["dbbits"], c["qlab"], c["dblab"], c["R"]))
+    with pytest.raises(ValueError):
+        MAP(c["qbits"], c["dbbits"], c["qlab"], c["dblab"], c["dbbits"].shape[0] + 1)
+
+
+def test_deterministic_and_geometry_independent(ctx, case_cache):
+    """Same lists whatever the segment geometry (unit count) and across repeats."""
+    c = case_cache("e_ragged")
+    _load(ctx, c)
+    base = None
+    for units, minseg in [(16384, 256), (7, 16), (100000, 16), (64, 4096), (16384, 256)]:
+        ctx.set_option("target_units", units)
+        ctx.set_option("min_segment", minseg)
+        ctx.topr(c["R"])
+        idx, dist = ctx.get_topr()
+        if base is None:
+            base = (idx.copy(), dist.copy())
+        assert np.array_equal(idx, base[0]) and np.array_equal(dist, base[1]), (units, minseg)
+    ctx.set_option("target_units", 16384)
+    ctx.set_option("min_segment", 256)
+
+
+def test_state_and_argument_errors(ctx, case_cache):
+    c = case_cache("e_b8")
+    _load(ctx, c)
+    with pytest.raises(_native.HashganNativeError) as e:
+        ctx.plan(10)                       # before hist
+    assert e.value.code == _native.HG_ERR_STATE
+    ctx.hist()
+    with pytest.raises(_native.HashganNativeError) as e:
+        ctx.plan(c["dbbits"].shape[0] + 1)  # R > N
+    assert e.value.code == _native.HG_ERR_ARG
+    with pytest.raises(_native.HashganNativeError):
+        ctx.set_option("no_such_option", 1)
