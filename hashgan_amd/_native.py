@@ -48,6 +48,7 @@ _SIGNATURES = {
     "hg_get_ap": [_p, _p, _p],
     "hg_get_hist": [_p, _p],
     "hg_set_option": [_p, C.c_char_p, _i64],
+    "hg_get_stat": [_p, C.c_char_p, C.POINTER(_i64)],
     "hg_timing_enable": [_p, C.c_int],
     "hg_timing_reset": [_p],
     "hg_timing_read": [_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_int)],
@@ -208,6 +209,11 @@ class Context:
     # -- tuning / timing ----------------------------------------------------------
     def set_option(self, key, value):
         check(self._lib.hg_set_option(self._h, key.encode(), int(value)))
+
+    def get_stat(self, key):
+        v = _i64()
+        check(self._lib.hg_get_stat(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     def timing_enable(self, on=True):
         check(self._lib.hg_timing_enable(self._h, 1 if on else 0))

@@ -56,10 +56,10 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_PREFIX, KI_SELECT, KI_ORDER,
-                KI_MATCH, KI_AP, KI_MERGE, KI_FILL, KI_COUNT };
-const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_prefix",
-                                            "k_select", "k_order", "k_match", "k_ap", "k_merge", "k_fill"};
+enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_LAYOUT, KI_GUESS, KI_SELECT, KI_CAND_HIST,
+                KI_ORDER, KI_MATCH, KI_AP, KI_MERGE, KI_COUNT };
+const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_layout", "k_guess",
+                                            "k_select", "k_cand_hist", "k_order", "k_match", "k_ap", "k_merge"};
 
 enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
 
@@ -106,12 +106,26 @@ struct hg_ctx {
     // options
     i64 target_units = 16384;
     i64 min_segment = 256;
+    i64 opt_enable = 1;        // one-shot calls may bet on a sampled threshold (verified, exact fallback)
+    i64 opt_stride = 0;        // sampling stride in row batches, 0 = auto
+    i64 opt_sigma = 6;         // safety margin of the guess, in standard deviations of the sample count
+    i64 staged_lists = 1;      // staged hg_select materialises the idx/dist lists
+
+    // run state
+    bool optimistic = false;   // records come from a guessed threshold (fixed-capacity slices)
+    bool want_lists = true;
+    bool lists_valid = false;
+    u32 cap = 0;               // optimistic slice capacity
+    i64 crow = 0;              // record-row stride
+    i64 opt_runs = 0, opt_fallbacks = 0;
+    int opt_consecutive_fail = 0;
 
     // device state
     DevBuf db, dblab, qc, qlab;
     DevBuf hist, hown, posbase, seglt, segtie;
-    DevBuf t, cnt_lt, quota, tie_before, n_lt, err;
-    DevBuf scr, out_idx, out_dist, mbits, shapes, ap, rel;
+    DevBuf t, tguess, cnt_lt, quota, tie_before, n_lt, err;
+    DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
+    DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel;
     i64 shapes_for_R = -1;
 
     // timing
@@ -184,6 +198,7 @@ void make_geometry(hg_ctx* c) {
     if (S < 1) S = 1;
     g.S = (int)S; g.L = L;
     g.nUnits = (i64)g.S * g.nQT;
+    g.hist_stride = 1;
     g.wpb = WPB;
     g.nBlk = (int)((g.nUnits + WPB - 1) / WPB);
 }
@@ -207,23 +222,23 @@ template <int NW> int launch_hist_t(hg_ctx* c) {
     return c->check_launch("k_hist");
 }
 
-template <int NW> int launch_select_t(hg_ctx* c) {
+template <int NW, int LW> int launch_select_t(hg_ctx* c) {
     const Geo& g = c->geo;
-    SelectArgs a{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(),
-                 c->seglt.as<u32>(), c->segtie.as<u32>()};
+    SelArgs a{c->optimistic ? c->tguess.as<int>() : c->t.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(),
+              c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, c->optimistic ? 1 : 0};
     c->t_begin(KI_SELECT);
-    hipLaunchKernelGGL(k_select<NW>, dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream,
-                       c->qc.as<u32>(), c->db.as<u32>(), a, c->scr.as<u32>(), c->out_idx.as<u32>(), c->out_dist.as<u8>(), g);
+    hipLaunchKernelGGL((k_select<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qc.as<u32>(),
+                       c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), a, c->cand.as<u64>(), g);
     c->t_end();
-    HG_TRY(c->check_launch("k_select"));
-    int nbits = 1;
-    while ((1 << nbits) < g.NB) ++nbits;
-    c->t_begin(KI_ORDER);
-    hipLaunchKernelGGL(k_order<NW>, dim3(grid_for(g.Q, WPB)), dim3(256), (size_t)WPB * g.NB * 4, c->stream,
-                       c->qc.as<u32>(), c->db.as<u32>(), c->scr.as<u32>(), c->n_lt.as<u32>(), c->t.as<int>(),
-                       c->posbase.as<u32>(), c->out_idx.as<u32>(), c->out_dist.as<u8>(), nbits, g);
-    c->t_end();
-    return c->check_launch("k_order");
+    return c->check_launch("k_select");
+}
+
+template <int NW> int launch_select_nw(hg_ctx* c) {
+    switch (c->LW) {
+        case 1: return launch_select_t<NW, 1>(c);
+        case 2: return launch_select_t<NW, 2>(c);
+        default: return launch_select_t<NW, 0>(c);   // > 128 classes: match bits come from k_match
+    }
 }
 
 #define HG_DISPATCH_NW(fn, c)                                   \
@@ -240,7 +255,31 @@ template <int NW> int launch_select_t(hg_ctx* c) {
     }
 
 int launch_hist(hg_ctx* c) { HG_DISPATCH_NW(launch_hist_t, c) }
-int launch_select(hg_ctx* c) { HG_DISPATCH_NW(launch_select_t, c) }
+int launch_select(hg_ctx* c) { HG_DISPATCH_NW(launch_select_nw, c) }
+
+// rows k_hist visits with batch stride `stride` (mirrors its loop)
+template <int NW> i64 sampled_rows_t(const Geo& g, int stride) {
+    constexpr int B = Batch<NW>::rows;
+    i64 total = 0;
+    for (int s = 0; s < g.S; ++s) {
+        const i64 lo = (i64)s * g.L, hi = lo + g.L < g.N ? lo + g.L : g.N;
+        const i64 nb = (hi - lo) / B;
+        total += (nb + stride - 1) / stride * B;
+    }
+    return total;
+}
+i64 sampled_rows(hg_ctx* c, int stride) {
+    switch (c->NW) {
+        case 1: return sampled_rows_t<1>(c->geo, stride);
+        case 2: return sampled_rows_t<2>(c->geo, stride);
+        case 3: return sampled_rows_t<3>(c->geo, stride);
+        case 4: return sampled_rows_t<4>(c->geo, stride);
+        case 5: return sampled_rows_t<5>(c->geo, stride);
+        case 6: return sampled_rows_t<6>(c->geo, stride);
+        case 7: return sampled_rows_t<7>(c->geo, stride);
+        default: return sampled_rows_t<8>(c->geo, stride);
+    }
+}
 
 int need(hg_ctx* c, unsigned st, const char* who, const char* what) {
     if (!c) return fail(HG_ERR_ARG, "%s: null context", who);
@@ -298,8 +337,9 @@ int hg_destroy(hg_ctx* c) {
     c->t_collect();
     for (auto e : c->pool) (void)hipEventDestroy(e);
     DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
-                     &c->t, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->scr, &c->out_idx,
-                     &c->out_dist, &c->mbits, &c->shapes, &c->ap, &c->rel};
+                     &c->t, &c->tguess, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
+                     &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
+                     &c->shapes, &c->ap, &c->rel};
     for (auto* d : all) d->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -355,8 +395,9 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     return HG_OK;
 }
 
-static int do_hist(hg_ctx* c) {
+static int do_hist(hg_ctx* c, int stride) {
     make_geometry(c);
+    c->geo.hist_stride = stride;
     const Geo& g = c->geo;
     const size_t plane = (size_t)g.NB * g.Qpad * 4;
     HG_TRY(c->hist.reserve(plane * g.S));
@@ -367,13 +408,13 @@ static int do_hist(hg_ctx* c) {
                        c->hist.as<u32>(), c->hown.as<u32>(), g);
     c->t_end();
     HG_TRY(c->check_launch("k_hist_reduce"));
-    c->stage = ST_DB | ST_Q | ST_HIST;
+    c->stage = ST_DB | ST_Q | (stride == 1 ? ST_HIST : 0);
     return HG_OK;
 }
 
 int hg_hist(hg_ctx* c) {
     HG_TRY(need(c, ST_DB | ST_Q, "hg_hist", "hg_set_database + hg_set_queries"));
-    HG_TRY(do_hist(c));
+    HG_TRY(do_hist(c, 1));
     return c->sync();
 }
 
@@ -384,47 +425,70 @@ int hg_hist_buffer(hg_ctx* c, void** dev_ptr, int64_t* nbytes) {
     return HG_OK;
 }
 
-static int do_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
-    if (G < 1 || rank < 0 || rank >= G) return fail(HG_ERR_ARG, "hg_plan: rank %d of %d", rank, G);
-    if (G > 1 && !dev_hist_all) return fail(HG_ERR_ARG, "hg_plan: G > 1 needs the gathered histograms");
+static int set_R(hg_ctx* c, int64_t R, int G, int rank) {
+    if (G < 1 || rank < 0 || rank >= G) return fail(HG_ERR_ARG, "rank %d of %d", rank, G);
     if (R < 1 || R > c->n_total)
-        return fail(HG_ERR_ARG, "hg_plan: R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->n_total);
+        return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->n_total);
     c->R = R; c->G = G; c->rank = rank;
     c->geo.R = R;
     c->RW = (R + 63) / 64;
+    return HG_OK;
+}
+
+// k_plan on c->hown (full histogram, or the records' histogram in optimistic mode)
+static int launch_plan(hg_ctx* c, const uint32_t* dev_hist_all) {
     const Geo& g = c->geo;
     const size_t qb = (size_t)g.Qpad * 4;
     HG_TRY(c->posbase.reserve((size_t)g.NB * qb));
     HG_TRY(c->t.reserve(qb)); HG_TRY(c->cnt_lt.reserve(qb)); HG_TRY(c->quota.reserve(qb));
     HG_TRY(c->tie_before.reserve(qb)); HG_TRY(c->n_lt.reserve(qb)); HG_TRY(c->err.reserve(4));
-    HG_TRY(c->seglt.reserve((size_t)g.S * qb)); HG_TRY(c->segtie.reserve((size_t)g.S * qb));
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     Plan pl{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->n_lt.as<u32>(),
             c->posbase.as<u32>(), c->err.as<int>()};
     c->t_begin(KI_PLAN);
     hipLaunchKernelGGL(k_plan, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(),
-                       (const u32*)dev_hist_all, G, rank, pl, g);
+                       (const u32*)dev_hist_all, c->G, c->rank, pl, g);
     c->t_end();
-    HG_TRY(c->check_launch("k_plan"));
+    return c->check_launch("k_plan");
+}
+
+// exact plan: threshold from the full histogram, then the exact record-row layout
+static int do_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
+    if (G > 1 && !dev_hist_all) return fail(HG_ERR_ARG, "hg_plan: G > 1 needs the gathered histograms");
+    HG_TRY(set_R(c, R, G, rank));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(launch_plan(c, dev_hist_all));
+    HG_TRY(c->seglt.reserve((size_t)g.S * qb)); HG_TRY(c->segtie.reserve((size_t)g.S * qb));
+    HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
+    HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
     c->t_begin(KI_SEG_COUNTS);
     hipLaunchKernelGGL(k_seg_counts, dim3(grid_for((i64)g.S * g.Qpad)), dim3(256), 0, c->stream, c->hist.as<u32>(),
                        c->t.as<int>(), c->seglt.as<u32>(), c->segtie.as<u32>(), g);
     c->t_end();
     HG_TRY(c->check_launch("k_seg_counts"));
-    c->t_begin(KI_SEG_PREFIX);
-    hipLaunchKernelGGL(k_seg_prefix, dim3(grid_for(g.Qpad)), dim3(256), 0, c->stream, c->seglt.as<u32>(),
-                       c->segtie.as<u32>(), g);
+    c->t_begin(KI_SEG_LAYOUT);
+    hipLaunchKernelGGL(k_seg_layout, dim3(grid_for(g.Qpad)), dim3(256), 0, c->stream, c->seglt.as<u32>(),
+                       c->segtie.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->sl_start.as<u32>(),
+                       c->sl_tie.as<u32>(), c->tot.as<u32>(), g);
     c->t_end();
-    HG_TRY(c->check_launch("k_seg_prefix"));
+    HG_TRY(c->check_launch("k_seg_layout"));
+    c->optimistic = false;
+    c->crow = R;
+    c->cap = 0;
     c->stage = ST_DB | ST_Q | ST_HIST | ST_PLAN;
     return HG_OK;
 }
 
-// The plan kernel flags R > (rows in the gathered histograms); read it back with the results.
+// The plan kernel flags R > (rows in the histograms it saw); read it back with the results.
+static int read_plan_flag(hg_ctx* c, int* flag) {
+    HG_HIP(hipMemcpyAsync(flag, c->err.p, 4, hipMemcpyDeviceToHost, c->stream));
+    return c->sync();
+}
+
 static int check_plan_flag(hg_ctx* c) {
     int err = 0;
-    HG_HIP(hipMemcpyAsync(&err, c->err.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HG_TRY(c->sync());
+    HG_TRY(read_plan_flag(c, &err));
     if (err) {
         c->stage = ST_DB | ST_Q | ST_HIST;
         return fail(HG_ERR_ARG, "R=%lld exceeds the rows present in the gathered histograms", (long long)c->R);
@@ -438,30 +502,59 @@ int hg_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank)
     return check_plan_flag(c);
 }
 
+// record pass + ordering (+ gather-based label match when labels are too wide for the record pass)
+static int do_match(hg_ctx* c);
 static int do_select(hg_ctx* c) {
     const Geo& g = c->geo;
     const size_t slots = (size_t)g.Q * g.R;
-    HG_TRY(c->scr.reserve(slots * 4));
-    HG_TRY(c->out_idx.reserve(slots * 4));
-    HG_TRY(c->out_dist.reserve(slots));
-    if (c->G > 1) {  // slots of other shards stay IDX_NONE / 0xFF
+    if (c->LW > 2) c->want_lists = true;                  // k_match gathers through the idx list
+    HG_TRY(c->cand.reserve((size_t)g.Q * c->crow * 8));
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    HG_TRY(c->out_idx.reserve(c->want_lists ? slots * 4 : 16));
+    HG_TRY(c->out_dist.reserve(c->want_lists ? slots : 16));
+    if (c->want_lists && c->G > 1) {  // slots of other shards stay IDX_NONE / 0xFF
         HG_HIP(hipMemsetAsync(c->out_idx.p, 0xFF, slots * 4, c->stream));
         HG_HIP(hipMemsetAsync(c->out_dist.p, 0xFF, slots, c->stream));
     }
     HG_TRY(launch_select(c));
-    c->stage = ST_DB | ST_Q | ST_HIST | ST_PLAN | ST_SELECT;
+    if (c->optimistic) {   // verify the guess: exact histogram of the records -> exact plan
+        c->t_begin(KI_CAND_HIST);
+        hipLaunchKernelGGL(k_cand_hist, dim3(grid_for(g.Q, WPB)), dim3(256), (size_t)WPB * g.NB * 4, c->stream,
+                           c->cand.as<u64>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->hown.as<u32>(), c->cap, c->crow, g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_cand_hist"));
+        HG_TRY(launch_plan(c, nullptr));
+    }
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    const size_t lds_words = (size_t)g.NB + 2 * (size_t)c->RW;
+    const int bits_lds = WPB * lds_words * 4 <= 64 * 1024;
+    if (!bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+    OrdArgs oa{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(),
+               c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0,
+               bits_lds, c->RW};
+    c->t_begin(KI_ORDER);
+    hipLaunchKernelGGL(k_order, dim3(grid_for(g.Q, WPB)), dim3(256),
+                       (size_t)WPB * (g.NB + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4, c->stream, c->cand.as<u64>(), oa,
+                       c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_order"));
+    c->lists_valid = c->want_lists;
+    c->stage = (c->stage & (ST_DB | ST_Q | ST_HIST | ST_PLAN)) | ST_PLAN | ST_SELECT;
+    if (c->LW <= 2) c->stage |= ST_MATCH;                 // match bits came with the records
+    else HG_TRY(do_match(c));
     return HG_OK;
 }
 
 int hg_select(hg_ctx* c) {
     HG_TRY(need(c, ST_PLAN, "hg_select", "hg_plan"));
+    c->want_lists = c->staged_lists != 0;
     HG_TRY(do_select(c));
     return c->sync();
 }
 
 static int do_match(hg_ctx* c) {
     const Geo& g = c->geo;
-    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
     const i64 nKB = (g.R + 255) / 256;
     const i64 blocks = nKB * g.Q;
     if (blocks > 0x7FFFFFFFll) return fail(HG_ERR_ARG, "hg_match: Q*R too large for one launch");
@@ -475,8 +568,11 @@ static int do_match(hg_ctx* c) {
     return HG_OK;
 }
 
+// Label-match bits are produced together with the ranking (k_select/k_order) for
+// up to 128 classes; this stage exists for wider label sets and for API symmetry.
 int hg_match(hg_ctx* c) {
     HG_TRY(need(c, ST_SELECT, "hg_match", "hg_select"));
+    if (c->stage & ST_MATCH) return HG_OK;
     HG_TRY(do_match(c));
     return c->sync();
 }
@@ -529,6 +625,7 @@ int hg_ap(hg_ctx* c) {
 
 int hg_topr_buffers(hg_ctx* c, void** dev_idx, void** dev_dist, int64_t* n_slots) {
     HG_TRY(need(c, ST_SELECT, "hg_topr_buffers", "hg_select"));
+    if (!c->lists_valid) return fail(HG_ERR_STATE, "ranked lists were not materialised by the last call (use hg_topr / staged_lists)");
     if (dev_idx) *dev_idx = c->out_idx.p;
     if (dev_dist) *dev_dist = c->out_dist.p;
     if (n_slots) *n_slots = (int64_t)c->geo.Q * c->geo.R;
@@ -537,6 +634,7 @@ int hg_topr_buffers(hg_ctx* c, void** dev_idx, void** dev_dist, int64_t* n_slots
 
 int hg_merge_topr(hg_ctx* c, const uint32_t* dev_idx_all, const uint8_t* dev_dist_all, int G) {
     HG_TRY(need(c, ST_SELECT, "hg_merge_topr", "hg_select"));
+    if (!c->lists_valid) return fail(HG_ERR_STATE, "ranked lists were not materialised by the last call");
     if (!dev_idx_all || !dev_dist_all || G < 1) return fail(HG_ERR_ARG, "hg_merge_topr: bad argument");
     const i64 n = (i64)c->geo.Q * c->geo.R;
     c->t_begin(KI_MERGE);
@@ -547,28 +645,99 @@ int hg_merge_topr(hg_ctx* c, const uint32_t* dev_idx_all, const uint8_t* dev_dis
     return c->sync();
 }
 
-// One-shot forms enqueue every stage back to back and synchronise once.
+// ---- one-shot forms: every stage enqueued back to back, one synchronisation ----
+// Optimistic bet (single shard, R << N): instead of a full histogram pass, sample
+// every stride-th row batch, guess the threshold a few sigma high, select a
+// superset with it, then verify: the records' exact histogram must contain R rows
+// and no slice may have overflowed.  The verified result is identical to the
+// exact path's; a failed bet reruns the exact path.
+static bool optimistic_eligible(hg_ctx* c, int64_t R, int* stride_out, u32* need_out) {
+    if (!c->opt_enable || c->opt_consecutive_fail >= 2) return false;
+    if (R * 8 > c->N || c->N < 65536) return false;
+    make_geometry(c);
+    int stride = (int)c->opt_stride;
+    if (stride <= 0) {
+        stride = (int)(R / 320);
+        if (stride > 16) stride = 16;
+    }
+    if (stride < 2) return false;
+    const i64 sampled = sampled_rows(c, stride);
+    const double fr = (double)R * (double)sampled / (double)c->N;   // expected sample count at the true cut
+    if (fr < 64.0) return false;
+    const double need = fr + (double)c->opt_sigma * std::sqrt(fr) + 1.0;
+    *stride_out = stride;
+    *need_out = (u32)std::ceil(need);
+    return true;
+}
+
+static int enqueue_exact(hg_ctx* c, int64_t R) {
+    HG_TRY(do_hist(c, 1));
+    HG_TRY(do_plan(c, R, nullptr, 1, 0));
+    return do_select(c);
+}
+
+static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
+    HG_TRY(do_hist(c, stride));
+    HG_TRY(set_R(c, R, 1, 0));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(c->tguess.reserve(qb));
+    HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
+    HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
+    HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
+    c->t_begin(KI_GUESS);
+    hipLaunchKernelGGL(k_guess, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(), need_cnt, c->tguess.as<int>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_guess"));
+    // slice capacity: a guessed cut keeps at most ~2.6 R rows (distance buckets grow < 2x per step in
+    // the tail where the cut lies, and the guess overshoots by at most one bucket), spread over S segments
+    const double mean = 2.6 * (double)R / (double)g.S;
+    u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
+    cap = (cap + 7u) & ~7u;
+    c->optimistic = true;
+    c->cap = cap;
+    c->crow = (i64)g.S * cap;
+    c->stage = ST_DB | ST_Q | ST_PLAN;
+    return do_select(c);
+}
+
+static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
+    int stride = 0;
+    u32 need_cnt = 0;
+    if (R < 1 || R > c->n_total)
+        return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->n_total);
+    c->want_lists = lists;
+    const bool bet = optimistic_eligible(c, R, &stride, &need_cnt);
+    int flag = 0;
+    if (bet) {
+        c->opt_runs++;
+        HG_TRY(enqueue_optimistic(c, R, stride, need_cnt));
+        if (with_ap) HG_TRY(do_ap(c));
+        HG_TRY(read_plan_flag(c, &flag));
+        if (!flag) { c->opt_consecutive_fail = 0; return HG_OK; }
+        c->opt_fallbacks++;                        // the bet failed for some query: exact path for all
+        c->opt_consecutive_fail++;
+        c->want_lists = lists;
+    }
+    HG_TRY(enqueue_exact(c, R));
+    if (with_ap) HG_TRY(do_ap(c));
+    return check_plan_flag(c);
+}
+
 int hg_topr(hg_ctx* c, int64_t R) {
     HG_TRY(need(c, ST_DB | ST_Q, "hg_topr", "hg_set_database + hg_set_queries"));
-    HG_TRY(do_hist(c));
-    HG_TRY(do_plan(c, R, nullptr, 1, 0));
-    HG_TRY(do_select(c));
-    return check_plan_flag(c);
+    return run_oneshot(c, R, true, false);
 }
 
 int hg_map(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
     HG_TRY(need(c, ST_DB | ST_Q, "hg_map", "hg_set_database + hg_set_queries"));
-    HG_TRY(do_hist(c));
-    HG_TRY(do_plan(c, R, nullptr, 1, 0));
-    HG_TRY(do_select(c));
-    HG_TRY(do_match(c));
-    HG_TRY(do_ap(c));
-    HG_TRY(check_plan_flag(c));
+    HG_TRY(run_oneshot(c, R, false, true));
     return hg_get_ap(c, host_ap, host_rel);
 }
 
 int hg_get_topr(hg_ctx* c, uint32_t* host_idx, uint8_t* host_dist) {
     HG_TRY(need(c, ST_SELECT, "hg_get_topr", "hg_select"));
+    if (!c->lists_valid) return fail(HG_ERR_STATE, "ranked lists were not materialised by the last call (hg_map skips them; use hg_topr)");
     const size_t slots = (size_t)c->geo.Q * c->geo.R;
     if (host_idx) HG_HIP(hipMemcpyAsync(host_idx, c->out_idx.p, slots * 4, hipMemcpyDeviceToHost, c->stream));
     if (host_dist) HG_HIP(hipMemcpyAsync(host_dist, c->out_dist.p, slots, hipMemcpyDeviceToHost, c->stream));
@@ -618,9 +787,33 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "min_segment")) {
         if (value < 16) return fail(HG_ERR_ARG, "min_segment must be >= 16");
         c->min_segment = value;
+    } else if (!strcmp(key, "optimistic")) {
+        c->opt_enable = value != 0;
+        c->opt_consecutive_fail = 0;
+    } else if (!strcmp(key, "sample_stride")) {
+        if (value < 0 || value > 1024) return fail(HG_ERR_ARG, "sample_stride must be 0 (auto) .. 1024");
+        c->opt_stride = value;
+    } else if (!strcmp(key, "guess_sigma")) {
+        if (value < 0 || value > 64) return fail(HG_ERR_ARG, "guess_sigma must be 0..64");
+        c->opt_sigma = value;
+    } else if (!strcmp(key, "staged_lists")) {
+        c->staged_lists = value != 0;
     } else {
         return fail(HG_ERR_ARG, "hg_set_option: unknown key '%s'", key);
     }
+    return HG_OK;
+}
+
+int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
+    if (!c || !key || !value) return fail(HG_ERR_ARG, "hg_get_stat: null argument");
+    if (!strcmp(key, "optimistic_runs")) *value = c->opt_runs;
+    else if (!strcmp(key, "optimistic_fallbacks")) *value = c->opt_fallbacks;
+    else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
+    else if (!strcmp(key, "segments")) *value = c->geo.S;
+    else if (!strcmp(key, "segment_rows")) *value = c->geo.L;
+    else if (!strcmp(key, "slice_capacity")) *value = c->cap;
+    else if (!strcmp(key, "record_row")) *value = c->crow;
+    else return fail(HG_ERR_ARG, "hg_get_stat: unknown key '%s'", key);
     return HG_OK;
 }
 

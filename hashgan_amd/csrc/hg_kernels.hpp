@@ -39,6 +39,7 @@ struct Geo {
     i64 R;              // ranked-list length
     u32 idx_base;       // global index of shard row 0
     i64 nUnits;         // S * nQT
+    int hist_stride;    // k_hist visits every hist_stride-th row batch (1 = all rows; >1 = sampling pass)
     int wpb;            // wavefronts (= units) per block of the launch this Geo goes to
     int nBlk;           // logical blocks = ceil(nUnits / wpb); the grid is padded to a multiple of 8
 };
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(256) void k_hist(const u32* __restrict__ qc, const 
     const u32* __restrict__ p = db + lo * NW;
     i64 n = lo;
     constexpr int B = Batch<NW>::rows;
-    for (; n + B <= hi; n += B, p += B * NW) {
+    const i64 step = (i64)B * g.hist_stride;
+    for (; n + B <= hi; n += step, p += step * NW) {
         u32 c[B * NW];
 #pragma unroll
         for (int i = 0; i < B * NW; ++i) c[i] = p[i];
@@ -119,9 +121,11 @@ __global__ __launch_bounds__(256) void k_hist(const u32* __restrict__ qc, const 
             atomicAdd(&h[d * 64 + lane], 1u);
         }
     }
-    for (; n < hi; ++n, p += NW) {
-        const u32 d = hamming<NW>(qw, p);
-        atomicAdd(&h[d * 64 + lane], 1u);
+    if (g.hist_stride == 1) {   // ragged tail of the segment (the sampling pass skips it)
+        for (; n < hi; ++n, p += NW) {
+            const u32 d = hamming<NW>(qw, p);
+            atomicAdd(&h[d * 64 + lane], 1u);
+        }
     }
     u32* __restrict__ out = hist + (i64)s * g.NB * g.Qpad + q;
     for (int d = 0; d < g.NB; ++d) out[(i64)d * g.Qpad] = h[d * 64 + lane];
@@ -211,41 +215,91 @@ __global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ hist
     segtie[i] = tie;
 }
 
-// K2d  exclusive prefix over segments (in place), one thread per query.
-__global__ __launch_bounds__(256) void k_seg_prefix(u32* __restrict__ seglt, u32* __restrict__ segtie, const Geo g) {
+// K2d  one thread per query walks the segments in order and turns the counts
+// into the exact layout of the query's record row: segment s writes its
+// (closer-than-t rows + kept ties) at sl_start[s][q]; sl_tie[s][q] = how many of
+// the segment's ties are still inside the quota (ties are ranked shard-globally:
+// lower-ranked shards first, then index order).  tot[q] = records of the row.
+__global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ seglt, const u32* __restrict__ segtie,
+                                                    const u32* __restrict__ quota, const u32* __restrict__ tie_before,
+                                                    u32* __restrict__ sl_start, u32* __restrict__ sl_tie,
+                                                    u32* __restrict__ tot, const Geo g) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= g.Qpad) return;
-    u32 a = 0, b = 0;
+    u32 pos = 0;
+    u64 tierank = q < g.Q ? tie_before[q] : 0;
+    const u64 qt = q < g.Q ? quota[q] : 0;
     for (int s = 0; s < g.S; ++s) {
         const i64 o = (i64)s * g.Qpad + q;
-        const u32 x = seglt[o], y = segtie[o];
-        seglt[o] = a; segtie[o] = b;
-        a += x; b += y;
+        const u32 lt = seglt[o], tie = segtie[o];
+        const u64 room = tierank < qt ? qt - tierank : 0;
+        const u32 keep = tie < room ? tie : (u32)room;
+        sl_start[o] = pos;
+        sl_tie[o] = keep;
+        pos += lt + keep;
+        tierank += tie;
     }
+    tot[q] = pos;
+}
+
+// K2e  optimistic plan: threshold guess from a SAMPLED histogram.  hs = this
+// query's histogram over the sampled rows; need = sampled-count that makes
+// #(dist <= T over all rows) >= R all but certain (host: f*R + z*sqrt(f*R) + 1).
+// The guess is only a performance bet: k_cand_hist + k_plan verify it exactly.
+__global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, u32 need, int* __restrict__ T, const Geo g) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= g.Q) return;
+    u32 cum = 0;
+    int t = g.NB - 1;                                  // sample too thin: take everything
+    for (int d = 0; d < g.NB; ++d) {
+        cum += hs[(i64)d * g.Qpad + q];
+        if (cum >= need) { t = d; break; }
+    }
+    T[q] = t;
 }
 
 // ----------------------------------------------------------------------------
-// K3  select.   Second pass over the pairs.  A lane walks its query through the
-// segment in index order and appends
-//   rows closer than t  -> scratch list scr[q][..]   (index order; K4 buckets them)
-//   rows at t           -> straight to their final slots out_idx[q][cnt_lt + tie rank]
-//                          while the (shard-global) tie rank is below the quota.
-// Both streams start at offsets known from the histograms, so the result does
-// not depend on scheduling: no atomics, no cross-lane traffic.
+// K3  select.   The pass over the pairs that produces ranked-list members.  A
+// lane walks its query through the segment in index order; every row with
+//   dist <  T,  or  dist == T and still inside the lane's tie allowance
+// becomes one 8-byte record {idx:32 | dist:8 | match:1} appended to the lane's
+// slice of the query's record row.  The match bit (metric.py:17-19: the row
+// shares a positive label with the query) is computed here because the row's
+// label words are wave-uniform scalars at this point -- no gather later.
+//   exact mode      T = t from the full histogram, slices are exact-sized, ties
+//                   limited per slice (k_seg_layout): the row ends up holding
+//                   precisely this shard's members of the top R.
+//   optimistic mode T = guess, fixed-capacity slices, all ties: a superset of
+//                   the members unless a slice overflows (-> fail flag).
+// Rows are visited in index order and slices are per (query, segment), so the
+// records of a row, read slice by slice, are in index order: no atomics, no
+// cross-lane traffic, result independent of scheduling.
 // ----------------------------------------------------------------------------
-struct SelectArgs {
-    const int* t;
-    const u32* cnt_lt;
-    const u32* quota;
-    const u32* tie_before;
-    const u32* seglt;    // [S][Qpad] exclusive prefix
-    const u32* segtie;   // [S][Qpad] exclusive prefix
+struct SelArgs {
+    const int* T;          // [Qpad] threshold (t or guess)
+    const u32* sl_start;   // [S][Qpad] exact mode
+    const u32* sl_tie;     // [S][Qpad] exact mode
+    u32* sl_cnt;           // [S][Qpad] out: records in the slice
+    u32* fail;             // [Qpad] out, optimistic mode: a slice overflowed
+    u32 cap;               // optimistic mode: slice capacity (records)
+    i64 crow;              // record-row stride
+    int optimistic;
 };
 
-template <int NW>
-__global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, const u32* __restrict__ db,
-                                                const SelectArgs a, u32* __restrict__ scr_all,
-                                                u32* __restrict__ out_idx, u8* __restrict__ out_dist, const Geo g) {
+constexpr int sel_batch_rows(int words) {
+    int r = 64 / words, p = 1;
+    while (p * 2 <= r) p *= 2;
+    return p > 16 ? 16 : (p < 2 ? 2 : p);
+}
+
+__device__ __forceinline__ u64 make_rec(u32 idx, u32 d, bool m) {
+    return (u64)idx | ((u64)(d | (m ? 0x100u : 0u)) << 32);
+}
+
+template <int NW, int LW>   // LW = 0: labels wider than 128 classes, match bit left 0 (k_match runs later)
+__global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, const u64* __restrict__ qlab,
+                                                const u32* __restrict__ db, const u64* __restrict__ dblab,
+                                                const SelArgs a, u64* __restrict__ cand, const Geo g) {
     const int lb = logical_block(g.nBlk);
     if (lb < 0) return;
     const int lane = threadIdx.x & 63;
@@ -256,49 +310,55 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
     const int qt = (int)(unit - (i64)s * g.nQT);
     const int q = qt * 64 + lane;
     const bool live = q < g.Q;
+    constexpr int LWA = LW > 0 ? LW : 1;
 
     u32 qw[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) qw[w] = live ? qc[(i64)q * NW + w] : 0u;
-    const int t = live ? a.t[q] : -1;                 // -1: nothing is ever selected
-    const u32 quota = live ? a.quota[q] : 0u;
+    u64 ql[LWA];
+#pragma unroll
+    for (int w = 0; w < LWA; ++w) ql[w] = (LW > 0 && live) ? qlab[(i64)q * LW + w] : 0ull;
+    const int T = live ? a.T[q] : -1;                 // -1: nothing is ever selected
     const i64 so = (i64)s * g.Qpad + q;
-    u32 ltpos = a.seglt[so];
-    u32 tierank = (live ? a.tie_before[q] : 0u) + a.segtie[so];
-    const u32 cntlt = live ? a.cnt_lt[q] : 0u;
-    const i64 rowoff = (i64)(live ? q : 0) * g.R;
-    u32* __restrict__ scr = scr_all + rowoff;
-    u32* __restrict__ oi = out_idx + rowoff + cntlt;    // first tie slot of this query
-    u8* __restrict__ od = out_dist + rowoff + cntlt;
+    u32 start, end, tielim;
+    if (a.optimistic) { start = (u32)s * a.cap; end = start + a.cap; tielim = 0xFFFFFFFFu; }
+    else { start = a.sl_start[so]; end = 0xFFFFFFFFu; tielim = a.sl_tie[so]; }
+    u32 pos = start, ties = 0;
+    u64* __restrict__ row = cand + (i64)(live ? q : 0) * a.crow;
 
     const i64 lo = (i64)s * g.L;
     const i64 hi = lo + g.L < g.N ? lo + g.L : g.N;
     const u32* __restrict__ p = db + lo * NW;
+    const u64* __restrict__ pl = dblab + lo * LWA;
     i64 n = lo;
 
-#define HG_SELECT_ONE(D, NIDX)                                          \
+#define HG_SELECT_ONE(D, NIDX, LABP)                                    \
     {                                                                   \
         const int d = (int)(D);                                         \
-        if (d <= t) {                                                   \
-            const u32 gi = g.idx_base + (u32)(NIDX);                    \
-            if (d < t) {                                                \
-                scr[ltpos] = gi;                                        \
-                ++ltpos;                                                \
-            } else {                                                    \
-                if (tierank < quota) {                                  \
-                    oi[tierank] = gi;                                   \
-                    od[tierank] = (u8)d;                                \
+        if (__builtin_expect(d <= T, 0)) {                              \
+            bool keep = d < T;                                          \
+            if (!keep) { keep = ties < tielim; ++ties; }                \
+            if (keep) {                                                 \
+                u64 any = 0;                                            \
+                if (LW > 0) {                                           \
+                    _Pragma("unroll") for (int w = 0; w < LWA; ++w) any |= (LABP)[w] & ql[w]; \
                 }                                                       \
-                ++tierank;                                              \
+                if (pos < end) row[pos] = make_rec(g.idx_base + (u32)(NIDX), (u32)d, any != 0); \
+                ++pos;                                                  \
             }                                                           \
         }                                                               \
     }
 
-    constexpr int B = Batch<NW>::rows;
-    for (; n + B <= hi; n += B, p += B * NW) {
+    constexpr int B = sel_batch_rows(NW + 2 * LW);
+    for (; n + B <= hi; n += B, p += B * NW, pl += B * LWA) {
         u32 c[B * NW];
 #pragma unroll
         for (int i = 0; i < B * NW; ++i) c[i] = p[i];
+        u64 lab[B * LWA];
+        if (LW > 0) {
+#pragma unroll
+            for (int i = 0; i < B * LWA; ++i) lab[i] = pl[i];
+        }
         u32 dd[B];
 #pragma unroll
         for (int j = 0; j < B; ++j) {
@@ -308,68 +368,145 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
             dd[j] = d;
         }
 #pragma unroll
-        for (int j = 0; j < B; ++j) HG_SELECT_ONE(dd[j], n + j)
+        for (int j = 0; j < B; ++j) HG_SELECT_ONE(dd[j], n + j, lab + j * LWA)
     }
-    for (; n < hi; ++n, p += NW) HG_SELECT_ONE(hamming<NW>(qw, p), n)
+    for (; n < hi; ++n, p += NW, pl += LWA) HG_SELECT_ONE(hamming<NW>(qw, p), n, pl)
 #undef HG_SELECT_ONE
+
+    const u32 written = pos - start;
+    const bool over = a.optimistic && written > a.cap;
+    a.sl_cnt[so] = over ? a.cap : written;
+    if (over && live) a.fail[q] = 1u;                  // several lanes may store the same 1
 }
 
 // ----------------------------------------------------------------------------
-// K4  order.   Stable counting sort of a query's scratch list (rows closer than
-// t, index order) by distance into the final slots: one wavefront per query,
-// 64 entries per step.  The distance is recomputed from the row's code (one
-// 4*NW-byte gather per entry) instead of being carried through scratch.
-// Rank among equal-distance lanes of a step: bit-sliced match over the NBITS
-// bits of d (ballots), then popcount below the lane; per-bucket running
-// positions live in the wave's LDS row pb[d].
+// K3b  exact histogram of a query's records (optimistic mode): which distances
+// the candidate superset really holds.  k_plan then derives the true threshold
+// from it; if the superset has fewer than R rows (guess too low) or a slice
+// overflowed, the plan flags the query and the host reruns the exact path.
+// One wavefront per query.
 // ----------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(256) void k_order(const u32* __restrict__ qc, const u32* __restrict__ db,
-                                               const u32* __restrict__ scr, const u32* __restrict__ n_lt,
-                                               const int* __restrict__ tq, const u32* __restrict__ posbase,
-                                               u32* __restrict__ out_idx, u8* __restrict__ out_dist,
-                                               int nbits, const Geo g) {
+__global__ __launch_bounds__(256) void k_cand_hist(const u64* __restrict__ cand, const u32* __restrict__ sl_cnt,
+                                                   const u32* __restrict__ fail, u32* __restrict__ hown,
+                                                   u32 cap, i64 crow, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
     if (q >= g.Q) return;
-    u32* pb = lds + wave * g.NB;
-    const int t = tq[q];
-    for (int d = lane; d < t; d += 64) pb[d] = posbase[(i64)d * g.Qpad + q];
+    u32* h = lds + wave * g.NB;
+    for (int d = lane; d < g.NB; d += 64) h[d] = 0u;
     wave_lds_sync();
-    u32 qw[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) qw[w] = qc[(i64)q * NW + w];
-    const u32 cnt = n_lt[q];
-    const u32* __restrict__ src = scr + (i64)q * g.R;
+    if (!fail[q]) {
+        const u64* __restrict__ row = cand + (i64)q * crow;
+        for (int s = 0; s < g.S; ++s) {
+            const u32 cnt = sl_cnt[(i64)s * g.Qpad + q];
+            const u64* __restrict__ sl = row + (i64)s * cap;
+            for (u32 i = lane; i < cnt; i += 64) atomicAdd(&h[(u32)(sl[i] >> 32) & 0xFFu], 1u);
+        }
+    }
+    wave_lds_sync();
+    for (int d = lane; d < g.NB; d += 64) hown[(i64)d * g.Qpad + q] = h[d];
+}
+
+// ----------------------------------------------------------------------------
+// K4  order.   metric.py:14 finished: a query's records (index order) go to
+// their final rank positions, canonical order, by a stable counting sort over
+// the distance -- one wavefront per query, 64 records per step:
+//   dist <  t : position = running start of the bucket (LDS row pb[d]) + rank
+//               among the step's lanes of the same distance (bit-sliced match
+//               over the bits of d via ballots, popcount below the lane);
+//   dist == t : position = cnt_lt + shard-global tie rank, kept while the rank
+//               is below the quota;
+//   dist >  t : dropped (only optimistic supersets contain such rows).
+// The record's match bit lands in the query's bit row at that position (LDS
+// bitmap, written out coalesced), so label matching costs no extra pass; the
+// idx/dist lists are written only when the caller wants them.
+// ----------------------------------------------------------------------------
+struct OrdArgs {
+    const int* t;
+    const u32* cnt_lt;
+    const u32* quota;
+    const u32* tie_before;
+    const u32* posbase;    // [NB][Qpad]
+    const u32* sl_cnt;     // [S][Qpad] (optimistic) slices of `cap` records
+    const u32* tot;        // [Qpad]    (exact) one dense run of tot[q] records
+    u32 cap;
+    i64 crow;
+    int dense;
+    int want_lists;
+    int bits_lds;          // bit row fits the wave's LDS share; else global atomics on a zeroed row
+    i64 RW;                // 64-bit words per bit row
+};
+
+__global__ __launch_bounds__(256) void k_order(const u64* __restrict__ cand, const OrdArgs a,
+                                               u32* __restrict__ out_idx, u8* __restrict__ out_dist,
+                                               u32* __restrict__ mbits32, int nbits, const Geo g) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+    if (q >= g.Q) return;
+    const int bmw = a.bits_lds ? (int)(2 * a.RW) : 0;       // 32-bit words of the LDS bitmap
+    u32* pb = lds + wave * (g.NB + bmw);
+    u32* bm = pb + g.NB;
+    const int t = a.t[q];
+    u32* __restrict__ grow = mbits32 + (i64)q * 2 * a.RW;
+    if (t < 0) return;                                      // flagged query: the host reruns the exact path
+    for (int d = lane; d < t; d += 64) pb[d] = a.posbase[(i64)d * g.Qpad + q];
+    for (int w = lane; w < bmw; w += 64) bm[w] = 0u;
+    wave_lds_sync();
+    const u32 cntlt = a.cnt_lt[q], quota = a.quota[q], tiebef = a.tie_before[q];
+    const u64* __restrict__ row = cand + (i64)q * a.crow;
     u32* __restrict__ oi = out_idx + (i64)q * g.R;
     u8* __restrict__ od = out_dist + (i64)q * g.R;
     const u64 below = (1ull << lane) - 1ull;
-
-    for (u32 base = 0; base < cnt; base += 64) {
-        const u32 i = base + lane;
-        const bool valid = i < cnt;
-        u32 gi = 0, d = 0;
-        if (valid) {
-            gi = src[i];
-            d = hamming<NW>(qw, db + (i64)(gi - g.idx_base) * NW);
+    u32 tie_run = 0;
+    const int nsl = a.dense ? 1 : g.S;
+    for (int s = 0; s < nsl; ++s) {
+        const u32 cnt = a.dense ? a.tot[q] : a.sl_cnt[(i64)s * g.Qpad + q];
+        const u64* __restrict__ sl = row + (a.dense ? 0 : (i64)s * a.cap);
+        for (u32 base = 0; base < cnt; base += 64) {
+            const u32 i = base + lane;
+            const bool valid = i < cnt;
+            const u64 rec = valid ? sl[i] : 0ull;
+            const u32 gi = (u32)rec;
+            const u32 meta = (u32)(rec >> 32);
+            const u32 d = meta & 0xFFu;
+            const bool is_lt = valid && (int)d < t;
+            const bool is_tie = valid && (int)d == t;
+            u64 peers = __ballot(is_lt);
+            for (int k = 0; k < nbits; ++k) {
+                const bool bit = (d >> k) & 1u;
+                const u64 m = __ballot(is_lt && bit);
+                peers &= bit ? m : ~m;
+            }
+            const u64 tmask = __ballot(is_tie);
+            u32 pos = IDX_NONE;
+            if (is_lt) {
+                const u32 rank = (u32)__popcll(peers & below);
+                const u32 npeer = (u32)__popcll(peers);
+                const u32 start = pb[d];
+                pos = start + rank;
+                if (rank == npeer - 1) pb[d] = start + npeer;   // last peer advances the bucket
+            } else if (is_tie) {
+                const u32 gr = tiebef + tie_run + (u32)__popcll(tmask & below);
+                if (gr < quota) pos = cntlt + gr;
+            }
+            tie_run += (u32)__popcll(tmask);
+            if (pos != IDX_NONE) {
+                if (a.want_lists) { oi[pos] = gi; od[pos] = (u8)d; }
+                if (meta & 0x100u) {
+                    if (a.bits_lds) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
+                    else atomicOr(&grow[pos >> 5], 1u << (pos & 31));
+                }
+            }
+            wave_lds_sync();
         }
-        u64 peers = __ballot(valid);
-        for (int k = 0; k < nbits; ++k) {
-            const bool bit = (d >> k) & 1u;
-            const u64 m = __ballot(valid && bit);
-            peers &= bit ? m : ~m;
-        }
-        const u32 rank = (u32)__popcll(peers & below);
-        const u32 npeer = (u32)__popcll(peers);
-        if (valid) {
-            const u32 start = pb[d];
-            oi[start + rank] = gi;
-            od[start + rank] = (u8)d;
-            if (rank == npeer - 1) pb[d] = start + npeer;   // last peer advances the bucket
-        }
+    }
+    if (a.bits_lds) {
         wave_lds_sync();
+        for (int w = lane; w < bmw; w += 64) grow[w] = bm[w];
     }
 }
 

@@ -77,8 +77,11 @@ int hg_set_queries(hg_ctx* ctx, const uint64_t* host_codes, const uint64_t* host
  *                           NULL, G = 1, rank = 0 on a single GPU.
  * hg_select  metric.py:14 + [0:R] at :19   second pass over the pairs: emits the
  *                           shard's members of the global top-R into their
- *                           global rank positions, canonical order.
- * hg_match   metric.py:17-19  label match of every ranked slot -> bit rows.
+ *                           global rank positions, canonical order, together
+ *                           with their label-match bits (metric.py:17-19).
+ * hg_match   metric.py:17-19  label match -> bit rows.  Already done by
+ *                           hg_select for C <= 128 classes (then a no-op);
+ *                           a gather pass over the ranked lists otherwise.
  * hg_merge_match            OR of G shards' bit rows (after an all-gather).
  * hg_ap      metric.py:20-23  per-query AP in float64, same rounding and
  *                           summation order as NumPy (pairwise, 8192 chunks).
@@ -99,9 +102,14 @@ int hg_topr_buffers(hg_ctx* ctx, void** dev_idx, void** dev_dist, int64_t* n_slo
  * the one owner of every slot). dev_idx_all: [G][Q][R], dev_dist_all likewise. */
 int hg_merge_topr(hg_ctx* ctx, const uint32_t* dev_idx_all, const uint8_t* dev_dist_all, int G);
 
-/* ---- one-shot forms ---------------------------------------------------------- */
-int hg_topr(hg_ctx* ctx, int64_t R);                       /* hist + plan + select, one shard */
-int hg_map(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel); /* ... + match + ap + download */
+/* ---- one-shot forms (single shard) --------------------------------------------
+ * Every stage is enqueued back to back with one synchronisation.  When R << N
+ * they replace the full histogram pass by a sampled one and a verified guess of
+ * the threshold (identical results; falls back to the staged sequence if the
+ * verification fails).  hg_map skips the idx/dist lists -- mAP only needs the
+ * match bits; use hg_topr when the ranked lists themselves are wanted. */
+int hg_topr(hg_ctx* ctx, int64_t R);
+int hg_map(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel);
 
 /* ---- results to the host ----------------------------------------------------- */
 int hg_get_topr(hg_ctx* ctx, uint32_t* host_idx, uint8_t* host_dist);   /* [Q][R] each */
@@ -110,8 +118,14 @@ int hg_get_ap(hg_ctx* ctx, double* host_ap, int64_t* host_rel);         /* [Q]; 
 int hg_get_hist(hg_ctx* ctx, uint32_t* host_hist);                      /* [b+1][Q] of this shard */
 
 /* ---- tuning and measurement -------------------------------------------------- */
-/* key: "target_units" (waves the pair passes are split into), "min_segment". */
+/* key: "target_units" (wavefront-sized units the pair passes are split into),
+ * "min_segment" (rows), "optimistic" (0/1: one-shot calls may bet on a sampled
+ * threshold -- verified on device, exact fallback), "sample_stride" (0 = auto),
+ * "guess_sigma", "staged_lists" (0/1: hg_select materialises idx/dist lists). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
+/* key: "optimistic_runs", "optimistic_fallbacks", "last_optimistic", "segments",
+ * "segment_rows", "slice_capacity", "record_row". */
+int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
 /* HIP-event timing of every kernel launched on the context's stream. */
 int hg_timing_enable(hg_ctx* ctx, int on);
 int hg_timing_reset(hg_ctx* ctx);

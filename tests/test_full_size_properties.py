@@ -23,10 +23,15 @@ def test_c2_full_properties():
     qw, dw = metric.pack_codes(c["qbits"]), metric.pack_codes(c["dbbits"])
     ctx.set_database(dw, metric.pack_labels(c["dblab"]), b, 10)
     ctx.set_queries(qw, metric.pack_labels(c["qlab"]))
-    ap, rel = ctx.map(R)
+    ap, rel = ctx.map(R)                              # one-shot (sampled-threshold bet)
+    assert ctx.get_stat("last_optimistic") == 1
     g = cases.load_golden("c2_q64")
     # anchor: the first 64 queries are exactly the golden case
     assert np.array_equal(ap[:64], g["ap"], equal_nan=True)
+    # staged exact path: full histogram -> plan -> select; must agree with the one-shot result
+    ctx.hist(); ctx.plan(R); ctx.select(); ctx.ap()
+    ap2, rel2 = ctx.get_ap()
+    assert np.array_equal(ap, ap2, equal_nan=True) and np.array_equal(rel, rel2)
     idx, dist = ctx.get_topr()
     # canonical order: (dist, idx) strictly increasing along every ranked list
     key = dist.astype(np.int64) * (1 << 32) + idx.astype(np.int64)

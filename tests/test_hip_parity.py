@@ -81,14 +81,22 @@ def test_big_cases_match_golden(name, ctx, case_cache):
     c = case_cache(name)
     g = cases.load_golden(name)
     _load(ctx, c)
-    ap, rel = ctx.map(c["R"])
-    assert np.array_equal(ap, g["ap"], equal_nan=True), "ap vs golden: " + _first_diff(ap, g["ap"])
-    assert metric.mean_over_hits(ap, rel) == g["map"]
-    # ranked lists against the oracle on the first queries
     nq = min(8, c["qbits"].shape[0])
     idx_ref, dist_ref = O.topr_from_codes(c["qbits"][:nq], c["dbbits"], c["R"])
-    idx, dist = ctx.get_topr()
-    assert np.array_equal(idx[:nq], idx_ref) and np.array_equal(dist[:nq], dist_ref)
+    for optimistic in (1, 0):          # sampled-threshold bet (verified on device) and the exact two-pass path
+        ctx.set_option("optimistic", optimistic)
+        runs0 = ctx.get_stat("optimistic_runs")
+        ap, rel = ctx.map(c["R"])
+        assert ctx.get_stat("optimistic_runs") - runs0 == optimistic
+        assert np.array_equal(ap, g["ap"], equal_nan=True), "ap vs golden: " + _first_diff(ap, g["ap"])
+        assert metric.mean_over_hits(ap, rel) == g["map"]
+        with pytest.raises(_native.HashganNativeError):
+            ctx.get_topr()             # hg_map does not materialise the lists
+        # ranked lists against the oracle on the first queries
+        ctx.topr(c["R"])
+        idx, dist = ctx.get_topr()
+        assert np.array_equal(idx[:nq], idx_ref) and np.array_equal(dist[:nq], dist_ref)
+    ctx.set_option("optimistic", 1)
 
 
 def test_c1_cifar_full_golden(ctx, case_cache):
@@ -137,6 +145,38 @@ def test_deterministic_and_geometry_independent(ctx, case_cache):
         assert np.array_equal(idx, base[0]) and np.array_equal(dist, base[1]), (units, minseg)
     ctx.set_option("target_units", 16384)
     ctx.set_option("min_segment", 256)
+
+
+def test_failed_bet_falls_back_to_exact(ctx):
+    """The optimistic path is a bet, never an approximation: when the guessed
+    threshold is too low (sigma 0, thin sample) or a slice overflows (database
+    sorted so that all near rows sit in one segment) the device flags it and the
+    exact path reruns -- results stay bit-exact."""
+    from hashgan_amd import synth
+    Q, N, b, R, C = 256, 131072, 32, 4000, 10
+    dl, cls = synth.onehot_labels(71, N, C)
+    ql, _ = synth.onehot_labels(72, Q, C)
+    db = synth.planted_codes(73, dl, b, 0.2)
+    qb = synth.planted_codes(73, ql, b, 0.2)
+    order = np.argsort(cls, kind="stable")           # clustered by class: near rows are contiguous
+    db, dl = db[order], dl[order]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m_ref, ap_ref, *_ = O.map_from_codes(qb[:32], db, ql[:32], dl, R)
+    ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
+    ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
+    for sigma in (6, 0):
+        ctx.set_option("optimistic", 1)              # also clears the consecutive-failure latch
+        ctx.set_option("guess_sigma", sigma)
+        r0, f0 = ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks")
+        ap, rel = ctx.map(R)
+        assert ctx.get_stat("optimistic_runs") == r0 + 1
+        assert np.array_equal(ap[:32], ap_ref, equal_nan=True)
+        fell_back = ctx.get_stat("optimistic_fallbacks") - f0
+        assert fell_back in (0, 1)
+        assert ctx.get_stat("last_optimistic") == 1 - fell_back
+    ctx.set_option("guess_sigma", 6)
+    ctx.set_option("optimistic", 1)
 
 
 def test_state_and_argument_errors(ctx, case_cache):
