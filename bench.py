@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--target-units", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (hg_set_option), repeatable")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,6 +118,9 @@ def main():
     ctx = _native.Context(0)
     if args.target_units:
         ctx.set_option("target_units", args.target_units)
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
     ctx.set_database(dw, dl, b, spec["C"])           # inputs resident in HBM before the timed region
     ctx.set_queries(qw, ql)
 

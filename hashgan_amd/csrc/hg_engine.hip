@@ -222,22 +222,30 @@ template <int NW> int launch_hist_t(hg_ctx* c) {
     return c->check_launch("k_hist");
 }
 
-template <int NW, int LW> int launch_select_t(hg_ctx* c) {
+template <int NW, int LW, bool OPT> int launch_select_t(hg_ctx* c) {
     const Geo& g = c->geo;
     SelArgs a{c->optimistic ? c->tguess.as<int>() : c->t.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(),
               c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, c->optimistic ? 1 : 0};
     c->t_begin(KI_SELECT);
-    hipLaunchKernelGGL((k_select<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qc.as<u32>(),
+    hipLaunchKernelGGL((k_select<NW, LW, OPT>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), a, c->cand.as<u64>(), g);
     c->t_end();
     return c->check_launch("k_select");
 }
 
 template <int NW> int launch_select_nw(hg_ctx* c) {
-    switch (c->LW) {
-        case 1: return launch_select_t<NW, 1>(c);
-        case 2: return launch_select_t<NW, 2>(c);
-        default: return launch_select_t<NW, 0>(c);   // > 128 classes: match bits come from k_match
+    const int lw = c->LW <= 2 ? c->LW : 0;           // > 128 classes: match bits come from k_match
+    if (c->optimistic) {
+        switch (lw) {
+            case 1: return launch_select_t<NW, 1, true>(c);
+            case 2: return launch_select_t<NW, 2, true>(c);
+            default: return launch_select_t<NW, 0, true>(c);
+        }
+    }
+    switch (lw) {
+        case 1: return launch_select_t<NW, 1, false>(c);
+        case 2: return launch_select_t<NW, 2, false>(c);
+        default: return launch_select_t<NW, 0, false>(c);
     }
 }
 

@@ -296,7 +296,9 @@ __device__ __forceinline__ u64 make_rec(u32 idx, u32 d, bool m) {
     return (u64)idx | ((u64)(d | (m ? 0x100u : 0u)) << 32);
 }
 
-template <int NW, int LW>   // LW = 0: labels wider than 128 classes, match bit left 0 (k_match runs later)
+// LW = 0: labels wider than 128 classes, match bit left 0 (k_match runs later).
+// OPT: optimistic mode (compile-time so the hot emission block carries no tie logic).
+template <int NW, int LW, bool OPT>
 __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, const u64* __restrict__ qlab,
                                                 const u32* __restrict__ db, const u64* __restrict__ dblab,
                                                 const SelArgs a, u64* __restrict__ cand, const Geo g) {
@@ -320,11 +322,14 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
     for (int w = 0; w < LWA; ++w) ql[w] = (LW > 0 && live) ? qlab[(i64)q * LW + w] : 0ull;
     const int T = live ? a.T[q] : -1;                 // -1: nothing is ever selected
     const i64 so = (i64)s * g.Qpad + q;
-    u32 start, end, tielim;
-    if (a.optimistic) { start = (u32)s * a.cap; end = start + a.cap; tielim = 0xFFFFFFFFu; }
-    else { start = a.sl_start[so]; end = 0xFFFFFFFFu; tielim = a.sl_tie[so]; }
-    u32 pos = start, ties = 0;
+    u32 start, tielim = 0xFFFFFFFFu;
+    if (OPT) start = (u32)s * a.cap;
+    else { start = a.sl_start[so]; tielim = a.sl_tie[so]; }
+    u32 ties = 0;
     u64* __restrict__ row = cand + (i64)(live ? q : 0) * a.crow;
+    u64* __restrict__ wp = row + start;                    // next record of this lane's slice
+    u64* const wend = OPT ? wp + a.cap : wp;               // optimistic: capacity limit (exact mode cannot overflow)
+    u32 dropped = 0;
 
     const i64 lo = (i64)s * g.L;
     const i64 hi = lo + g.L < g.N ? lo + g.L : g.N;
@@ -336,15 +341,18 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
     {                                                                   \
         const int d = (int)(D);                                         \
         if (__builtin_expect(d <= T, 0)) {                              \
-            bool keep = d < T;                                          \
-            if (!keep) { keep = ties < tielim; ++ties; }                \
+            bool keep = true;                                           \
+            if (!OPT) {                                                 \
+                keep = d < T;                                           \
+                if (!keep) { keep = ties < tielim; ++ties; }            \
+            }                                                           \
             if (keep) {                                                 \
                 u64 any = 0;                                            \
                 if (LW > 0) {                                           \
                     _Pragma("unroll") for (int w = 0; w < LWA; ++w) any |= (LABP)[w] & ql[w]; \
                 }                                                       \
-                if (pos < end) row[pos] = make_rec(g.idx_base + (u32)(NIDX), (u32)d, any != 0); \
-                ++pos;                                                  \
+                if (!OPT || wp < wend) { *wp = make_rec(g.idx_base + (u32)(NIDX), (u32)d, any != 0); ++wp; } \
+                else ++dropped;                                         \
             }                                                           \
         }                                                               \
     }
@@ -373,10 +381,8 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
     for (; n < hi; ++n, p += NW, pl += LWA) HG_SELECT_ONE(hamming<NW>(qw, p), n, pl)
 #undef HG_SELECT_ONE
 
-    const u32 written = pos - start;
-    const bool over = a.optimistic && written > a.cap;
-    a.sl_cnt[so] = over ? a.cap : written;
-    if (over && live) a.fail[q] = 1u;                  // several lanes may store the same 1
+    a.sl_cnt[so] = (u32)(wp - (row + start));
+    if (OPT && dropped && live) a.fail[q] = 1u;        // several lanes may store the same 1
 }
 
 // ----------------------------------------------------------------------------
@@ -402,7 +408,10 @@ __global__ __launch_bounds__(256) void k_cand_hist(const u64* __restrict__ cand,
         for (int s = 0; s < g.S; ++s) {
             const u32 cnt = sl_cnt[(i64)s * g.Qpad + q];
             const u64* __restrict__ sl = row + (i64)s * cap;
-            for (u32 i = lane; i < cnt; i += 64) atomicAdd(&h[(u32)(sl[i] >> 32) & 0xFFu], 1u);
+            for (u32 i = lane; i < cnt; i += 64) {
+                const u32 d = (u32)(sl[i] >> 32) & 0xFFu;
+                if (d < (u32)g.NB) atomicAdd(&h[d], 1u);
+            }
         }
     }
     wave_lds_sync();

@@ -66,7 +66,7 @@ def multihot_labels(seed, n, C, mean_pos=2.43):
     return lab
 
 
-def planted_codes(seed, label, b, flip_p):
+def planted_codes(seed, label, b, flip_p, noise_seed=None):
     """Codes correlated with labels: class prototype XOR Bernoulli(flip_p) noise.
 
     A row's prototype is the XOR of the prototypes of its positive classes, so
@@ -75,5 +75,5 @@ def planted_codes(seed, label, b, flip_p):
     n, C = label.shape
     proto = random_bits(seed ^ 0xA5A5A5A5, C, b)            # [C, b]
     base = (label.astype(np.int64) @ proto.astype(np.int64)) & 1
-    noise = _uniform01(seed, n * b).reshape(n, b) < flip_p
+    noise = _uniform01(seed if noise_seed is None else noise_seed, n * b).reshape(n, b) < flip_p
     return (base.astype(np.uint8) ^ noise.astype(np.uint8)).astype(np.uint8)

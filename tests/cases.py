@@ -56,9 +56,10 @@ def build_case(name):
         qbits = synth.planted_codes(seed, qlab, b, c["flip"])       # same prototypes, own noise below
         qbits = qbits ^ (synth.random_bits(seed + 17, Q, b) & synth.random_bits(seed + 18, Q, b) & synth.random_bits(seed + 19, Q, b))
     elif kind == "planted":
-        dblab, _ = synth.onehot_labels(seed * 3 + 1, N, C)
+        shard = c.get("shard", 0)          # extra database shards: same prototypes, own labels and noise
+        dblab, _ = synth.onehot_labels(seed * 3 + 1 + 7919 * shard, N, C)
         qlab, _ = synth.onehot_labels(seed * 3 + 2, Q, C)
-        dbbits = synth.planted_codes(seed, dblab, b, c["flip"])
+        dbbits = synth.planted_codes(seed, dblab, b, c["flip"], noise_seed=seed + 104729 * shard if shard else None)
         qbits = synth.planted_codes(seed, qlab, b, c["flip"]) ^ (
             synth.random_bits(seed + 17, Q, b) & synth.random_bits(seed + 18, Q, b))
     elif kind == "multihot":

@@ -1,0 +1,71 @@
+"""A CPU stand-in for HipShardEngine, used ONLY to drive
+hashgan_amd.sharded.evaluate_shard under gloo (world_size 2, no GPU): same five
+methods, NumPy + the oracle's expressions inside.  It restates the counting
+plan of k_plan / k_order in the simplest possible form."""
+import numpy as np
+import torch
+from oracle import hamming_map as O
+
+
+class NumpyShardEngine:
+    def __init__(self, qbits, qlab, dbbits, dblab, idx_base):
+        self.q, self.ql, self.db, self.dl, self.base = qbits, qlab, dbbits, dblab, idx_base
+        self.D = O.hamming_matrix(O.pack_bits(qbits), O.pack_bits(dbbits))      # [Q, Nshard]
+        self.NB = qbits.shape[1] + 1
+
+    def hist(self):
+        h = np.stack([np.bincount(self.D[i], minlength=self.NB) for i in range(self.D.shape[0])])
+        self.h = h.astype(np.int64)
+        return torch.from_numpy(self.h.astype(np.int32))
+
+    def plan(self, R, gathered, world, rank):
+        H = gathered.numpy().astype(np.int64) if world > 1 else self.h[None]
+        self.R, self.rank = R, rank
+        tot = H.sum(0)                                   # [Q, NB]
+        cum = np.cumsum(tot, 1)
+        self.t = (cum >= R).argmax(1)
+        before = H[:rank].sum(0)
+        start = cum - tot                                 # global start of each bucket
+        self.posbase = start + before                     # my first slot per bucket
+        self.cnt_lt = np.array([start[q, self.t[q]] for q in range(tot.shape[0])])
+        self.quota = R - self.cnt_lt
+        self.tie_before = np.array([before[q, self.t[q]] for q in range(tot.shape[0])])
+
+    def select_match(self):
+        Q, R = self.D.shape[0], self.R
+        self.idx = np.full((Q, R), 0xFFFFFFFF, dtype=np.int64)
+        bits = np.zeros((Q, R), dtype=bool)
+        for q in range(Q):
+            order = np.argsort(self.D[q], kind="stable")
+            run = {}
+            ties = 0
+            for n in order:
+                d = self.D[q, n]
+                if d < self.t[q]:
+                    pos = self.posbase[q, d] + run.get(d, 0)
+                    run[d] = run.get(d, 0) + 1
+                elif d == self.t[q]:
+                    gr = self.tie_before[q] + ties
+                    ties += 1
+                    if gr >= self.quota[q]:
+                        continue
+                    pos = self.cnt_lt[q] + gr
+                else:
+                    break
+                self.idx[q, pos] = self.base + n
+                bits[q, pos] = O.label_match(self.ql[q], self.dl[n:n + 1])[0]
+        self.bits = bits
+        return torch.from_numpy(np.packbits(bits, axis=1, bitorder="little"))
+
+    def finish(self, gathered_bits, world):
+        packed = gathered_bits.numpy() if world > 1 else np.packbits(self.bits, axis=1, bitorder="little")[None]
+        merged = np.bitwise_or.reduce(packed, axis=0)
+        m = np.unpackbits(merged, axis=1, bitorder="little")[:, :self.R].astype(bool)
+        ap = np.full(m.shape[0], np.nan)
+        rel = np.zeros(m.shape[0], dtype=np.int64)
+        for q in range(m.shape[0]):
+            a, r = O.average_precision(m[q], self.R)
+            rel[q] = r
+            if a is not None:
+                ap[q] = a
+        return ap, rel
