@@ -5,6 +5,7 @@ fails to load, or finds no GPU, the error propagates (HashganNativeError).
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -67,6 +68,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own copy of the HIP/HSA runtime.  Two runtimes in one process do not
+    # coexist (the second one finds no GPU), and the dynamic loader keeps whichever comes first.
+    # If the application has torch imported (sharded mode exchanges through torch.distributed),
+    # let torch bring its runtime up first; this library then binds to the same one.
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:      # noqa: BLE001 -- CPU-only torch, or no GPU: nothing to coordinate
+            pass
     path = library_path()
     if not os.path.exists(path):
         raise HashganNativeError(HG_ERR_STATE, "%s not built -- run `python -m hashgan_amd.build` "

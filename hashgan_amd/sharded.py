@@ -95,7 +95,12 @@ class _DevView:
 
 def _as_tensor(ptr, nbytes, device):
     import torch
-    return torch.as_tensor(_DevView(ptr, nbytes), device=torch.device("cuda", device))
+    try:
+        return torch.as_tensor(_DevView(ptr, nbytes), device=torch.device("cuda", device))
+    except RuntimeError as e:
+        raise RuntimeError("torch cannot see the GPU this context runs on.  Import torch (and let it initialise "
+                           "CUDA/HIP) BEFORE creating the first hashgan_amd context: a process can host only one "
+                           "HIP runtime, and torch bundles its own.  (%s)" % e) from e
 
 
 class HipShardEngine:

@@ -6,6 +6,7 @@ import threading
 import warnings
 import numpy as np
 import pytest
+import torch  # noqa: F401  (imported before the native library loads: one HIP runtime per process, see _native.load)
 from tests import cases
 from hashgan_amd import _native, metric, sharded
 
