@@ -286,18 +286,29 @@ struct SelArgs {
     int optimistic;
 };
 
-constexpr int sel_batch_rows(int words) {
-    int r = 64 / words, p = 1;
+constexpr int sel_batch_rows(int nw) {          // rows per scalar-load batch: <= 64 SGPRs of code words, <= 32 rows
+    int r = 64 / nw, p = 1;
     while (p * 2 <= r) p *= 2;
-    return p > 16 ? 16 : (p < 2 ? 2 : p);
+    return p > 32 ? 32 : (p < 2 ? 2 : p);
 }
 
 __device__ __forceinline__ u64 make_rec(u32 idx, u32 d, bool m) {
     return (u64)idx | ((u64)(d | (m ? 0x100u : 0u)) << 32);
 }
 
+// Hot loop of k_select, per (query, row) pair -- 2*NW + 1 VALU ops and NO branch:
+//   dp = popcount(q ^ row) - T - 1      the -T-1 rides in as the first v_bcnt accumulator,
+//                                        so the sign bit of dp IS the test (dist <= T);
+//   hm = alignbit(hm, dp, 31)            = (hm << 1) | sign(dp): one op shifts the lane's hit
+//                                        mask and appends this row's bit.
+// After a batch of <= 32 rows every lane holds the bit mask of ITS hits in the batch.  Hits are
+// rare (R/N per pair), so instead of branching on every row whose 64 lanes contain a hit, the
+// wave drains the masks afterwards: per round every lane with hits left takes its earliest one
+// (different lanes, different rows), re-reads that row's words with a per-lane load, and writes
+// the record.  Rounds per batch = max hits of any one lane (~2 at R/N = 0.5%), instead of one
+// divergent block per hit row (~10 per batch).
 // LW = 0: labels wider than 128 classes, match bit left 0 (k_match runs later).
-// OPT: optimistic mode (compile-time so the hot emission block carries no tie logic).
+// OPT: optimistic mode (compile-time so the drain carries no tie logic).
 template <int NW, int LW, bool OPT>
 __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, const u64* __restrict__ qlab,
                                                 const u32* __restrict__ db, const u64* __restrict__ dblab,
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
 #pragma unroll
     for (int w = 0; w < LWA; ++w) ql[w] = (LW > 0 && live) ? qlab[(i64)q * LW + w] : 0ull;
     const int T = live ? a.T[q] : -1;                 // -1: nothing is ever selected
+    const u32 bias = (u32)(-T - 1);                   // dist + bias < 0  <=>  dist <= T
     const i64 so = (i64)s * g.Qpad + q;
     u32 start, tielim = 0xFFFFFFFFu;
     if (OPT) start = (u32)s * a.cap;
@@ -334,52 +346,62 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
     const i64 lo = (i64)s * g.L;
     const i64 hi = lo + g.L < g.N ? lo + g.L : g.N;
     const u32* __restrict__ p = db + lo * NW;
-    const u64* __restrict__ pl = dblab + lo * LWA;
     i64 n = lo;
 
-#define HG_SELECT_ONE(D, NIDX, LABP)                                    \
-    {                                                                   \
-        const int d = (int)(D);                                         \
-        if (__builtin_expect(d <= T, 0)) {                              \
-            bool keep = true;                                           \
-            if (!OPT) {                                                 \
-                keep = d < T;                                           \
-                if (!keep) { keep = ties < tielim; ++ties; }            \
-            }                                                           \
-            if (keep) {                                                 \
-                u64 any = 0;                                            \
-                if (LW > 0) {                                           \
-                    _Pragma("unroll") for (int w = 0; w < LWA; ++w) any |= (LABP)[w] & ql[w]; \
-                }                                                       \
-                if (!OPT || wp < wend) { *wp = make_rec(g.idx_base + (u32)(NIDX), (u32)d, any != 0); ++wp; } \
-                else ++dropped;                                         \
-            }                                                           \
-        }                                                               \
-    }
+    // drain the hit masks of `cnt` rows starting at row n0 (bit cnt-1-j <-> row n0+j)
+    auto drain = [&](u32 hm, i64 n0, int cnt) {
+        while (__any(hm != 0u)) {
+            if (hm != 0u) {
+                const int k = 31 - __clz(hm);
+                hm ^= 1u << k;
+                const i64 nr = n0 + (cnt - 1 - k);
+                const u32* __restrict__ rp = db + nr * NW;       // per-lane re-read; the batch was just streamed (L2)
+                u32 d = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) d += __builtin_popcount(qw[w] ^ rp[w]);
+                bool keep = true;
+                if (!OPT) {
+                    keep = (int)d < T;
+                    if (!keep) { keep = ties < tielim; ++ties; }
+                }
+                if (keep) {
+                    u64 any = 0;
+                    if (LW > 0) {
+                        const u64* __restrict__ lp = dblab + nr * LWA;
+#pragma unroll
+                        for (int w = 0; w < LWA; ++w) any |= lp[w] & ql[w];
+                    }
+                    if (!OPT || wp < wend) { *wp = make_rec(g.idx_base + (u32)nr, d, any != 0); ++wp; }
+                    else ++dropped;
+                }
+            }
+        }
+    };
 
-    constexpr int B = sel_batch_rows(NW + 2 * LW);
-    for (; n + B <= hi; n += B, p += B * NW, pl += B * LWA) {
+    constexpr int B = sel_batch_rows(NW);
+    for (; n + B <= hi; n += B, p += B * NW) {
         u32 c[B * NW];
 #pragma unroll
         for (int i = 0; i < B * NW; ++i) c[i] = p[i];
-        u64 lab[B * LWA];
-        if (LW > 0) {
-#pragma unroll
-            for (int i = 0; i < B * LWA; ++i) lab[i] = pl[i];
-        }
-        u32 dd[B];
+        u32 hm = 0;
 #pragma unroll
         for (int j = 0; j < B; ++j) {
-            u32 d = 0;
+            u32 dp = bias;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) d += __builtin_popcount(qw[w] ^ c[j * NW + w]);
-            dd[j] = d;
+            for (int w = 0; w < NW; ++w) dp += __builtin_popcount(qw[w] ^ c[j * NW + w]);
+            hm = __builtin_amdgcn_alignbit(hm, dp, 31);
         }
-#pragma unroll
-        for (int j = 0; j < B; ++j) HG_SELECT_ONE(dd[j], n + j, lab + j * LWA)
+        if (__builtin_expect(__any(hm != 0u), 0)) drain(hm, n, B);
     }
-    for (; n < hi; ++n, p += NW, pl += LWA) HG_SELECT_ONE(hamming<NW>(qw, p), n, pl)
-#undef HG_SELECT_ONE
+    if (n < hi) {                                          // ragged tail of the segment: < B rows
+        u32 hm = 0;
+        const int cnt = (int)(hi - n);
+        for (int j = 0; j < cnt; ++j) {
+            const u32 dp = bias + hamming<NW>(qw, p + j * NW);
+            hm = __builtin_amdgcn_alignbit(hm, dp, 31);
+        }
+        drain(hm, n, cnt);
+    }
 
     a.sl_cnt[so] = (u32)(wp - (row + start));
     if (OPT && dropped && live) a.fail[q] = 1u;        // several lanes may store the same 1
