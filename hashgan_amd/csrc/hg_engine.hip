@@ -57,9 +57,9 @@ struct DevBuf {
 };
 
 enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_LAYOUT, KI_GUESS, KI_SELECT, KI_CAND_HIST,
-                KI_ORDER, KI_MATCH, KI_AP, KI_MERGE, KI_COUNT };
+                KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_COUNT };
 const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_layout", "k_guess",
-                                            "k_select", "k_cand_hist", "k_order", "k_match", "k_ap", "k_merge"};
+                                            "k_select", "k_cand_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge"};
 
 enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
 
@@ -205,8 +205,21 @@ void make_geometry(hg_ctx* c) {
 
 int padded_grid(int nBlk) { return (nBlk + 7) / 8 * 8; }
 
-template <int NW> int launch_hist_t(hg_ctx* c) {
+// The sampled pass only needs the shard total: use 2x longer segments so the per-segment
+// histogram array (and its reduction) shrinks with the work.
+Geo hist_geometry(const hg_ctx* c) {
     Geo g = c->geo;
+    if (g.hist_stride > 1) {
+        const i64 L = g.L * 2;
+        g.L = L;
+        g.S = (int)((g.N + L - 1) / L);
+        g.nUnits = (i64)g.S * g.nQT;
+    }
+    return g;
+}
+
+template <int NW> int launch_hist_t(hg_ctx* c) {
+    Geo g = hist_geometry(c);
     // LDS: one u32 histogram column per lane: wpb * NB * 64 * 4 bytes (<= 160 KiB per workgroup)
     int wpb = WPB;
     while (wpb > 1 && (size_t)wpb * g.NB * 256 > 160u * 1024u) wpb >>= 1;
@@ -266,7 +279,13 @@ int launch_hist(hg_ctx* c) { HG_DISPATCH_NW(launch_hist_t, c) }
 int launch_select(hg_ctx* c) { HG_DISPATCH_NW(launch_select_nw, c) }
 
 // rows k_hist visits with batch stride `stride` (mirrors its loop)
-template <int NW> i64 sampled_rows_t(const Geo& g, int stride) {
+template <int NW> i64 sampled_rows_t(Geo g, int stride) {
+    g.hist_stride = stride;
+    {
+        const i64 L = g.L * 2;                      // mirrors hist_geometry()
+        g.L = L;
+        g.S = (int)((g.N + L - 1) / L);
+    }
     constexpr int B = Batch<NW>::rows;
     i64 total = 0;
     for (int s = 0; s < g.S; ++s) {
@@ -411,9 +430,10 @@ static int do_hist(hg_ctx* c, int stride) {
     HG_TRY(c->hist.reserve(plane * g.S));
     HG_TRY(c->hown.reserve(plane));
     HG_TRY(launch_hist(c));
+    const Geo gh = hist_geometry(c);
     c->t_begin(KI_HIST_REDUCE);
     hipLaunchKernelGGL(k_hist_reduce, dim3(grid_for((i64)g.NB * g.Qpad)), dim3(256), 0, c->stream,
-                       c->hist.as<u32>(), c->hown.as<u32>(), g);
+                       c->hist.as<u32>(), c->hown.as<u32>(), gh);
     c->t_end();
     HG_TRY(c->check_launch("k_hist_reduce"));
     c->stage = ST_DB | ST_Q | (stride == 1 ? ST_HIST : 0);
@@ -525,28 +545,36 @@ static int do_select(hg_ctx* c) {
         HG_HIP(hipMemsetAsync(c->out_dist.p, 0xFF, slots, c->stream));
     }
     HG_TRY(launch_select(c));
-    if (c->optimistic) {   // verify the guess: exact histogram of the records -> exact plan
-        c->t_begin(KI_CAND_HIST);
-        hipLaunchKernelGGL(k_cand_hist, dim3(grid_for(g.Q, WPB)), dim3(256), (size_t)WPB * g.NB * 4, c->stream,
-                           c->cand.as<u64>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->hown.as<u32>(), c->cap, c->crow, g);
-        c->t_end();
-        HG_TRY(c->check_launch("k_cand_hist"));
-        HG_TRY(launch_plan(c, nullptr));
-    }
     int nbits = 1;
     while ((1 << nbits) < g.NB) ++nbits;
-    const size_t lds_words = (size_t)g.NB + 2 * (size_t)c->RW;
-    const int bits_lds = WPB * lds_words * 4 <= 64 * 1024;
-    if (!bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
-    OrdArgs oa{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(),
-               c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0,
-               bits_lds, c->RW};
-    c->t_begin(KI_ORDER);
-    hipLaunchKernelGGL(k_order, dim3(grid_for(g.Q, WPB)), dim3(256),
-                       (size_t)WPB * (g.NB + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4, c->stream, c->cand.as<u64>(), oa,
-                       c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
-    c->t_end();
-    HG_TRY(c->check_launch("k_order"));
+    if (c->optimistic) {
+        // verify the guess + plan + order, one block per query (k_rank_fused)
+        const size_t fixed_words = 5 * (size_t)g.NB + 8;
+        const int bits_lds = (fixed_words + 2 * (size_t)c->RW) * 4 <= 64 * 1024;
+        if (!bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+        HG_TRY(c->err.reserve(4));
+        HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+        RankArgs ra{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->cap, c->crow, c->want_lists ? 1 : 0,
+                    bits_lds, c->RW};
+        c->t_begin(KI_RANK_FUSED);
+        hipLaunchKernelGGL(k_rank_fused, dim3(g.Q), dim3(256), (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4,
+                           c->stream, c->cand.as<u64>(), ra, c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(),
+                           nbits, g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_rank_fused"));
+    } else {
+        const size_t lds_words = (size_t)g.NB + 2 * (size_t)c->RW;
+        const int bits_lds = WPB * lds_words * 4 <= 64 * 1024;
+        if (!bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+        OrdArgs oa{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(),
+                   c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, 1, c->want_lists ? 1 : 0, bits_lds, c->RW};
+        c->t_begin(KI_ORDER);
+        hipLaunchKernelGGL(k_order, dim3(grid_for(g.Q, WPB)), dim3(256),
+                           (size_t)WPB * (g.NB + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4, c->stream, c->cand.as<u64>(), oa,
+                           c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_order"));
+    }
     c->lists_valid = c->want_lists;
     c->stage = (c->stage & (ST_DB | ST_Q | ST_HIST | ST_PLAN)) | ST_PLAN | ST_SELECT;
     if (c->LW <= 2) c->stage |= ST_MATCH;                 // match bits came with the records

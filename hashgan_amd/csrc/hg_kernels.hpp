@@ -109,16 +109,40 @@ __global__ __launch_bounds__(256) void k_hist(const u32* __restrict__ qc, const 
     i64 n = lo;
     constexpr int B = Batch<NW>::rows;
     const i64 step = (i64)B * g.hist_stride;
-    for (; n + B <= hi; n += step, p += step * NW) {
+    // Software prefetch: the next batch's scalar loads are issued right after the FIRST row of the
+    // current batch has been consumed (so the s_waitcnt that guards the current batch has just
+    // retired and covers nothing else) and have the other B-1 rows of work to land.
+    if (n + B <= hi) {
         u32 c[B * NW];
 #pragma unroll
         for (int i = 0; i < B * NW; ++i) c[i] = p[i];
+        for (; n + B <= hi; n += step, p += step * NW) {
+            const bool more = n + step + B <= hi;
+            {
+                u32 d = 0;
 #pragma unroll
-        for (int j = 0; j < B; ++j) {
-            u32 d = 0;
+                for (int w = 0; w < NW; ++w) d += __builtin_popcount(qw[w] ^ c[w]);
+                atomicAdd(&h[d * 64 + lane], 1u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            u32 cn[B * NW];
+            if (more) {
 #pragma unroll
-            for (int w = 0; w < NW; ++w) d += __builtin_popcount(qw[w] ^ c[j * NW + w]);
-            atomicAdd(&h[d * 64 + lane], 1u);
+                for (int i = 0; i < B * NW; ++i) cn[i] = p[step * NW + i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < B * NW; ++i) cn[i] = 0u;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 1; j < B; ++j) {
+                u32 d = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) d += __builtin_popcount(qw[w] ^ c[j * NW + w]);
+                atomicAdd(&h[d * 64 + lane], 1u);
+            }
+#pragma unroll
+            for (int i = 0; i < B * NW; ++i) c[i] = cn[i];
         }
     }
     if (g.hist_stride == 1) {   // ragged tail of the segment (the sampling pass skips it)
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
     u32 ties = 0;
     u64* __restrict__ row = cand + (i64)(live ? q : 0) * a.crow;
     u64* __restrict__ wp = row + start;                    // next record of this lane's slice
-    u64* const wend = OPT ? wp + a.cap : wp;               // optimistic: capacity limit (exact mode cannot overflow)
+    u32 room = OPT ? a.cap : 0xFFFFFFFFu;                  // optimistic: slice capacity (exact-mode slices are exact-sized)
     u32 dropped = 0;
 
     const i64 lo = (i64)s * g.L;
@@ -348,14 +372,16 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
     const u32* __restrict__ p = db + lo * NW;
     i64 n = lo;
 
-    // drain the hit masks of `cnt` rows starting at row n0 (bit cnt-1-j <-> row n0+j)
-    auto drain = [&](u32 hm, i64 n0, int cnt) {
-        while (__any(hm != 0u)) {
-            if (hm != 0u) {
-                const int k = 31 - __clz(hm);
-                hm ^= 1u << k;
-                const i64 nr = n0 + (cnt - 1 - k);
-                const u32* __restrict__ rp = db + nr * NW;       // per-lane re-read; the batch was just streamed (L2)
+    // Drain the hit masks of a window of `cnt` <= 64 rows that starts at row n0 (= uniform pointers
+    // wp0 / wl0 into the code and label tables): bit cnt-1-j of hm <-> row n0+j, so the highest set
+    // bit is the lane's earliest hit.  Per round every lane with hits left handles one of them.
+    auto drain = [&](u64 hm, i64 n0, const u32* __restrict__ wp0, const u64* __restrict__ wl0, int cnt) {
+        while (__any(hm != 0ull)) {
+            if (hm != 0ull) {
+                const int k = 63 - __clzll((long long)hm);
+                hm ^= 1ull << k;
+                const u32 j = (u32)(cnt - 1 - k);                 // row inside the window (32-bit offsets)
+                const u32* __restrict__ rp = wp0 + j * NW;        // per-lane re-read; the window was just streamed (L2)
                 u32 d = 0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) d += __builtin_popcount(qw[w] ^ rp[w]);
@@ -367,40 +393,54 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
                 if (keep) {
                     u64 any = 0;
                     if (LW > 0) {
-                        const u64* __restrict__ lp = dblab + nr * LWA;
+                        const u64* __restrict__ lp = wl0 + j * LWA;
 #pragma unroll
                         for (int w = 0; w < LWA; ++w) any |= lp[w] & ql[w];
                     }
-                    if (!OPT || wp < wend) { *wp = make_rec(g.idx_base + (u32)nr, d, any != 0); ++wp; }
-                    else ++dropped;
+                    if (!OPT || room) {
+                        *wp = make_rec(g.idx_base + (u32)n0 + j, d, any != 0);
+                        ++wp;
+                        --room;
+                    } else {
+                        ++dropped;
+                    }
                 }
             }
         }
     };
 
-    constexpr int B = sel_batch_rows(NW);
-    for (; n + B <= hi; n += B, p += B * NW) {
-        u32 c[B * NW];
+    constexpr int B = sel_batch_rows(NW);                  // rows per scalar-load batch
+    constexpr int WIN = B >= 32 ? 2 : 1;                   // batches per drain window (<= 64 rows)
+    const u64* __restrict__ pl = dblab + lo * LWA;
+    for (; n + B * WIN <= hi; n += B * WIN, p += B * WIN * NW, pl += B * WIN * LWA) {
+        u32 hmw[WIN];
 #pragma unroll
-        for (int i = 0; i < B * NW; ++i) c[i] = p[i];
-        u32 hm = 0;
+        for (int kb = 0; kb < WIN; ++kb) {
+            u32 c[B * NW];
 #pragma unroll
-        for (int j = 0; j < B; ++j) {
-            u32 dp = bias;
+            for (int i = 0; i < B * NW; ++i) c[i] = p[kb * B * NW + i];
+            u32 hm = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) dp += __builtin_popcount(qw[w] ^ c[j * NW + w]);
-            hm = __builtin_amdgcn_alignbit(hm, dp, 31);
+            for (int j = 0; j < B; ++j) {
+                u32 dp = bias;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) dp += __builtin_popcount(qw[w] ^ c[j * NW + w]);
+                hm = __builtin_amdgcn_alignbit(hm, dp, 31);
+            }
+            hmw[kb] = hm;
         }
-        if (__builtin_expect(__any(hm != 0u), 0)) drain(hm, n, B);
+        // window mask: first batch in the high bits
+        const u64 hm64 = WIN == 2 ? (((u64)hmw[0] << 32) | hmw[WIN - 1]) : ((u64)hmw[0]);
+        if (__builtin_expect(__any(hm64 != 0ull), 0)) drain(hm64, n, p, pl, B * WIN);
     }
-    if (n < hi) {                                          // ragged tail of the segment: < B rows
-        u32 hm = 0;
+    if (n < hi) {                                          // ragged end of the segment: < B*WIN rows
+        u64 hm = 0;
         const int cnt = (int)(hi - n);
         for (int j = 0; j < cnt; ++j) {
             const u32 dp = bias + hamming<NW>(qw, p + j * NW);
-            hm = __builtin_amdgcn_alignbit(hm, dp, 31);
+            hm = (hm << 1) | (u64)(dp >> 31);
         }
-        drain(hm, n, cnt);
+        drain(hm, n, p, pl, cnt);
     }
 
     a.sl_cnt[so] = (u32)(wp - (row + start));
@@ -538,6 +578,171 @@ __global__ __launch_bounds__(256) void k_order(const u64* __restrict__ cand, con
     if (a.bits_lds) {
         wave_lds_sync();
         for (int w = lane; w < bmw; w += 64) grow[w] = bm[w];
+    }
+}
+
+// ----------------------------------------------------------------------------
+// K4f  verify + plan + order in one launch (optimistic mode, single shard).
+// One 256-thread block per query; the query's slices are split into four
+// contiguous ranges, one per wavefront:
+//   phase 1  every wave histograms the distances of its records          (= k_cand_hist)
+//   phase 2  bucket totals -> threshold t, quota; per-wave bucket starts  (= k_plan, G = 1)
+//            fewer than R records, or an overflowed slice: *err = 1, the host reruns the
+//            exact path
+//   phase 3  every wave places its records exactly like k_order; match bits go to a
+//            block-wide LDS bitmap, written out coalesced.
+// Ranks are stable across the four ranges because wave w's bucket d starts after the
+// bucket-d records of waves < w (and ties are ranked the same way).
+// ----------------------------------------------------------------------------
+struct RankArgs {
+    const u32* sl_cnt;     // [S][Qpad]
+    const u32* fail;       // [Qpad]
+    int* err;
+    u32 cap;
+    i64 crow;
+    int want_lists;
+    int bits_lds;
+    i64 RW;
+};
+
+__global__ __launch_bounds__(256) void k_rank_fused(const u64* __restrict__ cand, const RankArgs a,
+                                                    u32* __restrict__ out_idx, u8* __restrict__ out_dist,
+                                                    u32* __restrict__ mbits32, int nbits, const Geo g) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NB = g.NB;
+    const int bmw = a.bits_lds ? (int)(2 * a.RW) : 0;
+    u32* hw = lds;                    // [4][NB]  per-wave histograms, then per-wave bucket positions
+    u32* tot = hw + 4 * NB;           // [NB]     bucket totals, then global bucket starts
+    u32* misc = tot + NB;             // [8]      t, cnt_lt, quota, tie_before[4]
+    u32* bm = misc + 8;               // [bmw]
+    u32* __restrict__ grow = mbits32 + (i64)q * 2 * a.RW;
+    if (a.fail[q]) {                                  // a slice of this query overflowed
+        if (tid == 0) atomicExch(a.err, 1);
+        return;
+    }
+    for (int i = tid; i < 5 * NB + 8 + bmw; i += 256) lds[i] = 0u;
+    __syncthreads();
+    const u64* __restrict__ row = cand + (i64)q * a.crow;
+    const int s0 = (int)((i64)g.S * wave / 4), s1 = (int)((i64)g.S * (wave + 1) / 4);
+    // A wave walks its slices 64 records per step.  Global-load latency, not work, bounds this
+    // kernel, so the walker runs one step ahead: the next step's records (and the next slice's
+    // count) are requested before the current step is processed.  Records are read up to the slice
+    // CAPACITY and masked by the count afterwards, so the two loads do not depend on each other.
+    struct Walk { int s; u32 base, cnt; };
+    auto slice_cnt = [&](int s) -> u32 { return s < s1 ? a.sl_cnt[(i64)s * g.Qpad + q] : 0u; };
+    auto first = [&]() { Walk w{s0, 0u, slice_cnt(s0)}; return w; };
+    auto next = [&](Walk w) {
+        w.base += 64;
+        if (w.base >= a.cap || w.base >= w.cnt) { ++w.s; w.base = 0; w.cnt = slice_cnt(w.s); }
+        return w;
+    };
+    auto fetch = [&](const Walk& w) -> u64 {
+        const u32 i = w.base + lane;
+        return (w.s < s1 && i < a.cap) ? row[(i64)w.s * a.cap + i] : 0ull;
+    };
+    // phase 1
+    u32* myh = hw + wave * NB;
+    {
+        Walk w = first();
+        u64 rec = fetch(w);
+        while (w.s < s1) {
+            const Walk wn = next(w);
+            const u64 recn = fetch(wn);
+            if (w.base + lane < w.cnt) {
+                const u32 d = (u32)(rec >> 32) & 0xFFu;
+                if (d < (u32)NB) atomicAdd(&myh[d], 1u);
+            }
+            w = wn;
+            rec = recn;
+        }
+    }
+    __syncthreads();
+    // phase 2
+    for (int d = tid; d < NB; d += 256) tot[d] = hw[d] + hw[NB + d] + hw[2 * NB + d] + hw[3 * NB + d];
+    __syncthreads();
+    if (tid == 0) {
+        u64 cum = 0;
+        int t = -1;
+        for (int d = 0; d < NB; ++d) {
+            const u32 c = tot[d];
+            tot[d] = (u32)cum;                        // global start of bucket d
+            if (cum + c >= (u64)g.R) { t = d; break; }
+            cum += c;
+        }
+        misc[0] = (u32)t;
+        misc[1] = (u32)cum;                           // cnt_lt
+        misc[2] = (u32)((u64)g.R - cum);              // quota
+        if (t < 0) atomicExch(a.err, 1);              // the superset is too small: bet lost
+    }
+    __syncthreads();
+    const int t = (int)misc[0];
+    if (t < 0) return;
+    for (int d = tid; d <= t && d < NB; d += 256) {   // per-wave starts: bucket start + records of earlier waves
+        const u32 h0 = hw[d], h1 = hw[NB + d], h2 = hw[2 * NB + d];
+        const u32 st = d < t ? tot[d] : 0u;           // for d == t the "start" is the tie rank offset
+        hw[d] = st;
+        hw[NB + d] = st + h0;
+        hw[2 * NB + d] = st + h0 + h1;
+        hw[3 * NB + d] = st + h0 + h1 + h2;
+    }
+    __syncthreads();
+    // phase 3
+    u32* pb = hw + wave * NB;
+    const u32 cntlt = misc[1], quota = misc[2];
+    u32 tie_run = pb[t];                              // ties owned by earlier waves
+    u32* __restrict__ oi = out_idx + (i64)q * g.R;
+    u8* __restrict__ od = out_dist + (i64)q * g.R;
+    const u64 below = (1ull << lane) - 1ull;
+    {
+        Walk w = first();
+        u64 rec = fetch(w);
+        while (w.s < s1) {
+            const Walk wn = next(w);
+            const u64 recn = fetch(wn);
+            const bool valid = w.base + lane < w.cnt;
+            const u32 gi = (u32)rec;
+            const u32 meta = (u32)(rec >> 32);
+            const u32 d = meta & 0xFFu;
+            const bool is_lt = valid && (int)d < t;
+            const bool is_tie = valid && (int)d == t;
+            u64 peers = __ballot(is_lt);
+            for (int k = 0; k < nbits; ++k) {
+                const bool bit = (d >> k) & 1u;
+                const u64 m = __ballot(is_lt && bit);
+                peers &= bit ? m : ~m;
+            }
+            const u64 tmask = __ballot(is_tie);
+            u32 pos = IDX_NONE;
+            if (is_lt) {
+                const u32 rank = (u32)__popcll(peers & below);
+                const u32 npeer = (u32)__popcll(peers);
+                const u32 start = pb[d];
+                pos = start + rank;
+                if (rank == npeer - 1) pb[d] = start + npeer;
+            } else if (is_tie) {
+                const u32 gr = tie_run + (u32)__popcll(tmask & below);
+                if (gr < quota) pos = cntlt + gr;
+            }
+            tie_run += (u32)__popcll(tmask);
+            if (pos != IDX_NONE) {
+                if (a.want_lists) { oi[pos] = gi; od[pos] = (u8)d; }
+                if (meta & 0x100u) {
+                    if (a.bits_lds) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
+                    else atomicOr(&grow[pos >> 5], 1u << (pos & 31));
+                }
+            }
+            wave_lds_sync();
+            w = wn;
+            rec = recn;
+        }
+    }
+    if (a.bits_lds) {
+        __syncthreads();
+        for (int w = tid; w < bmw; w += 256) grow[w] = bm[w];
     }
 }
 
