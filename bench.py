@@ -24,7 +24,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VALU_PEAK_TLANEOPS = 78.6     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md)
+# Integer VALU peak: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz.  Measured on this part
+# (profiles/r01_ubench2_valu_rates.txt): v_xor_b32, v_bcnt_u32_b32, v_add_u32 and v_cmp all issue at
+# 4.1-4.2 cycles per wave64 instruction per SIMD (37-38 T lane-ops/s sustained); the 78.6 T figure of
+# MI355X_MICROARCH.md (32 lanes/clk) is the packed-FP32 rate and is not reachable by these ops.
+VALU_PEAK_TLANEOPS = 39.3
+VALU_NOMINAL_FP32_TLANEOPS = 78.6
 HBM_PEAK_GBS = 8000.0         # HBM3E spec (6.3 TB/s achievable)
 
 WORKLOADS = {
@@ -46,23 +51,44 @@ def build_inputs(spec):
         del cases.CASES["_bench"]
 
 
-def cpu_baseline(c, spec, budget_queries=48):
+def cpu_baseline(c, spec, budget_s=12.0, chunk=128):
     """metric.py:12-24 as written (float32 np.dot -> np.argsort(-ips,1) -> Python
-    loop; oracle.reference_as_written) on a bounded query sample, host cores."""
+    loop; oracle.reference_as_written) on the GPU box's host cores, over query
+    chunks (rows are independent; a chunk bounds the reference's 16 B/pair) until
+    ~budget_s seconds of CPU work are done."""
     from oracle import hamming_map as O
-    nq = min(budget_queries, c["qbits"].shape[0])
+    Q = c["qbits"].shape[0]
     dbf = c["dbbits"].astype(np.float32) * 2 - 1
-    qf = c["qbits"][:nq].astype(np.float32) * 2 - 1
-    dl, ql = c["dblab"].astype(np.int64), c["qlab"][:nq].astype(np.int64)
-    t0 = time.perf_counter()
+    dl = c["dblab"].astype(np.int64)
+    chunk = max(1, min(chunk, int(2e9 // (16 * dbf.shape[0])) or 1))
+    done, t0 = 0, time.perf_counter()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        O.reference_as_written(dbf, dl, qf, ql, c["R"])
+        while done < Q and time.perf_counter() - t0 < budget_s:
+            sl = slice(done, min(Q, done + chunk))
+            O.reference_as_written(dbf, dl, c["qbits"][sl].astype(np.float32) * 2 - 1, c["qlab"][sl].astype(np.int64), c["R"])
+            done = sl.stop
     dt = time.perf_counter() - t0
-    return {"value": nq / dt, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d of %d queries x full N=%d database, float32 +-1 features, "
-                      "np.dot (BLAS, all cores) + np.argsort + per-query loop (1 core): %.1f s"
-                      % (nq, c["qbits"].shape[0], c["dbbits"].shape[0], dt)}
+    try:
+        import threadpoolctl
+        blas = [(p.get("internal_api"), p.get("num_threads")) for p in threadpoolctl.threadpool_info()]
+    except Exception:      # noqa: BLE001
+        blas = None
+    return {"value": done / dt, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d of %d queries (chunks of %d) x full N=%d database in %.1f s; float32 +-1 features; np.dot on "
+                      "BLAS threads %s, np.argsort and the per-query loop on 1 core; numpy %s"
+                      % (done, Q, chunk, c["dbbits"].shape[0], dt, blas, np.__version__)}
+
+
+def traffic_from_profiles(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass
+    (profiles/latest_traffic.json, written by tools/pmc_traffic.py), or None."""
+    path = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def kernel_rooflines(timing, steps, spec, geo_bytes):
@@ -78,8 +104,12 @@ def kernel_rooflines(timing, steps, spec, geo_bytes):
     laneops = pairs * 2 * NW                      # one v_xor_b32 + one v_bcnt_u32_b32 per 32-bit word per pair
     alg_bytes = geo_bytes.get(dom, 0)
     roof = {"bound": "valu", "kernel": dom, "achieved": laneops / t / 1e12, "peak": VALU_PEAK_TLANEOPS,
-            "unit": "Tlaneop/s", "frac": laneops / t / 1e12 / VALU_PEAK_TLANEOPS, "traffic": None,
+            "unit": "Tlaneop/s", "frac": laneops / t / 1e12 / VALU_PEAK_TLANEOPS, "traffic": traffic_from_profiles(dom),
             "avg_launch_ms": out[dom]["avg_ms"],
+            "algorithmic_laneops": laneops,
+            "note": "integer bit-count path: xor+popcount lane-ops (2 per 32-bit code word per pair) against the "
+                    "integer VALU issue peak (16 lanes/clk/SIMD); frac vs the 78.6 T packed-FP32 figure is %.3f"
+                    % (laneops / t / 1e12 / VALU_NOMINAL_FP32_TLANEOPS),
             "hbm": {"algorithmic_bytes": alg_bytes, "achieved": alg_bytes / t / 1e9, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": alg_bytes / t / 1e9 / HBM_PEAK_GBS}}
     return roof, out
@@ -149,9 +179,10 @@ def main():
     NB = b + 1
     Qpad = (Q + 63) // 64 * 64
     code_bytes = (Q + N) * NW * 4
-    geo_bytes = {  # algorithmic (compulsory) HBM bytes per launch, DESIGN.md section 5
+    LW = (spec["C"] + 63) // 64
+    geo_bytes = {  # algorithmic (compulsory) HBM bytes per launch, DESIGN.md section 4
         "k_hist": code_bytes + NB * Qpad * 4,
-        "k_select": code_bytes + Q * R * 4,
+        "k_select": code_bytes + (Q + N) * LW * 8 + Q * R * 8,      # codes + labels in, >= R records of 8 B out per query
     }
     roof, per_kernel = kernel_rooflines(timing, args.steps, spec, geo_bytes)
     ms = dt / args.steps * 1e3
@@ -163,6 +194,7 @@ def main():
         "config": {"workload": "%s: Q=%d N=%d b=%d R=%d C=%d, planted codes" % (args.workload.upper(), Q, N, b, R, spec["C"]),
                    "parallelism": "1 GPU"},
         "map": float(m), "parity_vs_reference_golden": parity,
+        "optimistic_runs": ctx.get_stat("optimistic_runs"), "optimistic_fallbacks": ctx.get_stat("optimistic_fallbacks"),
         "pairs_per_sec": Q * N / (dt / args.steps),
         "roofline": roof,
         "kernels": {k_: {"avg_ms": round(v["avg_ms"], 5), "launches": v["launches"]} for k_, v in per_kernel.items()},
