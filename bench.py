@@ -141,7 +141,7 @@ def main():
     qw, ql = metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"])
     dw, dl = metric.pack_codes(c["dbbits"]), metric.pack_labels(c["dblab"])
 
-    if world > 1:
+    if world > 1 or os.environ.get("HG_BENCH_FORCE_SHARDED") == "1":
         from bench_sharded import run_sharded
         return run_sharded(args, spec, c, (qw, ql, dw, dl), rank, local_rank, world)
 

@@ -46,8 +46,10 @@ def run_sharded(args, spec, c0, packed0, rank, local_rank, world):
     ctx.set_queries(qw, ql)
     eng = sharded.HipShardEngine(ctx, want_lists=False)
 
+    force = os.environ.get("HG_BENCH_FORCE_SHARDED") == "1"   # one-rank dry run of this leg over real RCCL
+
     def step():
-        ap, rel = sharded.evaluate_shard(eng, comm, R)
+        ap, rel = sharded.evaluate_shard(eng, comm, R, always_gather=force)
         return sharded.mean_ap(ap, rel)
 
     for _ in range(args.warmup):

@@ -36,6 +36,11 @@ _SIGNATURES = {
     "hg_hist_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
     "hg_plan": [_p, _i64, _p, C.c_int, C.c_int],
     "hg_select": [_p],
+    "hg_bet_eligible": [_p, _i64, C.c_int, C.POINTER(C.c_int)],
+    "hg_sample_hist": [_p, _i64],
+    "hg_guess": [_p, _i64, _p, C.c_int, C.c_int],
+    "hg_select_candidates": [_p],
+    "hg_rank": [_p, _p, C.c_int, C.c_int, C.POINTER(C.c_int)],
     "hg_match": [_p],
     "hg_match_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
     "hg_merge_match": [_p, _p, C.c_int],
@@ -160,6 +165,26 @@ class Context:
 
     def select(self):
         check(self._lib.hg_select(self._h))
+
+    def bet_eligible(self, R, world=1):
+        v = C.c_int()
+        check(self._lib.hg_bet_eligible(self._h, int(R), int(world), C.byref(v)))
+        return bool(v.value)
+
+    def sample_hist(self, R):
+        check(self._lib.hg_sample_hist(self._h, int(R)))
+
+    def guess(self, R, dev_hist_all=None, G=1, rank=0):
+        check(self._lib.hg_guess(self._h, int(R), _p(dev_hist_all) if dev_hist_all else None, int(G), int(rank)))
+        self.R = int(R)
+
+    def select_candidates(self):
+        check(self._lib.hg_select_candidates(self._h))
+
+    def rank(self, dev_hist_all=None, G=1, rank=0):
+        lost = C.c_int()
+        check(self._lib.hg_rank(self._h, _p(dev_hist_all) if dev_hist_all else None, int(G), int(rank), C.byref(lost)))
+        return bool(lost.value)
 
     def match(self):
         check(self._lib.hg_match(self._h))

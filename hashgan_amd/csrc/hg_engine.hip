@@ -428,7 +428,13 @@ static int do_hist(hg_ctx* c, int stride) {
     const Geo& g = c->geo;
     const size_t plane = (size_t)g.NB * g.Qpad * 4;
     HG_TRY(c->hist.reserve(plane * g.S));
-    HG_TRY(c->hown.reserve(plane));
+    HG_TRY(c->hown.reserve(plane + TAIL_WORDS * 4));
+    {   // tail of the exported histogram: [0] overflow flag, [1] rows this pass visited
+        u32 tail[TAIL_WORDS] = {0};
+        tail[1] = (u32)(stride == 1 ? g.N : sampled_rows(c, stride));
+        HG_HIP(hipMemcpyAsync(c->hown.as<char>() + plane, tail, sizeof tail, hipMemcpyHostToDevice, c->stream));
+        HG_HIP(hipStreamSynchronize(c->stream));   // `tail` is a stack buffer
+    }
     HG_TRY(launch_hist(c));
     const Geo gh = hist_geometry(c);
     c->t_begin(KI_HIST_REDUCE);
@@ -447,9 +453,10 @@ int hg_hist(hg_ctx* c) {
 }
 
 int hg_hist_buffer(hg_ctx* c, void** dev_ptr, int64_t* nbytes) {
-    HG_TRY(need(c, ST_HIST, "hg_hist_buffer", "hg_hist"));
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_hist_buffer", "hg_hist / hg_sample_hist / hg_select_candidates"));
+    if (!c->hown.p) return fail(HG_ERR_STATE, "hg_hist_buffer: no histogram computed yet");
     if (dev_ptr) *dev_ptr = c->hown.p;
-    if (nbytes) *nbytes = (int64_t)c->geo.NB * c->geo.Qpad * 4;
+    if (nbytes) *nbytes = ((int64_t)c->geo.NB * c->geo.Qpad + TAIL_WORDS) * 4;
     return HG_OK;
 }
 
@@ -681,6 +688,125 @@ int hg_merge_topr(hg_ctx* c, const uint32_t* dev_idx_all, const uint8_t* dev_dis
     return c->sync();
 }
 
+// ---- staged optimistic sequence (multi-shard): sample -> [gather] -> guess -> candidates ->
+// [gather] -> rank.  Mirrors the one-shot bet, with the two histogram exchanges made explicit.
+static int auto_stride(hg_ctx* c, int64_t R) {
+    int stride = (int)c->opt_stride;
+    if (stride <= 0) {
+        stride = (int)(R / 320);
+        if (stride > 16) stride = 16;
+    }
+    return stride;
+}
+
+int hg_bet_eligible(hg_ctx* c, int64_t R, int world, int* eligible) {
+    if (!c || !eligible || world < 1) return fail(HG_ERR_ARG, "hg_bet_eligible: bad argument");
+    // only shard-independent quantities: every rank must reach the same verdict
+    const int stride = auto_stride(c, R);
+    const i64 per_shard = c->n_total / world;
+    *eligible = c->opt_enable && c->opt_consecutive_fail < 2 && stride >= 2 && R * 8 <= c->n_total &&
+                per_shard >= 65536 && (double)R / stride >= 64.0;
+    return HG_OK;
+}
+
+int hg_sample_hist(hg_ctx* c, int64_t R) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_sample_hist", "hg_set_database + hg_set_queries"));
+    const int stride = auto_stride(c, R);
+    if (stride < 2) return fail(HG_ERR_ARG, "hg_sample_hist: R=%lld is too small to sample for", (long long)R);
+    HG_TRY(do_hist(c, stride));
+    return c->sync();
+}
+
+int hg_guess(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_guess", "hg_sample_hist"));
+    if (G > 1 && !dev_hist_all) return fail(HG_ERR_ARG, "hg_guess: G > 1 needs the gathered sample histograms");
+    HG_TRY(set_R(c, R, G, rank));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(c->tguess.reserve(qb));
+    HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
+    HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
+    HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
+    c->t_begin(KI_GUESS);
+    hipLaunchKernelGGL(k_guess, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(), (const u32*)dev_hist_all, G,
+                       (double)c->opt_sigma, (i64)c->n_total, c->tguess.as<int>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_guess"));
+    // a guessed cut keeps at most ~2.6 R rows over ALL shards; a shard's share is proportional to its size,
+    // with the same 6-sigma headroom per slice as the one-shot bet
+    const double share = (double)c->N / (double)c->n_total;
+    const double mean = 2.6 * (double)R * share / (double)g.S;
+    u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
+    cap = (cap + 7u) & ~7u;
+    c->optimistic = true;
+    c->cap = cap;
+    c->crow = (i64)g.S * cap;
+    c->stage = ST_DB | ST_Q | ST_PLAN;
+    return c->sync();
+}
+
+int hg_select_candidates(hg_ctx* c) {
+    HG_TRY(need(c, ST_PLAN, "hg_select_candidates", "hg_guess"));
+    if (!c->optimistic) return fail(HG_ERR_STATE, "hg_select_candidates: no guess in force (use hg_select after hg_plan)");
+    const Geo& g = c->geo;
+    HG_TRY(c->cand.reserve((size_t)g.Q * c->crow * 8));
+    HG_TRY(launch_select(c));
+    const size_t plane = (size_t)g.NB * g.Qpad * 4;
+    HG_HIP(hipMemsetAsync(c->hown.as<char>() + plane, 0, TAIL_WORDS * 4, c->stream));
+    c->t_begin(KI_CAND_HIST);
+    hipLaunchKernelGGL(k_cand_hist, dim3(grid_for(g.Q, WPB)), dim3(256), (size_t)WPB * g.NB * 4, c->stream,
+                       c->cand.as<u64>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->hown.as<u32>(), c->cap, c->crow, g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_cand_hist"));
+    return c->sync();
+}
+
+int hg_rank(hg_ctx* c, const uint32_t* dev_hist_all, int G, int rank, int* bet_lost) {
+    HG_TRY(need(c, ST_PLAN, "hg_rank", "hg_select_candidates"));
+    if (!c->optimistic) return fail(HG_ERR_STATE, "hg_rank: no guess in force");
+    if (!bet_lost || G < 1 || (G > 1 && !dev_hist_all)) return fail(HG_ERR_ARG, "hg_rank: bad argument");
+    const Geo& g = c->geo;
+    c->G = G; c->rank = rank;
+    c->want_lists = c->staged_lists != 0 || c->LW > 2;
+    const size_t slots = (size_t)g.Q * g.R;
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    HG_TRY(c->out_idx.reserve(c->want_lists ? slots * 4 : 16));
+    HG_TRY(c->out_dist.reserve(c->want_lists ? slots : 16));
+    if (c->want_lists && G > 1) {
+        HG_HIP(hipMemsetAsync(c->out_idx.p, 0xFF, slots * 4, c->stream));
+        HG_HIP(hipMemsetAsync(c->out_dist.p, 0xFF, slots, c->stream));
+    }
+    HG_TRY(launch_plan(c, dev_hist_all));
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    const size_t lds_words = (size_t)g.NB + 2 * (size_t)c->RW;
+    const int bits_lds = WPB * lds_words * 4 <= 64 * 1024;
+    if (!bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+    OrdArgs oa{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(),
+               c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, 0, c->want_lists ? 1 : 0, bits_lds, c->RW};
+    c->t_begin(KI_ORDER);
+    hipLaunchKernelGGL(k_order, dim3(grid_for(g.Q, WPB)), dim3(256), (size_t)WPB * (g.NB + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4,
+                       c->stream, c->cand.as<u64>(), oa, c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_order"));
+    int flag = 0;
+    HG_TRY(read_plan_flag(c, &flag));
+    *bet_lost = flag;
+    c->opt_runs++;
+    if (flag) {
+        c->opt_fallbacks++;
+        c->opt_consecutive_fail++;
+        c->stage = ST_DB | ST_Q;
+        return HG_OK;
+    }
+    c->opt_consecutive_fail = 0;
+    c->lists_valid = c->want_lists;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT;
+    if (c->LW <= 2) c->stage |= ST_MATCH;
+    else HG_TRY(do_match(c));
+    return c->sync();
+}
+
 // ---- one-shot forms: every stage enqueued back to back, one synchronisation ----
 // Optimistic bet (single shard, R << N): instead of a full histogram pass, sample
 // every stride-th row batch, guess the threshold a few sigma high, select a
@@ -722,7 +848,8 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
     HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
     c->t_begin(KI_GUESS);
-    hipLaunchKernelGGL(k_guess, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(), need_cnt, c->tguess.as<int>(), g);
+    hipLaunchKernelGGL(k_guess, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(), (const u32*)nullptr, 1,
+                       (double)c->opt_sigma, (i64)c->n_total, c->tguess.as<int>(), g);
     c->t_end();
     HG_TRY(c->check_launch("k_guess"));
     // slice capacity: a guessed cut keeps at most ~2.6 R rows (distance buckets grow < 2x per step in

@@ -29,6 +29,7 @@ constexpr u32 IDX_NONE = 0xFFFFFFFFu;  // slot of the ranked list owned by anoth
 constexpr int AP_CHUNK = 8192;         // NumPy's reduction buffer (elements) -- np.sum order
 constexpr int AP_LEAF = 128;           // NumPy's pairwise-sum block
 constexpr int AP_THREADS = 128;
+constexpr int TAIL_WORDS = 64;         // words appended to an exported histogram: [0] overflow flag, [1] sampled rows
 
 struct Geo {
     int Q, Qpad, nQT;   // queries, padded to 64, query tiles
@@ -185,8 +186,13 @@ struct Plan {
 __global__ __launch_bounds__(256) void k_plan(const u32* __restrict__ hown, const u32* __restrict__ hall, int G, int rank,
                                               Plan pl, const Geo g) {
     const int q = blockIdx.x * 256 + threadIdx.x;
+    const i64 plane = (i64)g.NB * g.Qpad + TAIL_WORDS;     // stride between the gathered shard histograms
+    if (q == 0) {                                           // a shard reported overflowed slices: the whole bet is off
+        u32 flag = hown[plane - TAIL_WORDS];
+        if (G > 1) for (int r = 0; r < G; ++r) flag |= hall[(i64)r * plane + plane - TAIL_WORDS];
+        if (flag) atomicExch(pl.err, 1);
+    }
     if (q >= g.Q) return;
-    const i64 plane = (i64)g.NB * g.Qpad;
     u64 cum = 0;
     u32 nlt = 0;
     int t = -1;
@@ -266,17 +272,29 @@ __global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ segl
     tot[q] = pos;
 }
 
-// K2e  optimistic plan: threshold guess from a SAMPLED histogram.  hs = this
-// query's histogram over the sampled rows; need = sampled-count that makes
-// #(dist <= T over all rows) >= R all but certain (host: f*R + z*sqrt(f*R) + 1).
-// The guess is only a performance bet: k_cand_hist + k_plan verify it exactly.
-__global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, u32 need, int* __restrict__ T, const Geo g) {
+// K2e  optimistic plan: threshold guess from SAMPLED histograms (this shard's, or the G
+// gathered ones).  With f = sampled rows / all rows, the guess is the smallest T whose sample
+// count reaches f*R + sigma*sqrt(f*R) + 1, i.e. #(dist <= T over all rows) >= R all but
+// certainly.  The guess is only a performance bet: the records' exact histogram goes through
+// k_plan afterwards (k_cand_hist / k_rank_fused) and a lost bet reruns the exact path.
+__global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, const u32* __restrict__ hall, int G,
+                                               double sigma, i64 n_total, int* __restrict__ T, const Geo g) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= g.Q) return;
-    u32 cum = 0;
+    const i64 plane = (i64)g.NB * g.Qpad + TAIL_WORDS;
+    // sampled rows over all shards -> sample count that makes #(dist <= T over all rows) >= R all but certain
+    u64 sampled = 0;
+    if (G > 1) for (int r = 0; r < G; ++r) sampled += hall[(i64)r * plane + plane - TAIL_WORDS + 1];
+    else sampled = hs[plane - TAIL_WORDS + 1];
+    const double fr = (double)g.R * (double)sampled / (double)n_total;
+    const double needd = fr + sigma * sqrt(fr) + 1.0;
+    const u64 need = (u64)ceil(needd);
+    u64 cum = 0;
     int t = g.NB - 1;                                  // sample too thin: take everything
     for (int d = 0; d < g.NB; ++d) {
-        cum += hs[(i64)d * g.Qpad + q];
+        const i64 o = (i64)d * g.Qpad + q;
+        if (G > 1) for (int r = 0; r < G; ++r) cum += hall[(i64)r * plane + o];
+        else cum += hs[o];
         if (cum >= need) { t = d; break; }
     }
     T[q] = t;
@@ -465,7 +483,9 @@ __global__ __launch_bounds__(256) void k_cand_hist(const u64* __restrict__ cand,
     u32* h = lds + wave * g.NB;
     for (int d = lane; d < g.NB; d += 64) h[d] = 0u;
     wave_lds_sync();
-    if (!fail[q]) {
+    if (fail[q]) {
+        if (lane == 0) atomicOr(&hown[(i64)g.NB * g.Qpad], 1u);   // tail word 0: this shard lost the bet
+    } else {
         const u64* __restrict__ row = cand + (i64)q * crow;
         for (int s = 0; s < g.S; ++s) {
             const u32 cnt = sl_cnt[(i64)s * g.Qpad + q];

@@ -116,16 +116,39 @@ class HipShardEngine:
         return _as_tensor(ptr, n, self.ctx.device)
 
     def plan(self, R, gathered, world, rank):
-        self.ctx.plan(R, gathered.data_ptr() if world > 1 else None, world, rank)
+        self.ctx.plan(R, gathered.data_ptr() if (world > 1 and gathered is not None) else None, world, rank)
 
     def select_match(self):
         self.ctx.select()
+        return self.match_bits()
+
+    def match_bits(self):
         self.ctx.match()
         ptr, n = self.ctx.match_buffer()
         return _as_tensor(ptr, n, self.ctx.device)
 
+    # -- optimistic sequence (one pass over the pairs) --------------------------------
+    def bet_eligible(self, R, world):
+        return self.ctx.bet_eligible(R, world)
+
+    def sample_hist(self, R):
+        self.ctx.sample_hist(R)
+        ptr, n = self.ctx.hist_buffer()
+        return _as_tensor(ptr, n, self.ctx.device)
+
+    def guess(self, R, gathered, world, rank):
+        self.ctx.guess(R, gathered.data_ptr() if gathered is not None else None, world, rank)
+
+    def select_candidates(self):
+        self.ctx.select_candidates()
+        ptr, n = self.ctx.hist_buffer()
+        return _as_tensor(ptr, n, self.ctx.device)
+
+    def rank_candidates(self, gathered, world, rank):
+        return self.ctx.rank(gathered.data_ptr() if gathered is not None else None, world, rank)
+
     def finish(self, gathered_bits, world):
-        if world > 1:
+        if gathered_bits is not None:
             self.ctx.merge_match(gathered_bits.data_ptr(), world)
         self.ctx.ap()
         return self.ctx.get_ap()
@@ -140,7 +163,7 @@ class HipShardEngine:
 
 
 # ------------------------------------------------------------------ orchestration
-def evaluate_shard(engine, comm, R, gather_topr=False):
+def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=True):
     """Run one rank's part of the sharded evaluation.
 
     engine: HipShardEngine (or any object with the same five methods -- the CPU
@@ -148,15 +171,24 @@ def evaluate_shard(engine, comm, R, gather_topr=False):
     Returns (ap [Q] float64 with nan for skipped queries, rel [Q] int64) -- and
     (idx, dist) of the merged global top-R when gather_topr is set.
     """
-    h = engine.hist()
-    H = comm.all_gather(h) if comm.world > 1 else None
-    engine.plan(R, H, comm.world, comm.rank)
-    bits = engine.select_match()
-    B = comm.all_gather(bits) if comm.world > 1 else None
+    multi = comm.world > 1 or always_gather          # always_gather: exercise the collectives even with one rank
+    gather = (lambda t: comm.all_gather(t)) if multi else (lambda t: None)
+    bits = None
+    if bet and hasattr(engine, "bet_eligible") and engine.bet_eligible(R, comm.world):
+        # one pass over the pairs: sampled histograms -> shared guess -> candidate records ->
+        # exact record histograms -> shared exact plan.  `lost` is the same on every rank.
+        engine.guess(R, gather(engine.sample_hist(R)), comm.world, comm.rank)
+        lost = engine.rank_candidates(gather(engine.select_candidates()), comm.world, comm.rank)
+        if not lost:
+            bits = engine.match_bits()
+    if bits is None:                                 # exact two-pass sequence
+        engine.plan(R, gather(engine.hist()), comm.world, comm.rank)
+        bits = engine.select_match()
+    B = gather(bits)
     lists = None
     if gather_topr:
         ti, td = engine.topr_tensors()
-        if comm.world > 1:
+        if multi:
             lists = engine.merge_topr(comm.all_gather(ti), comm.all_gather(td), comm.world)
         else:
             lists = engine.ctx.get_topr()

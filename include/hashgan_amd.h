@@ -87,13 +87,30 @@ int hg_set_queries(hg_ctx* ctx, const uint64_t* host_codes, const uint64_t* host
  *                           summation order as NumPy (pairwise, 8192 chunks).
  */
 int hg_hist(hg_ctx* ctx);
-int hg_hist_buffer(hg_ctx* ctx, void** dev_ptr, int64_t* nbytes);  /* uint32 [b+1][Qpad] */
+/* The exchange unit of every histogram stage: uint32 [b+1][Qpad] followed by 64 tail words
+ * ([0] "a slice overflowed" flag, [1] rows the pass visited). */
+int hg_hist_buffer(hg_ctx* ctx, void** dev_ptr, int64_t* nbytes);
 int hg_plan(hg_ctx* ctx, int64_t R, const uint32_t* dev_hist_all, int G, int rank);
 int hg_select(hg_ctx* ctx);
 int hg_match(hg_ctx* ctx);
 int hg_match_buffer(hg_ctx* ctx, void** dev_ptr, int64_t* nbytes); /* uint64 [Q][ceil(R/64)] */
 int hg_merge_match(hg_ctx* ctx, const uint64_t* dev_bits_all, int G);
 int hg_ap(hg_ctx* ctx);
+
+/* ---- staged optimistic sequence (R << N): one pass over the pairs instead of two ----
+ * hg_bet_eligible      same verdict on every rank (uses only R, n_total, world, options)
+ * hg_sample_hist       histogram of every k-th row batch            -> hg_hist_buffer -> all-gather
+ * hg_guess             threshold guess from the G sample histograms (6 sigma high)
+ * hg_select_candidates ONE pass over the pairs: superset of the members as records, plus the
+ *                      exact histogram of those records              -> hg_hist_buffer -> all-gather
+ * hg_rank              exact plan from the G record histograms + ordering + match bits.
+ *                      *bet_lost = 1 (on every rank alike) when the superset was short of R rows
+ *                      or a slice overflowed anywhere: run hg_hist/hg_plan/hg_select instead. */
+int hg_bet_eligible(hg_ctx* ctx, int64_t R, int world, int* eligible);
+int hg_sample_hist(hg_ctx* ctx, int64_t R);
+int hg_guess(hg_ctx* ctx, int64_t R, const uint32_t* dev_hist_all, int G, int rank);
+int hg_select_candidates(hg_ctx* ctx);
+int hg_rank(hg_ctx* ctx, const uint32_t* dev_hist_all, int G, int rank, int* bet_lost);
 
 /* Ranked lists in global-position space: uint32 idx [Q][R] (HG_IDX_NONE where a
  * slot belongs to another shard), uint8 dist [Q][R] (0xFF there). */

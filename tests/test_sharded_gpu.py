@@ -18,6 +18,7 @@ def _run_virtual(c, G, gather_topr):
     qw, ql = metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"])
     comms = sharded.LocalComm.create(G)
     results = [None] * G
+    stats = [None] * G
     errors = []
 
     def work(r):
@@ -29,6 +30,7 @@ def _run_virtual(c, G, gather_topr):
             ctx.set_queries(qw, ql)
             eng = sharded.HipShardEngine(ctx, want_lists=gather_topr)
             results[r] = sharded.evaluate_shard(eng, comms[r], c["R"], gather_topr=gather_topr)
+            stats[r] = (ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks"))
             ctx.close()
         except Exception as e:       # noqa: BLE001
             errors.append(e)
@@ -42,6 +44,7 @@ def _run_virtual(c, G, gather_topr):
     [t.join() for t in th]
     if errors:
         raise errors[0]
+    _run_virtual.last_stats = stats
     return results
 
 
@@ -66,3 +69,39 @@ def test_virtual_shards_equal_single_shard(name, G, case_cache):
         warnings.simplefilter("ignore")
         m = sharded.mean_ap(*res[0][:2])
     assert (np.isnan(m) and np.isnan(g["map"])) or m == g["map"]
+
+
+@pytest.mark.parametrize("name,G", [("c2_q64", 4), ("c5_b128_q32", 2), ("c3_nus_q64", 2)])
+def test_virtual_shards_optimistic_sequence(name, G, case_cache):
+    """Big enough for the sharded bet (sample -> guess -> candidates -> rank): must equal the golden
+    AP of the unmodified reference, and really have taken the one-pass route."""
+    c = case_cache(name)
+    g = cases.load_golden(name)
+    res = _run_virtual(c, G, gather_topr=False)
+    for r in range(G):
+        ap, rel = res[r]
+        assert np.array_equal(ap, g["ap"], equal_nan=True), (name, G, r)
+    assert sharded.mean_ap(*res[0]) == g["map"]
+    assert all(st == (1, 0) for st in _run_virtual.last_stats), _run_virtual.last_stats
+
+
+def test_virtual_shards_lost_bet_is_consistent():
+    """Database sorted by class: near rows pile up in a few segments of one shard, slices overflow
+    there, every rank must see the bet as lost and rerun the exact sequence -- same result."""
+    from hashgan_amd import synth
+    from oracle import hamming_map as O
+    Q, N, b, R, C = 128, 262144, 32, 4000, 10
+    dl, cls = synth.onehot_labels(81, N, C)
+    ql, _ = synth.onehot_labels(82, Q, C)
+    db = synth.planted_codes(83, dl, b, 0.2)
+    qb = synth.planted_codes(83, ql, b, 0.2)
+    order = np.argsort(cls, kind="stable")
+    c = dict(qbits=qb, dbbits=db[order], qlab=ql, dblab=dl[order], R=R, b=b)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb[:24], c["dbbits"], ql[:24], c["dblab"], R)
+    res = _run_virtual(c, 2, gather_topr=False)
+    for r in range(2):
+        assert np.array_equal(res[r][0][:24], ap_ref, equal_nan=True)
+    st = _run_virtual.last_stats
+    assert st[0] == st[1] and st[0][0] == 1, st          # both ranks took the bet, and agree on its outcome
