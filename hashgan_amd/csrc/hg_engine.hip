@@ -735,7 +735,7 @@ int hg_guess(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank
     // a guessed cut keeps at most ~2.6 R rows over ALL shards; a shard's share is proportional to its size,
     // with the same 6-sigma headroom per slice as the one-shot bet
     const double share = (double)c->N / (double)c->n_total;
-    const double mean = 2.6 * (double)R * share / (double)g.S;
+    const double mean = 4.0 * (double)R * share / (double)g.S;
     u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
     cap = (cap + 7u) & ~7u;
     c->optimistic = true;
@@ -852,9 +852,11 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
                        (double)c->opt_sigma, (i64)c->n_total, c->tguess.as<int>(), g);
     c->t_end();
     HG_TRY(c->check_launch("k_guess"));
-    // slice capacity: a guessed cut keeps at most ~2.6 R rows (distance buckets grow < 2x per step in
-    // the tail where the cut lies, and the guess overshoots by at most one bucket), spread over S segments
-    const double mean = 2.6 * (double)R / (double)g.S;
+    // slice capacity: a guessed cut typically keeps 1.3-3 R rows (the guess overshoots by at most one
+    // distance bucket, and cumulative counts grow ~2x per bucket in the tail where the cut lies; clustered
+    // codes grow faster) -- budget 4 R per query over the S segments plus 6 sigma per slice.  HBM is
+    // plentiful (2.5 GB at C2); an overflow only costs the exact rerun.
+    const double mean = 4.0 * (double)R / (double)g.S;
     u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
     cap = (cap + 7u) & ~7u;
     c->optimistic = true;
