@@ -110,6 +110,7 @@ struct hg_ctx {
     i64 opt_stride = 0;        // sampling stride in row batches, 0 = auto
     i64 opt_sigma = 6;         // safety margin of the guess, in standard deviations of the sample count
     i64 staged_lists = 1;      // staged hg_select materialises the idx/dist lists
+    i64 cand_budget_x10 = 40;  // optimistic record budget per query, in tenths of R
 
     // run state
     bool optimistic = false;   // records come from a guessed threshold (fixed-capacity slices)
@@ -246,8 +247,26 @@ template <int NW, int LW, bool OPT> int launch_select_t(hg_ctx* c) {
     return c->check_launch("k_select");
 }
 
+template <int NW, int LW> int launch_select_dense_t(hg_ctx* c) {
+    const Geo& g = c->geo;
+    SelArgs a{c->t.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
+              c->cap, c->crow, 0};
+    c->t_begin(KI_SELECT);
+    hipLaunchKernelGGL((k_select_dense<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qc.as<u32>(),
+                       c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), a, c->cand.as<u64>(), g);
+    c->t_end();
+    return c->check_launch("k_select_dense");
+}
+
 template <int NW> int launch_select_nw(hg_ctx* c) {
     const int lw = c->LW <= 2 ? c->LW : 0;           // > 128 classes: match bits come from k_match
+    if (!c->optimistic && c->R * 4 >= c->n_total) {  // dense regime: most pairs are selected
+        switch (lw) {
+            case 1: return launch_select_dense_t<NW, 1>(c);
+            case 2: return launch_select_dense_t<NW, 2>(c);
+            default: return launch_select_dense_t<NW, 0>(c);
+        }
+    }
     if (c->optimistic) {
         switch (lw) {
             case 1: return launch_select_t<NW, 1, true>(c);
@@ -554,19 +573,26 @@ static int do_select(hg_ctx* c) {
     HG_TRY(launch_select(c));
     int nbits = 1;
     while ((1 << nbits) < g.NB) ++nbits;
-    if (c->optimistic) {
-        // verify the guess + plan + order, one block per query (k_rank_fused)
-        const size_t fixed_words = 5 * (size_t)g.NB + 8;
+    if (c->optimistic || c->G == 1) {
+        // one block per query: verify (optimistic) + plan + order.  Exact single-shard rows hold
+        // precisely the top R, so the same counting plan reproduces t and the bucket starts.
+        const int nwav = (c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4;   // records per query ~ 3R / R
+        const size_t fixed_words = (size_t)(nwav + 1) * g.NB + 8;
         const int bits_lds = (fixed_words + 2 * (size_t)c->RW) * 4 <= 64 * 1024;
         if (!bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
         HG_TRY(c->err.reserve(4));
-        HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
-        RankArgs ra{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->cap, c->crow, c->want_lists ? 1 : 0,
-                    bits_lds, c->RW};
+        if (c->optimistic) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+        else HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
+        RankArgs ra{c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->failq.as<u32>(), c->err.as<int>(),
+                    c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW};
         c->t_begin(KI_RANK_FUSED);
-        hipLaunchKernelGGL(k_rank_fused, dim3(g.Q), dim3(256), (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4,
-                           c->stream, c->cand.as<u64>(), ra, c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(),
-                           nbits, g);
+        const size_t lds_bytes = (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4;
+        if (nwav == 16)
+            hipLaunchKernelGGL(k_rank_fused<16>, dim3(g.Q), dim3(1024), lds_bytes, c->stream, c->cand.as<u64>(), ra,
+                               c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+        else
+            hipLaunchKernelGGL(k_rank_fused<4>, dim3(g.Q), dim3(256), lds_bytes, c->stream, c->cand.as<u64>(), ra,
+                               c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
         c->t_end();
         HG_TRY(c->check_launch("k_rank_fused"));
     } else {
@@ -735,7 +761,7 @@ int hg_guess(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank
     // a guessed cut keeps at most ~2.6 R rows over ALL shards; a shard's share is proportional to its size,
     // with the same 6-sigma headroom per slice as the one-shot bet
     const double share = (double)c->N / (double)c->n_total;
-    const double mean = 4.0 * (double)R * share / (double)g.S;
+    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)R * share / (double)g.S;
     u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
     cap = (cap + 7u) & ~7u;
     c->optimistic = true;
@@ -856,7 +882,7 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     // distance bucket, and cumulative counts grow ~2x per bucket in the tail where the cut lies; clustered
     // codes grow faster) -- budget 4 R per query over the S segments plus 6 sigma per slice.  HBM is
     // plentiful (2.5 GB at C2); an overflow only costs the exact rerun.
-    const double mean = 4.0 * (double)R / (double)g.S;
+    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)R / (double)g.S;
     u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
     cap = (cap + 7u) & ~7u;
     c->optimistic = true;
@@ -963,6 +989,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_sigma = value;
     } else if (!strcmp(key, "staged_lists")) {
         c->staged_lists = value != 0;
+    } else if (!strcmp(key, "cand_budget_x10")) {
+        if (value < 11 || value > 1000) return fail(HG_ERR_ARG, "cand_budget_x10 must be 11..1000");
+        c->cand_budget_x10 = value;
     } else {
         return fail(HG_ERR_ARG, "hg_set_option: unknown key '%s'", key);
     }

@@ -466,6 +466,71 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
 }
 
 // ----------------------------------------------------------------------------
+// K3d  select, dense regime (exact mode, R/N >= 1/4 -- e.g. the reference's own CIFAR-10
+// configuration R = N).  When most pairs are selected the output is the bottleneck, so the
+// mapping is transposed: lane <-> database row (64 consecutive rows), the query is wave-
+// uniform (code, threshold and label words in SGPRs), the wave loops over the 64 queries of
+// its tile.  Kept rows are compacted with a ballot + prefix popcount, so a query's records
+// leave as ONE coalesced store per 64 rows, in index order; tie ranks are a running uniform
+// count.  Same record rows, slices and counts as k_select: downstream is unchanged.
+// ----------------------------------------------------------------------------
+template <int NW, int LW>
+__global__ __launch_bounds__(256) void k_select_dense(const u32* __restrict__ qc, const u64* __restrict__ qlab,
+                                                      const u32* __restrict__ db, const u64* __restrict__ dblab,
+                                                      const SelArgs a, u64* __restrict__ cand, const Geo g) {
+    const int lb = logical_block(g.nBlk);
+    if (lb < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const i64 unit = (i64)lb * g.wpb + wave;
+    if (unit >= g.nUnits) return;
+    const int s = (int)(unit / g.nQT);
+    const int qt = (int)(unit - (i64)s * g.nQT);
+    constexpr int LWA = LW > 0 ? LW : 1;
+    const i64 lo = (i64)s * g.L;
+    const i64 hi = lo + g.L < g.N ? lo + g.L : g.N;
+    const u64 below = (1ull << lane) - 1ull;
+    const int qend = (qt + 1) * 64 < g.Q ? (qt + 1) * 64 : g.Q;
+    for (int q = qt * 64; q < qend; ++q) {                  // wave-uniform
+        const int T = a.T[q];
+        const i64 so = (i64)s * g.Qpad + q;
+        const u32 start = a.sl_start[so], tielim = a.sl_tie[so];
+        u32 qw[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) qw[w] = qc[(i64)q * NW + w];
+        u64 ql[LWA];
+#pragma unroll
+        for (int w = 0; w < LWA; ++w) ql[w] = LW > 0 ? qlab[(i64)q * LW + w] : 0ull;
+        u64* __restrict__ row = cand + (i64)q * a.crow;
+        u32 pos = start, ties = 0;
+        for (i64 n0 = lo; n0 < hi; n0 += 64) {
+            const i64 n = n0 + lane;
+            const bool valid = n < hi;
+            u32 d = 0;
+            if (valid) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) d += __builtin_popcount(qw[w] ^ db[n * NW + w]);
+            }
+            const bool is_tie = valid && (int)d == T;
+            const u64 tmask = __ballot(is_tie);
+            const bool keep = valid && ((int)d < T || (is_tie && ties + (u32)__popcll(tmask & below) < tielim));
+            ties += (u32)__popcll(tmask);
+            const u64 kmask = __ballot(keep);
+            if (keep) {
+                u64 any = 0;
+                if (LW > 0) {
+#pragma unroll
+                    for (int w = 0; w < LWA; ++w) any |= dblab[n * LWA + w] & ql[w];
+                }
+                row[pos + (u32)__popcll(kmask & below)] = make_rec(g.idx_base + (u32)n, d, any != 0);
+            }
+            pos += (u32)__popcll(kmask);
+        }
+        if (lane == 0) a.sl_cnt[so] = pos - start;
+    }
+}
+
+// ----------------------------------------------------------------------------
 // K3b  exact histogram of a query's records (optimistic mode): which distances
 // the candidate superset really holds.  k_plan then derives the true threshold
 // from it; if the superset has fewer than R rows (guess too low) or a slice
@@ -615,17 +680,20 @@ __global__ __launch_bounds__(256) void k_order(const u64* __restrict__ cand, con
 // bucket-d records of waves < w (and ties are ranked the same way).
 // ----------------------------------------------------------------------------
 struct RankArgs {
-    const u32* sl_cnt;     // [S][Qpad]
+    const u32* sl_cnt;     // [S][Qpad]   (slice mode)
+    const u32* tot;        // [Qpad]      (dense mode: one run of tot[q] records, walked in chunks of `cap`)
     const u32* fail;       // [Qpad]
     int* err;
     u32 cap;
     i64 crow;
+    int dense;
     int want_lists;
     int bits_lds;
     i64 RW;
 };
 
-__global__ __launch_bounds__(256) void k_rank_fused(const u64* __restrict__ cand, const RankArgs a,
+template <int NWAV>   // wavefronts per query: 4, or 16 for long lists
+__global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict__ cand, const RankArgs a,
                                                     u32* __restrict__ out_idx, u8* __restrict__ out_dist,
                                                     u32* __restrict__ mbits32, int nbits, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -634,26 +702,46 @@ __global__ __launch_bounds__(256) void k_rank_fused(const u64* __restrict__ cand
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NB = g.NB;
+    constexpr int nthr = NWAV * 64;
+    constexpr int nwav = NWAV;
     const int bmw = a.bits_lds ? (int)(2 * a.RW) : 0;
-    u32* hw = lds;                    // [4][NB]  per-wave histograms, then per-wave bucket positions
-    u32* tot = hw + 4 * NB;           // [NB]     bucket totals, then global bucket starts
-    u32* misc = tot + NB;             // [8]      t, cnt_lt, quota, tie_before[4]
+    u32* hw = lds;                    // [nwav][NB]  per-wave histograms, then per-wave bucket positions
+    u32* tot = hw + nwav * NB;        // [NB]     bucket totals, then global bucket starts
+    u32* misc = tot + NB;             // [8]      t, cnt_lt, quota
     u32* bm = misc + 8;               // [bmw]
     u32* __restrict__ grow = mbits32 + (i64)q * 2 * a.RW;
     if (a.fail[q]) {                                  // a slice of this query overflowed
         if (tid == 0) atomicExch(a.err, 1);
         return;
     }
-    for (int i = tid; i < 5 * NB + 8 + bmw; i += 256) lds[i] = 0u;
+    for (int i = tid; i < (nwav + 1) * NB + 8 + bmw; i += nthr) lds[i] = 0u;
     __syncthreads();
     const u64* __restrict__ row = cand + (i64)q * a.crow;
-    const int s0 = (int)((i64)g.S * wave / 4), s1 = (int)((i64)g.S * (wave + 1) / 4);
+    // slice mode: S slices of capacity cap; dense mode: the run of tot[q] records cut into chunks of cap
+    const u32 dense_tot = a.dense ? a.tot[q] : 0u;
+    const int nsl = a.dense ? (int)((dense_tot + a.cap - 1) / a.cap) : g.S;
+    const int s0 = (int)((i64)nsl * wave / nwav), s1 = (int)((i64)nsl * (wave + 1) / nwav);
     // A wave walks its slices 64 records per step.  Global-load latency, not work, bounds this
     // kernel, so the walker runs one step ahead: the next step's records (and the next slice's
     // count) are requested before the current step is processed.  Records are read up to the slice
     // CAPACITY and masked by the count afterwards, so the two loads do not depend on each other.
     struct Walk { int s; u32 base, cnt; };
-    auto slice_cnt = [&](int s) -> u32 { return s < s1 ? a.sl_cnt[(i64)s * g.Qpad + q] : 0u; };
+    // slice counts of this wave's range, 64 at a time in one vector load (lane i <-> slice c0 + i);
+    // a slice's count is then a v_readlane away instead of a dependent scalar load per slice
+    int c0 = s0;
+    u32 cnts = (!a.dense && s0 + lane < s1) ? a.sl_cnt[(i64)(s0 + lane) * g.Qpad + q] : 0u;
+    auto slice_cnt = [&](int s) -> u32 {
+        if (s >= s1) return 0u;
+        if (a.dense) {
+            const u32 left = dense_tot - (u32)s * a.cap;
+            return left < a.cap ? left : a.cap;
+        }
+        if (s >= c0 + 64 || s < c0) {                  // uniform: refill the window (ranges longer than 64 slices)
+            c0 = s;
+            cnts = (s + lane < s1) ? a.sl_cnt[(i64)(s + lane) * g.Qpad + q] : 0u;
+        }
+        return (u32)__builtin_amdgcn_readlane((int)cnts, s - c0);
+    };
     auto first = [&]() { Walk w{s0, 0u, slice_cnt(s0)}; return w; };
     auto next = [&](Walk w) {
         w.base += 64;
@@ -682,13 +770,18 @@ __global__ __launch_bounds__(256) void k_rank_fused(const u64* __restrict__ cand
     }
     __syncthreads();
     // phase 2
-    for (int d = tid; d < NB; d += 256) tot[d] = hw[d] + hw[NB + d] + hw[2 * NB + d] + hw[3 * NB + d];
+    for (int d = tid; d < NB; d += nthr) {
+        u32 acc = 0;
+        for (int w = 0; w < nwav; ++w) acc += hw[w * NB + d];
+        tot[d] = acc;
+    }
     __syncthreads();
     if (tid == 0) {
         u64 cum = 0;
-        int t = -1;
+        int t = -1, dmin = -1;
         for (int d = 0; d < NB; ++d) {
             const u32 c = tot[d];
+            if (c && dmin < 0) dmin = d;
             tot[d] = (u32)cum;                        // global start of bucket d
             if (cum + c >= (u64)g.R) { t = d; break; }
             cum += c;
@@ -696,23 +789,28 @@ __global__ __launch_bounds__(256) void k_rank_fused(const u64* __restrict__ cand
         misc[0] = (u32)t;
         misc[1] = (u32)cum;                           // cnt_lt
         misc[2] = (u32)((u64)g.R - cum);              // quota
+        misc[3] = (u32)(dmin < 0 ? 0 : dmin);         // smallest distance present
         if (t < 0) atomicExch(a.err, 1);              // the superset is too small: bet lost
     }
     __syncthreads();
     const int t = (int)misc[0];
     if (t < 0) return;
-    for (int d = tid; d <= t && d < NB; d += 256) {   // per-wave starts: bucket start + records of earlier waves
-        const u32 h0 = hw[d], h1 = hw[NB + d], h2 = hw[2 * NB + d];
-        const u32 st = d < t ? tot[d] : 0u;           // for d == t the "start" is the tie rank offset
-        hw[d] = st;
-        hw[NB + d] = st + h0;
-        hw[2 * NB + d] = st + h0 + h1;
-        hw[3 * NB + d] = st + h0 + h1 + h2;
+    for (int d = tid; d <= t && d < NB; d += nthr) {  // per-wave starts: bucket start + records of earlier waves
+        u32 run = d < t ? tot[d] : 0u;                // for d == t the "start" is the tie rank offset
+        for (int w = 0; w < nwav; ++w) {
+            const u32 h = hw[w * NB + d];
+            hw[w * NB + d] = run;
+            run += h;
+        }
     }
     __syncthreads();
     // phase 3
     u32* pb = hw + wave * NB;
     const u32 cntlt = misc[1], quota = misc[2];
+    // ranked distances of this query span [dmin, t): match on d - dmin, usually 4 bits instead of nbits
+    const u32 dmin = misc[3];
+    int kb = 0;
+    while (kb < nbits && (int)(dmin + (1u << kb)) < t) ++kb;
     u32 tie_run = pb[t];                              // ties owned by earlier waves
     u32* __restrict__ oi = out_idx + (i64)q * g.R;
     u8* __restrict__ od = out_dist + (i64)q * g.R;
@@ -730,8 +828,9 @@ __global__ __launch_bounds__(256) void k_rank_fused(const u64* __restrict__ cand
             const bool is_lt = valid && (int)d < t;
             const bool is_tie = valid && (int)d == t;
             u64 peers = __ballot(is_lt);
-            for (int k = 0; k < nbits; ++k) {
-                const bool bit = (d >> k) & 1u;
+            const u32 key = d - dmin;
+            for (int k = 0; k < kb; ++k) {
+                const bool bit = (key >> k) & 1u;
                 const u64 m = __ballot(is_lt && bit);
                 peers &= bit ? m : ~m;
             }
@@ -762,7 +861,7 @@ __global__ __launch_bounds__(256) void k_rank_fused(const u64* __restrict__ cand
     }
     if (a.bits_lds) {
         __syncthreads();
-        for (int w = tid; w < bmw; w += 256) grow[w] = bm[w];
+        for (int w = tid; w < bmw; w += nthr) grow[w] = bm[w];
     }
 }
 
