@@ -32,6 +32,9 @@ _SIGNATURES = {
     "hg_pack_sign_f32": [_p, _i64, C.c_int, _p],
     "hg_set_database": [_p, _p, _p, _i64, C.c_int, C.c_int, _i64, _i64],
     "hg_set_queries": [_p, _p, _p, _i64],
+    "hg_set_database_f32": [_p, _p, _p, _i64, C.c_int, C.c_int, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)],
+    "hg_set_queries_f32": [_p, _p, _p, _i64, C.POINTER(_i64), C.POINTER(_i64)],
+    "hg_get_packed": [_p, C.c_int, _p, _p],
     "hg_hist": [_p],
     "hg_hist_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
     "hg_plan": [_p, _i64, _p, C.c_int, C.c_int],
@@ -149,6 +152,34 @@ class Context:
         labels = _carray(labels_u64, np.uint64)
         check(self._lib.hg_set_queries(self._h, _ptr(codes), _ptr(labels), codes.shape[0]))
         self.Q = codes.shape[0]
+
+    def set_database_f32(self, features, labels, idx_base=0, n_total=None):
+        """float32 [N, b] features + int64 [N, C] labels; binarise + pack on the GPU.
+        -> (entries outside {-1,0,+1}, label entries outside {0,1})"""
+        x = _carray(features, np.float32)
+        lab = _carray(labels, np.int64)
+        N, b = x.shape
+        n_total = N if n_total is None else int(n_total)
+        bc, bl = _i64(), _i64()
+        check(self._lib.hg_set_database_f32(self._h, _ptr(x), _ptr(lab), N, b, lab.shape[1], int(idx_base), n_total,
+                                            C.byref(bc), C.byref(bl)))
+        self.N, self.b, self.C = N, b, lab.shape[1]
+        return bc.value, bl.value
+
+    def set_queries_f32(self, features, labels):
+        x = _carray(features, np.float32)
+        lab = _carray(labels, np.int64)
+        bc, bl = _i64(), _i64()
+        check(self._lib.hg_set_queries_f32(self._h, _ptr(x), _ptr(lab), x.shape[0], C.byref(bc), C.byref(bl)))
+        self.Q = x.shape[0]
+        return bc.value, bl.value
+
+    def get_packed(self, which):
+        n = self.Q if which else self.N
+        codes = np.empty((n, (self.b + 31) // 32), dtype=np.uint32)
+        labels = np.empty((n, (self.C + 63) // 64), dtype=np.uint64)
+        check(self._lib.hg_get_packed(self._h, int(which), _ptr(codes), _ptr(labels)))
+        return codes, labels
 
     # -- stages -----------------------------------------------------------------
     def hist(self):

@@ -57,9 +57,9 @@ struct DevBuf {
 };
 
 enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_LAYOUT, KI_GUESS, KI_SELECT, KI_CAND_HIST,
-                KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_COUNT };
+                KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_PACK, KI_COUNT };
 const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_layout", "k_guess",
-                                            "k_select", "k_cand_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge"};
+                                            "k_select", "k_cand_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge", "k_pack"};
 
 enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
 
@@ -126,7 +126,7 @@ struct hg_ctx {
     DevBuf hist, hown, posbase, seglt, segtie;
     DevBuf t, tguess, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
-    DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel;
+    DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt;
     i64 shapes_for_R = -1;
 
     // timing
@@ -385,7 +385,7 @@ int hg_destroy(hg_ctx* c) {
     DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
                      &c->t, &c->tguess, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
-                     &c->shapes, &c->ap, &c->rel};
+                     &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt};
     for (auto* d : all) d->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -426,6 +426,76 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     HG_TRY(c->sync());
     c->stage = ST_DB;   // queries must be (re)set after the database: b, C may have changed
     return HG_OK;
+}
+
+// float32 features + int64 labels -> packed device tables (k_pack_sign_f32 / k_pack_labels_i64)
+static int pack_on_device(hg_ctx* c, const float* x, const int64_t* lab, i64 n, DevBuf& codes, DevBuf& labels,
+                          int64_t* bad_codes, int64_t* bad_labels) {
+    const int b = c->b, C = c->C, NW = c->NW, LW = c->LW;
+    const size_t xb = (size_t)n * b * 4, lb = (size_t)n * C * 8;
+    HG_TRY(c->stage_in.reserve(xb > lb ? xb : lb));
+    HG_TRY(c->badcnt.reserve(16));
+    HG_TRY(codes.reserve((size_t)n * NW * 4 + 64 * 4));
+    HG_TRY(labels.reserve((size_t)n * LW * 8));
+    HG_HIP(hipMemsetAsync(c->badcnt.p, 0, 16, c->stream));
+    HG_HIP(hipMemcpyAsync(c->stage_in.p, x, xb, hipMemcpyHostToDevice, c->stream));
+    c->t_begin(KI_PACK);
+    hipLaunchKernelGGL(k_pack_sign_f32, dim3(grid_for(n, WPB)), dim3(256), 0, c->stream, c->stage_in.as<float>(),
+                       codes.as<u32>(), n, b, NW, c->badcnt.as<unsigned long long>());
+    c->t_end();
+    HG_TRY(c->check_launch("k_pack_sign_f32"));
+    HG_HIP(hipMemcpyAsync(c->stage_in.p, lab, lb, hipMemcpyHostToDevice, c->stream));   // stream order: after the kernel
+    c->t_begin(KI_PACK);
+    hipLaunchKernelGGL(k_pack_labels_i64, dim3(grid_for(n, WPB)), dim3(256), 0, c->stream, c->stage_in.as<long long>(),
+                       labels.as<u64>(), n, C, LW, c->badcnt.as<unsigned long long>());
+    c->t_end();
+    HG_TRY(c->check_launch("k_pack_labels_i64"));
+    unsigned long long bad[2] = {0, 0};
+    HG_HIP(hipMemcpyAsync(bad, c->badcnt.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HG_TRY(c->sync());
+    if (bad_codes) *bad_codes = (int64_t)bad[0];
+    if (bad_labels) *bad_labels = (int64_t)bad[1];
+    return HG_OK;
+}
+
+int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labels, int64_t N, int b, int C,
+                        int64_t idx_base, int64_t n_total, int64_t* bad_codes, int64_t* bad_labels) {
+    if (!c) return fail(HG_ERR_ARG, "hg_set_database_f32: null context");
+    if (N < 1 || !host_x || !host_labels) return fail(HG_ERR_ARG, "hg_set_database_f32: need N >= 1 and data");
+    if (b < 1 || b > HG_MAX_BITS) return fail(HG_ERR_ARG, "hg_set_database_f32: b=%d outside 1..%d", b, HG_MAX_BITS);
+    if (C < 1) return fail(HG_ERR_ARG, "hg_set_database_f32: C=%d", C);
+    if (idx_base < 0 || n_total < N || idx_base + N > n_total || n_total >= 0xFFFFFFFFll)
+        return fail(HG_ERR_ARG, "hg_set_database_f32: shard [%lld, %lld) does not fit a database of %lld rows (< 2^32 - 1)",
+                    (long long)idx_base, (long long)(idx_base + N), (long long)n_total);
+    HG_TRY(c->use());
+    c->N = N; c->b = b; c->C = C; c->n_total = n_total;
+    c->NW = (b + 31) / 32; c->NB = b + 1; c->LW = (C + 63) / 64;
+    c->idx_base = (u32)idx_base;
+    HG_TRY(pack_on_device(c, host_x, host_labels, N, c->db, c->dblab, bad_codes, bad_labels));
+    c->stage = ST_DB;
+    return HG_OK;
+}
+
+int hg_set_queries_f32(hg_ctx* c, const float* host_x, const int64_t* host_labels, int64_t Q, int64_t* bad_codes,
+                       int64_t* bad_labels) {
+    HG_TRY(need(c, ST_DB, "hg_set_queries_f32", "hg_set_database"));
+    if (Q < 1 || !host_x || !host_labels) return fail(HG_ERR_ARG, "hg_set_queries_f32: need Q >= 1 and data");
+    if (Q > 0x7FFFFFC0ll) return fail(HG_ERR_ARG, "hg_set_queries_f32: Q too large");
+    c->Q = Q;
+    HG_TRY(pack_on_device(c, host_x, host_labels, Q, c->qc, c->qlab, bad_codes, bad_labels));
+    c->stage = ST_DB | ST_Q;
+    return HG_OK;
+}
+
+// packed tables back to the host (tests; also lets a caller keep the packed form)
+int hg_get_packed(hg_ctx* c, int which, uint32_t* host_codes, uint64_t* host_labels) {
+    HG_TRY(need(c, which ? (ST_DB | ST_Q) : ST_DB, "hg_get_packed", "hg_set_database / hg_set_queries"));
+    const i64 n = which ? c->Q : c->N;
+    DevBuf& cd = which ? c->qc : c->db;
+    DevBuf& lb = which ? c->qlab : c->dblab;
+    if (host_codes) HG_HIP(hipMemcpyAsync(host_codes, cd.p, (size_t)n * c->NW * 4, hipMemcpyDeviceToHost, c->stream));
+    if (host_labels) HG_HIP(hipMemcpyAsync(host_labels, lb.p, (size_t)n * c->LW * 8, hipMemcpyDeviceToHost, c->stream));
+    return c->sync();
 }
 
 int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int64_t Q) {

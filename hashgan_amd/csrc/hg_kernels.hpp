@@ -1014,6 +1014,50 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
     }
 }
 
+// ----------------------------------------------------------------------------
+// K0  binarise + pack on device.  The step upstream of the metric: forward_all()
+// (main.py:151-158) hands float32 features [n][b] and integer labels [n][C]; the
+// reference never binarises (tanh outputs go straight into np.dot), the hashing
+// evaluation does: bit j = (x[j] > 0).  One wavefront per row, 64 columns per ballot.
+// Also counts entries outside {-1, 0, +1} (codes) / {0, 1} (labels) so the host can refuse
+// inputs that are not binary codes instead of silently ranking something else.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_sign_f32(const float* __restrict__ x, u32* __restrict__ out, i64 n, int b,
+                                                       int NW, unsigned long long* __restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const i64 r = (i64)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (r >= n) return;
+    u32 nbad = 0;
+    for (int c0 = 0; c0 < b; c0 += 64) {
+        const int col = c0 + lane;
+        const float v = col < b ? x[r * b + col] : 0.0f;
+        nbad += !(v == 1.0f || v == -1.0f || v == 0.0f);
+        const u64 word = __ballot(v > 0.0f);
+        const int w = c0 >> 5;
+        if (lane == 0) {
+            out[r * NW + w] = (u32)word;
+            if (w + 1 < NW) out[r * NW + w + 1] = (u32)(word >> 32);
+        }
+    }
+    if (nbad) atomicAdd(bad, (unsigned long long)nbad);
+}
+
+__global__ __launch_bounds__(256) void k_pack_labels_i64(const long long* __restrict__ lab, u64* __restrict__ out, i64 n, int C,
+                                                         int LW, unsigned long long* __restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const i64 r = (i64)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (r >= n) return;
+    u32 nbad = 0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int col = c0 + lane;
+        const long long v = col < C ? lab[r * C + col] : 0;
+        nbad += !(v == 0 || v == 1);
+        const u64 word = __ballot(v != 0);
+        if (lane == 0) out[r * LW + (c0 >> 6)] = word;
+    }
+    if (nbad) atomicAdd(bad + 1, (unsigned long long)nbad);
+}
+
 // fill helpers
 __global__ __launch_bounds__(256) void k_fill_u32(u32* __restrict__ p, u32 v, i64 n) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;

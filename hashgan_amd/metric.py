@@ -117,21 +117,30 @@ def _engine(device):
     return _engines[device]
 
 
-def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device):
+def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, binarize=False):
     db_codes, q_codes = np.asarray(db_codes), np.asarray(q_codes)
     db_labels, q_labels = np.asarray(db_labels), np.asarray(q_labels)
     if db_codes.ndim != 2 or q_codes.ndim != 2 or db_codes.shape[1] != q_codes.shape[1]:
         raise ValueError("query and database codes must be [n, b] with the same b")
+    if db_labels.ndim != 2 or q_labels.ndim != 2 or db_labels.shape[1] != q_labels.shape[1]:
+        raise ValueError("query and database labels must be [n, C] with the same C")
+    if db_labels.shape[0] != db_codes.shape[0] or q_labels.shape[0] != q_codes.shape[0]:
+        raise ValueError("codes and labels must have the same number of rows")
     N = db_codes.shape[0]
     if not 1 <= R <= N:
         # metric.py:21 fails the same way: a length-N px cannot be divided by arange(1, R+1)
         raise ValueError("R=%d must be in 1..N (N=%d database rows)" % (R, N))
-    if not (is_binary(db_codes) and is_binary(q_codes)):
+    eng = _engine(device)
+    # float32 features and int64 labels go to the GPU as they are; sign-binarise, bit packing and
+    # the "is this really a binary code / indicator label" check all run there (k_pack_*)
+    bad_c, bad_l = eng.ctx.set_database_f32(db_codes, db_labels)
+    eng.b, eng.C = db_codes.shape[1], db_labels.shape[1]
+    qbad_c, qbad_l = eng.ctx.set_queries_f32(q_codes, q_labels)
+    if bad_l or qbad_l:
+        raise ValueError("labels must be {0,1} indicator matrices")
+    if (bad_c or qbad_c) and not binarize:
         raise ValueError("features are not binary codes ({-1,+1} or {0,1}); binarise them first "
                          "(np.sign) or use MAPs(R, binarize=True)")
-    eng = _engine(device)
-    eng.set_database(db_codes, db_labels)
-    eng.set_queries(q_codes, q_labels)
     ap, rel = eng.average_precisions(R)
     return mean_over_hits(ap, rel), ap, rel
 
@@ -152,10 +161,8 @@ class MAPs:
 
     def get_maps_by_feature(self, database, query):
         """database/query: objects with .output [n, b] and .label [n, C] (main.py:157)."""
-        d_out, q_out = np.asarray(database.output), np.asarray(query.output)
-        if self.binarize:
-            d_out, q_out = np.where(d_out > 0, 1, -1), np.where(q_out > 0, 1, -1)
-        m, _, _ = _evaluate(q_out, d_out, query.label, database.label, int(self.R), self.device)
+        m, _, _ = _evaluate(query.output, database.output, query.label, database.label, int(self.R), self.device,
+                            binarize=self.binarize)
         return m
 
 

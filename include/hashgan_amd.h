@@ -67,6 +67,19 @@ int hg_set_database(hg_ctx* ctx, const uint64_t* host_codes, const uint64_t* hos
 /* query.output / query.label of metric.py:13,17. Same b and C as the database. */
 int hg_set_queries(hg_ctx* ctx, const uint64_t* host_codes, const uint64_t* host_labels, int64_t Q);
 
+/* The same two calls fed with what forward_all() (main.py:151-158) actually returns: float32
+ * features [n][b] and int64 labels [n][C].  Binarise (bit = x > 0) and pack run on the GPU.
+ * *bad_codes counts feature entries outside {-1, 0, +1}, *bad_labels label entries outside
+ * {0, 1}: the caller decides whether non-binary features are an error (the Python mirror raises
+ * unless binarize=True). */
+int hg_set_database_f32(hg_ctx* ctx, const float* host_features, const int64_t* host_labels, int64_t N, int b, int C,
+                        int64_t idx_base, int64_t n_total, int64_t* bad_codes, int64_t* bad_labels);
+int hg_set_queries_f32(hg_ctx* ctx, const float* host_features, const int64_t* host_labels, int64_t Q,
+                       int64_t* bad_codes, int64_t* bad_labels);
+/* Packed device tables back to the host: which = 0 database, 1 queries; codes as dense
+ * uint32 [n][ceil(b/32)], labels uint64 [n][ceil(C/64)]. */
+int hg_get_packed(hg_ctx* ctx, int which, uint32_t* host_codes, uint64_t* host_labels);
+
 /* ---- staged pipeline (what multi-GPU orchestration drives) ------------------
  * hg_hist    metric.py:13   XOR+popcount of every (query, db row) pair, reduced
  *                           to per-query distance histograms of this shard.

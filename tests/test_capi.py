@@ -68,7 +68,9 @@ def test_python_argument_errors_need_no_gpu():
     with pytest.raises(ValueError):
         MAP(q, d, ql, dl, 6)                           # R > N, like metric.py:21
     with pytest.raises(ValueError):
-        MAP(q * 0.5, d, ql, dl, 3)                     # not binary codes
+        MAP(q, d[:, :4], ql, dl, 3)                    # code lengths differ
+    with pytest.raises(ValueError):
+        MAP(q, d, ql[:1], dl, 3)                       # rows of codes and labels differ
 
 
 def test_product_never_imports_oracle():

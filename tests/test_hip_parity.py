@@ -130,6 +130,45 @@ def test_python_surface_matches_golden(case_cache):
         MAP(c["qbits"], c["dbbits"], c["qlab"], c["dblab"], c["dbbits"].shape[0] + 1)
 
 
+def test_device_pack_matches_host_pack(ctx):
+    """k_pack_sign_f32 / k_pack_labels_i64 against the NumPy packing, bit for bit, including
+    sign(0) -> 0, pad bits, odd word counts; and the non-binary detector."""
+    rng = np.random.default_rng(5)
+    for b, C in [(1, 1), (31, 10), (32, 64), (33, 65), (48, 81), (64, 10), (65, 128), (100, 3), (128, 200)]:
+        n = 777
+        x = rng.choice(np.array([-1.0, 1.0], np.float32), size=(n, b))
+        lab = (rng.random((n, C)) < 0.2).astype(np.int64)
+        bad = ctx.set_database_f32(x, lab)
+        assert bad == (0, 0)
+        codes, labels = ctx.get_packed(0)
+        ref = metric.pack_codes(x).view(np.uint32).reshape(n, -1)[:, :(b + 31) // 32]
+        assert np.array_equal(codes, ref), (b, C)
+        assert np.array_equal(labels, metric.pack_labels(lab)), (b, C)
+        x01 = (x > 0).astype(np.float32)                       # {0,1} spelling packs to the same words
+        assert ctx.set_database_f32(x01, lab) == (0, 0)
+        assert np.array_equal(ctx.get_packed(0)[0], ref)
+    x = rng.standard_normal((50, 16)).astype(np.float32)
+    lab = np.zeros((50, 3), np.int64); lab[7, 1] = 2
+    bad_c, bad_l = ctx.set_database_f32(x, lab)
+    assert bad_c == 50 * 16 and bad_l == 1
+
+
+def test_python_surface_rejects_non_binary(case_cache):
+    from hashgan_amd import MAP, MAPs
+    import types
+    c = case_cache("e_b8")
+    soft = np.tanh((c["dbbits"].astype(np.float32) * 2 - 1) * 1.5)             # what HashGAN's heads emit
+    qsoft = np.tanh((c["qbits"].astype(np.float32) * 2 - 1) * 1.5)
+    with pytest.raises(ValueError):
+        MAP(qsoft, soft, c["qlab"], c["dblab"], c["R"])
+    with pytest.raises(ValueError):
+        MAP(c["qbits"], c["dbbits"], c["qlab"] * 2, c["dblab"], c["R"])        # labels not {0,1}
+    g = cases.load_golden("e_b8")
+    database = types.SimpleNamespace(output=soft, label=c["dblab"].astype(np.int64))
+    query = types.SimpleNamespace(output=qsoft, label=c["qlab"].astype(np.int64))
+    assert MAPs(c["R"], binarize=True).get_maps_by_feature(database, query) == g["map"]
+
+
 def test_deterministic_and_geometry_independent(ctx, case_cache):
     """Same lists whatever the segment geometry (unit count) and across repeats."""
     c = case_cache("e_ragged")
