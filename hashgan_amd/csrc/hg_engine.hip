@@ -45,14 +45,20 @@ int fail(int code, const char* fmt, ...) {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;      // points into another context's allocation
     int reserve(size_t bytes) {
         if (bytes <= cap) return HG_OK;
-        if (p) { HG_HIP(hipFree(p)); p = nullptr; cap = 0; }
+        if (p && !borrowed) { HG_HIP(hipFree(p)); }
+        p = nullptr; cap = 0; borrowed = false;
         HG_HIP(hipMalloc(&p, bytes));
         cap = bytes;
         return HG_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void borrow(const DevBuf& o) {
+        if (p && !borrowed) (void)hipFree(p);
+        p = o.p; cap = o.cap; borrowed = true;
+    }
+    void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -118,15 +124,17 @@ struct hg_ctx {
     bool lists_valid = false;
     u32 cap = 0;               // optimistic slice capacity
     i64 crow = 0;              // record-row stride
-    i64 opt_runs = 0, opt_fallbacks = 0;
+    i64 opt_runs = 0, opt_fallbacks = 0, opt_requeried = 0;
     int opt_consecutive_fail = 0;
+    hg_ctx* sub = nullptr;     // child context (shares the database) that reruns single lost queries exactly
+    bool is_sub = false;
 
     // device state
     DevBuf db, dblab, qc, qlab;
     DevBuf hist, hown, posbase, seglt, segtie;
     DevBuf t, tguess, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
-    DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt;
+    DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist;
     i64 shapes_for_R = -1;
 
     // timing
@@ -385,9 +393,10 @@ int hg_destroy(hg_ctx* c) {
     DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
                      &c->t, &c->tguess, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
-                     &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt};
+                     &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist};
     for (auto* d : all) d->release();
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
+    if (c->stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
     delete c;
     return HG_OK;
 }
@@ -653,7 +662,8 @@ static int do_select(hg_ctx* c) {
         HG_TRY(c->err.reserve(4));
         if (c->optimistic) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
         else HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
-        RankArgs ra{c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->failq.as<u32>(), c->err.as<int>(),
+        HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
+        RankArgs ra{c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(),
                     c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW};
         c->t_begin(KI_RANK_FUSED);
         const size_t lds_bytes = (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4;
@@ -962,6 +972,66 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     return do_select(c);
 }
 
+static int enqueue_exact(hg_ctx* c, int64_t R);
+
+// Lost bets are per query (a short superset, an overflowed slice).  When only a few queries lost,
+// rerun just those through the exact sequence in a child context that borrows the database
+// tables, and patch their results into place.  *handled = false: too many, caller reruns all.
+static int rerun_lost_queries(hg_ctx* c, int64_t R, bool lists, bool with_ap, bool* handled) {
+    *handled = false;
+    const Geo g = c->geo;
+    std::vector<u32> bad((size_t)g.Q);
+    HG_HIP(hipMemcpyAsync(bad.data(), c->qbad.p, (size_t)g.Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HG_TRY(c->sync());
+    std::vector<u32> lost;
+    for (int q = 0; q < g.Q; ++q) if (bad[(size_t)q]) lost.push_back((u32)q);
+    const i64 nF = (i64)lost.size();
+    if (nF == 0 || nF * 8 > g.Q) return HG_OK;
+    if (!c->sub) {
+        c->sub = new hg_ctx();
+        c->sub->is_sub = true;
+        c->sub->device = c->device;
+        c->sub->stream = c->stream;                  // same stream: ordered with the parent's work
+    }
+    hg_ctx* s = c->sub;
+    s->N = c->N; s->b = c->b; s->C = c->C; s->n_total = c->n_total; s->NW = c->NW; s->NB = c->NB; s->LW = c->LW;
+    s->idx_base = c->idx_base;
+    s->target_units = c->target_units; s->min_segment = c->min_segment; s->opt_enable = 0;
+    s->timing = false;
+    s->db.borrow(c->db);
+    s->dblab.borrow(c->dblab);
+    s->Q = nF;
+    HG_TRY(c->flist.reserve((size_t)nF * 4));
+    HG_HIP(hipMemcpyAsync(c->flist.p, lost.data(), (size_t)nF * 4, hipMemcpyHostToDevice, c->stream));
+    HG_TRY(s->qc.reserve((size_t)nF * c->NW * 4 + 64 * 4));
+    HG_TRY(s->qlab.reserve((size_t)nF * c->LW * 8));
+    auto move = [&](const void* src, void* dst, i64 rowbytes, int gather) {
+        hipLaunchKernelGGL(k_move_rows, dim3((unsigned)nF), dim3(256), 0, c->stream, (const u8*)src, (u8*)dst,
+                           c->flist.as<u32>(), rowbytes, gather);
+    };
+    move(c->qc.p, s->qc.p, (i64)c->NW * 4, 1);
+    move(c->qlab.p, s->qlab.p, (i64)c->LW * 8, 1);
+    HG_TRY(c->check_launch("k_move_rows"));
+    s->stage = ST_DB | ST_Q;
+    s->want_lists = lists;
+    HG_TRY(enqueue_exact(s, R));
+    if (with_ap) HG_TRY(do_ap(s));
+    move(s->mbits.p, c->mbits.p, c->RW * 8, 0);
+    if (with_ap) {
+        move(s->ap.p, c->ap.p, 8, 0);
+        move(s->rel.p, c->rel.p, 4, 0);
+    }
+    if (lists) {
+        move(s->out_idx.p, c->out_idx.p, R * 4, 0);
+        move(s->out_dist.p, c->out_dist.p, R, 0);
+    }
+    HG_TRY(c->check_launch("k_move_rows"));
+    HG_TRY(c->sync());                               // `lost` (the H2D source) must outlive the copy
+    c->opt_requeried += nF;
+    *handled = true;
+    return HG_OK;
+}
+
 static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
     int stride = 0;
     u32 need_cnt = 0;
@@ -976,7 +1046,10 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
         if (with_ap) HG_TRY(do_ap(c));
         HG_TRY(read_plan_flag(c, &flag));
         if (!flag) { c->opt_consecutive_fail = 0; return HG_OK; }
-        c->opt_fallbacks++;                        // the bet failed for some query: exact path for all
+        bool handled = false;                      // some queries lost their bet
+        HG_TRY(rerun_lost_queries(c, R, lists, with_ap, &handled));
+        if (handled) { c->opt_consecutive_fail = 0; return HG_OK; }
+        c->opt_fallbacks++;                        // too many: exact path for all
         c->opt_consecutive_fail++;
         c->want_lists = lists;
     }
@@ -1072,6 +1145,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     if (!c || !key || !value) return fail(HG_ERR_ARG, "hg_get_stat: null argument");
     if (!strcmp(key, "optimistic_runs")) *value = c->opt_runs;
     else if (!strcmp(key, "optimistic_fallbacks")) *value = c->opt_fallbacks;
+    else if (!strcmp(key, "optimistic_requeried")) *value = c->opt_requeried;
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
     else if (!strcmp(key, "segments")) *value = c->geo.S;
     else if (!strcmp(key, "segment_rows")) *value = c->geo.L;

@@ -684,6 +684,7 @@ struct RankArgs {
     const u32* tot;        // [Qpad]      (dense mode: one run of tot[q] records, walked in chunks of `cap`)
     const u32* fail;       // [Qpad]
     int* err;
+    u32* qbad;             // [Q] out: 1 = this query's bet was lost (rerun it exactly), 0 = ranked
     u32 cap;
     i64 crow;
     int dense;
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     u32* bm = misc + 8;               // [bmw]
     u32* __restrict__ grow = mbits32 + (i64)q * 2 * a.RW;
     if (a.fail[q]) {                                  // a slice of this query overflowed
-        if (tid == 0) atomicExch(a.err, 1);
+        if (tid == 0) { atomicExch(a.err, 1); a.qbad[q] = 1u; }
         return;
     }
     for (int i = tid; i < (nwav + 1) * NB + 8 + bmw; i += nthr) lds[i] = 0u;
@@ -791,6 +792,7 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
         misc[2] = (u32)((u64)g.R - cum);              // quota
         misc[3] = (u32)(dmin < 0 ? 0 : dmin);         // smallest distance present
         if (t < 0) atomicExch(a.err, 1);              // the superset is too small: bet lost
+        a.qbad[q] = t < 0 ? 1u : 0u;
     }
     __syncthreads();
     const int t = (int)misc[0];
@@ -1056,6 +1058,23 @@ __global__ __launch_bounds__(256) void k_pack_labels_i64(const long long* __rest
         if (lane == 0) out[r * LW + (c0 >> 6)] = word;
     }
     if (nbad) atomicAdd(bad + 1, (unsigned long long)nbad);
+}
+
+// Row gather / scatter between a full query set and the compacted set of queries whose bet
+// was lost: block i moves row (gather ? list[i] -> i : i -> list[i]) of `rowbytes` bytes.
+__global__ __launch_bounds__(256) void k_move_rows(const u8* __restrict__ src, u8* __restrict__ dst,
+                                                   const u32* __restrict__ list, i64 rowbytes, int gather) {
+    const i64 i = blockIdx.x;
+    const i64 r = list[i];
+    const u8* __restrict__ s = src + (gather ? r : i) * rowbytes;
+    u8* __restrict__ d = dst + (gather ? i : r) * rowbytes;
+    if (((rowbytes | (i64)(size_t)s | (i64)(size_t)d) & 3) == 0) {
+        const u32* __restrict__ s4 = (const u32*)s;
+        u32* __restrict__ d4 = (u32*)d;
+        for (i64 k = threadIdx.x; k < rowbytes / 4; k += 256) d4[k] = s4[k];
+    } else {
+        for (i64 k = threadIdx.x; k < rowbytes; k += 256) d[k] = s[k];
+    }
 }
 
 // fill helpers

@@ -153,7 +153,8 @@ int hg_get_hist(hg_ctx* ctx, uint32_t* host_hist);                      /* [b+1]
  * threshold -- verified on device, exact fallback), "sample_stride" (0 = auto),
  * "guess_sigma", "staged_lists" (0/1: hg_select materialises idx/dist lists). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
-/* key: "optimistic_runs", "optimistic_fallbacks", "last_optimistic", "segments",
+/* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
+ * (single queries rerun exactly after losing their bet), "last_optimistic", "segments",
  * "segment_rows", "slice_capacity", "record_row". */
 int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
 /* HIP-event timing of every kernel launched on the context's stream. */
