@@ -221,8 +221,9 @@ def test_failed_bet_falls_back_to_exact(ctx):
 
 def test_single_lost_query_is_rerun_alone(ctx):
     """One query has 3000 exact duplicates of its code in one contiguous block of the database:
-    its slices overflow there, every other query's bet holds.  Only that query is rerun (exactly)
-    and patched in; AP and the ranked lists equal the oracle's for it and for its neighbours."""
+    its slices overflow there (and those of the few queries whose code is within their threshold
+    of it); every other query's bet holds.  Only the lost queries are rerun (exactly) and patched
+    in; AP and the ranked lists equal the oracle's for the lost query and for ordinary ones."""
     from hashgan_amd import synth
     Q, N, b, R, C = 256, 131072, 32, 4000, 10
     dl, _ = synth.onehot_labels(91, N, C)
@@ -239,10 +240,11 @@ def test_single_lost_query_is_rerun_alone(ctx):
     ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
     f0, p0 = ctx.get_stat("optimistic_fallbacks"), ctx.get_stat("optimistic_requeried")
     ap, rel = ctx.map(R)
-    assert ctx.get_stat("optimistic_fallbacks") == f0 and ctx.get_stat("optimistic_requeried") == p0 + 1
+    n_lost = ctx.get_stat("optimistic_requeried") - p0
+    assert ctx.get_stat("optimistic_fallbacks") == f0 and 1 <= n_lost < Q // 8
     assert np.array_equal(ap[probe], ap_ref, equal_nan=True)
     ctx.topr(R)                                      # same thing with the lists materialised
-    assert ctx.get_stat("optimistic_requeried") == p0 + 2
+    assert ctx.get_stat("optimistic_requeried") == p0 + 2 * n_lost
     idx, dist = ctx.get_topr()
     assert np.array_equal(idx[probe], idx_ref) and np.array_equal(dist[probe], dist_ref)
     ctx.ap()
