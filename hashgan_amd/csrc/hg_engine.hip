@@ -376,6 +376,9 @@ int hg_init(int device, hg_ctx** out) {
     HG_HIP(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(HG_ERR_ARG, "hg_init: device %d out of range (%d visible)", device, n);
     HG_HIP(hipSetDevice(device));
+    // A step is a few milliseconds and ends in one stream synchronisation: spin instead of sleeping on it.
+    // (Refused when the device is already initialised, e.g. by torch -- harmless.)
+    if (hipSetDeviceFlags(hipDeviceScheduleSpin) != hipSuccess) (void)hipGetLastError();
     hg_ctx* c = new hg_ctx();
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
