@@ -390,15 +390,21 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
     const u32* __restrict__ p = db + lo * NW;
     i64 n = lo;
 
-    // Drain the hit masks of a window of `cnt` <= 64 rows that starts at row n0 (= uniform pointers
-    // wp0 / wl0 into the code and label tables): bit cnt-1-j of hm <-> row n0+j, so the highest set
-    // bit is the lane's earliest hit.  Per round every lane with hits left handles one of them.
-    auto drain = [&](u64 hm, i64 n0, const u32* __restrict__ wp0, const u64* __restrict__ wl0, int cnt) {
-        while (__any(hm != 0ull)) {
-            if (hm != 0ull) {
-                const int k = 63 - __clzll((long long)hm);
-                hm ^= 1ull << k;
-                const u32 j = (u32)(cnt - 1 - k);                 // row inside the window (32-bit offsets)
+    // Drain the hit masks of a window of up to 128 rows that starts at row n0 (= uniform pointers
+    // wp0 / wl0 into the code and label tables).  The window is two halves of <= 64 rows: bit
+    // cntA-1-j of hmA <-> row n0+j, bit cntB-1-j of hmB <-> row n0+cntA+j, so within a half the
+    // highest set bit is the lane's earliest hit and half A precedes half B.  Per round every lane
+    // with hits left handles its earliest one; rounds = the largest hit count of any lane.
+    auto drain = [&](u64 hmA, u64 hmB, i64 n0, const u32* __restrict__ wp0, const u64* __restrict__ wl0,
+                     int cntA, int cntB) {
+        while (__any((hmA | hmB) != 0ull)) {
+            if ((hmA | hmB) != 0ull) {
+                const bool inA = hmA != 0ull;
+                u64 cur = inA ? hmA : hmB;
+                const int k = 63 - __clzll((long long)cur);
+                cur ^= 1ull << k;
+                if (inA) hmA = cur; else hmB = cur;
+                const u32 j = inA ? (u32)(cntA - 1 - k) : (u32)(cntA + cntB - 1 - k);  // row inside the window
                 const u32* __restrict__ rp = wp0 + j * NW;        // per-lane re-read; the window was just streamed (L2)
                 u32 d = 0;
 #pragma unroll
@@ -428,37 +434,44 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
     };
 
     constexpr int B = sel_batch_rows(NW);                  // rows per scalar-load batch
-    constexpr int WIN = B >= 32 ? 2 : 1;                   // batches per drain window (<= 64 rows)
+    constexpr int HB = B >= 32 ? 2 : 1;                    // batches per 64-bit half mask
+    constexpr int WROWS = 2 * HB * B;                      // rows per drain window (128 for short codes)
     const u64* __restrict__ pl = dblab + lo * LWA;
-    for (; n + B * WIN <= hi; n += B * WIN, p += B * WIN * NW, pl += B * WIN * LWA) {
-        u32 hmw[WIN];
+    for (; n + WROWS <= hi; n += WROWS, p += WROWS * NW, pl += WROWS * LWA) {
+        u64 half[2];
 #pragma unroll
-        for (int kb = 0; kb < WIN; ++kb) {
-            u32 c[B * NW];
+        for (int h = 0; h < 2; ++h) {
+            u64 hm64 = 0;
 #pragma unroll
-            for (int i = 0; i < B * NW; ++i) c[i] = p[kb * B * NW + i];
-            u32 hm = 0;
+            for (int kb = 0; kb < HB; ++kb) {
+                u32 c[B * NW];
 #pragma unroll
-            for (int j = 0; j < B; ++j) {
-                u32 dp = bias;
+                for (int i = 0; i < B * NW; ++i) c[i] = p[(h * HB + kb) * B * NW + i];
+                u32 hm = 0;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) dp += __builtin_popcount(qw[w] ^ c[j * NW + w]);
-                hm = __builtin_amdgcn_alignbit(hm, dp, 31);
+                for (int j = 0; j < B; ++j) {
+                    u32 dp = bias;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) dp += __builtin_popcount(qw[w] ^ c[j * NW + w]);
+                    hm = __builtin_amdgcn_alignbit(hm, dp, 31);
+                }
+                hm64 = (hm64 << B) | hm;                   // earlier batch in the higher bits
             }
-            hmw[kb] = hm;
+            half[h] = hm64;
         }
-        // window mask: first batch in the high bits
-        const u64 hm64 = WIN == 2 ? (((u64)hmw[0] << 32) | hmw[WIN - 1]) : ((u64)hmw[0]);
-        if (__builtin_expect(__any(hm64 != 0ull), 0)) drain(hm64, n, p, pl, B * WIN);
+        if (__builtin_expect(__any((half[0] | half[1]) != 0ull), 0))
+            drain(half[0], half[1], n, p, pl, HB * B, HB * B);
     }
-    if (n < hi) {                                          // ragged end of the segment: < B*WIN rows
-        u64 hm = 0;
+    if (n < hi) {                                          // ragged end of the segment: < WROWS rows
+        u64 hmA = 0, hmB = 0;
         const int cnt = (int)(hi - n);
+        const int cntA = cnt < 64 ? cnt : 64, cntB = cnt - cntA;
         for (int j = 0; j < cnt; ++j) {
             const u32 dp = bias + hamming<NW>(qw, p + j * NW);
-            hm = (hm << 1) | (u64)(dp >> 31);
+            if (j < 64) hmA = (hmA << 1) | (u64)(dp >> 31);
+            else hmB = (hmB << 1) | (u64)(dp >> 31);
         }
-        drain(hm, n, p, pl, cnt);
+        drain(hmA, hmB, n, p, pl, cntA, cntB);
     }
 
     a.sl_cnt[so] = (u32)(wp - (row + start));
