@@ -29,7 +29,7 @@ def run_sharded(args, spec, c0, packed0, rank, local_rank, world):
         dist.init_process_group(backend="gloo")
     else:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    comm = sharded.TorchComm()
+    comm = sharded.TorchComm(host_sync=dry)                 # real runs: one stream, no host syncs between stages
 
     qw, ql, _, _ = packed0
     shard_spec = dict(spec)
@@ -44,7 +44,7 @@ def run_sharded(args, spec, c0, packed0, rank, local_rank, world):
         ctx.set_option(k_, int(v_))
     ctx.set_database(dw, dl, b, spec["C"], idx_base=rank * N, n_total=world * N)
     ctx.set_queries(qw, ql)
-    eng = sharded.HipShardEngine(ctx, want_lists=False)
+    eng = sharded.HipShardEngine(ctx, want_lists=False, share_stream=not dry)
 
     force = os.environ.get("HG_BENCH_FORCE_SHARDED") == "1"   # one-rank dry run of this leg over real RCCL
 

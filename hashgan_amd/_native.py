@@ -56,6 +56,7 @@ _SIGNATURES = {
     "hg_get_match": [_p, _p],
     "hg_get_ap": [_p, _p, _p],
     "hg_get_hist": [_p, _p],
+    "hg_set_stream": [_p, _p],
     "hg_set_option": [_p, C.c_char_p, _i64],
     "hg_get_stat": [_p, C.c_char_p, C.POINTER(_i64)],
     "hg_timing_enable": [_p, C.c_int],
@@ -275,6 +276,10 @@ class Context:
         return h
 
     # -- tuning / timing ----------------------------------------------------------
+    def set_stream(self, stream_handle):
+        """Run on the caller's HIP stream (an int handle, e.g. torch.cuda.current_stream().cuda_stream); None = private."""
+        check(self._lib.hg_set_stream(self._h, _p(stream_handle) if stream_handle else None))
+
     def set_option(self, key, value):
         check(self._lib.hg_set_option(self._h, key.encode(), int(value)))
 

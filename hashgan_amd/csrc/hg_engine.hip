@@ -99,6 +99,9 @@ void build_shape(int n, ApShape& sh) {
 struct hg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;    // false: the stream belongs to the caller (hg_set_stream) or to the parent context
+    bool stage_sync = true;    // staged calls synchronise the stream before returning
+    u32 tail_host[TAIL_WORDS] = {0};   // staging for the histogram tail words (must outlive the async copy)
     unsigned stage = ST_NONE;
 
     // problem
@@ -177,6 +180,9 @@ struct hg_ctx {
         t_collect();
         return HG_OK;
     }
+    // end of a staged call that only enqueued work: synchronise unless the caller orders everything on
+    // one stream itself (hg_set_stream + stage_sync = 0, e.g. torch's current stream in sharded mode)
+    int stage_end() { return stage_sync ? sync() : HG_OK; }
     int check_launch(const char* what) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(HG_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
@@ -399,7 +405,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist};
     for (auto* d : all) d->release();
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
-    if (c->stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
     delete c;
     return HG_OK;
 }
@@ -531,10 +537,12 @@ static int do_hist(hg_ctx* c, int stride) {
     HG_TRY(c->hist.reserve(plane * g.S));
     HG_TRY(c->hown.reserve(plane + TAIL_WORDS * 4));
     {   // tail of the exported histogram: [0] overflow flag, [1] rows this pass visited
-        u32 tail[TAIL_WORDS] = {0};
-        tail[1] = (u32)(stride == 1 ? g.N : sampled_rows(c, stride));
-        HG_HIP(hipMemcpyAsync(c->hown.as<char>() + plane, tail, sizeof tail, hipMemcpyHostToDevice, c->stream));
-        HG_HIP(hipStreamSynchronize(c->stream));   // `tail` is a stack buffer
+        const u32 visited = (u32)(stride == 1 ? g.N : sampled_rows(c, stride));
+        if (c->tail_host[1] != visited) {          // the staging words must not change under a copy in flight
+            HG_HIP(hipStreamSynchronize(c->stream));
+            c->tail_host[1] = visited;
+        }
+        HG_HIP(hipMemcpyAsync(c->hown.as<char>() + plane, c->tail_host, sizeof c->tail_host, hipMemcpyHostToDevice, c->stream));
     }
     HG_TRY(launch_hist(c));
     const Geo gh = hist_geometry(c);
@@ -550,7 +558,7 @@ static int do_hist(hg_ctx* c, int stride) {
 int hg_hist(hg_ctx* c) {
     HG_TRY(need(c, ST_DB | ST_Q, "hg_hist", "hg_set_database + hg_set_queries"));
     HG_TRY(do_hist(c, 1));
-    return c->sync();
+    return c->stage_end();
 }
 
 int hg_hist_buffer(hg_ctx* c, void** dev_ptr, int64_t* nbytes) {
@@ -635,7 +643,9 @@ static int check_plan_flag(hg_ctx* c) {
 int hg_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
     HG_TRY(need(c, ST_HIST, "hg_plan", "hg_hist"));
     HG_TRY(do_plan(c, R, dev_hist_all, G, rank));
-    return check_plan_flag(c);
+    // the device flag says "R exceeds the rows in the gathered histograms"; R <= n_total was checked on
+    // the host already, so an unsynchronised caller loses nothing by skipping the read-back
+    return c->stage_sync ? check_plan_flag(c) : HG_OK;
 }
 
 // record pass + ordering (+ gather-based label match when labels are too wide for the record pass)
@@ -702,7 +712,7 @@ int hg_select(hg_ctx* c) {
     HG_TRY(need(c, ST_PLAN, "hg_select", "hg_plan"));
     c->want_lists = c->staged_lists != 0;
     HG_TRY(do_select(c));
-    return c->sync();
+    return c->stage_end();
 }
 
 static int do_match(hg_ctx* c) {
@@ -726,7 +736,7 @@ int hg_match(hg_ctx* c) {
     HG_TRY(need(c, ST_SELECT, "hg_match", "hg_select"));
     if (c->stage & ST_MATCH) return HG_OK;
     HG_TRY(do_match(c));
-    return c->sync();
+    return c->stage_end();
 }
 
 int hg_match_buffer(hg_ctx* c, void** dev_ptr, int64_t* nbytes) {
@@ -744,7 +754,7 @@ int hg_merge_match(hg_ctx* c, const uint64_t* dev_bits_all, int G) {
     hipLaunchKernelGGL(k_or_bits, dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dev_bits_all, c->mbits.as<u64>(), n, G);
     c->t_end();
     HG_TRY(c->check_launch("k_or_bits"));
-    return c->sync();
+    return c->stage_end();
 }
 
 static int do_ap(hg_ctx* c) {
@@ -772,7 +782,7 @@ static int do_ap(hg_ctx* c) {
 int hg_ap(hg_ctx* c) {
     HG_TRY(need(c, ST_MATCH, "hg_ap", "hg_match"));
     HG_TRY(do_ap(c));
-    return c->sync();
+    return c->stage_end();
 }
 
 int hg_topr_buffers(hg_ctx* c, void** dev_idx, void** dev_dist, int64_t* n_slots) {
@@ -794,7 +804,7 @@ int hg_merge_topr(hg_ctx* c, const uint32_t* dev_idx_all, const uint8_t* dev_dis
                        (const u8*)dev_dist_all, c->out_idx.as<u32>(), c->out_dist.as<u8>(), n, G);
     c->t_end();
     HG_TRY(c->check_launch("k_min_topr"));
-    return c->sync();
+    return c->stage_end();
 }
 
 // ---- staged optimistic sequence (multi-shard): sample -> [gather] -> guess -> candidates ->
@@ -823,7 +833,7 @@ int hg_sample_hist(hg_ctx* c, int64_t R) {
     const int stride = auto_stride(c, R);
     if (stride < 2) return fail(HG_ERR_ARG, "hg_sample_hist: R=%lld is too small to sample for", (long long)R);
     HG_TRY(do_hist(c, stride));
-    return c->sync();
+    return c->stage_end();
 }
 
 int hg_guess(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
@@ -851,7 +861,7 @@ int hg_guess(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank
     c->cap = cap;
     c->crow = (i64)g.S * cap;
     c->stage = ST_DB | ST_Q | ST_PLAN;
-    return c->sync();
+    return c->stage_end();
 }
 
 int hg_select_candidates(hg_ctx* c) {
@@ -867,7 +877,7 @@ int hg_select_candidates(hg_ctx* c) {
                        c->cand.as<u64>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->hown.as<u32>(), c->cap, c->crow, g);
     c->t_end();
     HG_TRY(c->check_launch("k_cand_hist"));
-    return c->sync();
+    return c->stage_end();
 }
 
 int hg_rank(hg_ctx* c, const uint32_t* dev_hist_all, int G, int rank, int* bet_lost) {
@@ -1116,8 +1126,25 @@ int hg_get_hist(hg_ctx* c, uint32_t* host_hist) {
     return c->sync();
 }
 
+int hg_set_stream(hg_ctx* c, void* stream) {
+    if (!c) return fail(HG_ERR_ARG, "hg_set_stream: null context");
+    HG_TRY(c->use());
+    HG_TRY(c->sync());                               // drain the old stream first
+    if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        HG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    if (c->sub) c->sub->stream = c->stream;
+    return HG_OK;
+}
+
 int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return fail(HG_ERR_ARG, "hg_set_option: null argument");
+    if (!strcmp(key, "stage_sync")) { c->stage_sync = value != 0; return HG_OK; }
     if (!strcmp(key, "target_units")) {
         if (value < 1) return fail(HG_ERR_ARG, "target_units must be >= 1");
         c->target_units = value;

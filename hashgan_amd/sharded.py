@@ -28,10 +28,13 @@ import numpy as np
 class TorchComm:
     """all_gather over a torch.distributed process group (nccl = RCCL, or gloo)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, host_sync=True):
+        """host_sync=False: the engine runs on torch's current stream (HipShardEngine(share_stream=True)),
+        collectives are stream-ordered with its kernels and nothing waits on the host."""
         import torch.distributed as dist
         self._dist = dist
         self.group = group
+        self.host_sync = host_sync
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
@@ -45,7 +48,7 @@ class TorchComm:
             return host.to(t.device).view((self.world,) + tuple(t.shape))
         out = torch.empty(self.world * flat.numel(), dtype=t.dtype, device=t.device)
         self._dist.all_gather_into_tensor(out, flat, group=self.group)
-        if t.is_cuda:
+        if t.is_cuda and self.host_sync:
             torch.cuda.synchronize(t.device)       # the engine's own stream reads `out` next
         return out.view((self.world,) + tuple(t.shape))
 
@@ -106,9 +109,16 @@ def _as_tensor(ptr, nbytes, device):
 class HipShardEngine:
     """The staged C ABI of one context (one shard on one GPU), speaking torch tensors."""
 
-    def __init__(self, ctx, want_lists=False):
+    def __init__(self, ctx, want_lists=False, share_stream=False):
+        """share_stream: put the context on torch's current stream and stop synchronising per stage --
+        use with TorchComm(host_sync=False)."""
         self.ctx = ctx
         ctx.set_option("staged_lists", 1 if want_lists else 0)
+        self._keep = []                           # gathered tensors stay alive until the step's last kernel ran
+        if share_stream:
+            import torch
+            ctx.set_stream(torch.cuda.current_stream(torch.device("cuda", ctx.device)).cuda_stream)
+            ctx.set_option("stage_sync", 0)
 
     def hist(self):
         self.ctx.hist()
@@ -116,6 +126,7 @@ class HipShardEngine:
         return _as_tensor(ptr, n, self.ctx.device)
 
     def plan(self, R, gathered, world, rank):
+        self._keep = [gathered]
         self.ctx.plan(R, gathered.data_ptr() if (world > 1 and gathered is not None) else None, world, rank)
 
     def select_match(self):
@@ -137,6 +148,7 @@ class HipShardEngine:
         return _as_tensor(ptr, n, self.ctx.device)
 
     def guess(self, R, gathered, world, rank):
+        self._keep = [gathered]
         self.ctx.guess(R, gathered.data_ptr() if gathered is not None else None, world, rank)
 
     def select_candidates(self):
@@ -145,13 +157,17 @@ class HipShardEngine:
         return _as_tensor(ptr, n, self.ctx.device)
 
     def rank_candidates(self, gathered, world, rank):
+        self._keep.append(gathered)
         return self.ctx.rank(gathered.data_ptr() if gathered is not None else None, world, rank)
 
     def finish(self, gathered_bits, world):
         if gathered_bits is not None:
+            self._keep.append(gathered_bits)
             self.ctx.merge_match(gathered_bits.data_ptr(), world)
         self.ctx.ap()
-        return self.ctx.get_ap()
+        out = self.ctx.get_ap()                   # synchronises
+        self._keep = []
+        return out
 
     def topr_tensors(self):
         pi, pd, n = self.ctx.topr_buffers()

@@ -147,8 +147,14 @@ int hg_get_match(hg_ctx* ctx, uint8_t* host_imatch);                    /* [Q][R
 int hg_get_ap(hg_ctx* ctx, double* host_ap, int64_t* host_rel);         /* [Q]; ap = NaN where rel == 0 */
 int hg_get_hist(hg_ctx* ctx, uint32_t* host_hist);                      /* [b+1][Q] of this shard */
 
+/* Run the context on a stream of the caller's (NULL: back to a private one).  With option
+ * "stage_sync" = 0 the staged calls only enqueue; together this lets a sharded caller put every
+ * stage and the collectives between them on ONE stream (torch's current stream) with no host
+ * synchronisation except hg_rank's verdict and the final hg_get_*. */
+int hg_set_stream(hg_ctx* ctx, void* hip_stream);
+
 /* ---- tuning and measurement -------------------------------------------------- */
-/* key: "target_units" (wavefront-sized units the pair passes are split into),
+/* key: "stage_sync" (see hg_set_stream), "target_units" (wavefront-sized units the pair passes are split into),
  * "min_segment" (rows), "optimistic" (0/1: one-shot calls may bet on a sampled
  * threshold -- verified on device, exact fallback), "sample_stride" (0 = auto),
  * "guess_sigma", "staged_lists" (0/1: hg_select materialises idx/dist lists). */
