@@ -65,7 +65,7 @@ struct DevBuf {
 enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_LAYOUT, KI_GUESS, KI_SELECT, KI_CAND_HIST,
                 KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_PACK, KI_COUNT };
 const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_layout", "k_guess",
-                                            "k_select", "k_cand_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge", "k_pack"};
+                                            "k_select", "k_rank_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge", "k_pack"};
 
 enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
 
@@ -137,7 +137,7 @@ struct hg_ctx {
     DevBuf hist, hown, posbase, seglt, segtie;
     DevBuf t, tguess, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
-    DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist;
+    DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist, hwq;
     i64 shapes_for_R = -1;
 
     // timing
@@ -402,7 +402,7 @@ int hg_destroy(hg_ctx* c) {
     DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
                      &c->t, &c->tguess, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
-                     &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist};
+                     &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq};
     for (auto* d : all) d->release();
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
@@ -648,6 +648,37 @@ int hg_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank)
     return c->stage_sync ? check_plan_flag(c) : HG_OK;
 }
 
+// k_rank_fused in one of its modes: 0 = histogram + plan + placement in one launch (single shard),
+// 1 = histogram phase (several shards, before the exchange), 2 = placement phase (after k_plan).
+static int launch_rank(hg_ctx* c, int mode, int nbits) {
+    const Geo& g = c->geo;
+    const int nwav = (c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4;   // records per query ~ 3R / R
+    const size_t fixed_words = (size_t)(nwav + 1) * g.NB + 8;
+    const int bits_lds = (fixed_words + 2 * (size_t)c->RW) * 4 <= 64 * 1024;
+    if (mode != 1 && !bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+    HG_TRY(c->err.reserve(4));
+    HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
+    if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
+    if (mode == 0) {
+        if (c->optimistic) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+        else HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
+    }
+    RankArgs ra{c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(),
+                mode, c->hwq.as<u32>(), c->hown.as<u32>(), c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(),
+                c->tie_before.as<u32>(), c->posbase.as<u32>(),
+                c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW};
+    const size_t lds_bytes = (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4;
+    c->t_begin(mode == 1 ? KI_CAND_HIST : KI_RANK_FUSED);
+    if (nwav == 16)
+        hipLaunchKernelGGL(k_rank_fused<16>, dim3(g.Q), dim3(1024), lds_bytes, c->stream, c->cand.as<u64>(), ra,
+                           c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+    else
+        hipLaunchKernelGGL(k_rank_fused<4>, dim3(g.Q), dim3(256), lds_bytes, c->stream, c->cand.as<u64>(), ra,
+                           c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+    c->t_end();
+    return c->check_launch("k_rank_fused");
+}
+
 // record pass + ordering (+ gather-based label match when labels are too wide for the record pass)
 static int do_match(hg_ctx* c);
 static int do_select(hg_ctx* c) {
@@ -668,32 +699,13 @@ static int do_select(hg_ctx* c) {
     if (c->optimistic || c->G == 1) {
         // one block per query: verify (optimistic) + plan + order.  Exact single-shard rows hold
         // precisely the top R, so the same counting plan reproduces t and the bucket starts.
-        const int nwav = (c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4;   // records per query ~ 3R / R
-        const size_t fixed_words = (size_t)(nwav + 1) * g.NB + 8;
-        const int bits_lds = (fixed_words + 2 * (size_t)c->RW) * 4 <= 64 * 1024;
-        if (!bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
-        HG_TRY(c->err.reserve(4));
-        if (c->optimistic) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
-        else HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
-        HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
-        RankArgs ra{c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(),
-                    c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW};
-        c->t_begin(KI_RANK_FUSED);
-        const size_t lds_bytes = (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4;
-        if (nwav == 16)
-            hipLaunchKernelGGL(k_rank_fused<16>, dim3(g.Q), dim3(1024), lds_bytes, c->stream, c->cand.as<u64>(), ra,
-                               c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
-        else
-            hipLaunchKernelGGL(k_rank_fused<4>, dim3(g.Q), dim3(256), lds_bytes, c->stream, c->cand.as<u64>(), ra,
-                               c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
-        c->t_end();
-        HG_TRY(c->check_launch("k_rank_fused"));
+        HG_TRY(launch_rank(c, 0, nbits));
     } else {
         const size_t lds_words = (size_t)g.NB + 2 * (size_t)c->RW;
         const int bits_lds = WPB * lds_words * 4 <= 64 * 1024;
         if (!bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
         OrdArgs oa{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(),
-                   c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, 1, c->want_lists ? 1 : 0, bits_lds, c->RW};
+                   c->tot.as<u32>(), c->crow, c->want_lists ? 1 : 0, bits_lds, c->RW};
         c->t_begin(KI_ORDER);
         hipLaunchKernelGGL(k_order, dim3(grid_for(g.Q, WPB)), dim3(256),
                            (size_t)WPB * (g.NB + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4, c->stream, c->cand.as<u64>(), oa,
@@ -872,11 +884,9 @@ int hg_select_candidates(hg_ctx* c) {
     HG_TRY(launch_select(c));
     const size_t plane = (size_t)g.NB * g.Qpad * 4;
     HG_HIP(hipMemsetAsync(c->hown.as<char>() + plane, 0, TAIL_WORDS * 4, c->stream));
-    c->t_begin(KI_CAND_HIST);
-    hipLaunchKernelGGL(k_cand_hist, dim3(grid_for(g.Q, WPB)), dim3(256), (size_t)WPB * g.NB * 4, c->stream,
-                       c->cand.as<u64>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->hown.as<u32>(), c->cap, c->crow, g);
-    c->t_end();
-    HG_TRY(c->check_launch("k_cand_hist"));
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    HG_TRY(launch_rank(c, 1, nbits));                // per-wave and shard histograms of the records
     return c->stage_end();
 }
 
@@ -898,16 +908,7 @@ int hg_rank(hg_ctx* c, const uint32_t* dev_hist_all, int G, int rank, int* bet_l
     HG_TRY(launch_plan(c, dev_hist_all));
     int nbits = 1;
     while ((1 << nbits) < g.NB) ++nbits;
-    const size_t lds_words = (size_t)g.NB + 2 * (size_t)c->RW;
-    const int bits_lds = WPB * lds_words * 4 <= 64 * 1024;
-    if (!bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
-    OrdArgs oa{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(),
-               c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, 0, c->want_lists ? 1 : 0, bits_lds, c->RW};
-    c->t_begin(KI_ORDER);
-    hipLaunchKernelGGL(k_order, dim3(grid_for(g.Q, WPB)), dim3(256), (size_t)WPB * (g.NB + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4,
-                       c->stream, c->cand.as<u64>(), oa, c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
-    c->t_end();
-    HG_TRY(c->check_launch("k_order"));
+    HG_TRY(launch_rank(c, 2, nbits));                // placement with the shared plan
     int flag = 0;
     HG_TRY(read_plan_flag(c, &flag));
     *bet_lost = flag;

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ segl
 // gathered ones).  With f = sampled rows / all rows, the guess is the smallest T whose sample
 // count reaches f*R + sigma*sqrt(f*R) + 1, i.e. #(dist <= T over all rows) >= R all but
 // certainly.  The guess is only a performance bet: the records' exact histogram goes through
-// k_plan afterwards (k_cand_hist / k_rank_fused) and a lost bet reruns the exact path.
+// k_plan afterwards (k_rank_fused) and a lost bet reruns the exact path.
 __global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, const u32* __restrict__ hall, int G,
                                                double sigma, i64 n_total, int* __restrict__ T, const Geo g) {
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -544,44 +544,10 @@ __global__ __launch_bounds__(256) void k_select_dense(const u32* __restrict__ qc
 }
 
 // ----------------------------------------------------------------------------
-// K3b  exact histogram of a query's records (optimistic mode): which distances
-// the candidate superset really holds.  k_plan then derives the true threshold
-// from it; if the superset has fewer than R rows (guess too low) or a slice
-// overflowed, the plan flags the query and the host reruns the exact path.
-// One wavefront per query.
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cand_hist(const u64* __restrict__ cand, const u32* __restrict__ sl_cnt,
-                                                   const u32* __restrict__ fail, u32* __restrict__ hown,
-                                                   u32 cap, i64 crow, const Geo g) {
-    extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-    if (q >= g.Q) return;
-    u32* h = lds + wave * g.NB;
-    for (int d = lane; d < g.NB; d += 64) h[d] = 0u;
-    wave_lds_sync();
-    if (fail[q]) {
-        if (lane == 0) atomicOr(&hown[(i64)g.NB * g.Qpad], 1u);   // tail word 0: this shard lost the bet
-    } else {
-        const u64* __restrict__ row = cand + (i64)q * crow;
-        for (int s = 0; s < g.S; ++s) {
-            const u32 cnt = sl_cnt[(i64)s * g.Qpad + q];
-            const u64* __restrict__ sl = row + (i64)s * cap;
-            for (u32 i = lane; i < cnt; i += 64) {
-                const u32 d = (u32)(sl[i] >> 32) & 0xFFu;
-                if (d < (u32)g.NB) atomicAdd(&h[d], 1u);
-            }
-        }
-    }
-    wave_lds_sync();
-    for (int d = lane; d < g.NB; d += 64) hown[(i64)d * g.Qpad + q] = h[d];
-}
-
-// ----------------------------------------------------------------------------
-// K4  order.   metric.py:14 finished: a query's records (index order) go to
-// their final rank positions, canonical order, by a stable counting sort over
-// the distance -- one wavefront per query, 64 records per step:
+// K4  order (exact mode with several shards: the plan comes from gathered histograms).
+// metric.py:14 finished: a query's records (index order) go to their final rank
+// positions, canonical order, by a stable counting sort over the distance -- one
+// wavefront per query, 64 records per step:
 //   dist <  t : position = running start of the bucket (LDS row pb[d]) + rank
 //               among the step's lanes of the same distance (bit-sliced match
 //               over the bits of d via ballots, popcount below the lane);
@@ -598,11 +564,8 @@ struct OrdArgs {
     const u32* quota;
     const u32* tie_before;
     const u32* posbase;    // [NB][Qpad]
-    const u32* sl_cnt;     // [S][Qpad] (optimistic) slices of `cap` records
-    const u32* tot;        // [Qpad]    (exact) one dense run of tot[q] records
-    u32 cap;
+    const u32* tot;        // [Qpad] records of the query (one dense run: exact-mode rows)
     i64 crow;
-    int dense;
     int want_lists;
     int bits_lds;          // bit row fits the wave's LDS share; else global atomics on a zeroed row
     i64 RW;                // 64-bit words per bit row
@@ -631,10 +594,9 @@ __global__ __launch_bounds__(256) void k_order(const u64* __restrict__ cand, con
     u8* __restrict__ od = out_dist + (i64)q * g.R;
     const u64 below = (1ull << lane) - 1ull;
     u32 tie_run = 0;
-    const int nsl = a.dense ? 1 : g.S;
-    for (int s = 0; s < nsl; ++s) {
-        const u32 cnt = a.dense ? a.tot[q] : a.sl_cnt[(i64)s * g.Qpad + q];
-        const u64* __restrict__ sl = row + (a.dense ? 0 : (i64)s * a.cap);
+    {
+        const u32 cnt = a.tot[q];
+        const u64* __restrict__ sl = row;
         for (u32 base = 0; base < cnt; base += 64) {
             const u32 i = base + lane;
             const bool valid = i < cnt;
@@ -683,7 +645,7 @@ __global__ __launch_bounds__(256) void k_order(const u64* __restrict__ cand, con
 // K4f  verify + plan + order in one launch (optimistic mode, single shard).
 // One 256-thread block per query; the query's slices are split into four
 // contiguous ranges, one per wavefront:
-//   phase 1  every wave histograms the distances of its records          (= k_cand_hist)
+//   phase 1  every wave histograms the distances of its records
 //   phase 2  bucket totals -> threshold t, quota; per-wave bucket starts  (= k_plan, G = 1)
 //            fewer than R records, or an overflowed slice: *err = 1, the host reruns the
 //            exact path
@@ -698,6 +660,17 @@ struct RankArgs {
     const u32* fail;       // [Qpad]
     int* err;
     u32* qbad;             // [Q] out: 1 = this query's bet was lost (rerun it exactly), 0 = ranked
+    // several shards: the plan needs the gathered histograms, so the kernel runs twice --
+    // mode 1 = histogram phase only (per-wave histograms -> hwq, shard totals -> hown, then the
+    // exchange and k_plan), mode 2 = placement phase only, plan taken from the arrays below.
+    int mode;              // 0 fused (one shard), 1 histogram phase, 2 placement phase
+    u32* hwq;              // [Q][NWAV][NB] per-wave histograms between the two phases
+    u32* hown;             // [NB][Qpad] (+ tail) shard histogram out (mode 1)
+    const int* xt;         // external plan (mode 2): threshold
+    const u32* xcnt_lt;
+    const u32* xquota;
+    const u32* xtie_before;
+    const u32* xposbase;   // [NB][Qpad]
     u32 cap;
     i64 crow;
     int dense;
@@ -725,7 +698,11 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     u32* bm = misc + 8;               // [bmw]
     u32* __restrict__ grow = mbits32 + (i64)q * 2 * a.RW;
     if (a.fail[q]) {                                  // a slice of this query overflowed
-        if (tid == 0) { atomicExch(a.err, 1); a.qbad[q] = 1u; }
+        if (tid == 0) {
+            if (a.mode == 1) atomicOr(&a.hown[(i64)NB * g.Qpad], 1u);   // tail word 0: this shard lost the bet
+            else { atomicExch(a.err, 1); a.qbad[q] = 1u; }
+        }
+        if (a.mode == 1) for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = 0u;
         return;
     }
     for (int i = tid; i < (nwav + 1) * NB + 8 + bmw; i += nthr) lds[i] = 0u;
@@ -768,7 +745,9 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     };
     // phase 1
     u32* myh = hw + wave * NB;
-    {
+    if (a.mode == 2) {                                // histograms were computed by the mode-1 launch
+        for (int i = tid; i < nwav * NB; i += nthr) hw[i] = a.hwq[(i64)q * nwav * NB + i];
+    } else {
         Walk w = first();
         u64 rec = fetch(w);
         while (w.s < s1) {
@@ -790,7 +769,28 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
         tot[d] = acc;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (a.mode == 1) {                                // hand the histograms over and stop
+        for (int i = tid; i < nwav * NB; i += nthr) a.hwq[(i64)q * nwav * NB + i] = hw[i];
+        for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = tot[d];
+        return;
+    }
+    if (a.mode == 2) {
+        if (tid == 0) {
+            const int t = a.xt[q];
+            int dmin = 0;
+            while (dmin < NB - 1 && tot[dmin] == 0u) ++dmin;
+            misc[0] = (u32)t;
+            misc[1] = a.xcnt_lt[q];
+            misc[2] = a.xquota[q];
+            misc[3] = (u32)dmin;
+            a.qbad[q] = t < 0 ? 1u : 0u;
+        }
+        __syncthreads();
+        for (int d = tid; d < NB; d += nthr)          // my rows of bucket d start here in the global list
+            tot[d] = a.xposbase[(i64)d * g.Qpad + q];
+        __syncthreads();
+    }
+    if (a.mode == 0 && tid == 0) {
         u64 cum = 0;
         int t = -1, dmin = -1;
         for (int d = 0; d < NB; ++d) {
@@ -810,8 +810,9 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     __syncthreads();
     const int t = (int)misc[0];
     if (t < 0) return;
+    const u32 tie0 = a.mode == 2 ? a.xtie_before[q] : 0u;    // ties owned by lower-ranked shards
     for (int d = tid; d <= t && d < NB; d += nthr) {  // per-wave starts: bucket start + records of earlier waves
-        u32 run = d < t ? tot[d] : 0u;                // for d == t the "start" is the tie rank offset
+        u32 run = d < t ? tot[d] : tie0;              // for d == t the "start" is the tie rank offset
         for (int w = 0; w < nwav; ++w) {
             const u32 h = hw[w * NB + d];
             hw[w * NB + d] = run;
