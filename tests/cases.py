@@ -36,6 +36,41 @@ CASES = {
 
 SMALL = [k for k in CASES if k.startswith("e_") and k != "e_big_r"]
 
+# Real-valued (tanh-like) feature cases for the float ranking path.  Features sit on
+# the grid k/64, where float32 inner products are exact in any summation order (oracle/real_map.py).
+REAL_CASES = {
+    "real_small":  dict(Q=50, N=3000, b=32, R=500, C=10, seed=0xF1, labels="onehot"),
+    "real_b64":    dict(Q=70, N=20000, b=64, R=2000, C=10, seed=0xF2, labels="onehot"),
+    "real_multi":  dict(Q=33, N=9000, b=48, R=900, C=81, seed=0xF3, labels="multihot"),
+    "real_dups":   dict(Q=20, N=4000, b=16, R=1500, C=5, seed=0xF4, labels="onehot", dups=True),
+    "real_b128":   dict(Q=16, N=5000, b=128, R=5000, C=10, seed=0xF5, labels="onehot"),
+    "real_bet":    dict(Q=96, N=150000, b=64, R=3000, C=10, seed=0xF6, labels="onehot"),
+}
+
+
+def build_real_case(name):
+    """-> dict(qf, dbf float32 on the 1/64 grid; qlab, dblab int8; R, b)."""
+    from oracle import real_map as RM
+    c = REAL_CASES[name]
+    Q, N, b, C, seed = c["Q"], c["N"], c["b"], c["C"], c["seed"]
+    if c["labels"] == "onehot":
+        dblab, dcls = synth.onehot_labels(seed * 3 + 1, N, C)
+        qlab, qcls = synth.onehot_labels(seed * 3 + 2, Q, C)
+    else:
+        dblab = synth.multihot_labels(seed * 3 + 1, N, C)
+        qlab = synth.multihot_labels(seed * 3 + 2, Q, C)
+    # class-correlated real features: a per-class prototype plus noise, squashed to [-1, 1], snapped to the grid
+    proto = RM.quantised_features(seed ^ 0x77, C, b).astype(np.float64)
+    def feats(lab, s):
+        base = lab.astype(np.float64) @ proto
+        noise = RM.quantised_features(s, lab.shape[0], b).astype(np.float64)
+        x = np.tanh(0.8 * base + 0.9 * noise)
+        return (np.round(x * 64) / 64).astype(np.float32)
+    dbf, qf = feats(dblab, seed + 11), feats(qlab, seed + 12)
+    if c.get("dups"):
+        dbf[N // 2:] = dbf[:N - N // 2]               # the second half duplicates the first: exact ties
+    return dict(qf=qf, dbf=dbf, qlab=qlab, dblab=dblab, R=c["R"], b=b, name=name)
+
 
 def _cifar_labels():
     z = np.load(os.path.join(GOLDEN_DIR, "cifar10_labels.npz"))

@@ -71,8 +71,34 @@ def run_case(name):
     print("%-16s Q=%-5d N=%-9d R=%-6d map=%.17g skipped=%d" % (name, Q, N, R, m, int(np.isnan(ap).sum())))
 
 
+def run_real_case(name):
+    """Real-valued features on the 1/64 grid (exact float arithmetic in any order): the unmodified
+    reference on float64 copies + the tie-breaking coordinate (oracle.real_map.tie_free_real_features)."""
+    from tests import cases
+    from oracle import real_map as RM
+    c = cases.build_real_case(name)
+    N, R = c["dbf"].shape[0], c["R"]
+    database = types.SimpleNamespace(output=RM.tie_free_real_features(c["dbf"], False, N), label=c["dblab"].astype(np.int64))
+    qfeat = RM.tie_free_real_features(c["qf"], True, N)
+    qlab = c["qlab"].astype(np.int64)
+    Q = qfeat.shape[0]
+    ap = np.empty(Q, dtype=np.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(Q):
+            one = types.SimpleNamespace(output=qfeat[i:i + 1], label=qlab[i:i + 1])
+            ap[i] = MAPs(R).get_maps_by_feature(database, one)
+        m = MAPs(R).get_maps_by_feature(database, types.SimpleNamespace(output=qfeat, label=qlab))
+    out = dict(ap=ap, map=np.float64(m))
+    if N * Q <= 2_000_000:
+        out["idx"] = np.argsort(-np.dot(qfeat, database.output.T), 1)[:, :R].astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-16s Q=%-5d N=%-9d R=%-6d map=%.17g skipped=%d" % (name, Q, N, R, m, int(np.isnan(ap).sum())))
+
+
 if __name__ == "__main__":
     cifar_labels()
     from tests import cases
-    for nm in (sys.argv[1:] or list(cases.CASES)):
-        run_case(nm)
+    names = sys.argv[1:] or (list(cases.CASES) + list(cases.REAL_CASES))
+    for nm in names:
+        (run_real_case if nm in cases.REAL_CASES else run_case)(nm)

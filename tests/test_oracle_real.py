@@ -1,0 +1,50 @@
+"""The real-valued oracle (oracle/real_map.py): its float32 fma emulation against exact rational
+arithmetic, and the oracle against golden fixtures from the UNMODIFIED reference."""
+from fractions import Fraction
+import warnings
+import numpy as np
+import pytest
+from tests import cases
+from oracle import real_map as RM
+
+
+def _exact_fma32(a, b, c):
+    v = Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))
+    f = np.float32(float(v))
+    best = None
+    for x in (f, np.nextafter(f, np.float32(-np.inf)), np.nextafter(f, np.float32(np.inf))):
+        if np.isfinite(x):
+            key = (abs(Fraction(float(x)) - v), int(np.float32(x).view(np.uint32)) & 1)
+            if best is None or key < best[0]:
+                best = (key, x)
+    return best[1]
+
+
+def test_fma32_is_correctly_rounded():
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal(3000).astype(np.float32)
+    b = rng.standard_normal(3000).astype(np.float32)
+    c = rng.standard_normal(3000).astype(np.float32)
+    # products whose sum with c lands exactly on / next to float32 rounding boundaries
+    t = np.float32(1.0) + np.float32(2.0 ** -23) * rng.integers(0, 8, 3000).astype(np.float32)
+    a2 = (np.float32(1.0) + np.float32(2.0 ** -12) * rng.integers(1, 4000, 3000).astype(np.float32))
+    b2 = (np.float32(1.0) + np.float32(2.0 ** -12) * rng.integers(1, 4000, 3000).astype(np.float32))
+    for A, B, C in [(a, b, c), (a2, b2, t), (a2, b2, -t), (a * np.float32(1e-4), b, c * np.float32(1e3))]:
+        r = RM.fma32(A, B, C)
+        ref = np.array([_exact_fma32(x, y, z) for x, y, z in zip(A, B, C)], dtype=np.float32)
+        assert np.array_equal(r.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["real_small", "real_b64", "real_multi", "real_dups", "real_b128"])
+def test_real_oracle_matches_reference_golden(name):
+    c = cases.build_real_case(name)
+    g = cases.load_golden(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, ap, idx, score = RM.map_from_features(c["qf"], c["dbf"], c["qlab"], c["dblab"], c["R"])
+    assert np.array_equal(ap, g["ap"], equal_nan=True) and m == g["map"]
+    if "idx" in g:
+        assert np.array_equal(idx, g["idx"])
+    # on the grid the float32 chain equals the exact value, whatever the order
+    exact = (c["qf"].astype(np.float64) @ c["dbf"].astype(np.float64).T)
+    assert np.array_equal(RM.inner_products(c["qf"], c["dbf"]).astype(np.float64), exact)
