@@ -52,6 +52,9 @@ _SIGNATURES = {
     "hg_merge_topr": [_p, _p, _p, C.c_int],
     "hg_topr": [_p, _i64],
     "hg_map": [_p, _i64, _p, _p],
+    "hg_map_real": [_p, _i64, _p, _p],
+    "hg_topr_real": [_p, _i64],
+    "hg_get_topr_real": [_p, _p, _p],
     "hg_get_topr": [_p, _p, _p],
     "hg_get_match": [_p, _p],
     "hg_get_ap": [_p, _p, _p],
@@ -251,6 +254,22 @@ class Context:
         check(self._lib.hg_map(self._h, int(R), _ptr(ap), _ptr(rel)))
         self.R = int(R)
         return ap, rel
+
+    # -- real-valued features ---------------------------------------------------
+    def map_real(self, R):
+        ap = np.empty(self.Q, dtype=np.float64)
+        rel = np.empty(self.Q, dtype=np.int64)
+        check(self._lib.hg_map_real(self._h, int(R), _ptr(ap), _ptr(rel)))
+        self.R = int(R)
+        return ap, rel
+
+    def topr_real(self, R):
+        check(self._lib.hg_topr_real(self._h, int(R)))
+        self.R = int(R)
+        idx = np.empty((self.Q, self.R), dtype=np.uint32)
+        score = np.empty((self.Q, self.R), dtype=np.float32)
+        check(self._lib.hg_get_topr_real(self._h, _ptr(idx), _ptr(score)))
+        return idx, score
 
     # -- results ----------------------------------------------------------------
     def get_topr(self):

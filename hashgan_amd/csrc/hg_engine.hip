@@ -2,6 +2,7 @@
 // the C ABI declared in include/hashgan_amd.h.  No torch, no CPU compute path:
 // every entry point either runs the HIP kernels of hg_kernels.hpp or fails.
 #include "hg_kernels.hpp"
+#include "hg_real_kernels.hpp"
 #include "../../include/hashgan_amd.h"
 
 #include <cmath>
@@ -63,9 +64,11 @@ struct DevBuf {
 };
 
 enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_LAYOUT, KI_GUESS, KI_SELECT, KI_CAND_HIST,
-                KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_PACK, KI_COUNT };
+                KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_PACK, KI_REAL_SAMPLE, KI_REAL_GUESS, KI_REAL_SELECT,
+                KI_RADIX, KI_REAL_FINISH, KI_COUNT };
 const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_layout", "k_guess",
-                                            "k_select", "k_rank_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge", "k_pack"};
+                                            "k_select", "k_rank_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge", "k_pack",
+                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish"};
 
 enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
 
@@ -138,6 +141,9 @@ struct hg_ctx {
     DevBuf t, tguess, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
     DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist, hwq;
+    DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
+    int bpad = 0;              // feature count padded to a multiple of 16 (0: no float tables loaded)
+    bool real_lists = false;
     i64 shapes_for_R = -1;
 
     // timing
@@ -361,6 +367,40 @@ int upload_codes(hg_ctx* c, DevBuf& dst, const uint64_t* host, i64 n, int W, int
     return HG_OK;
 }
 
+template <int BP> int real_launch_sample(hg_ctx* c, i64 M, i64 stride) {
+    const Geo& g = c->geo;
+    const i64 units = (M + 63) / 64 * g.nQT;
+    c->t_begin(KI_REAL_SAMPLE);
+    hipLaunchKernelGGL(k_real_sample<BP>, dim3(grid_for(units, WPB)), dim3(256), (size_t)WPB * 64 * 65 * 4, c->stream,
+                       c->qf.as<float>(), c->dbf.as<float>(), c->samp.as<float>(), M, stride, g);
+    c->t_end();
+    return c->check_launch("k_real_sample");
+}
+template <int BP> int real_launch_select(hg_ctx* c) {
+    const Geo& g = c->geo;
+    RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
+    c->t_begin(KI_REAL_SELECT);
+    hipLaunchKernelGGL(k_real_select<BP>, dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(),
+                       c->dbf.as<float>(), a, c->cand.as<u64>(), g);
+    c->t_end();
+    return c->check_launch("k_real_select");
+}
+#define HG_DISPATCH_BP(fn, c, ...)                                  \
+    switch ((c)->bpad / 2) {                                        \
+        case 8: return fn<8>(c, ##__VA_ARGS__);                     \
+        case 16: return fn<16>(c, ##__VA_ARGS__);                   \
+        case 24: return fn<24>(c, ##__VA_ARGS__);                   \
+        case 32: return fn<32>(c, ##__VA_ARGS__);                   \
+        case 40: return fn<40>(c, ##__VA_ARGS__);                   \
+        case 48: return fn<48>(c, ##__VA_ARGS__);                   \
+        case 56: return fn<56>(c, ##__VA_ARGS__);                   \
+        case 64: return fn<64>(c, ##__VA_ARGS__);                   \
+        default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 128 features (have %d)", (c)->b); \
+    }
+int real_sample(hg_ctx* c, i64 M, i64 stride) { HG_DISPATCH_BP(real_launch_sample, c, M, stride) }
+int real_select(hg_ctx* c) { HG_DISPATCH_BP(real_launch_select, c) }
+
+
 }  // namespace
 
 // =============================================================================
@@ -402,7 +442,8 @@ int hg_destroy(hg_ctx* c) {
     DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
                      &c->t, &c->tguess, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
-                     &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq};
+                     &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
+                     &c->sortA, &c->sortB, &c->scores};
     for (auto* d : all) d->release();
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
@@ -438,6 +479,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     c->N = N; c->b = b; c->C = C; c->n_total = n_total;
     c->NW = (b + 31) / 32; c->NB = b + 1; c->LW = (C + 63) / 64;
     c->idx_base = (u32)idx_base;
+    c->bpad = 0;                                       // packed input: no float tables for the real-valued path
     HG_TRY(upload_codes(c, c->db, codes, N, (b + 63) / 64, c->NW));
     HG_TRY(c->dblab.reserve((size_t)(N > 0 ? N : 1) * c->LW * 8));
     if (N) HG_HIP(hipMemcpyAsync(c->dblab.p, labels, (size_t)N * c->LW * 8, hipMemcpyHostToDevice, c->stream));
@@ -448,21 +490,27 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
 
 // float32 features + int64 labels -> packed device tables (k_pack_sign_f32 / k_pack_labels_i64)
 static int pack_on_device(hg_ctx* c, const float* x, const int64_t* lab, i64 n, DevBuf& codes, DevBuf& labels,
-                          int64_t* bad_codes, int64_t* bad_labels) {
+                          DevBuf& feats, int64_t* bad_codes, int64_t* bad_labels) {
     const int b = c->b, C = c->C, NW = c->NW, LW = c->LW;
-    const size_t xb = (size_t)n * b * 4, lb = (size_t)n * C * 8;
-    HG_TRY(c->stage_in.reserve(xb > lb ? xb : lb));
+    // the float table stays resident, zero-padded to a multiple of 16 features: the real-valued
+    // ranking (hg_map_real) streams it, and padding keeps its scalar loads 64-byte aligned
+    const int bpad = (b + 15) / 16 * 16;
+    c->bpad = bpad;
+    const size_t fb = (size_t)n * bpad * 4, lb = (size_t)n * C * 8;
+    HG_TRY(feats.reserve(fb + 256));
+    HG_TRY(c->stage_in.reserve(lb));
     HG_TRY(c->badcnt.reserve(16));
     HG_TRY(codes.reserve((size_t)n * NW * 4 + 64 * 4));
     HG_TRY(labels.reserve((size_t)n * LW * 8));
     HG_HIP(hipMemsetAsync(c->badcnt.p, 0, 16, c->stream));
-    HG_HIP(hipMemcpyAsync(c->stage_in.p, x, xb, hipMemcpyHostToDevice, c->stream));
+    if (bpad != b) HG_HIP(hipMemsetAsync(feats.p, 0, fb, c->stream));
+    HG_HIP(hipMemcpy2DAsync(feats.p, (size_t)bpad * 4, x, (size_t)b * 4, (size_t)b * 4, (size_t)n, hipMemcpyHostToDevice, c->stream));
     c->t_begin(KI_PACK);
-    hipLaunchKernelGGL(k_pack_sign_f32, dim3(grid_for(n, WPB)), dim3(256), 0, c->stream, c->stage_in.as<float>(),
+    hipLaunchKernelGGL(k_pack_sign_f32, dim3(grid_for(n, WPB)), dim3(256), 0, c->stream, feats.as<float>(), (i64)bpad,
                        codes.as<u32>(), n, b, NW, c->badcnt.as<unsigned long long>());
     c->t_end();
     HG_TRY(c->check_launch("k_pack_sign_f32"));
-    HG_HIP(hipMemcpyAsync(c->stage_in.p, lab, lb, hipMemcpyHostToDevice, c->stream));   // stream order: after the kernel
+    HG_HIP(hipMemcpyAsync(c->stage_in.p, lab, lb, hipMemcpyHostToDevice, c->stream));
     c->t_begin(KI_PACK);
     hipLaunchKernelGGL(k_pack_labels_i64, dim3(grid_for(n, WPB)), dim3(256), 0, c->stream, c->stage_in.as<long long>(),
                        labels.as<u64>(), n, C, LW, c->badcnt.as<unsigned long long>());
@@ -489,7 +537,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->N = N; c->b = b; c->C = C; c->n_total = n_total;
     c->NW = (b + 31) / 32; c->NB = b + 1; c->LW = (C + 63) / 64;
     c->idx_base = (u32)idx_base;
-    HG_TRY(pack_on_device(c, host_x, host_labels, N, c->db, c->dblab, bad_codes, bad_labels));
+    HG_TRY(pack_on_device(c, host_x, host_labels, N, c->db, c->dblab, c->dbf, bad_codes, bad_labels));
     c->stage = ST_DB;
     return HG_OK;
 }
@@ -500,7 +548,7 @@ int hg_set_queries_f32(hg_ctx* c, const float* host_x, const int64_t* host_label
     if (Q < 1 || !host_x || !host_labels) return fail(HG_ERR_ARG, "hg_set_queries_f32: need Q >= 1 and data");
     if (Q > 0x7FFFFFC0ll) return fail(HG_ERR_ARG, "hg_set_queries_f32: Q too large");
     c->Q = Q;
-    HG_TRY(pack_on_device(c, host_x, host_labels, Q, c->qc, c->qlab, bad_codes, bad_labels));
+    HG_TRY(pack_on_device(c, host_x, host_labels, Q, c->qc, c->qlab, c->qf, bad_codes, bad_labels));
     c->stage = ST_DB | ST_Q;
     return HG_OK;
 }
@@ -1047,6 +1095,7 @@ static int rerun_lost_queries(hg_ctx* c, int64_t R, bool lists, bool with_ap, bo
 }
 
 static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
+    c->real_lists = false;
     int stride = 0;
     u32 need_cnt = 0;
     if (R < 1 || R > c->n_total)
@@ -1081,6 +1130,115 @@ int hg_map(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
     HG_TRY(need(c, ST_DB | ST_Q, "hg_map", "hg_set_database + hg_set_queries"));
     HG_TRY(run_oneshot(c, R, false, true));
     return hg_get_ap(c, host_ap, host_rel);
+}
+
+// ---- real-valued ranking: sample -> guess -> select -> 4-pass radix sort -> finish ----
+// one attempt; *lost = some query came up short of R records or overflowed a slice (bet mode only)
+static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double budget, bool with_ap, int* lost) {
+    make_geometry(c);
+    HG_TRY(set_R(c, R, 1, 0));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(c->thr.reserve(qb)); HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->failq.reserve(qb));
+    HG_TRY(c->tot.reserve(qb)); HG_TRY(c->err.reserve(4)); HG_TRY(c->qbad.reserve(qb));
+    HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
+    HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+    if (bet) {
+        // sample so that about 64 of a query's top R rows are in it; guess the cut `sigma` deviations deep
+        i64 stride = (i64)((double)R / 64.0);
+        if (stride < 1) stride = 1;
+        const i64 M = (c->N + stride - 1) / stride;
+        const double fr = (double)R * (double)M / (double)c->N;
+        const u32 rank_s = (u32)std::ceil(fr + sigma * std::sqrt(fr)) + 1u;
+        HG_TRY(c->samp.reserve((size_t)g.Q * M * 4));
+        HG_TRY(real_sample(c, M, stride));
+        c->t_begin(KI_REAL_GUESS);
+        hipLaunchKernelGGL(k_real_guess, dim3(g.Q), dim3(256), 0, c->stream, c->samp.as<float>(), M, rank_s, c->thr.as<float>());
+        c->t_end();
+        HG_TRY(c->check_launch("k_real_guess"));
+        const double mean = budget * (double)R / (double)g.S;
+        u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
+        c->cap = (cap + 7u) & ~7u;
+    } else {
+        // no bet: every row becomes a record (thr = -inf), slices are whole segments
+        std::vector<float> ninf((size_t)g.Q, -INFINITY);
+        HG_HIP(hipMemcpyAsync(c->thr.p, ninf.data(), (size_t)g.Q * 4, hipMemcpyHostToDevice, c->stream));
+        HG_HIP(hipStreamSynchronize(c->stream));
+        c->cap = (u32)g.L;
+    }
+    c->crow = (i64)g.S * c->cap;
+    const size_t rows = (size_t)g.Q * c->crow * 8;
+    if (rows * 3 > (size_t)200 << 30)
+        return fail(HG_ERR_NOMEM, "real-valued ranking: %zu GB of records needed (Q=%d, %lld per query)", rows * 3 >> 30, g.Q, (long long)c->crow);
+    HG_TRY(c->cand.reserve(rows)); HG_TRY(c->sortA.reserve(rows)); HG_TRY(c->sortB.reserve(rows));
+    HG_TRY(real_select(c));
+    const int nwav = c->crow >= 16384 ? 16 : 4;
+    const size_t lds = (size_t)(nwav + 1) * 256 * 4;
+    u64* bufs[2] = {c->sortA.as<u64>(), c->sortB.as<u64>()};
+    const u64* in = c->cand.as<u64>();
+    for (int pass = 0; pass < 4; ++pass) {
+        RadixArgs ra{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, c->crow, pass == 0, 32 + 8 * pass};
+        u64* out = bufs[pass & 1];
+        c->t_begin(KI_RADIX);
+        if (nwav == 16) hipLaunchKernelGGL(k_radix_pass<16>, dim3(g.Q), dim3(1024), lds, c->stream, in, out, ra, g);
+        else hipLaunchKernelGGL(k_radix_pass<4>, dim3(g.Q), dim3(256), lds, c->stream, in, out, ra, g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_radix_pass"));
+        in = out;
+    }
+    const size_t slots = (size_t)g.Q * g.R;
+    HG_TRY(c->out_idx.reserve(slots * 4));
+    HG_TRY(c->scores.reserve(slots * 4));
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    c->t_begin(KI_REAL_FINISH);
+    hipLaunchKernelGGL(k_real_finish, dim3(grid_for(g.R), g.Q), dim3(256), 0, c->stream, in, c->crow, c->tot.as<u32>(),
+                       c->out_idx.as<u32>(), c->scores.as<float>(), c->err.as<int>(), c->qbad.as<u32>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_real_finish"));
+    c->stage = ST_DB | ST_Q | ST_SELECT;
+    HG_TRY(do_match(c));                               // label gather through the ranked idx list
+    if (with_ap) HG_TRY(do_ap(c));
+    HG_TRY(read_plan_flag(c, lost));
+    return HG_OK;
+}
+
+static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
+    if (!c->bpad || !c->dbf.p || !c->qf.p)
+        return fail(HG_ERR_STATE, "real-valued ranking needs float features: load them with hg_set_database_f32 / hg_set_queries_f32");
+    if (c->n_total != c->N) return fail(HG_ERR_STATE, "real-valued ranking is single-shard");
+    if (R < 1 || R > c->N) return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->N);
+    if (c->Q > 65535) return fail(HG_ERR_ARG, "real-valued ranking: at most 65535 queries per call");
+    int lost = 0;
+    if (R * 8 <= c->N && c->N >= 65536) {              // bet on a sampled cut; retry once deeper, then give up betting
+        HG_TRY(real_attempt(c, R, true, 6.0, 3.0, with_ap, &lost));
+        if (!lost) { c->real_lists = true; return HG_OK; }
+        HG_TRY(real_attempt(c, R, true, 16.0, 6.0, with_ap, &lost));
+        if (!lost) { c->real_lists = true; return HG_OK; }
+    }
+    HG_TRY(real_attempt(c, R, false, 0.0, 0.0, with_ap, &lost));
+    if (lost) return fail(HG_ERR_HIP, "real-valued ranking: internal error, exhaustive pass came up short");
+    c->real_lists = true;
+    return HG_OK;
+}
+
+int hg_topr_real(hg_ctx* c, int64_t R) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_topr_real", "hg_set_database_f32 + hg_set_queries_f32"));
+    return run_real(c, R, false);
+}
+
+int hg_map_real(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_map_real", "hg_set_database_f32 + hg_set_queries_f32"));
+    HG_TRY(run_real(c, R, true));
+    return hg_get_ap(c, host_ap, host_rel);
+}
+
+int hg_get_topr_real(hg_ctx* c, uint32_t* host_idx, float* host_scores) {
+    HG_TRY(need(c, ST_SELECT, "hg_get_topr_real", "hg_topr_real / hg_map_real"));
+    if (!c->real_lists) return fail(HG_ERR_STATE, "hg_get_topr_real: the last ranking was not a real-valued one");
+    const size_t slots = (size_t)c->geo.Q * c->geo.R;
+    if (host_idx) HG_HIP(hipMemcpyAsync(host_idx, c->out_idx.p, slots * 4, hipMemcpyDeviceToHost, c->stream));
+    if (host_scores) HG_HIP(hipMemcpyAsync(host_scores, c->scores.p, slots * 4, hipMemcpyDeviceToHost, c->stream));
+    return c->sync();
 }
 
 int hg_get_topr(hg_ctx* c, uint32_t* host_idx, uint8_t* host_dist) {

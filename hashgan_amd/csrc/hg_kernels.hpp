@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
 // Also counts entries outside {-1, 0, +1} (codes) / {0, 1} (labels) so the host can refuse
 // inputs that are not binary codes instead of silently ranking something else.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_sign_f32(const float* __restrict__ x, u32* __restrict__ out, i64 n, int b,
+__global__ __launch_bounds__(256) void k_pack_sign_f32(const float* __restrict__ x, i64 ld, u32* __restrict__ out, i64 n, int b,
                                                        int NW, unsigned long long* __restrict__ bad) {
     const int lane = threadIdx.x & 63;
     const i64 r = (i64)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_pack_sign_f32(const float* __restrict__
     u32 nbad = 0;
     for (int c0 = 0; c0 < b; c0 += 64) {
         const int col = c0 + lane;
-        const float v = col < b ? x[r * b + col] : 0.0f;
+        const float v = col < b ? x[r * ld + col] : 0.0f;     // ld: row pitch of the (zero-padded) feature table
         nbad += !(v == 1.0f || v == -1.0f || v == 0.0f);
         const u64 word = __ballot(v > 0.0f);
         const int w = c0 >> 5;

@@ -9,12 +9,13 @@ plus the spellings BASELINE.json's north star names (query first):
     MAP(query_codes, db_codes, query_labels, db_labels, R)
     calc_map(query_codes, db_codes, query_labels, db_labels, R)
 
-Inputs are binary codes (+-1 features or {0,1} bits; bit = value > 0) and {0,1}
-label matrices.  Ranking is by Hamming distance with ties broken by ascending
-database index (the canonical order; for +-1 codes exactly the order of
-np.argsort(-np.dot(q, db.T)) once ties are broken by index).  All ranking work
-runs in the HIP kernels behind hashgan_amd._native; the host only packs bits
-and takes the final mean (metric.py:24).
+Binary codes (+-1 features or {0,1} bits) are ranked by Hamming distance with ties broken by
+ascending database index -- for +-1 codes exactly the order of np.argsort(-np.dot(q, db.T))
+once ties are broken by index.  Real-valued features (HashGAN's tanh outputs, what main.py
+feeds when nothing is binarised) are ranked by float32 inner product like metric.py:13-14
+(MAPs only; `binarize=True` applies sign() first instead).  Labels are {0,1} matrices.  All
+ranking work runs in the HIP kernels behind hashgan_amd._native; the host only checks
+arguments and takes the final mean (metric.py:24).
 """
 import warnings
 
@@ -117,7 +118,7 @@ def _engine(device):
     return _engines[device]
 
 
-def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, binarize=False):
+def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, binarize=False, real="rank"):
     db_codes, q_codes = np.asarray(db_codes), np.asarray(q_codes)
     db_labels, q_labels = np.asarray(db_labels), np.asarray(q_labels)
     if db_codes.ndim != 2 or q_codes.ndim != 2 or db_codes.shape[1] != q_codes.shape[1]:
@@ -139,9 +140,15 @@ def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, binarize=False)
     if bad_l or qbad_l:
         raise ValueError("labels must be {0,1} indicator matrices")
     if (bad_c or qbad_c) and not binarize:
-        raise ValueError("features are not binary codes ({-1,+1} or {0,1}); binarise them first "
-                         "(np.sign) or use MAPs(R, binarize=True)")
-    ap, rel = eng.average_precisions(R)
+        # real-valued features (HashGAN's tanh outputs): rank by inner product like metric.py:13-14
+        if real == "error":
+            raise ValueError("features are not binary codes ({-1,+1} or {0,1}); binarise them first "
+                             "(np.sign), use binarize=True, or allow the inner-product ranking")
+        if db_codes.shape[1] > 128:
+            raise ValueError("inner-product ranking supports up to 128 features (have %d)" % db_codes.shape[1])
+        ap, rel = eng.ctx.map_real(R)
+    else:
+        ap, rel = eng.average_precisions(R)
     return mean_over_hits(ap, rel), ap, rel
 
 
@@ -167,8 +174,9 @@ class MAPs:
 
 
 def MAP(query_codes, db_codes, query_labels, db_labels, R, device=0):
-    """mAP@R of binary codes, query-first argument order (BASELINE.json north star)."""
-    return _evaluate(query_codes, db_codes, query_labels, db_labels, int(R), device)[0]
+    """mAP@R of binary codes, query-first argument order (BASELINE.json north star).  Codes must
+    be binary ({0,1} or +-1); real-valued features belong to MAPs.get_maps_by_feature."""
+    return _evaluate(query_codes, db_codes, query_labels, db_labels, int(R), device, real="error")[0]
 
 
 calc_map = MAP

@@ -141,6 +141,17 @@ int hg_merge_topr(hg_ctx* ctx, const uint32_t* dev_idx_all, const uint8_t* dev_d
 int hg_topr(hg_ctx* ctx, int64_t R);
 int hg_map(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel);
 
+/* ---- real-valued features (what main.py feeds when nothing is binarised) ----
+ * Ranking by float32 inner product, lib/metric.py:13-14 as written, on the float tables kept by
+ * hg_set_database_f32 / hg_set_queries_f32 (b <= 128, one shard).  Order: inner product descending,
+ * database index ascending.  The product's summation order is fixed (even-k and odd-k float32 fma
+ * chains, then their sum) and restated exactly by oracle/real_map.py; it equals the reference's
+ * np.dot wherever float32 rounding does not reorder near-equal products, exactly so on inputs
+ * whose arithmetic is exact.  hg_map_real = ranking + label match + AP; hg_topr_real = ranking only. */
+int hg_map_real(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel);
+int hg_topr_real(hg_ctx* ctx, int64_t R);
+int hg_get_topr_real(hg_ctx* ctx, uint32_t* host_idx, float* host_scores);   /* [Q][R] each */
+
 /* ---- results to the host ----------------------------------------------------- */
 int hg_get_topr(hg_ctx* ctx, uint32_t* host_idx, uint8_t* host_dist);   /* [Q][R] each */
 int hg_get_match(hg_ctx* ctx, uint8_t* host_imatch);                    /* [Q][R] of 0/1 */

@@ -1,0 +1,74 @@
+"""Real-valued feature ranking on the GPU (hg_map_real / hg_topr_real) against
+the oracle's exact restatement (oracle/real_map.py) and the unmodified reference's goldens."""
+import types
+import warnings
+import numpy as np
+import pytest
+from tests import cases
+from oracle import real_map as RM
+from hashgan_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def _load(ctx, c):
+    assert ctx.set_database_f32(c["dbf"], c["dblab"].astype(np.int64))[1] == 0
+    assert ctx.set_queries_f32(c["qf"], c["qlab"].astype(np.int64))[1] == 0
+
+
+@pytest.mark.parametrize("name", list(cases.REAL_CASES))
+def test_grid_features_match_reference_golden(name, ctx):
+    """Grid features: float arithmetic is exact, so the GPU must reproduce the UNMODIFIED reference."""
+    c = cases.build_real_case(name)
+    g = cases.load_golden(name)
+    _load(ctx, c)
+    ap, rel = ctx.map_real(c["R"])
+    assert np.array_equal(ap, g["ap"], equal_nan=True), name
+    assert np.mean(ap[rel != 0]) == g["map"]
+    idx, score = ctx.topr_real(c["R"])
+    if "idx" in g:
+        assert np.array_equal(idx, g["idx"]), name
+    exact = np.einsum("qb,qrb->qr", c["qf"].astype(np.float64), c["dbf"].astype(np.float64)[idx.astype(np.int64)])
+    assert np.array_equal(score.astype(np.float64), exact)
+
+
+@pytest.mark.parametrize("Q,N,b,R,C", [(40, 3000, 20, 700, 7), (65, 70000, 64, 2500, 10), (10, 2000, 128, 2000, 3),
+                                       (3, 500, 1, 40, 2), (33, 5000, 33, 1200, 70)])
+def test_generic_float_features_match_oracle_bit_for_bit(Q, N, b, R, C, ctx):
+    """Arbitrary float32 features (tanh of Gaussians): the kernel's summation order is restated
+    exactly by the oracle (fma32 chains), so scores, order and AP agree bit for bit."""
+    rng = np.random.default_rng(Q * 7 + b)
+    dbf = np.tanh(rng.standard_normal((N, b))).astype(np.float32)
+    qf = np.tanh(rng.standard_normal((Q, b))).astype(np.float32)
+    dbf[N // 3] = dbf[N // 3 + 1]                                  # a duplicated row: exact tie, index order
+    dl = (rng.random((N, C)) < 0.25).astype(np.int8)
+    ql = (rng.random((Q, C)) < 0.25).astype(np.int8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, ap_ref, idx_ref, score_ref = RM.map_from_features(qf, dbf, ql, dl, R)
+    ctx.set_database_f32(dbf, dl.astype(np.int64))
+    ctx.set_queries_f32(qf, ql.astype(np.int64))
+    idx, score = ctx.topr_real(R)
+    assert np.array_equal(score.view(np.uint32), score_ref.view(np.uint32))
+    assert np.array_equal(idx, idx_ref)
+    ap, rel = ctx.map_real(R)
+    assert np.array_equal(ap, ap_ref, equal_nan=True)
+
+
+def test_python_surface_ranks_real_features_like_the_reference():
+    """MAPs(R).get_maps_by_feature on tanh-like features = the reference's own semantics."""
+    from hashgan_amd import MAPs, MAP
+    c = cases.build_real_case("real_multi")
+    g = cases.load_golden("real_multi")
+    database = types.SimpleNamespace(output=c["dbf"], label=c["dblab"].astype(np.int64))
+    query = types.SimpleNamespace(output=c["qf"], label=c["qlab"].astype(np.int64))
+    assert MAPs(c["R"]).get_maps_by_feature(database, query) == g["map"]
+    with pytest.raises(ValueError):
+        MAP(c["qf"], c["dbf"], c["qlab"], c["dblab"], c["R"])          # MAP() is the binary-code spelling
