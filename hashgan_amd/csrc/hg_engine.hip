@@ -123,6 +123,7 @@ struct hg_ctx {
     i64 opt_sigma = 6;         // safety margin of the guess, in standard deviations of the sample count
     i64 staged_lists = 1;      // staged hg_select materialises the idx/dist lists
     i64 cand_budget_x10 = 40;  // optimistic record budget per query, in tenths of R
+    i64 opt_real_seg_bytes = 512 * 1024;   // real-valued path: bytes of feature rows per segment
 
     // run state
     bool optimistic = false;   // records come from a guessed threshold (fixed-capacity slices)
@@ -377,10 +378,15 @@ template <int BP> int real_launch_sample(hg_ctx* c, i64 M, i64 stride) {
     return c->check_launch("k_real_sample");
 }
 template <int BP> int real_launch_select(hg_ctx* c) {
-    const Geo& g = c->geo;
+    constexpr int QPL = BP <= 32 ? 2 : 1;              // queries per lane (see k_real_select)
+    Geo g = c->geo;
+    g.nQT = (g.Q + 64 * QPL - 1) / (64 * QPL);
+    g.nUnits = (i64)g.S * g.nQT;
+    g.wpb = WPB;
+    g.nBlk = (int)((g.nUnits + WPB - 1) / WPB);
     RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
     c->t_begin(KI_REAL_SELECT);
-    hipLaunchKernelGGL(k_real_select<BP>, dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(),
+    hipLaunchKernelGGL((k_real_select<BP, QPL>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(),
                        c->dbf.as<float>(), a, c->cand.as<u64>(), g);
     c->t_end();
     return c->check_launch("k_real_select");
@@ -1136,6 +1142,19 @@ int hg_map(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
 // one attempt; *lost = some query came up short of R records or overflowed a slice (bet mode only)
 static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double budget, bool with_ap, int* lost) {
     make_geometry(c);
+    {   // Float rows are 4*bpad bytes (32x a 64-bit code): keep a segment's rows within ~512 KB so the few
+        // segments an XCD works on at a time stay in its 4 MiB L2 while all query tiles pass over them.
+        Geo& gg = c->geo;
+        i64 L = (i64)c->opt_real_seg_bytes / ((i64)c->bpad * 4);
+        L = L / 16 * 16;
+        if (L < 64) L = 64;
+        if (gg.L > L) {
+            gg.L = L;
+            gg.S = (int)((gg.N + L - 1) / L);
+            gg.nUnits = (i64)gg.S * gg.nQT;
+            gg.nBlk = (int)((gg.nUnits + WPB - 1) / WPB);
+        }
+    }
     HG_TRY(set_R(c, R, 1, 0));
     const Geo& g = c->geo;
     const size_t qb = (size_t)g.Qpad * 4;
@@ -1321,6 +1340,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_sigma = value;
     } else if (!strcmp(key, "staged_lists")) {
         c->staged_lists = value != 0;
+    } else if (!strcmp(key, "real_segment_bytes")) {
+        if (value < 4096) return fail(HG_ERR_ARG, "real_segment_bytes must be >= 4096");
+        c->opt_real_seg_bytes = value;
     } else if (!strcmp(key, "cand_budget_x10")) {
         if (value < 11 || value > 1000) return fail(HG_ERR_ARG, "cand_budget_x10 must be 11..1000");
         c->cand_budget_x10 = value;

@@ -129,7 +129,10 @@ struct RealSelArgs {
     i64 crow;              // record-row stride
 };
 
-template <int BP>
+// QPL queries per lane: the row stream through the scalar cache (2*BP*4 bytes per row per wave)
+// is the bottleneck of this kernel (measured: ~3 B/clk/CU), so for short feature vectors every
+// lane carries two queries and each scalar-loaded row is used for 128 pairs instead of 64.
+template <int BP, int QPL>
 __global__ __launch_bounds__(256) void k_real_select(const float* __restrict__ qf, const float* __restrict__ dbf,
                                                      const RealSelArgs a, u64* __restrict__ cand, const Geo g) {
     const int lb = logical_block(g.nBlk);
@@ -138,50 +141,68 @@ __global__ __launch_bounds__(256) void k_real_select(const float* __restrict__ q
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const i64 unit = (i64)lb * g.wpb + wave;
     if (unit >= g.nUnits) return;
-    const int s = (int)(unit / g.nQT);
+    const int s = (int)(unit / g.nQT);                        // g.nQT counts tiles of 64*QPL queries here
     const int qt = (int)(unit - (i64)s * g.nQT);
-    const int q = qt * 64 + lane;
-    const bool live = q < g.Q;
-    f2 qv[BP];
+    int q[QPL];
+    bool live[QPL];
+    f2 qv[QPL][BP];
+    float thr[QPL];
+    u64* wp[QPL];
+    u64* wp0[QPL];
+    u32 room[QPL], dropped[QPL];
 #pragma unroll
-    for (int p = 0; p < BP; ++p) qv[p] = live ? ((const f2*)(qf + (i64)q * 2 * BP))[p] : f2{0.0f, 0.0f};
-    const float thr = live ? a.thr[q] : __uint_as_float(0x7F800000u);   // +inf: nothing qualifies
-    const i64 so = (i64)s * g.Qpad + q;
-    u64* __restrict__ wp = cand + (i64)(live ? q : 0) * a.crow + (i64)s * a.cap;
-    u64* const wp0 = wp;
-    u32 room = a.cap, dropped = 0;
+    for (int u = 0; u < QPL; ++u) {
+        q[u] = (qt * QPL + u) * 64 + lane;
+        live[u] = q[u] < g.Q;
+#pragma unroll
+        for (int p = 0; p < BP; ++p) qv[u][p] = live[u] ? ((const f2*)(qf + (i64)q[u] * 2 * BP))[p] : f2{0.0f, 0.0f};
+        thr[u] = live[u] ? a.thr[q[u]] : __uint_as_float(0x7F800000u);   // +inf: nothing qualifies
+        wp[u] = cand + (i64)(live[u] ? q[u] : 0) * a.crow + (i64)s * a.cap;
+        wp0[u] = wp[u];
+        room[u] = a.cap;
+        dropped[u] = 0;
+    }
     const i64 lo = (i64)s * g.L;
     const i64 hi = lo + g.L < g.N ? lo + g.L : g.N;
 
-    auto drain = [&](u64 hm, i64 n0, int cnt) {               // bit cnt-1-j <-> row n0+j
-        while (__any(hm != 0ull)) {
-            if (hm != 0ull) {
-                const int k = 63 - __clzll((long long)hm);
-                hm ^= 1ull << k;
-                const i64 nr = n0 + (cnt - 1 - k);
-                const float ip = ip_row<BP>(qv, (const f2*)(dbf + nr * 2 * BP));   // per-lane re-read (L2)
-                if (room) {
-                    *wp = ((u64)(~mono_key(ip)) << 32) | (u64)(g.idx_base + (u32)nr);
-                    ++wp;
-                    --room;
-                } else {
-                    ++dropped;
+    for (i64 n0 = lo; n0 < hi; n0 += 64) {
+        const int cnt = (int)(hi - n0 < 64 ? hi - n0 : 64);
+        u64 hm[QPL];
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) hm[u] = 0;
+        for (int j = 0; j < cnt; ++j) {                       // wave-uniform rows: scalar loads
+            const f2* __restrict__ row = (const f2*)(dbf + (n0 + j) * 2 * BP);
+#pragma unroll
+            for (int u = 0; u < QPL; ++u) {
+                const float ip = ip_row<BP>(qv[u], row);
+                hm[u] = (hm[u] << 1) | (u64)(__float_as_uint(thr[u] - ip) >> 31);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) {                       // drain: bit cnt-1-j <-> row n0+j
+            u64 m = hm[u];
+            while (__any(m != 0ull)) {
+                if (m != 0ull) {
+                    const int k = 63 - __clzll((long long)m);
+                    m ^= 1ull << k;
+                    const i64 nr = n0 + (cnt - 1 - k);
+                    const float ip = ip_row<BP>(qv[u], (const f2*)(dbf + nr * 2 * BP));   // per-lane re-read (L2)
+                    if (room[u]) {
+                        *wp[u] = ((u64)(~mono_key(ip)) << 32) | (u64)(g.idx_base + (u32)nr);
+                        ++wp[u];
+                        --room[u];
+                    } else {
+                        ++dropped[u];
+                    }
                 }
             }
         }
-    };
-
-    for (i64 n0 = lo; n0 < hi; n0 += 64) {
-        const int cnt = (int)(hi - n0 < 64 ? hi - n0 : 64);
-        u64 hm = 0;
-        for (int j = 0; j < cnt; ++j) {                       // wave-uniform rows: scalar loads
-            const float ip = ip_row<BP>(qv, (const f2*)(dbf + (n0 + j) * 2 * BP));
-            hm = (hm << 1) | (u64)(__float_as_uint(thr - ip) >> 31);
-        }
-        if (__any(hm != 0ull)) drain(hm, n0, cnt);
     }
-    a.sl_cnt[so] = (u32)(wp - wp0);
-    if (dropped && live) a.fail[q] = 1u;
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+        if (q[u] < g.Qpad) a.sl_cnt[(i64)s * g.Qpad + q[u]] = (u32)(wp[u] - wp0[u]);
+        if (dropped[u] && live[u]) a.fail[q[u]] = 1u;
+    }
 }
 
 // ----------------------------------------------------------------------------

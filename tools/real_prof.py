@@ -1,0 +1,10 @@
+import numpy as np, sys
+sys.path.insert(0,"/root/repo")
+from hashgan_amd import _native
+rng=np.random.default_rng(0)
+Q,N,b,R=10000,1000000,64,5000
+dbf=np.tanh(rng.standard_normal((N,b))).astype(np.float32); qf=np.tanh(rng.standard_normal((Q,b))).astype(np.float32)
+dl=np.zeros((N,10),np.int64); dl[np.arange(N),rng.integers(0,10,N)]=1
+ql=np.zeros((Q,10),np.int64); ql[np.arange(Q),rng.integers(0,10,Q)]=1
+ctx=_native.Context(0); ctx.set_database_f32(dbf,dl); ctx.set_queries_f32(qf,ql)
+for _ in range(2): ctx.map_real(R)
