@@ -139,7 +139,7 @@ struct hg_ctx {
     // device state
     DevBuf db, dblab, qc, qlab;
     DevBuf hist, hown, posbase, seglt, segtie;
-    DevBuf t, tguess, cnt_lt, quota, tie_before, n_lt, err;
+    DevBuf t, tguess, sstar, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
     DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist, hwq;
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
@@ -260,7 +260,7 @@ template <int NW> int launch_hist_t(hg_ctx* c) {
 template <int NW, int LW, bool OPT> int launch_select_t(hg_ctx* c) {
     const Geo& g = c->geo;
     SelArgs a{c->optimistic ? c->tguess.as<int>() : c->t.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(),
-              c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, c->optimistic ? 1 : 0};
+              c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, c->optimistic ? 1 : 0, c->sstar.as<int>()};
     c->t_begin(KI_SELECT);
     hipLaunchKernelGGL((k_select<NW, LW, OPT>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), a, c->cand.as<u64>(), g);
@@ -271,7 +271,7 @@ template <int NW, int LW, bool OPT> int launch_select_t(hg_ctx* c) {
 template <int NW, int LW> int launch_select_dense_t(hg_ctx* c) {
     const Geo& g = c->geo;
     SelArgs a{c->t.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
-              c->cap, c->crow, 0};
+              c->cap, c->crow, 0, nullptr};
     c->t_begin(KI_SELECT);
     hipLaunchKernelGGL((k_select_dense<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), a, c->cand.as<u64>(), g);
@@ -446,7 +446,7 @@ int hg_destroy(hg_ctx* c) {
     c->t_collect();
     for (auto e : c->pool) (void)hipEventDestroy(e);
     DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
-                     &c->t, &c->tguess, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
+                     &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
                      &c->sortA, &c->sortB, &c->scores};
@@ -913,8 +913,11 @@ int hg_guess(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank
     HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
     HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
     c->t_begin(KI_GUESS);
+    const Geo gh = hist_geometry(c);                   // the sampled pass ran on coarser segments
+    HG_TRY(c->sstar.reserve(qb));
     hipLaunchKernelGGL(k_guess, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(), (const u32*)dev_hist_all, G,
-                       (double)c->opt_sigma, (i64)c->n_total, c->tguess.as<int>(), g);
+                       rank, c->hist.as<u32>(), gh.S, (int)(gh.L / g.L), (double)c->opt_sigma, (i64)c->n_total,
+                       c->tguess.as<int>(), c->sstar.as<int>(), g);
     c->t_end();
     HG_TRY(c->check_launch("k_guess"));
     // a guessed cut keeps at most ~2.6 R rows over ALL shards; a shard's share is proportional to its size,
@@ -1022,8 +1025,11 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
     HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
     c->t_begin(KI_GUESS);
-    hipLaunchKernelGGL(k_guess, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(), (const u32*)nullptr, 1,
-                       (double)c->opt_sigma, (i64)c->n_total, c->tguess.as<int>(), g);
+    const Geo gh = hist_geometry(c);                   // the sampled pass ran on coarser segments
+    HG_TRY(c->sstar.reserve(qb));
+    hipLaunchKernelGGL(k_guess, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(), (const u32*)nullptr, 1, 0,
+                       c->hist.as<u32>(), gh.S, (int)(gh.L / g.L), (double)c->opt_sigma, (i64)c->n_total,
+                       c->tguess.as<int>(), c->sstar.as<int>(), g);
     c->t_end();
     HG_TRY(c->check_launch("k_guess"));
     // slice capacity: a guessed cut typically keeps 1.3-3 R rows (the guess overshoots by at most one

@@ -277,8 +277,20 @@ __global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ segl
 // count reaches f*R + sigma*sqrt(f*R) + 1, i.e. #(dist <= T over all rows) >= R all but
 // certainly.  The guess is only a performance bet: the records' exact histogram goes through
 // k_plan afterwards (k_rank_fused) and a lost bet reruns the exact path.
-__global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, const u32* __restrict__ hall, int G,
-                                               double sigma, i64 n_total, int* __restrict__ T, const Geo g) {
+// The cut bucket T is usually far larger than what is still missing below it (its first `quota` rows
+// in index order are all that can enter the list), so the guess is two-dimensional: T, and the last
+// segment `sstar` up to which rows AT distance T are still collected -- the smallest prefix of the
+// database (lower-ranked shards first, then this shard's segments in order) whose sampled count of
+// {dist < T} + {dist == T inside the prefix} reaches the same `need`.  Segments past sstar select
+// dist < T only.  Exactness is untouched: the records at distance T form a prefix in index order,
+// so either that prefix holds the true quota (the plan finds t = T with the right first rows) or the
+// records come up short of R and the bet is lost.
+// hseg: this shard's per-segment sample histograms [Sh][NB][Qpad] (k_hist's raw output), Sh segments
+// of `ratio` select-segments each.
+__global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, const u32* __restrict__ hall, int G, int rank,
+                                               const u32* __restrict__ hseg, int Sh, int ratio,
+                                               double sigma, i64 n_total, int* __restrict__ T, int* __restrict__ sstar,
+                                               const Geo g) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= g.Q) return;
     const i64 plane = (i64)g.NB * g.Qpad + TAIL_WORDS;
@@ -289,15 +301,33 @@ __global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, const
     const double fr = (double)g.R * (double)sampled / (double)n_total;
     const double needd = fr + sigma * sqrt(fr) + 1.0;
     const u64 need = (u64)ceil(needd);
-    u64 cum = 0;
+    u64 cum = 0, below = 0;
     int t = g.NB - 1;                                  // sample too thin: take everything
+    bool found = false;
     for (int d = 0; d < g.NB; ++d) {
         const i64 o = (i64)d * g.Qpad + q;
+        below = cum;
         if (G > 1) for (int r = 0; r < G; ++r) cum += hall[(i64)r * plane + o];
         else cum += hs[o];
-        if (cum >= need) { t = d; break; }
+        if (cum >= need) { t = d; found = true; break; }
     }
     T[q] = t;
+    int ss = g.S - 1;                                  // default: collect distance T everywhere
+    if (found) {
+        u64 have = below;                              // {dist < T} everywhere ...
+        const i64 ot = (i64)t * g.Qpad + q;
+        if (G > 1) for (int r = 0; r < rank; ++r) have += hall[(i64)r * plane + ot];   // ... + {dist == T} on lower shards
+        if (have >= need) {
+            ss = -1;                                   // the lower shards already hold the prefix
+        } else {
+            for (int sh = 0; sh < Sh; ++sh) {
+                have += hseg[((i64)sh * g.NB + t) * g.Qpad + q];
+                if (have >= need) { ss = (sh + 1) * ratio - 1; break; }
+            }
+            if (ss > g.S - 1) ss = g.S - 1;
+        }
+    }
+    sstar[q] = ss;
 }
 
 // ----------------------------------------------------------------------------
@@ -326,6 +356,7 @@ struct SelArgs {
     u32 cap;               // optimistic mode: slice capacity (records)
     i64 crow;              // record-row stride
     int optimistic;
+    const int* sstar;      // optimistic mode: [Qpad] last segment that still collects dist == T (k_guess)
 };
 
 constexpr int sel_batch_rows(int nw) {          // rows per scalar-load batch: <= 64 SGPRs of code words, <= 32 rows
@@ -373,7 +404,9 @@ __global__ __launch_bounds__(256) void k_select(const u32* __restrict__ qc, cons
     u64 ql[LWA];
 #pragma unroll
     for (int w = 0; w < LWA; ++w) ql[w] = (LW > 0 && live) ? qlab[(i64)q * LW + w] : 0ull;
-    const int T = live ? a.T[q] : -1;                 // -1: nothing is ever selected
+    // -1: nothing is ever selected.  Optimistic mode: past the query's last tie-collecting segment
+    // only rows strictly closer than the guessed cut are taken.
+    const int T = live ? (OPT ? a.T[q] - (s > a.sstar[q] ? 1 : 0) : a.T[q]) : -1;
     const u32 bias = (u32)(-T - 1);                   // dist + bias < 0  <=>  dist <= T
     const i64 so = (i64)s * g.Qpad + q;
     u32 start, tielim = 0xFFFFFFFFu;
