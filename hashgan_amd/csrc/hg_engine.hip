@@ -124,6 +124,7 @@ struct hg_ctx {
     i64 staged_lists = 1;      // staged hg_select materialises the idx/dist lists
     i64 cand_budget_x10 = 40;  // optimistic record budget per query, in tenths of R
     i64 opt_real_seg_bytes = 512 * 1024;   // real-valued path: bytes of feature rows per segment
+    i64 opt_real_qpl = 1;      // real-valued path: queries per lane (1 or 2)
 
     // run state
     bool optimistic = false;   // records come from a guessed threshold (fixed-capacity slices)
@@ -377,8 +378,7 @@ template <int BP> int real_launch_sample(hg_ctx* c, i64 M, i64 stride) {
     c->t_end();
     return c->check_launch("k_real_sample");
 }
-template <int BP> int real_launch_select(hg_ctx* c) {
-    constexpr int QPL = BP <= 32 ? 2 : 1;              // queries per lane (see k_real_select)
+template <int BP, int QPL> int real_launch_select_q(hg_ctx* c) {
     Geo g = c->geo;
     g.nQT = (g.Q + 64 * QPL - 1) / (64 * QPL);
     g.nUnits = (i64)g.S * g.nQT;
@@ -390,6 +390,11 @@ template <int BP> int real_launch_select(hg_ctx* c) {
                        c->dbf.as<float>(), a, c->cand.as<u64>(), g);
     c->t_end();
     return c->check_launch("k_real_select");
+}
+template <int BP> int real_launch_select(hg_ctx* c) {
+    // queries per lane (see k_real_select): two while their features fit the register file comfortably
+    if (BP <= 32 && c->opt_real_qpl == 2) return real_launch_select_q<BP, (BP <= 32 ? 2 : 1)>(c);
+    return real_launch_select_q<BP, 1>(c);
 }
 #define HG_DISPATCH_BP(fn, c, ...)                                  \
     switch ((c)->bpad / 2) {                                        \
@@ -1216,8 +1221,10 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     HG_TRY(c->scores.reserve(slots * 4));
     HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
     c->t_begin(KI_REAL_FINISH);
-    hipLaunchKernelGGL(k_real_finish, dim3(grid_for(g.R), g.Q), dim3(256), 0, c->stream, in, c->crow, c->tot.as<u32>(),
-                       c->out_idx.as<u32>(), c->scores.as<float>(), c->err.as<int>(), c->qbad.as<u32>(), g);
+    const i64 nKB = grid_for(g.R);
+    if (nKB * g.Q > 0x7FFFFFFFll) return fail(HG_ERR_ARG, "real-valued ranking: Q*R too large for one launch");
+    hipLaunchKernelGGL(k_real_finish, dim3((unsigned)(nKB * g.Q)), dim3(256), 0, c->stream, in, c->crow, c->tot.as<u32>(),
+                       c->out_idx.as<u32>(), c->scores.as<float>(), c->err.as<int>(), c->qbad.as<u32>(), (int)nKB, g);
     c->t_end();
     HG_TRY(c->check_launch("k_real_finish"));
     c->stage = ST_DB | ST_Q | ST_SELECT;
@@ -1232,7 +1239,6 @@ static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
         return fail(HG_ERR_STATE, "real-valued ranking needs float features: load them with hg_set_database_f32 / hg_set_queries_f32");
     if (c->n_total != c->N) return fail(HG_ERR_STATE, "real-valued ranking is single-shard");
     if (R < 1 || R > c->N) return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->N);
-    if (c->Q > 65535) return fail(HG_ERR_ARG, "real-valued ranking: at most 65535 queries per call");
     int lost = 0;
     if (R * 8 <= c->N && c->N >= 65536) {              // bet on a sampled cut; retry once deeper, then give up betting
         HG_TRY(real_attempt(c, R, true, 6.0, 3.0, with_ap, &lost));
@@ -1346,6 +1352,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_sigma = value;
     } else if (!strcmp(key, "staged_lists")) {
         c->staged_lists = value != 0;
+    } else if (!strcmp(key, "real_queries_per_lane")) {
+        if (value != 1 && value != 2) return fail(HG_ERR_ARG, "real_queries_per_lane must be 1 or 2");
+        c->opt_real_qpl = value;
     } else if (!strcmp(key, "real_segment_bytes")) {
         if (value < 4096) return fail(HG_ERR_ARG, "real_segment_bytes must be >= 4096");
         c->opt_real_seg_bytes = value;

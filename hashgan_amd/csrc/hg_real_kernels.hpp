@@ -4,8 +4,8 @@
 // features in VGPRs), database rows wave-uniform through scalar loads, hit masks + drain.
 //
 // Arithmetic (fixed, restated exactly by oracle/real_map.py):
-//   ip = (fma chain over even k + fma chain over odd k) + 0.0   in float32, k ascending;
-// both chains advance in one v_pk_fma_f32.  Ranking: ip descending, database index ascending.
+//   ip = ((c0 + c1) + (c2 + c3)) + 0.0, c_j = float32 fma chain over k = j mod 4, k ascending;
+// two v_pk_fma_f32 accumulators carry the four chains.  Ranking: ip descending, database index ascending.
 // Sortable record: (~mono(ip) << 32) | idx, mono() = the usual order-preserving map of float
 // bits to unsigned; ascending records = descending ip, ascending index.
 #pragma once
@@ -24,12 +24,17 @@ __device__ __forceinline__ float mono_inv(u32 k) {
     return __uint_as_float(b);
 }
 
-template <int BP>   // BP = padded feature count / 2
+template <int BP>   // BP = padded feature count / 2 (a multiple of 8)
 __device__ __forceinline__ float ip_row(const f2 (&q)[BP], const f2* __restrict__ row) {
-    f2 acc = {0.0f, 0.0f};
+    // four float32 fma chains, k mod 4 (two independent v_pk_fma_f32 accumulators: half the dependent
+    // chain length of a single one), combined as ((c0 + c1) + (c2 + c3)) + 0.0
+    f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
 #pragma unroll
-    for (int p = 0; p < BP; ++p) acc = __builtin_elementwise_fma(q[p], row[p], acc);
-    return (acc.x + acc.y) + 0.0f;
+    for (int p = 0; p < BP; p += 2) {
+        a = __builtin_elementwise_fma(q[p], row[p], a);
+        b = __builtin_elementwise_fma(q[p + 1], row[p + 1], b);
+    }
+    return ((a.x + a.y) + (b.x + b.y)) + 0.0f;
 }
 
 // ----------------------------------------------------------------------------
@@ -303,9 +308,9 @@ __global__ __launch_bounds__(NWAV * 64) void k_radix_pass(const u64* __restrict_
 // fewer than R records (guess too high) or an overflowed slice is flagged for the host.
 __global__ __launch_bounds__(256) void k_real_finish(const u64* __restrict__ sorted, i64 crow, const u32* __restrict__ tot,
                                                      u32* __restrict__ out_idx, float* __restrict__ scores,
-                                                     int* __restrict__ err, u32* __restrict__ qbad, const Geo g) {
-    const int q = blockIdx.y;
-    const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
+                                                     int* __restrict__ err, u32* __restrict__ qbad, int nKB, const Geo g) {
+    const int q = (int)(blockIdx.x / (u32)nKB);                  // nKB = ceil(R / 256) blocks per query
+    const i64 k = (i64)(blockIdx.x - (u32)q * (u32)nKB) * 256 + threadIdx.x;
     const u32 n = tot[q];
     const bool bad = n == 0xFFFFFFFFu || (i64)n < g.R;
     if (k == 0) { qbad[q] = bad ? 1u : 0u; if (bad) atomicExch(err, 1); }
