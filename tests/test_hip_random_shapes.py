@@ -1,6 +1,7 @@
 """Randomised small shapes through the whole HIP path against the oracle: odd Q/N/b/R/C, tiny
 and degenerate sizes, heavy ties (few bits), high and low R/N, multi-hot and empty-label rows,
 every segment geometry the engine may pick.  Bit-exact AP, ranked lists, match bits."""
+import os
 import warnings
 import numpy as np
 import pytest
@@ -44,10 +45,11 @@ def _one(ctx, rng, Q, N, b, R, C, kind):
 
 
 def test_random_small_shapes():
-    rng = np.random.default_rng(20260928)
+    iters = int(os.environ.get("HG_RANDOM_ITERS", "60"))           # a longer campaign: HG_RANDOM_ITERS=1000
+    rng = np.random.default_rng(20260928 + iters)
     ctx = _native.Context(0)
     try:
-        for it in range(60):
+        for it in range(iters):
             b = int(rng.choice([1, 2, 5, 8, 16, 31, 32, 33, 48, 63, 64, 65, 96, 100, 128, 129, 200, 256]))
             Q = int(rng.choice([1, 2, 63, 64, 65, 100, 130]))
             N = int(rng.choice([1, 2, 15, 16, 17, 255, 256, 257, 1000, 4097]))
@@ -83,5 +85,32 @@ def test_random_bet_shapes():
             ctx.topr(R)
             idx, dist = ctx.get_topr()
             assert np.array_equal(idx, idx_ref) and np.array_equal(dist, dist_ref), (b, C, R)
+    finally:
+        ctx.close()
+
+
+def test_very_long_lists_use_the_global_bit_rows():
+    """R beyond what a block's LDS bitmap holds (~0.5M slots): match bits go through global atomics
+    on a zeroed row instead.  One shard and two virtual shards' worth of plan (staged, G = 1)."""
+    rng = np.random.default_rng(11)
+    Q, N, b, R, C = 3, 600000, 32, 530000, 4
+    qb = rng.integers(0, 2, (Q, b), dtype=np.uint8)
+    db = rng.integers(0, 2, (N, b), dtype=np.uint8)
+    dl = (rng.random((N, C)) < 0.3).astype(np.int8)
+    ql = (rng.random((Q, C)) < 0.5).astype(np.int8)
+    ql[:, 0] = 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, im_ref, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
+    ctx = _native.Context(0)
+    try:
+        ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
+        ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
+        ap, rel = ctx.map(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        ctx.topr(R)
+        idx, dist = ctx.get_topr()
+        assert np.array_equal(idx, idx_ref) and np.array_equal(dist, dist_ref)
+        assert np.array_equal(ctx.get_match().astype(bool), im_ref)
     finally:
         ctx.close()
