@@ -62,6 +62,7 @@ _SIGNATURES = {
     "hg_set_stream": [_p, _p],
     "hg_set_option": [_p, C.c_char_p, _i64],
     "hg_get_stat": [_p, C.c_char_p, C.POINTER(_i64)],
+    "hg_trim": [_p],
     "hg_timing_enable": [_p, C.c_int],
     "hg_timing_reset": [_p],
     "hg_timing_read": [_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_int)],
@@ -301,6 +302,10 @@ class Context:
 
     def set_option(self, key, value):
         check(self._lib.hg_set_option(self._h, key.encode(), int(value)))
+
+    def trim(self):
+        """Free the work buffers (they only grow); the loaded tables stay."""
+        check(self._lib.hg_trim(self._h))
 
     def get_stat(self, key):
         v = _i64()

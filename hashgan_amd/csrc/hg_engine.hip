@@ -1367,12 +1367,38 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     return HG_OK;
 }
 
+// Work buffers only grow (a big call leaves gigabytes behind for the next one to reuse); hg_trim
+// gives everything but the resident tables back.
+int hg_trim(hg_ctx* c) {
+    if (!c) return fail(HG_ERR_ARG, "hg_trim: null context");
+    HG_TRY(c->use());
+    HG_TRY(c->sync());
+    DevBuf* work[] = {&c->hist, &c->seglt, &c->segtie, &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->cand, &c->out_idx,
+                      &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->scores};
+    for (auto* d : work) d->release();
+    if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
+    c->stage &= (ST_DB | ST_Q);
+    c->lists_valid = false;
+    c->real_lists = false;
+    return HG_OK;
+}
+
 int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     if (!c || !key || !value) return fail(HG_ERR_ARG, "hg_get_stat: null argument");
     if (!strcmp(key, "optimistic_runs")) *value = c->opt_runs;
     else if (!strcmp(key, "optimistic_fallbacks")) *value = c->opt_fallbacks;
     else if (!strcmp(key, "optimistic_requeried")) *value = c->opt_requeried;
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
+    else if (!strcmp(key, "device_bytes")) {
+        DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
+                         &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err,
+                         &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
+                         &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
+                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores};
+        i64 total = 0;
+        for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
+        *value = total;
+    }
     else if (!strcmp(key, "segments")) *value = c->geo.S;
     else if (!strcmp(key, "segment_rows")) *value = c->geo.L;
     else if (!strcmp(key, "slice_capacity")) *value = c->cap;

@@ -171,9 +171,12 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * "guess_sigma", "staged_lists" (0/1: hg_select materialises idx/dist lists). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
 /* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
- * (single queries rerun exactly after losing their bet), "last_optimistic", "segments",
+ * (single queries rerun exactly after losing their bet), "last_optimistic", "device_bytes", "segments",
  * "segment_rows", "slice_capacity", "record_row". */
 int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
+/* Work buffers only grow; hg_trim frees everything except the resident code/label/feature tables
+ * (stat "device_bytes" reports what the context holds). */
+int hg_trim(hg_ctx* ctx);
 /* HIP-event timing of every kernel launched on the context's stream. */
 int hg_timing_enable(hg_ctx* ctx, int on);
 int hg_timing_reset(hg_ctx* ctx);

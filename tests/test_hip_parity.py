@@ -252,6 +252,21 @@ def test_single_lost_query_is_rerun_alone(ctx):
     assert np.array_equal(ap2[probe], ap_ref, equal_nan=True)
 
 
+def test_trim_frees_work_buffers_and_keeps_tables(ctx, case_cache):
+    c = case_cache("e_ragged")
+    g = cases.load_golden("e_ragged")
+    _load(ctx, c)
+    ap, _ = ctx.map(c["R"])
+    before = ctx.get_stat("device_bytes")
+    ctx.trim()
+    after = ctx.get_stat("device_bytes")
+    assert after < before
+    with pytest.raises(_native.HashganNativeError):
+        ctx.get_ap()                       # results went with the buffers' stage
+    ap2, _ = ctx.map(c["R"])               # tables are still loaded
+    assert np.array_equal(ap2, g["ap"], equal_nan=True)
+
+
 def test_state_and_argument_errors(ctx, case_cache):
     c = case_cache("e_b8")
     _load(ctx, c)
