@@ -125,6 +125,7 @@ struct hg_ctx {
     i64 cand_budget_x10 = 40;  // optimistic record budget per query, in tenths of R
     i64 opt_real_seg_bytes = 512 * 1024;   // real-valued path: bytes of feature rows per segment
     i64 opt_real_qpl = 1;      // real-valued path: queries per lane (1 or 2)
+    i64 opt_rank_waves = 0;    // k_rank_fused wavefronts per query: 0 = by list length, else 4 or 16
 
     // run state
     bool optimistic = false;   // records come from a guessed threshold (fixed-capacity slices)
@@ -711,7 +712,8 @@ int hg_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank)
 // 1 = histogram phase (several shards, before the exchange), 2 = placement phase (after k_plan).
 static int launch_rank(hg_ctx* c, int mode, int nbits) {
     const Geo& g = c->geo;
-    const int nwav = (c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4;   // records per query ~ 3R / R
+    const int nwav = c->opt_rank_waves ? (int)c->opt_rank_waves
+                                       : ((c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4);   // records per query ~ 3R / R
     const size_t fixed_words = (size_t)(nwav + 1) * g.NB + 8;
     const int bits_lds = (fixed_words + 2 * (size_t)c->RW) * 4 <= 64 * 1024;
     if (mode != 1 && !bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
@@ -1355,6 +1357,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "real_queries_per_lane")) {
         if (value != 1 && value != 2) return fail(HG_ERR_ARG, "real_queries_per_lane must be 1 or 2");
         c->opt_real_qpl = value;
+    } else if (!strcmp(key, "rank_waves")) {
+        if (value != 0 && value != 4 && value != 16) return fail(HG_ERR_ARG, "rank_waves must be 0, 4 or 16");
+        c->opt_rank_waves = value;
     } else if (!strcmp(key, "real_segment_bytes")) {
         if (value < 4096) return fail(HG_ERR_ARG, "real_segment_bytes must be >= 4096");
         c->opt_real_seg_bytes = value;
