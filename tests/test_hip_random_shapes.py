@@ -67,7 +67,7 @@ def test_random_bet_shapes():
     rng = np.random.default_rng(7)
     ctx = _native.Context(0)
     try:
-        for b, C, R in [(24, 5, 2000), (64, 70, 3333), (40, 130, 1000), (100, 10, 5000)]:
+        for b, C, R in [(24, 5, 2000), (64, 70, 3333), (40, 130, 1000), (100, 10, 5000), (64, 10, 1), (32, 3, 7), (48, 10, 100)]:
             Q, N = 97, 70000 + int(rng.integers(0, 999))
             qb = rng.integers(0, 2, (Q, b), dtype=np.uint8)
             db = rng.integers(0, 2, (N, b), dtype=np.uint8)
