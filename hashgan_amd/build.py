@@ -16,7 +16,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libhashgan_amd.so")
 SOURCES = [os.path.join(CSRC, "hg_engine.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "hg_kernels.hpp"), os.path.join(ROOT, "include", "hashgan_amd.h")]
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")] + [
+    os.path.join(ROOT, "include", "hashgan_amd.h")]
 # -ffp-contract=off: k_ap reproduces NumPy's float64 rounding; no fused multiply-adds.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]

@@ -3,6 +3,7 @@
 // every entry point either runs the HIP kernels of hg_kernels.hpp or fails.
 #include "hg_kernels.hpp"
 #include "hg_real_kernels.hpp"
+#include "hg_select_mx.hpp"
 #include "../../include/hashgan_amd.h"
 
 #include <cmath>
@@ -51,7 +52,7 @@ struct DevBuf {
         if (bytes <= cap) return HG_OK;
         if (p && !borrowed) { HG_HIP(hipFree(p)); }
         p = nullptr; cap = 0; borrowed = false;
-        HG_HIP(hipMalloc(&p, bytes));
+        HG_HIP(hipMalloc(&p, bytes + 64));      // slack: 16-byte wide copies may read past the last row of a table
         cap = bytes;
         return HG_OK;
     }
@@ -65,10 +66,10 @@ struct DevBuf {
 
 enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_LAYOUT, KI_GUESS, KI_SELECT, KI_CAND_HIST,
                 KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_PACK, KI_REAL_SAMPLE, KI_REAL_GUESS, KI_REAL_SELECT,
-                KI_RADIX, KI_REAL_FINISH, KI_COUNT };
+                KI_RADIX, KI_REAL_FINISH, KI_SELECT_MX, KI_COUNT };
 const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_layout", "k_guess",
                                             "k_select", "k_rank_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge", "k_pack",
-                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish"};
+                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish", "k_select_mx"};
 
 enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
 
@@ -101,6 +102,7 @@ void build_shape(int n, ApShape& sh) {
 
 struct hg_ctx {
     int device = 0;
+    int n_cu = 256;            // compute units of the device
     hipStream_t stream = nullptr;
     bool own_stream = true;    // false: the stream belongs to the caller (hg_set_stream) or to the parent context
     bool stage_sync = true;    // staged calls synchronise the stream before returning
@@ -126,6 +128,8 @@ struct hg_ctx {
     i64 opt_real_seg_bytes = 512 * 1024;   // real-valued path: bytes of feature rows per segment
     i64 opt_real_qpl = 1;      // real-valued path: queries per lane (1 or 2)
     i64 opt_rank_waves = 0;    // k_rank_fused wavefronts per query: 0 = by list length, else 4 or 16
+    i64 opt_select_mfma = 1;   // optimistic select: 1 = matrix-core kernel (k_select_mx), 0 = vector-ALU k_select
+    i64 opt_select_qt = 4;     // k_select_mx query tiles per wavefront for codes of <= 64 bits (2 or 4)
 
     // run state
     bool optimistic = false;   // records come from a guessed threshold (fixed-capacity slices)
@@ -140,6 +144,8 @@ struct hg_ctx {
 
     // device state
     DevBuf db, dblab, qc, qlab;
+    DevBuf dbx, qx;            // fp4 images of db / qc in MFMA fragment order for k_select_mx (built on first use)
+    bool dbx_valid = false, qx_valid = false;
     DevBuf hist, hown, posbase, seglt, segtie;
     DevBuf t, tguess, sstar, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
@@ -220,6 +226,23 @@ void make_geometry(hg_ctx* c) {
     if (L < 16) L = 16;
     S = (c->N + L - 1) / L;
     if (S < 1) S = 1;
+    if (c->opt_enable && c->opt_select_mfma && S >= 4) {
+        // k_select_mx runs (S / 2) x ceil(Q / 512) equal blocks, 2 resident per CU: pick the S near the
+        // target that fills a whole number of such rounds, so the last round is not a nearly empty one
+        const i64 nQB = (c->Q + 511) / 512;
+        const i64 slots = (i64)c->n_cu * 2;
+        i64 k = (S / 2 * nQB + slots / 2) / slots;
+        if (k < 1) k = 1;
+        i64 S2 = 2 * (slots * k / nQB);
+        if (S2 > maxS) S2 = maxS / 2 * 2;
+        for (; S2 >= 4; S2 -= 2) {                 // rounding L up to 16 rows can drop segments: land on an even count
+            i64 L2 = (c->N + S2 - 1) / S2;
+            L2 = (L2 + 15) / 16 * 16;
+            const i64 Sr = (c->N + L2 - 1) / L2;
+            if (Sr * 4 < S * 3) break;             // too far from the target: keep the plain choice
+            if (Sr % 2 == 0 && Sr * 4 <= S * 5 && (Sr / 2) * nQB <= slots * k) { S = Sr; L = L2; break; }
+        }
+    }
     g.S = (int)S; g.L = L;
     g.nUnits = (i64)g.S * g.nQT;
     g.hist_stride = 1;
@@ -270,6 +293,53 @@ template <int NW, int LW, bool OPT> int launch_select_t(hg_ctx* c) {
     return c->check_launch("k_select");
 }
 
+// matrix-core optimistic select: units = (pair of segments) x (group of 32 QT queries)
+// matrix-core optimistic select: blocks = (pair of segments) x (block of 512 queries)
+template <int NW, int LW> int launch_select_mx_t(hg_ctx* c) {
+    constexpr int NM = (NW + 1) / 2;
+    if (!c->dbx_valid) {
+        const i64 n16 = (c->N + 15) / 16 * 16;
+        HG_TRY(c->dbx.reserve((size_t)(n16 > 0 ? n16 : 16) * NM * 32));
+        const i64 items = n16 * 2 * NM;
+        c->t_begin(KI_PACK);
+        if (items) hipLaunchKernelGGL(k_expand_db, dim3(grid_for(items)), dim3(256), 0, c->stream, c->db.as<u32>(),
+                                      c->dbx.as<uint4>(), (i64)c->N, n16, NW, NM);
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_db"));
+        c->dbx_valid = true;
+    }
+    Geo g = c->geo;
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + 511) / 512;                 // query blocks
+    if (!c->qx_valid) {
+        const i64 qpad = (i64)nQB * 512;
+        HG_TRY(c->qx.reserve((size_t)qpad * NM * 32));
+        const i64 items = qpad * 2 * NM;
+        c->t_begin(KI_PACK);
+        hipLaunchKernelGGL(k_expand_queries, dim3(grid_for(items)), dim3(256), 0, c->stream, c->qc.as<u32>(), c->qx.as<uint4>(),
+                           (i64)c->Q, qpad, NW, NM);
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_queries"));
+        c->qx_valid = true;
+    }
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    const MxLds L = mx_lds_layout(NW, LW);
+    if (L.total > 64 * 1024)
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx<NW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   L.total));
+    SelArgs a{c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
+              c->cap, c->crow, (int)c->opt_select_mfma, c->sstar.as<int>()};
+    c->t_begin(KI_SELECT_MX);
+    hipLaunchKernelGGL((k_select_mx<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total, c->stream, c->qc.as<u32>(),
+                       c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx.as<u8>(), c->dblab.as<u64>(), a,
+                       c->cand.as<u64>(), g);
+    c->t_end();
+    return c->check_launch("k_select_mx");
+}
+
 template <int NW, int LW> int launch_select_dense_t(hg_ctx* c) {
     const Geo& g = c->geo;
     SelArgs a{c->t.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
@@ -288,6 +358,13 @@ template <int NW> int launch_select_nw(hg_ctx* c) {
             case 1: return launch_select_dense_t<NW, 1>(c);
             case 2: return launch_select_dense_t<NW, 2>(c);
             default: return launch_select_dense_t<NW, 0>(c);
+        }
+    }
+    if (c->optimistic && c->opt_select_mfma) {
+        switch (lw) {
+            case 1: return launch_select_mx_t<NW, 1>(c);
+            case 2: return launch_select_mx_t<NW, 2>(c);
+            default: return launch_select_mx_t<NW, 0>(c);
         }
     }
     if (c->optimistic) {
@@ -439,6 +516,8 @@ int hg_init(int device, hg_ctx** out) {
     if (hipSetDeviceFlags(hipDeviceScheduleSpin) != hipSuccess) (void)hipGetLastError();
     hg_ctx* c = new hg_ctx();
     c->device = device;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cu = cus;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(HG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = c;
@@ -455,7 +534,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx};
     for (auto* d : all) d->release();
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
@@ -497,6 +576,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     if (N) HG_HIP(hipMemcpyAsync(c->dblab.p, labels, (size_t)N * c->LW * 8, hipMemcpyHostToDevice, c->stream));
     HG_TRY(c->sync());
     c->stage = ST_DB;   // queries must be (re)set after the database: b, C may have changed
+    c->dbx_valid = false;
     return HG_OK;
 }
 
@@ -551,6 +631,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->idx_base = (u32)idx_base;
     HG_TRY(pack_on_device(c, host_x, host_labels, N, c->db, c->dblab, c->dbf, bad_codes, bad_labels));
     c->stage = ST_DB;
+    c->dbx_valid = false;
     return HG_OK;
 }
 
@@ -562,6 +643,7 @@ int hg_set_queries_f32(hg_ctx* c, const float* host_x, const int64_t* host_label
     c->Q = Q;
     HG_TRY(pack_on_device(c, host_x, host_labels, Q, c->qc, c->qlab, c->qf, bad_codes, bad_labels));
     c->stage = ST_DB | ST_Q;
+    c->qx_valid = false;
     return HG_OK;
 }
 
@@ -586,6 +668,7 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     HG_HIP(hipMemcpyAsync(c->qlab.p, labels, (size_t)Q * c->LW * 8, hipMemcpyHostToDevice, c->stream));
     HG_TRY(c->sync());
     c->stage = ST_DB | ST_Q;
+    c->qx_valid = false;
     return HG_OK;
 }
 
@@ -1354,6 +1437,10 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_waves")) {
         if (value != 0 && value != 4 && value != 16) return fail(HG_ERR_ARG, "rank_waves must be 0, 4 or 16");
         c->opt_rank_waves = value;
+    } else if (!strcmp(key, "select_mfma")) {
+        c->opt_select_mfma = value;
+    } else if (!strcmp(key, "select_qt")) {
+        c->opt_select_qt = value;
     } else if (!strcmp(key, "real_segment_bytes")) {
         if (value < 4096) return fail(HG_ERR_ARG, "real_segment_bytes must be >= 4096");
         c->opt_real_seg_bytes = value;
@@ -1393,7 +1480,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err,
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
-                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores};
+                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
         *value = total;
