@@ -360,7 +360,7 @@ template <int NW> int launch_select_nw(hg_ctx* c) {
             default: return launch_select_dense_t<NW, 0>(c);
         }
     }
-    if (c->optimistic && c->opt_select_mfma) {
+    if (c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS)) {
         switch (lw) {
             case 1: return launch_select_mx_t<NW, 1>(c);
             case 2: return launch_select_mx_t<NW, 2>(c);

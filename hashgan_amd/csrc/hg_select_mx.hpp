@@ -40,6 +40,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MX_QT = 4;                // query tiles (of 32) per wavefront
 constexpr int MX_WT = 8;                // row tiles per window
 constexpr int MX_WROWS = 16 * MX_WT;    // rows per lane-half per window
+constexpr int MX_QCAP = 2048;           // hit-queue entries per wavefront and window (mean fill at 2 R records per query: ~330)
+constexpr u32 MX_POS_BITS = 17;         // slice positions in a queue entry: cap < 2^17
 
 // 8 code bits -> 8 nibbles, bit j at bit 4 j
 __device__ __forceinline__ u32 spread8(u32 y) {
@@ -93,6 +95,7 @@ struct MxLds {                 // byte offsets inside the block's dynamic LDS
     int a, codes, labels;      // inside one stage
     int stage;                 // stage size
     int qcodes, qlabels;       // query tables (after the two stages)
+    int queue;                 // per-wave hit queues (MX_QCAP entries each)
     int total;
 };
 __host__ __device__ inline MxLds mx_lds_layout(int NW, int LW) {
@@ -105,7 +108,8 @@ __host__ __device__ inline MxLds mx_lds_layout(int NW, int LW) {
     l.stage = (l.stage + 1023) & ~1023;
     l.qcodes = 2 * l.stage;
     l.qlabels = l.qcodes + 512 * NW * 4;
-    l.total = l.qlabels + 512 * LW * 8;
+    l.queue = l.qlabels + 512 * LW * 8;
+    l.total = l.queue + WPB * MX_QCAP * 4;
     return l;
 }
 
@@ -138,7 +142,6 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
     // this lane's segment (lane-half h walks segment 2 sp + h)
     const int s = 2 * sp + h;
     const bool seg_ok = s < g.S;
-    const i64 lo = seg_ok ? (i64)s * g.L : 0;
     // wave-uniform row counts of the two segments
     const i64 lo0 = (i64)(2 * sp) * g.L, lo1 = lo0 + g.L;
     const i64 len0 = (lo0 + g.L < g.N ? g.L : g.N - lo0);
@@ -166,8 +169,8 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
     }
     i32x4 bq[QT][NM];
     f32x16 biasv[QT];
-    u64* wp[QT];
-    u32 room[QT], dropped[QT];
+    u32 cnt[QT], dropped[QT];                                        // records in the lane's slices so far / lost to overflow
+    u32 capl[QT];                                                    // slice capacity (0: dead lane)
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = q0w + t * 32 + j;
@@ -182,8 +185,8 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         const float bias = (float)(pop - T - 1);         // dist + (-T - 1) < 0  <=>  dist <= T;  dead lane: never
 #pragma unroll
         for (int r = 0; r < 16; ++r) biasv[t][r] = bias;
-        wp[t] = cand + (i64)(q < g.Q ? q : 0) * a.crow + (i64)(seg_ok ? s : 0) * a.cap;
-        room[t] = live ? a.cap : 0u;
+        cnt[t] = 0;
+        capl[t] = live ? a.cap : 0u;
         dropped[t] = 0;
     }
 
@@ -218,40 +221,72 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         }
     };
 
-    // Drain the hit masks of one window of the lane's segment (k_select's drain, reading LDS):
-    // bit 63-k of hmA <-> window row k, bit 63-k of hmB <-> window row 64 + k.
-    auto drain = [&](const int t, u64*& wpt, u32& roomt, u32& droppedt, u64 hmA, u64 hmB, const i64 n0, const u8* st) {
-        const u32* qcl = (const u32*)(mxlds + L.qcodes + (wave * 128 + t * 32 + j) * CB);
-        const u64* qll = (const u64*)(mxlds + L.qlabels + (wave * 128 + t * 32 + j) * LB);
-        while (__any((hmA | hmB) != 0ull)) {
+    // ---- drain, in two phases.  Hits are rare and unevenly spread over the lanes (~1 per lane, window and
+    // query tile; the busiest lane has ~5), so a loop in which every lane finishes its own hits keeps most
+    // lanes idle most of the time.  Phase 1 only ENUMERATES: each lane walks its hit masks in row order,
+    // gives every hit its final position in the (segment, query) slice -- which fixes the record order --
+    // and appends a 4-byte entry {pos | lane | tile | row} to the wavefront's queue in LDS.  Phase 2 then
+    // turns queue entries into records 64 at a time, every lane busy: exact distance and match bit from the
+    // packed rows staged in LDS, one 8-byte store.  Entries carry their destination, so queue order is free.
+    u32* queue = (u32*)(mxlds + L.queue) + wave * MX_QCAP;
+    u32 qfill = 0;                                                   // entries in the queue (wave-uniform)
+    i64 cur_win = 0;                                                 // window being drained, its stage
+    const u8* cur_st = mxlds;
+    auto emit = [&]() {
+        const i64 win = cur_win;
+        const u8* st = cur_st;
+        wave_lds_sync();
+        const u32 n = (a.optimistic & 8) ? 0u : (qfill < MX_QCAP ? qfill : MX_QCAP);
+        for (u32 i = lane; i < n; i += 64) {
+            const u32 e = queue[i];
+            if (e == 0xFFFFFFFFu) continue;
+            const u32 pos = e & ((1u << MX_POS_BITS) - 1u), src = (e >> MX_POS_BITS) & 63u, t = (e >> (MX_POS_BITS + 6)) & 3u;
+            const u32 wr = e >> (MX_POS_BITS + 8);
+            const u32 hs = src >> 5;                                  // the source lane's half = segment
+            const int ql = wave * 128 + (int)t * 32 + (int)(src & 31u);   // its query, block-local
+            const u32* qcl = (const u32*)(mxlds + L.qcodes + ql * CB);
+            const u32* rp = (const u32*)(st + L.codes + (hs * MX_WROWS + wr) * CB);
+            u32 d = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) d += __builtin_popcount(qcl[w] ^ rp[w]);
+            u64 any = 0;
+            if (LW > 0) {
+                const u64* qll = (const u64*)(mxlds + L.qlabels + ql * LB);
+                const u64* lp = (const u64*)(st + L.labels + (hs * MX_WROWS + wr) * LB);
+#pragma unroll
+                for (int w = 0; w < LWA; ++w) any |= lp[w] & qll[w];
+            }
+            const i64 q = (i64)qb * 512 + ql;
+            const i64 seg = 2 * sp + (int)hs;
+            if (!(a.optimistic & 4) || d == 0x7fffffffu) cand[q * a.crow + seg * a.cap + pos] = make_rec(g.idx_base + (u32)(seg * g.L + win * MX_WROWS + wr), d, any != 0);
+        }
+        wave_lds_sync();
+        qfill = 0;
+    };
+
+    auto enumerate = [&](const int t, u64 hmA, u64 hmB, u32& cntt, const u32 caplt, u32& droppedt) {
+        u64 bal = __ballot((hmA | hmB) != 0ull);
+        while (bal) {
             if ((hmA | hmB) != 0ull) {
                 const bool inA = hmA != 0ull;
                 u64 cur = inA ? hmA : hmB;
                 const int k = 63 - __clzll((long long)cur);
                 cur ^= 1ull << k;
                 if (inA) hmA = cur; else hmB = cur;
-                const int wr = inA ? 63 - k : 127 - k;               // row inside the window
-                const u32* rp = (const u32*)(st + L.codes + (h * MX_WROWS + wr) * CB);
-                u32 d = 0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) d += __builtin_popcount(qcl[w] ^ rp[w]);
-                u64 any = 0;
-                if (LW > 0) {
-                    const u64* lp = (const u64*)(st + L.labels + (h * MX_WROWS + wr) * LB);
-#pragma unroll
-                    for (int w = 0; w < LWA; ++w) any |= lp[w] & qll[w];
-                }
-                if (roomt) {
-                    *wpt = make_rec(g.idx_base + (u32)(n0 + wr), d, any != 0);
-                    ++wpt;
-                    --roomt;
-                } else {
-                    ++droppedt;
-                }
+                const u32 wr = inA ? 63 - k : 127 - k;               // row inside the window
+                // queue slot: rank of this lane among the lanes with a hit this round (any order would do)
+                const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                const bool ok = cntt < caplt && slot < MX_QCAP;
+                const u32 e = cntt | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) | (wr << (MX_POS_BITS + 8));
+                if (slot < MX_QCAP) queue[slot] = ok ? e : 0xFFFFFFFFu;
+                cntt += ok ? 1u : 0u;                                // (branch-free: a select between the two counters
+                droppedt += ok ? 0u : 1u;                            //  would send both arrays to scratch memory)
             }
+            qfill += (u32)__builtin_popcountll(bal);
+            if (qfill + 64 > MX_QCAP) emit();                        // dense windows: make room (uniform branch)
+            bal = __ballot((hmA | hmB) != 0ull);
         }
     };
-
     const int scale1 = 0x7F7F7F7F;                                   // E8M0 block scales: 2^0
     auto issue = [&](const i32x4 (&af)[NM], const int t) -> f32x16 {
         f32x16 acc = biasv[t];
@@ -276,6 +311,8 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         __syncthreads();
         if (win + 1 < nwin) stage_window(win + 1, buf ^ 1);
         const u8* st = mxlds + buf * L.stage;
+        cur_win = win;
+        cur_st = st;
 
         u32 m[QT][4];
 #pragma unroll
@@ -316,9 +353,9 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         for (int t = 0; t < QT; ++t) {
             const u64 hmA = ((u64)m[t][0] << 32) | m[t][1], hmB = ((u64)m[t][2] << 32) | m[t][3];
             if (a.optimistic & 2) { if (hmA == 0x123456789ull) dropped[t]++; }   // experiment: no drain
-            else if (__any((hmA | hmB) != 0ull))
-                drain(t, wp[t], room[t], dropped[t], hmA, hmB, lo + win * MX_WROWS, st);
+            else enumerate(t, hmA, hmB, cnt[t], capl[t], dropped[t]);
         }
+        if (!(a.optimistic & 2)) emit();
     }
 
 #pragma unroll
@@ -326,7 +363,7 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         const int q = q0w + t * 32 + j;
         if (seg_ok && q < g.Qpad) {
             const bool live = q < g.Q;
-            a.sl_cnt[(i64)s * g.Qpad + q] = live ? a.cap - room[t] : 0u;
+            a.sl_cnt[(i64)s * g.Qpad + q] = live ? cnt[t] : 0u;
             if (dropped[t] && live) a.fail[q] = 1u;
         }
     }
