@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 VALU_PEAK_TLANEOPS = 39.3
 VALU_NOMINAL_FP32_TLANEOPS = 78.6
 HBM_PEAK_GBS = 8000.0         # HBM3E spec (6.3 TB/s achievable)
+MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense MX-fp4 MFMA peak (MI355X_MICROARCH.md: ~10 PF dense; 9.1 PF measured)
 
 WORKLOADS = {
     # name: (case in tests/cases.py whose seeds/shape we reuse, Q, golden anchor)
@@ -101,8 +102,25 @@ def kernel_rooflines(timing, steps, spec, geo_bytes):
         out[name] = {"avg_ms": ms / max(cnt, 1), "launches": cnt}
     dom = max(out, key=lambda k: out[k]["avg_ms"] * out[k]["launches"])
     t = out[dom]["avg_ms"] * 1e-3
-    laneops = pairs * 2 * NW                      # one v_xor_b32 + one v_bcnt_u32_b32 per 32-bit word per pair
     alg_bytes = geo_bytes.get(dom, 0)
+    hbm = {"algorithmic_bytes": alg_bytes, "achieved": alg_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg_bytes / t / 1e9 / HBM_PEAK_GBS}
+    if dom == "k_select_mx":
+        # matrix-core select: one v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4) per 64 code bits and 32x32 tile of pairs
+        K = 64 * ((NW + 1) // 2)
+        flops = 2.0 * pairs * K
+        valu = pairs                                   # one v_alignbit_b32 per pair (sign of the accumulator -> hit mask)
+        roof = {"bound": "mfma", "kernel": dom, "achieved": flops / t / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / t / 1e12 / MFMA_FP4_PEAK_TFLOPS, "traffic": traffic_from_profiles(dom),
+                "avg_launch_ms": out[dom]["avg_ms"], "algorithmic_flops": flops,
+                "note": "fp4 MFMA inner product over K=%d code bits per pair (2 flops per bit), against the dense fp4 peak; the "
+                        "kernel's other per-pair cost is one v_alignbit_b32, which on gfx950 does not overlap the MFMAs "
+                        "(profiles/r01_ubench_mx.txt): see 'valu'" % K,
+                "valu": {"algorithmic_laneops": valu, "achieved": valu / t / 1e12, "peak": VALU_PEAK_TLANEOPS,
+                         "unit": "Tlaneop/s", "frac": valu / t / 1e12 / VALU_PEAK_TLANEOPS},
+                "hbm": hbm}
+        return roof, out
+    laneops = pairs * 2 * NW                      # one v_xor_b32 + one v_bcnt_u32_b32 per 32-bit word per pair
     roof = {"bound": "valu", "kernel": dom, "achieved": laneops / t / 1e12, "peak": VALU_PEAK_TLANEOPS,
             "unit": "Tlaneop/s", "frac": laneops / t / 1e12 / VALU_PEAK_TLANEOPS, "traffic": traffic_from_profiles(dom),
             "avg_launch_ms": out[dom]["avg_ms"],
@@ -110,8 +128,7 @@ def kernel_rooflines(timing, steps, spec, geo_bytes):
             "note": "integer bit-count path: xor+popcount lane-ops (2 per 32-bit code word per pair) against the "
                     "integer VALU issue peak (16 lanes/clk/SIMD); frac vs the 78.6 T packed-FP32 figure is %.3f"
                     % (laneops / t / 1e12 / VALU_NOMINAL_FP32_TLANEOPS),
-            "hbm": {"algorithmic_bytes": alg_bytes, "achieved": alg_bytes / t / 1e9, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": alg_bytes / t / 1e9 / HBM_PEAK_GBS}}
+            "hbm": hbm}
     return roof, out
 
 
@@ -184,6 +201,8 @@ def main():
     geo_bytes = {  # algorithmic (compulsory) HBM bytes per launch, DESIGN.md section 4
         "k_hist": code_bytes + NB * Qpad * 4,
         "k_select": code_bytes + (Q + N) * LW * 8 + Q * R * 8,      # codes + labels in, >= R records of 8 B out per query
+        # fp4 images of the codes (4 bits per code bit, 64-bit granules) + packed codes + labels in, records out
+        "k_select_mx": (Q + N) * ((NW + 1) // 2) * 32 + code_bytes + (Q + N) * LW * 8 + Q * R * 8,
     }
     roof, per_kernel = kernel_rooflines(timing, args.steps, spec, geo_bytes)
     ms = dt / args.steps * 1e3
@@ -191,7 +210,7 @@ def main():
         "metric": "queries/sec (mAP@R of Q queries vs N-code database, Hamming ranking)",
         "value": Q / (dt / args.steps), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32 (xor+popcount), int counters, f64 AP", "data": "synthetic",
+        "dtype": "fp4 (E2M1 0/+-1) x fp4 -> f32 exact distances; u32 xor+popcount elsewhere; f64 AP", "data": "synthetic",
         "config": {"workload": "%s: Q=%d N=%d b=%d R=%d C=%d, planted codes" % (args.workload.upper(), Q, N, b, R, spec["C"]),
                    "parallelism": "1 GPU"},
         "map": float(m), "parity_vs_reference_golden": parity,

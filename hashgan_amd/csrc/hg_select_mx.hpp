@@ -40,7 +40,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MX_QT = 4;                // query tiles (of 32) per wavefront
 constexpr int MX_WT = 8;                // row tiles per window
 constexpr int MX_WROWS = 16 * MX_WT;    // rows per lane-half per window
-constexpr int MX_QCAP = 2048;           // hit-queue entries per wavefront and window (mean fill at 2 R records per query: ~330)
+constexpr int MX_QCAP = 1024;           // hit-queue entries (8 bytes) per wavefront: one per lane, query tile and mask word
 constexpr u32 MX_POS_BITS = 17;         // slice positions in a queue entry: cap < 2^17
 
 // 8 code bits -> 8 nibbles, bit j at bit 4 j
@@ -95,7 +95,7 @@ struct MxLds {                 // byte offsets inside the block's dynamic LDS
     int a, codes, labels;      // inside one stage
     int stage;                 // stage size
     int qcodes, qlabels;       // query tables (after the two stages)
-    int queue;                 // per-wave hit queues (MX_QCAP entries each)
+    int queue;                 // per-wave hit queues (MX_QCAP entries of 8 bytes each)
     int total;
 };
 __host__ __device__ inline MxLds mx_lds_layout(int NW, int LW) {
@@ -109,7 +109,7 @@ __host__ __device__ inline MxLds mx_lds_layout(int NW, int LW) {
     l.qcodes = 2 * l.stage;
     l.qlabels = l.qcodes + 512 * NW * 4;
     l.queue = l.qlabels + 512 * LW * 8;
-    l.total = l.queue + WPB * MX_QCAP * 4;
+    l.total = l.queue + WPB * MX_QCAP * 8;
     return l;
 }
 
@@ -221,72 +221,78 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         }
     };
 
-    // ---- drain, in two phases.  Hits are rare and unevenly spread over the lanes (~1 per lane, window and
-    // query tile; the busiest lane has ~5), so a loop in which every lane finishes its own hits keeps most
-    // lanes idle most of the time.  Phase 1 only ENUMERATES: each lane walks its hit masks in row order,
-    // gives every hit its final position in the (segment, query) slice -- which fixes the record order --
-    // and appends a 4-byte entry {pos | lane | tile | row} to the wavefront's queue in LDS.  Phase 2 then
-    // turns queue entries into records 64 at a time, every lane busy: exact distance and match bit from the
-    // packed rows staged in LDS, one 8-byte store.  Entries carry their destination, so queue order is free.
-    u32* queue = (u32*)(mxlds + L.queue) + wave * MX_QCAP;
+    // ---- drain, in two phases.  Hits are rare (~1 per lane, window and query tile) and unevenly spread over
+    // the lanes, so a loop in which every lane works off its own hit masks keeps most lanes idle and pays its
+    // ~40 instructions per round for the busiest lane's count.  Instead:
+    //   push   branch-free, per (query tile, 32-row mask word): every lane whose word is non-zero appends
+    //          {word | slice position of its first hit | lane | tile | word index} to the wavefront's queue in
+    //          LDS (slot = rank among the pushing lanes) and advances its slice cursor by the word's popcount
+    //          -- the positions fix the record order, so the queue order is free;
+    //   emit   64 queue entries at a time, every lane busy: walk the word's bits (usually one), exact distance
+    //          and match bit from the packed rows staged in LDS, one 8-byte store per hit.
+    // A window has at most 64 x 4 x 4 words, so the queue (MX_QCAP) cannot overflow, dense windows included.
+    u64* queue = (u64*)(mxlds + L.queue) + wave * MX_QCAP;
     u32 qfill = 0;                                                   // entries in the queue (wave-uniform)
-    i64 cur_win = 0;                                                 // window being drained, its stage
-    const u8* cur_st = mxlds;
-    auto emit = [&]() {
-        const i64 win = cur_win;
-        const u8* st = cur_st;
+    auto push = [&](const int t, const int w, const u32 word, u32& cntt, const u32 caplt, u32& droppedt) {
+        const u64 bal = __ballot(word != 0u);
+        const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+        if (word != 0u)
+            queue[slot] = ((u64)word << 32) | (u64)(cntt | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
+                                                    ((u32)w << (MX_POS_BITS + 8)));
+        const u32 want = cntt + (u32)__builtin_popcount(word);
+        const u32 got = want < caplt ? want : caplt;                // the slice holds caplt records; the rest is lost
+        droppedt += want - got;
+        cntt = got;
+        qfill += (u32)__builtin_popcountll(bal);
+    };
+    auto emit = [&](const i64 win, const u8* st) {
         wave_lds_sync();
-        const u32 n = (a.optimistic & 8) ? 0u : (qfill < MX_QCAP ? qfill : MX_QCAP);
+        const u32 n = (a.optimistic & 8) ? 0u : qfill;
         for (u32 i = lane; i < n; i += 64) {
-            const u32 e = queue[i];
-            if (e == 0xFFFFFFFFu) continue;
-            const u32 pos = e & ((1u << MX_POS_BITS) - 1u), src = (e >> MX_POS_BITS) & 63u, t = (e >> (MX_POS_BITS + 6)) & 3u;
-            const u32 wr = e >> (MX_POS_BITS + 8);
+            const u64 e = queue[i];
+            u32 word = (u32)(e >> 32);
+            const u32 desc = (u32)e;
+            const u32 pos = desc & ((1u << MX_POS_BITS) - 1u), src = (desc >> MX_POS_BITS) & 63u;
+            const u32 t = (desc >> (MX_POS_BITS + 6)) & 3u, w = (desc >> (MX_POS_BITS + 8)) & 3u;
             const u32 hs = src >> 5;                                  // the source lane's half = segment
             const int ql = wave * 128 + (int)t * 32 + (int)(src & 31u);   // its query, block-local
-            const u32* qcl = (const u32*)(mxlds + L.qcodes + ql * CB);
-            const u32* rp = (const u32*)(st + L.codes + (hs * MX_WROWS + wr) * CB);
-            u32 d = 0;
+            u32 qcw[NW];
+            u64 qlw[LWA];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) d += __builtin_popcount(qcl[w] ^ rp[w]);
-            u64 any = 0;
-            if (LW > 0) {
-                const u64* qll = (const u64*)(mxlds + L.qlabels + ql * LB);
-                const u64* lp = (const u64*)(st + L.labels + (hs * MX_WROWS + wr) * LB);
+            for (int k = 0; k < NW; ++k) qcw[k] = ((const u32*)(mxlds + L.qcodes + ql * CB))[k];
 #pragma unroll
-                for (int w = 0; w < LWA; ++w) any |= lp[w] & qll[w];
-            }
+            for (int k = 0; k < LWA; ++k) qlw[k] = LW > 0 ? ((const u64*)(mxlds + L.qlabels + ql * LB))[k] : 0ull;
             const i64 q = (i64)qb * 512 + ql;
             const i64 seg = 2 * sp + (int)hs;
-            if (!(a.optimistic & 4) || d == 0x7fffffffu) cand[q * a.crow + seg * a.cap + pos] = make_rec(g.idx_base + (u32)(seg * g.L + win * MX_WROWS + wr), d, any != 0);
+            u64* out = cand + q * a.crow + seg * a.cap + pos;
+            u32 room = a.cap - pos;
+            const u32 row0 = hs * MX_WROWS + w * 32;                  // first row of the word in the stage tables
+            const u32 idx0 = g.idx_base + (u32)(seg * g.L + win * MX_WROWS) + w * 32;
+            while (word) {
+                const int k = 31 - __builtin_clz(word);
+                word ^= 1u << k;
+                const u32 r = 31 - k;                                 // highest bit = earliest row
+                const u32* rp = (const u32*)(st + L.codes + (row0 + r) * CB);
+                u32 d = 0;
+#pragma unroll
+                for (int c = 0; c < NW; ++c) d += __builtin_popcount(qcw[c] ^ rp[c]);
+                u64 any = 0;
+                if (LW > 0) {
+                    const u64* lp = (const u64*)(st + L.labels + (row0 + r) * LB);
+#pragma unroll
+                    for (int c = 0; c < LWA; ++c) any |= lp[c] & qlw[c];
+                }
+                if (room) {
+                    if (!(a.optimistic & 4) || d == 0x7fffffffu) *out = make_rec(idx0 + r, d, any != 0);
+                    ++out;
+                    --room;
+                }
+            }
         }
         wave_lds_sync();
         qfill = 0;
     };
 
-    auto enumerate = [&](const int t, u64 hmA, u64 hmB, u32& cntt, const u32 caplt, u32& droppedt) {
-        u64 bal = __ballot((hmA | hmB) != 0ull);
-        while (bal) {
-            if ((hmA | hmB) != 0ull) {
-                const bool inA = hmA != 0ull;
-                u64 cur = inA ? hmA : hmB;
-                const int k = 63 - __clzll((long long)cur);
-                cur ^= 1ull << k;
-                if (inA) hmA = cur; else hmB = cur;
-                const u32 wr = inA ? 63 - k : 127 - k;               // row inside the window
-                // queue slot: rank of this lane among the lanes with a hit this round (any order would do)
-                const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                const bool ok = cntt < caplt && slot < MX_QCAP;
-                const u32 e = cntt | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) | (wr << (MX_POS_BITS + 8));
-                if (slot < MX_QCAP) queue[slot] = ok ? e : 0xFFFFFFFFu;
-                cntt += ok ? 1u : 0u;                                // (branch-free: a select between the two counters
-                droppedt += ok ? 0u : 1u;                            //  would send both arrays to scratch memory)
-            }
-            qfill += (u32)__builtin_popcountll(bal);
-            if (qfill + 64 > MX_QCAP) emit();                        // dense windows: make room (uniform branch)
-            bal = __ballot((hmA | hmB) != 0ull);
-        }
-    };
     const int scale1 = 0x7F7F7F7F;                                   // E8M0 block scales: 2^0
     auto issue = [&](const i32x4 (&af)[NM], const int t) -> f32x16 {
         f32x16 acc = biasv[t];
@@ -311,8 +317,6 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         __syncthreads();
         if (win + 1 < nwin) stage_window(win + 1, buf ^ 1);
         const u8* st = mxlds + buf * L.stage;
-        cur_win = win;
-        cur_st = st;
 
         u32 m[QT][4];
 #pragma unroll
@@ -349,13 +353,16 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
                 for (int t = 0; t < QT; ++t) m[t][c] &= keep;
             }
         }
+        if (a.optimistic & 2) {                                      // experiment: no drain
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const u64 hmA = ((u64)m[t][0] << 32) | m[t][1], hmB = ((u64)m[t][2] << 32) | m[t][3];
-            if (a.optimistic & 2) { if (hmA == 0x123456789ull) dropped[t]++; }   // experiment: no drain
-            else enumerate(t, hmA, hmB, cnt[t], capl[t], dropped[t]);
+            for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][3] == 0x1234567u) dropped[t]++;
+        } else {
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) push(t, w, m[t][w], cnt[t], capl[t], dropped[t]);
+            emit(win, st);
         }
-        if (!(a.optimistic & 2)) emit();
     }
 
 #pragma unroll
