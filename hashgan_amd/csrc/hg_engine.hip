@@ -129,7 +129,7 @@ struct hg_ctx {
     i64 opt_real_qpl = 1;      // real-valued path: queries per lane (1 or 2)
     i64 opt_rank_waves = 0;    // k_rank_fused wavefronts per query: 0 = by list length, else 4 or 16
     i64 opt_select_mfma = 1;   // optimistic select: 1 = matrix-core kernel (k_select_mx), 0 = vector-ALU k_select
-    i64 opt_select_qt = 4;     // k_select_mx query tiles per wavefront for codes of <= 64 bits (2 or 4)
+    i64 opt_select_qt = 2;     // k_select_mx query tiles per wavefront (2: 4 wavefronts per SIMD, 4: 2)
 
     // run state
     bool optimistic = false;   // records come from a guessed threshold (fixed-capacity slices)
@@ -227,10 +227,12 @@ void make_geometry(hg_ctx* c) {
     S = (c->N + L - 1) / L;
     if (S < 1) S = 1;
     if (c->opt_enable && c->opt_select_mfma && S >= 4) {
-        // k_select_mx runs (S / 2) x ceil(Q / 512) equal blocks, 2 resident per CU: pick the S near the
+        // k_select_mx runs (S / 2) x ceil(Q / 256 or 512) equal blocks, 4 or 2 resident per CU: pick the S near the
         // target that fills a whole number of such rounds, so the last round is not a nearly empty one
-        const i64 nQB = (c->Q + 511) / 512;
-        const i64 slots = (i64)c->n_cu * 2;
+        const bool qt2 = c->NW <= 4 && c->opt_select_qt == 2;       // mirrors launch_select_mx_t
+        const i64 qblk = qt2 ? 256 : 512;
+        const i64 nQB = (c->Q + qblk - 1) / qblk;
+        const i64 slots = (i64)c->n_cu * (qt2 ? 4 : 2);
         i64 k = (S / 2 * nQB + slots / 2) / slots;
         if (k < 1) k = 1;
         i64 S2 = 2 * (slots * k / nQB);
@@ -295,8 +297,14 @@ template <int NW, int LW, bool OPT> int launch_select_t(hg_ctx* c) {
 
 // matrix-core optimistic select: units = (pair of segments) x (group of 32 QT queries)
 // matrix-core optimistic select: blocks = (pair of segments) x (block of 512 queries)
+template <int NW, int LW, int QT> int launch_select_mx_q(hg_ctx* c);
 template <int NW, int LW> int launch_select_mx_t(hg_ctx* c) {
+    // long codes need the registers of the 2-waves-per-SIMD variant (B fragments: 4 per query tile and 64 bits)
+    return (NW <= 4 && c->opt_select_qt == 2) ? launch_select_mx_q<NW, LW, (NW <= 4 ? 2 : 4)>(c) : launch_select_mx_q<NW, LW, 4>(c);
+}
+template <int NW, int LW, int QT> int launch_select_mx_q(hg_ctx* c) {
     constexpr int NM = (NW + 1) / 2;
+    constexpr int QBLK = WPB * 32 * QT;                // queries per block
     if (!c->dbx_valid) {
         const i64 n16 = (c->N + 15) / 16 * 16;
         HG_TRY(c->dbx.reserve((size_t)(n16 > 0 ? n16 : 16) * NM * 32));
@@ -310,9 +318,9 @@ template <int NW, int LW> int launch_select_mx_t(hg_ctx* c) {
     }
     Geo g = c->geo;
     const int nSP = (g.S + 1) / 2;
-    const int nQB = (g.Q + 511) / 512;                 // query blocks
+    const int nQB = (g.Q + QBLK - 1) / QBLK;           // query blocks
     if (!c->qx_valid) {
-        const i64 qpad = (i64)nQB * 512;
+        const i64 qpad = ((i64)c->Q + 511) / 512 * 512;
         HG_TRY(c->qx.reserve((size_t)qpad * NM * 32));
         const i64 items = qpad * 2 * NM;
         c->t_begin(KI_PACK);
@@ -326,14 +334,14 @@ template <int NW, int LW> int launch_select_mx_t(hg_ctx* c) {
     g.nUnits = (i64)nSP * nQB;
     g.wpb = WPB;
     g.nBlk = (int)g.nUnits;
-    const MxLds L = mx_lds_layout(NW, LW);
+    const MxLds L = mx_lds_layout(NW, LW, QT);
     if (L.total > 64 * 1024)
-        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx<NW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx<NW, LW, QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    L.total));
     SelArgs a{c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
               c->cap, c->crow, (int)c->opt_select_mfma, c->sstar.as<int>()};
     c->t_begin(KI_SELECT_MX);
-    hipLaunchKernelGGL((k_select_mx<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total, c->stream, c->qc.as<u32>(),
+    hipLaunchKernelGGL((k_select_mx<NW, LW, QT>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx.as<u8>(), c->dblab.as<u64>(), a,
                        c->cand.as<u64>(), g);
     c->t_end();
@@ -965,12 +973,14 @@ int hg_merge_topr(hg_ctx* c, const uint32_t* dev_idx_all, const uint8_t* dev_dis
 
 // ---- staged optimistic sequence (multi-shard): sample -> [gather] -> guess -> candidates ->
 // [gather] -> rank.  Mirrors the one-shot bet, with the two histogram exchanges made explicit.
-// Sampling stride of the bet, in row batches.  One row batch in 16: a fixed 6 % of a pass.  The
+// Sampling stride of the bet, in row batches.  One row batch in 24: a fixed 4 % of a pass (with the
+// matrix-core select the sampling pass is a visible share of the step; 16 -> 24 trades 0.05 ms of it for
+// ~3 % more surplus records).  The
 // guess's safety margin is relative to sqrt(sampled hits), so a small R only means relatively more
 // surplus records (R = 100: ~3.5 R of them) -- still far cheaper than a full histogram pass.
 static int auto_stride(hg_ctx* c, int64_t R) {
     (void)R;
-    return c->opt_stride > 0 ? (int)c->opt_stride : 16;
+    return c->opt_stride > 0 ? (int)c->opt_stride : 24;
 }
 
 int hg_bet_eligible(hg_ctx* c, int64_t R, int world, int* eligible) {

@@ -783,15 +783,20 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     } else {
         Walk w = first();
         u64 rec = fetch(w);
+        Walk w1 = next(w);
+        u64 rec1 = fetch(w1);
+        Walk w2 = next(w1);
+        u64 rec2 = fetch(w2);
         while (w.s < s1) {
-            const Walk wn = next(w);
-            const u64 recn = fetch(wn);
+            const Walk w3 = next(w2);                 // three steps of records in flight per wavefront
+            const u64 rec3 = fetch(w3);
             if (w.base + lane < w.cnt) {
                 const u32 d = (u32)(rec >> 32) & 0xFFu;
                 if (d < (u32)NB) atomicAdd(&myh[d], 1u);
             }
-            w = wn;
-            rec = recn;
+            w = w1; rec = rec1;
+            w1 = w2; rec1 = rec2;
+            w2 = w3; rec2 = rec3;
         }
     }
     __syncthreads();
@@ -867,9 +872,13 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     {
         Walk w = first();
         u64 rec = fetch(w);
+        Walk w1 = next(w);
+        u64 rec1 = fetch(w1);
+        Walk w2 = next(w1);
+        u64 rec2 = fetch(w2);
         while (w.s < s1) {
-            const Walk wn = next(w);
-            const u64 recn = fetch(wn);
+            const Walk w3 = next(w2);
+            const u64 rec3 = fetch(w3);
             const bool valid = w.base + lane < w.cnt;
             const u32 gi = (u32)rec;
             const u32 meta = (u32)(rec >> 32);
@@ -904,8 +913,9 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
                 }
             }
             wave_lds_sync();
-            w = wn;
-            rec = recn;
+            w = w1; rec = rec1;
+            w1 = w2; rec1 = rec2;
+            w2 = w3; rec2 = rec3;
         }
     }
     if (a.bits_lds) {

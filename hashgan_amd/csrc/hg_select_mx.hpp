@@ -37,10 +37,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MX_QT = 4;                // query tiles (of 32) per wavefront
 constexpr int MX_WT = 8;                // row tiles per window
 constexpr int MX_WROWS = 16 * MX_WT;    // rows per lane-half per window
-constexpr int MX_QCAP = 1024;           // hit-queue entries (8 bytes) per wavefront: one per lane, query tile and mask word
+constexpr int mx_qcap(int QT) { return 64 * 4 * QT; }   // hit-queue entries (8 bytes) per wavefront: one per lane, query tile and mask word
 constexpr u32 MX_POS_BITS = 17;         // slice positions in a queue entry: cap < 2^17
 
 // 8 code bits -> 8 nibbles, bit j at bit 4 j
@@ -98,7 +97,8 @@ struct MxLds {                 // byte offsets inside the block's dynamic LDS
     int queue;                 // per-wave hit queues (MX_QCAP entries of 8 bytes each)
     int total;
 };
-__host__ __device__ inline MxLds mx_lds_layout(int NW, int LW) {
+__host__ __device__ inline MxLds mx_lds_layout(int NW, int LW, int QT) {
+    const int QBLK = WPB * 32 * QT;            // queries per block
     const int NM = (NW + 1) / 2;
     MxLds l;
     l.a = 0;
@@ -107,9 +107,9 @@ __host__ __device__ inline MxLds mx_lds_layout(int NW, int LW) {
     l.stage = l.labels + 2 * MX_WROWS * LW * 8;
     l.stage = (l.stage + 1023) & ~1023;
     l.qcodes = 2 * l.stage;
-    l.qlabels = l.qcodes + 512 * NW * 4;
-    l.queue = l.qlabels + 512 * LW * 8;
-    l.total = l.queue + WPB * MX_QCAP * 8;
+    l.qlabels = l.qcodes + QBLK * NW * 4;
+    l.queue = l.qlabels + QBLK * LW * 8;
+    l.total = l.queue + WPB * mx_qcap(QT) * 8;
     return l;
 }
 
@@ -117,18 +117,21 @@ __host__ __device__ inline MxLds mx_lds_layout(int NW, int LW) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),          \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-// Geo as set by the launcher: g.nQT = query blocks (of 512 queries) per segment pair, g.nBlk = blocks.
-template <int NW, int LW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// Geo as set by the launcher: g.nQT = query blocks (of 128 QT queries) per segment pair, g.nBlk = blocks.
+// QT: query tiles (of 32) per wavefront -- 4: 512 queries per block, ~180 VGPRs, 2 wavefronts per SIMD;
+//     2: 256 queries per block, 4 wavefronts per SIMD.
+template <int NW, int LW, int QT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QT == 4 ? 2 : 4, QT == 4 ? 2 : 4)))
 void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const u8* __restrict__ qx,
                  const u32* __restrict__ db, const u8* __restrict__ dbx, const u64* __restrict__ dblab,
                  const SelArgs a, u64* __restrict__ cand, const Geo g) {
     extern __shared__ __attribute__((aligned(1024))) u8 mxlds[];
-    constexpr int QT = MX_QT;
+    constexpr int WQ = 32 * QT;                          // queries per wavefront
+    constexpr int MX_QCAP = mx_qcap(QT);
     constexpr int NM = (NW + 1) / 2;
     constexpr int CB = NW * 4, LB = LW * 8;
     constexpr int LWA = LW > 0 ? LW : 1;
-    const MxLds L = mx_lds_layout(NW, LW);
+    const MxLds L = mx_lds_layout(NW, LW, QT);
 
     const int lb = logical_block(g.nBlk);
     if (lb < 0) return;                                   // whole block: no barrier is skipped by a part of it
@@ -136,7 +139,7 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nQB = g.nQT;
     const int sp = lb / nQB;                             // segment pair
-    const int qb = lb - sp * nQB;                        // block of 512 queries
+    const int qb = lb - sp * nQB;                        // block of 128 QT queries
     const int h = lane >> 5, j = lane & 31;
 
     // this lane's segment (lane-half h walks segment 2 sp + h)
@@ -152,16 +155,16 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
     const i64 NG = (g.N + 15) >> 4;                                  // row groups in the image
 
     // ---- query side: LDS tables for the drain, B fragments, C = bias, slice cursors ----
-    const int q0w = (qb * 16 + wave * QT) * 32;                      // first query of this wavefront
+    const int q0w = (qb * WPB + wave) * WQ;                      // first query of this wavefront
     {
-        u32* qcl = (u32*)(mxlds + L.qcodes + wave * 128 * CB);
-        for (int e = lane; e < 128 * NW; e += 64) {
+        u32* qcl = (u32*)(mxlds + L.qcodes + wave * WQ * CB);
+        for (int e = lane; e < WQ * NW; e += 64) {
             const i64 q = q0w + e / NW;
             qcl[e] = q < g.Q ? qc[q * NW + (e % NW)] : 0u;
         }
         if (LW > 0) {
-            u64* qll = (u64*)(mxlds + L.qlabels + wave * 128 * LB);
-            for (int e = lane; e < 128 * LW; e += 64) {
+            u64* qll = (u64*)(mxlds + L.qlabels + wave * WQ * LB);
+            for (int e = lane; e < WQ * LW; e += 64) {
                 const i64 q = q0w + e / LWA;
                 qll[e] = q < g.Q ? qlab[q * LW + (e % LWA)] : 0ull;
             }
@@ -255,14 +258,14 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
             const u32 pos = desc & ((1u << MX_POS_BITS) - 1u), src = (desc >> MX_POS_BITS) & 63u;
             const u32 t = (desc >> (MX_POS_BITS + 6)) & 3u, w = (desc >> (MX_POS_BITS + 8)) & 3u;
             const u32 hs = src >> 5;                                  // the source lane's half = segment
-            const int ql = wave * 128 + (int)t * 32 + (int)(src & 31u);   // its query, block-local
+            const int ql = wave * WQ + (int)t * 32 + (int)(src & 31u);    // its query, block-local
             u32 qcw[NW];
             u64 qlw[LWA];
 #pragma unroll
             for (int k = 0; k < NW; ++k) qcw[k] = ((const u32*)(mxlds + L.qcodes + ql * CB))[k];
 #pragma unroll
             for (int k = 0; k < LWA; ++k) qlw[k] = LW > 0 ? ((const u64*)(mxlds + L.qlabels + ql * LB))[k] : 0ull;
-            const i64 q = (i64)qb * 512 + ql;
+            const i64 q = (i64)qb * (WPB * WQ) + ql;
             const i64 seg = 2 * sp + (int)hs;
             u64* out = cand + q * a.crow + seg * a.cap + pos;
             u32 room = a.cap - pos;
