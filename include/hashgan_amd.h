@@ -168,7 +168,13 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
 /* key: "stage_sync" (see hg_set_stream), "target_units" (wavefront-sized units the pair passes are split into),
  * "min_segment" (rows), "optimistic" (0/1: one-shot calls may bet on a sampled
  * threshold -- verified on device, exact fallback), "sample_stride" (0 = auto),
- * "guess_sigma", "staged_lists" (0/1: hg_select materialises idx/dist lists). */
+ * "guess_sigma", "staged_lists" (0/1: hg_select materialises idx/dist lists),
+ * "cand_budget_x10" (record budget of the bet per query, tenths of R), "rank_waves" (0 = auto, 4, 16),
+ * "select_mfma" (1: the bet's select pass runs on the matrix cores -- fp4 MFMA distance tiles,
+ * k_select_mx; 0: vector-ALU xor+popcount k_select; same records either way; values with bits 2/4/8 set
+ * switch parts of the drain off for measurements and make the bet fail),
+ * "select_qt" (k_select_mx query tiles per wavefront: 2 or 4),
+ * "real_queries_per_lane", "real_segment_bytes" (real-valued path). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
 /* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
  * (single queries rerun exactly after losing their bet), "last_optimistic", "device_bytes", "segments",

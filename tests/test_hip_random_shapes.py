@@ -63,12 +63,15 @@ def test_random_small_shapes():
 
 
 def test_random_bet_shapes():
-    """Shapes large enough for the sampled-threshold bet, with awkward R, b and label widths."""
+    """Shapes large enough for the sampled-threshold bet, with awkward R, b and label widths, through both
+    select kernels of the bet: the matrix-core one (fp4 MFMA tiles, k_select_mx) and the vector-ALU one."""
     rng = np.random.default_rng(7)
     ctx = _native.Context(0)
     try:
-        for b, C, R in [(24, 5, 2000), (64, 70, 3333), (40, 130, 1000), (100, 10, 5000), (64, 10, 1), (32, 3, 7), (48, 10, 100)]:
-            Q, N = 97, 70000 + int(rng.integers(0, 999))
+        for b, C, R, Q in [(24, 5, 2000, 97), (64, 70, 3333, 97), (40, 130, 1000, 97), (100, 10, 5000, 97), (64, 10, 1, 97),
+                           (32, 3, 7, 97), (48, 10, 100, 97), (256, 10, 700, 40), (33, 2, 500, 300), (160, 65, 900, 31),
+                           (64, 10, 8000, 520)]:
+            N = 70000 + int(rng.integers(0, 999))
             qb = rng.integers(0, 2, (Q, b), dtype=np.uint8)
             db = rng.integers(0, 2, (N, b), dtype=np.uint8)
             dl = (rng.random((N, C)) < 0.2).astype(np.int8)
@@ -78,39 +81,48 @@ def test_random_bet_shapes():
                 _, ap_ref, _, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
             ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
             ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
-            r0 = ctx.get_stat("optimistic_runs")
-            ap, rel = ctx.map(R)
-            assert ctx.get_stat("optimistic_runs") == r0 + 1, (b, C, R)
-            assert np.array_equal(ap, ap_ref, equal_nan=True), (b, C, R)
-            ctx.topr(R)
-            idx, dist = ctx.get_topr()
-            assert np.array_equal(idx, idx_ref) and np.array_equal(dist, dist_ref), (b, C, R)
+            for mfma in (1, 0):
+                ctx.set_option("select_mfma", mfma)
+                r0 = ctx.get_stat("optimistic_runs")
+                ap, rel = ctx.map(R)
+                assert ctx.get_stat("optimistic_runs") == r0 + 1, (b, C, R, mfma)
+                assert ctx.get_stat("last_optimistic") == 1, (b, C, R, mfma)
+                assert np.array_equal(ap, ap_ref, equal_nan=True), (b, C, R, mfma)
+                ctx.topr(R)
+                idx, dist = ctx.get_topr()
+                assert np.array_equal(idx, idx_ref) and np.array_equal(dist, dist_ref), (b, C, R, mfma)
     finally:
         ctx.close()
 
 
-def test_very_long_lists_use_the_global_bit_rows():
-    """R beyond what a block's LDS bitmap holds (~0.5M slots): match bits go through global atomics
-    on a zeroed row instead.  One shard and two virtual shards' worth of plan (staged, G = 1)."""
+def test_mx_select_segment_shapes():
+    """k_select_mx geometry corners: an unpaired last segment (odd segment count), a ragged last window,
+    segments shorter than one 128-row window, and both query-tile variants."""
     rng = np.random.default_rng(11)
-    Q, N, b, R, C = 3, 600000, 32, 530000, 4
-    qb = rng.integers(0, 2, (Q, b), dtype=np.uint8)
-    db = rng.integers(0, 2, (N, b), dtype=np.uint8)
-    dl = (rng.random((N, C)) < 0.3).astype(np.int8)
-    ql = (rng.random((Q, C)) < 0.5).astype(np.int8)
-    ql[:, 0] = 1
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        _, ap_ref, im_ref, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
     ctx = _native.Context(0)
     try:
-        ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
-        ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
-        ap, rel = ctx.map(R)
-        assert np.array_equal(ap, ap_ref, equal_nan=True)
-        ctx.topr(R)
-        idx, dist = ctx.get_topr()
-        assert np.array_equal(idx, idx_ref) and np.array_equal(dist, dist_ref)
-        assert np.array_equal(ctx.get_match().astype(bool), im_ref)
+        b, C, R, Q = 64, 10, 600, 70
+        for N, units, minseg, qt in [(65536 + 77, 7 * 2, 256, 2), (65536 + 77, 7 * 2, 256, 4), (70001, 1000 * 2, 48, 2),
+                                     (66000, 3 * 2, 256, 4), (80000, 16384, 256, 2)]:
+            qb = rng.integers(0, 2, (Q, b), dtype=np.uint8)
+            db = rng.integers(0, 2, (N, b), dtype=np.uint8)
+            dl = (rng.random((N, C)) < 0.2).astype(np.int8)
+            ql = (rng.random((Q, C)) < 0.2).astype(np.int8)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                _, ap_ref, _, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
+            ctx.set_option("target_units", units)
+            ctx.set_option("min_segment", minseg)
+            ctx.set_option("select_qt", qt)
+            ctx.set_option("optimistic", 1)
+            ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
+            ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
+            ap, rel = ctx.map(R)
+            key = (N, units, minseg, qt, ctx.get_stat("segments"), ctx.get_stat("segment_rows"))
+            assert ctx.get_stat("last_optimistic") == 1, key
+            assert np.array_equal(ap, ap_ref, equal_nan=True), key
+            ctx.topr(R)
+            idx, dist = ctx.get_topr()
+            assert np.array_equal(idx, idx_ref) and np.array_equal(dist, dist_ref), key
     finally:
         ctx.close()
