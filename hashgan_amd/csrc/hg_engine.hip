@@ -4,6 +4,7 @@
 #include "hg_kernels.hpp"
 #include "hg_real_kernels.hpp"
 #include "hg_select_mx.hpp"
+#include "hg_rank_lds.hpp"
 #include "../../include/hashgan_amd.h"
 
 #include <cmath>
@@ -66,10 +67,10 @@ struct DevBuf {
 
 enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_LAYOUT, KI_GUESS, KI_SELECT, KI_CAND_HIST,
                 KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_PACK, KI_REAL_SAMPLE, KI_REAL_GUESS, KI_REAL_SELECT,
-                KI_RADIX, KI_REAL_FINISH, KI_SELECT_MX, KI_COUNT };
+                KI_RADIX, KI_REAL_FINISH, KI_SELECT_MX, KI_RANK_LDS, KI_COUNT };
 const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_layout", "k_guess",
                                             "k_select", "k_rank_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge", "k_pack",
-                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish", "k_select_mx"};
+                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish", "k_select_mx", "k_rank_lds"};
 
 enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
 
@@ -129,6 +130,7 @@ struct hg_ctx {
     i64 opt_real_qpl = 1;      // real-valued path: queries per lane (1 or 2)
     i64 opt_rank_waves = 0;    // k_rank_fused wavefronts per query: 0 = by list length, else 4 or 16
     i64 opt_select_mfma = 1;   // optimistic select: 1 = matrix-core kernel (k_select_mx), 0 = vector-ALU k_select
+    i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
     i64 opt_select_qt = 2;     // k_select_mx query tiles per wavefront (2: 4 wavefronts per SIMD, 4: 2)
 
     // run state
@@ -149,7 +151,7 @@ struct hg_ctx {
     DevBuf hist, hown, posbase, seglt, segtie;
     DevBuf t, tguess, sstar, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
-    DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist, hwq;
+    DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
     int bpad = 0;              // feature count padded to a multiple of 16 (0: no float tables loaded)
     bool real_lists = false;
@@ -542,7 +544,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq};
     for (auto* d : all) d->release();
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
@@ -815,10 +817,32 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
         if (c->optimistic) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
         else HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
     }
+    const u32* only = nullptr;
+    if (mode == 0 && c->optimistic && c->opt_rank_lds) {
+        // records resident in LDS: room for ~2.5 R per query (the bet keeps 1.3-2 R), at most 64 KiB per block
+        const size_t fixed = ((size_t)5 * g.NB + 8 + 4 + 8 + 2 * (size_t)c->RW + (size_t)g.S + 2) * 4;
+        const size_t per_rec = c->want_lists ? 6 : 2;
+        i64 recs = (i64)(2.5 * (double)c->R) + 64;
+        const i64 fit = fixed < 64 * 1024 ? (i64)((64 * 1024 - fixed) / per_rec) : 0;
+        if (recs > fit) recs = fit;
+        recs = recs / 64 * 64;
+        if (recs >= 2 * c->R && recs >= 64) {
+            HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
+            RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
+                           c->cap, c->crow, c->want_lists ? 1 : 0, c->RW, (int)recs};
+            const size_t lb = fixed + (size_t)recs * per_rec;
+            c->t_begin(KI_RANK_LDS);
+            hipLaunchKernelGGL(k_rank_lds<4>, dim3(g.Q), dim3(256), lb, c->stream, c->cand.as<u64>(), la, c->out_idx.as<u32>(),
+                               c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+            c->t_end();
+            HG_TRY(c->check_launch("k_rank_lds"));
+            only = c->bigq.as<u32>();                // k_rank_fused below only ranks what did not fit
+        }
+    }
     RankArgs ra{c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(),
                 mode, c->hwq.as<u32>(), c->hown.as<u32>(), c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(),
                 c->tie_before.as<u32>(), c->posbase.as<u32>(),
-                c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW};
+                c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW, only};
     const size_t lds_bytes = (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4;
     c->t_begin(mode == 1 ? KI_CAND_HIST : KI_RANK_FUSED);
     if (nwav == 16)
@@ -1447,6 +1471,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_waves")) {
         if (value != 0 && value != 4 && value != 16) return fail(HG_ERR_ARG, "rank_waves must be 0, 4 or 16");
         c->opt_rank_waves = value;
+    } else if (!strcmp(key, "rank_lds")) {
+        c->opt_rank_lds = value != 0;
     } else if (!strcmp(key, "select_mfma")) {
         c->opt_select_mfma = value;
     } else if (!strcmp(key, "select_qt")) {
@@ -1490,7 +1516,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err,
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
-                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx};
+                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
         *value = total;

@@ -710,6 +710,7 @@ struct RankArgs {
     int want_lists;
     int bits_lds;
     i64 RW;
+    const u32* only;       // optional [Q]: handle only the flagged queries (the rest were ranked by k_rank_lds)
 };
 
 template <int NWAV>   // wavefronts per query: 4, or 16 for long lists
@@ -730,6 +731,7 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     u32* misc = tot + NB;             // [8]      t, cnt_lt, quota
     u32* bm = misc + 8;               // [bmw]
     u32* __restrict__ grow = mbits32 + (i64)q * 2 * a.RW;
+    if (a.only && !a.only[q]) return;
     if (a.fail[q]) {                                  // a slice of this query overflowed
         if (tid == 0) {
             if (a.mode == 1) atomicOr(&a.hown[(i64)NB * g.Qpad], 1u);   // tail word 0: this shard lost the bet
