@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--target-units", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (hg_set_option), repeatable")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events (overhead probe)")
+    ap.add_argument("--kernel-timing", default="pair-passes", choices=["pair-passes", "all"],
+                    help="HIP events around the passes over the pairs only (the roofline kernel; default) or around every "
+                         "kernel (+0.04 ms per step: events keep kernels from being dispatched back to back)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -178,7 +181,7 @@ def main():
 
     for _ in range(args.warmup):
         m, a = step()
-    ctx.timing_enable(not args.no_kernel_timing)
+    ctx.timing_enable(0 if args.no_kernel_timing else (2 if args.kernel_timing == "all" else 1))
     ctx.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -54,7 +54,7 @@ def run_sharded(args, spec, c0, packed0, rank, local_rank, world):
 
     for _ in range(args.warmup):
         m = step()
-    ctx.timing_enable(True)
+    ctx.timing_enable(1)                                # HIP events around the passes over the pairs only
     ctx.timing_reset()
     dist.barrier()
     torch.cuda.synchronize()
@@ -76,7 +76,8 @@ def run_sharded(args, spec, c0, packed0, rank, local_rank, world):
             "metric": "queries/sec (mAP@R of Q queries vs N-code database, Hamming ranking)",
             "value": Q * world / per_step, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 (xor+popcount), int counters, f64 AP", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "fp4 (E2M1 0/+-1) x fp4 -> f32 exact distances; u32 xor+popcount elsewhere; f64 AP", "data": "synthetic",
             "dry_run_not_a_measurement": dry,
             "config": {"workload": "%s sharded: Q=%d, %d shards x N=%d rows (database of %d rows), b=%d R=%d C=%d"
                                    % (args.workload.upper(), Q, world, N, world * N, b, R, spec["C"]),
@@ -88,6 +89,16 @@ def run_sharded(args, spec, c0, packed0, rank, local_rank, world):
             "map": maps[0], "map_identical_on_all_ranks": bool(all(x == maps[0] for x in maps)),
             "kernels_rank0": {k_: {"avg_ms": round(ms / max(cnt, 1), 5), "launches": cnt} for k_, (ms, cnt) in timing.items()},
         }
+        if timing:
+            import bench as B                          # rank 0's dominant kernel against its roofline (one shard's pairs)
+            NW, LW = (b + 31) // 32, (spec["C"] + 63) // 64
+            code_bytes = (Q + N) * NW * 4
+            geo = {"k_hist": code_bytes + (b + 1) * ((Q + 63) // 64 * 64) * 4,
+                   "k_select": code_bytes + (Q + N) * LW * 8 + Q * R * 8,
+                   "k_select_mx": (Q + N) * ((NW + 1) // 2) * 32 + code_bytes + (Q + N) * LW * 8 + Q * R * 8}
+            pair_passes = {k_: v for k_, v in timing.items() if k_ in geo}
+            if pair_passes:
+                out["roofline"], _ = B.kernel_rooflines(pair_passes, args.steps, dict(spec, Q=Q, N=N, b=b), geo)
         print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()

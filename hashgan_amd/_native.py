@@ -313,7 +313,9 @@ class Context:
         return v.value
 
     def timing_enable(self, on=True):
-        check(self._lib.hg_timing_enable(self._h, 1 if on else 0))
+        """on: False/0 off, True/2 every kernel, 1 only the pair passes (k_hist, k_select, k_select_mx)."""
+        level = 2 if on is True else (0 if on is False else int(on))
+        check(self._lib.hg_timing_enable(self._h, level))
 
     def timing_reset(self):
         check(self._lib.hg_timing_reset(self._h))

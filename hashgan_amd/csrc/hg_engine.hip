@@ -158,7 +158,7 @@ struct hg_ctx {
     i64 shapes_for_R = -1;
 
     // timing
-    bool timing = false;
+    int timing = 0;            // 0 off, 1 the pair passes only (hist, select), 2 every kernel
     double t_ms[KI_COUNT] = {0};
     i64 t_n[KI_COUNT] = {0};
     struct Pending { int id; hipEvent_t a, b; };
@@ -173,14 +173,20 @@ struct hg_ctx {
         (void)hipEventCreate(&e);
         return e;
     }
+    bool t_wanted(int id) const {
+        return timing >= 2 || (timing == 1 && (id == KI_HIST || id == KI_SELECT || id == KI_SELECT_MX));
+    }
+    bool t_open = false;
     void t_begin(int id) {
-        if (!timing) return;
+        t_open = t_wanted(id);
+        if (!t_open) return;
         Pending p{id, get_event(), get_event()};
         (void)hipEventRecord(p.a, stream);
         pending.push_back(p);
     }
     void t_end() {
-        if (!timing) return;
+        if (!t_open) return;
+        t_open = false;
         (void)hipEventRecord(pending.back().b, stream);
     }
     void t_collect() {   // after a stream sync
@@ -1189,7 +1195,7 @@ static int rerun_lost_queries(hg_ctx* c, int64_t R, bool lists, bool with_ap, bo
     s->N = c->N; s->b = c->b; s->C = c->C; s->n_total = c->n_total; s->NW = c->NW; s->NB = c->NB; s->LW = c->LW;
     s->idx_base = c->idx_base;
     s->target_units = c->target_units; s->min_segment = c->min_segment; s->opt_enable = 0;
-    s->timing = false;
+    s->timing = 0;
     s->db.borrow(c->db);
     s->dblab.borrow(c->dblab);
     s->Q = nF;
@@ -1531,7 +1537,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
 
 int hg_timing_enable(hg_ctx* c, int on) {
     if (!c) return fail(HG_ERR_ARG, "hg_timing_enable: null context");
-    c->timing = on != 0;
+    c->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
     return HG_OK;
 }
 

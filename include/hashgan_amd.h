@@ -183,7 +183,9 @@ int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
 /* Work buffers only grow; hg_trim frees everything except the resident code/label/feature tables
  * (stat "device_bytes" reports what the context holds). */
 int hg_trim(hg_ctx* ctx);
-/* HIP-event timing of every kernel launched on the context's stream. */
+/* HIP-event timing of the kernels launched on the context's stream.  on = 2: every kernel; 1: only the
+ * passes over the query x database pairs (k_hist, k_select, k_select_mx) -- two events per launch keep
+ * consecutive kernels from being dispatched back to back, ~4 us each; 0: off. */
 int hg_timing_enable(hg_ctx* ctx, int on);
 int hg_timing_reset(hg_ctx* ctx);
 /* Fills up to cap entries; name[i] points to static strings. Returns count via *n. */
