@@ -811,8 +811,23 @@ int hg_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank)
 // 1 = histogram phase (several shards, before the exchange), 2 = placement phase (after k_plan).
 static int launch_rank(hg_ctx* c, int mode, int nbits) {
     const Geo& g = c->geo;
-    const int nwav = c->opt_rank_waves ? (int)c->opt_rank_waves
-                                       : ((c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4);   // records per query ~ 3R / R
+    int nwav = c->opt_rank_waves ? (int)c->opt_rank_waves
+                                 : ((c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4);   // records per query ~ 3R / R
+    // k_rank_lds: the query's records resident in LDS -- room for ~2.5 R per query (the bet keeps 1.3-2 R),
+    // at most 64 KiB per block; queries with more are left to k_rank_fused (flagged in bigq)
+    bool use_lds = false;
+    i64 recs = 0;
+    const size_t fixed = ((size_t)5 * g.NB + 8 + 4 + 8 + 2 * (size_t)c->RW + (size_t)g.S + 2) * 4;
+    const size_t per_rec = c->want_lists ? 6 : 2;
+    if (c->optimistic && c->opt_rank_lds) {
+        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);    // this shard's part of the list
+        recs = (i64)(2.5 * (double)c->R * share) + 256;
+        const i64 fit = fixed < 64 * 1024 ? (i64)((64 * 1024 - fixed) / per_rec) : 0;
+        if (recs > fit) recs = fit;
+        recs = recs / 64 * 64;
+        use_lds = (double)recs >= 2.0 * (double)c->R * share && recs >= 64;
+        if (use_lds) nwav = 4;                        // the two kernels share hwq's [Q][4][NB] layout
+    }
     const size_t fixed_words = (size_t)(nwav + 1) * g.NB + 8;
     const int bits_lds = (fixed_words + 2 * (size_t)c->RW) * 4 <= 64 * 1024;
     if (mode != 1 && !bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
@@ -824,18 +839,13 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
         else HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
     }
     const u32* only = nullptr;
-    if (mode == 0 && c->optimistic && c->opt_rank_lds) {
-        // records resident in LDS: room for ~2.5 R per query (the bet keeps 1.3-2 R), at most 64 KiB per block
-        const size_t fixed = ((size_t)5 * g.NB + 8 + 4 + 8 + 2 * (size_t)c->RW + (size_t)g.S + 2) * 4;
-        const size_t per_rec = c->want_lists ? 6 : 2;
-        i64 recs = (i64)(2.5 * (double)c->R) + 64;
-        const i64 fit = fixed < 64 * 1024 ? (i64)((64 * 1024 - fixed) / per_rec) : 0;
-        if (recs > fit) recs = fit;
-        recs = recs / 64 * 64;
-        if (recs >= 2 * c->R && recs >= 64) {
+    if (use_lds) {
+        {
             HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
+            if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
             RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
-                           c->cap, c->crow, c->want_lists ? 1 : 0, c->RW, (int)recs};
+                           c->cap, c->crow, c->want_lists ? 1 : 0, c->RW, (int)recs, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
+                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>()};
             const size_t lb = fixed + (size_t)recs * per_rec;
             c->t_begin(KI_RANK_LDS);
             hipLaunchKernelGGL(k_rank_lds<4>, dim3(g.Q), dim3(256), lb, c->stream, c->cand.as<u64>(), la, c->out_idx.as<u32>(),

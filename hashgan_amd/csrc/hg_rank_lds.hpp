@@ -25,6 +25,16 @@ struct RankLdsArgs {
     int want_lists;
     i64 RW;
     int lds_recs;          // record capacity of the LDS arrays
+    // several shards (k_rank_fused's modes): 0 fused; 1 histogram phase only (per-wave histograms -> hwq,
+    // shard totals -> hown); 2 placement with the plan computed from the gathered histograms
+    int mode;
+    u32* hwq;              // [Q][NWAV][NB]
+    u32* hown;             // [NB][Qpad] (+ tail)
+    const int* xt;
+    const u32* xcnt_lt;
+    const u32* xquota;
+    const u32* xtie_before;
+    const u32* xposbase;   // [NB][Qpad]
 };
 
 template <int NWAV>
@@ -50,9 +60,14 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_lds(const u64* __restrict__ 
     u32* idx32 = (u32*)(rec16 + a.lds_recs);                              // [lds_recs] (lists only)
     u32* __restrict__ grow = mbits32 + (i64)q * 2 * a.RW;
 
-    if (tid == 0) a.big[q] = 0u;
+    if (a.mode == 2) { if (a.big[q]) return; }        // flagged by the histogram launch: k_rank_fused's
+    else if (tid == 0) a.big[q] = 0u;
     if (a.fail[q]) {                                  // a slice of this query overflowed
-        if (tid == 0) { atomicExch(a.err, 1); a.qbad[q] = 1u; }
+        if (tid == 0) {
+            if (a.mode == 1) atomicOr(&a.hown[(i64)NB * g.Qpad], 1u);   // tail word 0: this shard lost the bet
+            else { atomicExch(a.err, 1); a.qbad[q] = 1u; }
+        }
+        if (a.mode == 1) for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = 0u;
         return;
     }
     for (int i = tid; i < (NWAV + 1) * NB + 8 + NWAV + 8 + bmw; i += nthr) lds[i] = 0u;
@@ -122,9 +137,13 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_lds(const u64* __restrict__ 
     // ---- phase 1: per-wave histograms over contiguous quarters of the record list ----
     const u32 r0w = (u32)((u64)n * wave / NWAV), r1w = (u32)((u64)n * (wave + 1) / NWAV);
     u32* myh = hw + wave * NB;
-    for (u32 i = r0w + lane; i < r1w; i += 64) {
-        const u32 d = rec16[i] & 0xFFu;
-        if (d < (u32)NB) atomicAdd(&myh[d], 1u);
+    if (a.mode == 2) {                                // computed by the histogram launch
+        for (int i = tid; i < NWAV * NB; i += nthr) hw[i] = a.hwq[(i64)q * NWAV * NB + i];
+    } else {
+        for (u32 i = r0w + lane; i < r1w; i += 64) {
+            const u32 d = rec16[i] & 0xFFu;
+            if (d < (u32)NB) atomicAdd(&myh[d], 1u);
+        }
     }
     __syncthreads();
     // ---- phase 2: totals, threshold, quota, per-wave bucket starts (k_rank_fused's) ----
@@ -134,7 +153,27 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_lds(const u64* __restrict__ 
         tot[d] = acc;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (a.mode == 1) {                                // hand the histograms over and stop
+        for (int i = tid; i < NWAV * NB; i += nthr) a.hwq[(i64)q * NWAV * NB + i] = hw[i];
+        for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = tot[d];
+        return;
+    }
+    if (a.mode == 2) {
+        if (tid == 0) {
+            const int t = a.xt[q];
+            int dmin = 0;
+            while (dmin < NB - 1 && tot[dmin] == 0u) ++dmin;
+            misc[0] = (u32)t;
+            misc[1] = a.xcnt_lt[q];
+            misc[2] = a.xquota[q];
+            misc[3] = (u32)dmin;
+            a.qbad[q] = t < 0 ? 1u : 0u;
+        }
+        __syncthreads();
+        for (int d = tid; d < NB; d += nthr) tot[d] = a.xposbase[(i64)d * g.Qpad + q];   // my rows of bucket d start here
+        __syncthreads();
+    }
+    if (a.mode == 0 && tid == 0) {
         u64 cum = 0;
         int t = -1, dmin = -1;
         for (int d = 0; d < NB; ++d) {
@@ -154,8 +193,9 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_lds(const u64* __restrict__ 
     __syncthreads();
     const int t = (int)misc[0];
     if (t < 0) return;
+    const u32 tie0 = a.mode == 2 ? a.xtie_before[q] : 0u;    // ties owned by lower-ranked shards
     for (int d = tid; d <= t && d < NB; d += nthr) {  // per-wave starts: bucket start + records of earlier waves
-        u32 acc = d < t ? tot[d] : 0u;                // for d == t the "start" is the tie rank offset
+        u32 acc = d < t ? tot[d] : tie0;              // for d == t the "start" is the tie rank offset
         for (int w = 0; w < NWAV; ++w) {
             const u32 h = hw[w * NB + d];
             hw[w * NB + d] = acc;
