@@ -148,6 +148,7 @@ struct hg_ctx {
     DevBuf db, dblab, qc, qlab;
     DevBuf dbx, qx;            // fp4 images of db / qc in MFMA fragment order for k_select_mx (built on first use)
     bool dbx_valid = false, qx_valid = false;
+    bool err_zeroed = false;   // the guess kernel of a one-shot bet already cleared err
     DevBuf hist, hown, posbase, seglt, segtie;
     DevBuf t, tguess, sstar, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
@@ -688,14 +689,14 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     return HG_OK;
 }
 
-static int do_hist(hg_ctx* c, int stride) {
+static int do_hist(hg_ctx* c, int stride, bool reduce = true) {
     make_geometry(c);
     c->geo.hist_stride = stride;
     const Geo& g = c->geo;
     const size_t plane = (size_t)g.NB * g.Qpad * 4;
     HG_TRY(c->hist.reserve(plane * g.S));
     HG_TRY(c->hown.reserve(plane + TAIL_WORDS * 4));
-    {   // tail of the exported histogram: [0] overflow flag, [1] rows this pass visited
+    if (reduce) {   // tail of the exported histogram: [0] overflow flag, [1] rows this pass visited
         const u32 visited = (u32)(stride == 1 ? g.N : sampled_rows(c, stride));
         if (c->tail_host[1] != visited) {          // the staging words must not change under a copy in flight
             HG_HIP(hipStreamSynchronize(c->stream));
@@ -704,6 +705,7 @@ static int do_hist(hg_ctx* c, int stride) {
         HG_HIP(hipMemcpyAsync(c->hown.as<char>() + plane, c->tail_host, sizeof c->tail_host, hipMemcpyHostToDevice, c->stream));
     }
     HG_TRY(launch_hist(c));
+    if (!reduce) { c->stage = ST_DB | ST_Q; return HG_OK; }      // the caller reads the per-segment histograms itself
     const Geo gh = hist_geometry(c);
     c->t_begin(KI_HIST_REDUCE);
     hipLaunchKernelGGL(k_hist_reduce, dim3(grid_for((i64)g.NB * g.Qpad)), dim3(256), 0, c->stream,
@@ -835,8 +837,9 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
     HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
     if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
     if (mode == 0) {
-        if (c->optimistic) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+        if (c->optimistic) { if (!c->err_zeroed) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream)); }
         else HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
+        c->err_zeroed = false;
     }
     const u32* only = nullptr;
     if (use_lds) {
@@ -1150,22 +1153,24 @@ static int enqueue_exact(hg_ctx* c, int64_t R) {
 }
 
 static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
-    HG_TRY(do_hist(c, stride));
+    (void)need_cnt;
+    HG_TRY(do_hist(c, stride, false));
     HG_TRY(set_R(c, R, 1, 0));
     const Geo& g = c->geo;
     const size_t qb = (size_t)g.Qpad * 4;
     HG_TRY(c->tguess.reserve(qb));
     HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
     HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
-    HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
+    HG_TRY(c->err.reserve(4));
+    HG_TRY(c->sstar.reserve(qb));
     c->t_begin(KI_GUESS);
     const Geo gh = hist_geometry(c);                   // the sampled pass ran on coarser segments
-    HG_TRY(c->sstar.reserve(qb));
-    hipLaunchKernelGGL(k_guess, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(), (const u32*)nullptr, 1, 0,
-                       c->hist.as<u32>(), gh.S, (int)(gh.L / g.L), (double)c->opt_sigma, (i64)c->n_total,
-                       c->tguess.as<int>(), c->sstar.as<int>(), g);
+    hipLaunchKernelGGL(k_guess_direct, dim3(grid_for(g.Qpad, 64)), dim3(256), 0, c->stream, c->hist.as<u32>(), gh.S,
+                       (int)(gh.L / g.L), (double)c->opt_sigma, (i64)c->n_total, (u32)sampled_rows(c, stride),
+                       c->tguess.as<int>(), c->sstar.as<int>(), c->failq.as<u32>(), c->err.as<int>(), g);
     c->t_end();
-    HG_TRY(c->check_launch("k_guess"));
+    HG_TRY(c->check_launch("k_guess_direct"));
+    c->err_zeroed = true;                              // launch_rank need not clear the lost-bet flag again
     // slice capacity: a guessed cut typically keeps 1.3-3 R rows (the guess overshoots by at most one
     // distance bucket, and cumulative counts grow ~2x per bucket in the tail where the cut lies; clustered
     // codes grow faster) -- budget 4 R per query over the S segments plus 6 sigma per slice.  HBM is

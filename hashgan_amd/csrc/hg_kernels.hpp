@@ -330,6 +330,73 @@ __global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, const
     sstar[q] = ss;
 }
 
+// One-shot, single-shard form of k_hist_reduce + k_guess: sums the sampled pass's per-segment histograms
+// itself, bucket by bucket, and stops at the guessed cut -- a third of the planes at C2, no reduced copy,
+// one launch less.  Also clears the bet's per-query overflow flags and the lost-bet flag (two fills less).
+__global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hseg, int Sh, int ratio, double sigma,
+                                                      i64 n_total, u32 sampled, int* __restrict__ T, int* __restrict__ sstar,
+                                                      u32* __restrict__ failq, int* __restrict__ err, const Geo g) {
+    // 16 queries per wavefront, 4 lanes per query: lane part p sums segments [p * per, (p + 1) * per)
+    const int lane = threadIdx.x & 63, part = lane >> 4;
+    const int q = (blockIdx.x * WPB + (threadIdx.x >> 6)) * 16 + (lane & 15);
+    if (part == 0 && q < g.Qpad) failq[q] = 0u;
+    if (q == 0 && part == 0) *err = 0;
+    const bool live = q < g.Q;
+    const int qq = live ? q : 0;                       // dead lanes follow query 0 (shuffles need every lane)
+    const double fr = (double)g.R * (double)sampled / (double)n_total;
+    const u64 need = (u64)ceil(fr + sigma * sqrt(fr) + 1.0);
+    const i64 plane = (i64)g.NB * g.Qpad;
+    const int per = (Sh + 3) / 4;
+    const int s0 = part * per, s1 = s0 + per < Sh ? s0 + per : Sh;
+    u64 cum = 0, below = 0;
+    int t = g.NB - 1;                                  // sample too thin: take everything
+    bool found = false;
+    for (int d = 0; d < g.NB; ++d) {
+        u32 c = 0;
+        const u32* __restrict__ col = hseg + (i64)d * g.Qpad + qq;
+        int sh = s0;
+        for (; sh + 4 <= s1; sh += 4) {                 // independent loads in flight
+            u32 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = col[(i64)(sh + k) * plane];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c += v[k];
+        }
+        for (; sh < s1; ++sh) c += col[(i64)sh * plane];
+        c += (u32)__shfl_xor((int)c, 16);
+        c += (u32)__shfl_xor((int)c, 32);
+        below = cum;
+        cum += c;
+        if (cum >= need) { t = d; found = true; break; }
+    }
+    // all four parts of a query agree on t; a wave's queries may stop at different d: no shuffle after this point
+    // depends on lanes that left the loop early -- the ones below only pair lanes of the same query
+    int ss = g.S - 1;                                  // default: collect distance T everywhere
+    if (found) {
+        // {dist < T} everywhere + {dist == T} up to a segment: first segment (in order) where the count reaches need
+        const u32* __restrict__ col = hseg + (i64)t * g.Qpad + qq;
+        u32 mine = 0;
+        for (int sh = s0; sh < s1; ++sh) mine += col[(i64)sh * plane];
+        // exclusive prefix over the four parts of the query
+        const u32 a1 = (u32)__shfl_xor((int)mine, 16);           // partner in the same pair
+        const u32 pair = mine + a1;
+        const u32 a2 = (u32)__shfl_xor((int)pair, 32);           // the other pair's total
+        u64 have = below + ((part & 1) ? a1 : 0u) + ((part & 2) ? a2 : 0u);
+        int cand = 0x7FFFFFFF;
+        for (int sh = s0; sh < s1; ++sh) {
+            have += col[(i64)sh * plane];
+            if (have >= need) { cand = sh; break; }
+        }
+        int m = __shfl_xor(cand, 16);
+        cand = cand < m ? cand : m;
+        m = __shfl_xor(cand, 32);
+        cand = cand < m ? cand : m;
+        if (cand != 0x7FFFFFFF) ss = (cand + 1) * ratio - 1;
+        if (ss > g.S - 1) ss = g.S - 1;
+    }
+    if (live && part == 0) { T[q] = t; sstar[q] = ss; }
+}
+
 // ----------------------------------------------------------------------------
 // K3  select.   The pass over the pairs that produces ranked-list members.  A
 // lane walks its query through the segment in index order; every row with
