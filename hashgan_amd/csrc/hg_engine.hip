@@ -149,6 +149,11 @@ struct hg_ctx {
     DevBuf dbx, qx;            // fp4 images of db / qc in MFMA fragment order for k_select_mx (built on first use)
     bool dbx_valid = false, qx_valid = false;
     bool err_zeroed = false;   // the guess kernel of a one-shot bet already cleared err
+    // pinned landing zone for a one-shot call's results: AP, hit counts and the lost-bet flag come back with the
+    // call's single synchronisation instead of three blocking copies into pageable memory afterwards
+    void* pin = nullptr;
+    size_t pin_cap = 0;
+    bool ap_staged = false;
     DevBuf hist, hown, posbase, seglt, segtie;
     DevBuf t, tguess, sstar, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
@@ -554,6 +559,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq};
     for (auto* d : all) d->release();
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
+    if (c->pin) (void)hipHostFree(c->pin);
     if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
     delete c;
     return HG_OK;
@@ -965,6 +971,7 @@ int hg_merge_match(hg_ctx* c, const uint64_t* dev_bits_all, int G) {
 }
 
 static int do_ap(hg_ctx* c) {
+    c->ap_staged = false;
     const Geo& g = c->geo;
     if (c->shapes_for_R != g.R) {
         std::vector<ApShape> sh(2);
@@ -1257,8 +1264,25 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
     if (bet) {
         c->opt_runs++;
         HG_TRY(enqueue_optimistic(c, R, stride, need_cnt));
-        if (with_ap) HG_TRY(do_ap(c));
-        HG_TRY(read_plan_flag(c, &flag));
+        if (with_ap) {
+            HG_TRY(do_ap(c));
+            const size_t Q = (size_t)c->geo.Q, need_b = Q * 12 + 16;
+            if (c->pin_cap < need_b) {
+                if (c->pin) (void)hipHostFree(c->pin);
+                c->pin = nullptr; c->pin_cap = 0;
+                HG_HIP(hipHostMalloc(&c->pin, need_b, hipHostMallocDefault));
+                c->pin_cap = need_b;
+            }
+            char* pb = (char*)c->pin;                  // [flag 16 B][ap Q x 8][rel Q x 4]
+            HG_HIP(hipMemcpyAsync(pb, c->err.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HG_HIP(hipMemcpyAsync(pb + 16, c->ap.p, Q * 8, hipMemcpyDeviceToHost, c->stream));
+            HG_HIP(hipMemcpyAsync(pb + 16 + Q * 8, c->rel.p, Q * 4, hipMemcpyDeviceToHost, c->stream));
+            HG_TRY(c->sync());
+            flag = *(const int*)pb;
+            c->ap_staged = flag == 0;
+        } else {
+            HG_TRY(read_plan_flag(c, &flag));
+        }
         if (!flag) { c->opt_consecutive_fail = 0; return HG_OK; }
         bool handled = false;                      // some queries lost their bet
         HG_TRY(rerun_lost_queries(c, R, lists, with_ap, &handled));
@@ -1430,6 +1454,15 @@ int hg_get_match(hg_ctx* c, uint8_t* host_imatch) {
 int hg_get_ap(hg_ctx* c, double* host_ap, int64_t* host_rel) {
     HG_TRY(need(c, ST_AP, "hg_get_ap", "hg_ap"));
     const i64 Q = c->geo.Q;
+    if (c->ap_staged && c->pin) {                      // the one-shot call already brought them over
+        const char* pb = (const char*)c->pin;
+        if (host_ap) memcpy(host_ap, pb + 16, (size_t)Q * 8);
+        if (host_rel) {
+            const u32* r = (const u32*)(pb + 16 + (size_t)Q * 8);
+            for (i64 q = 0; q < Q; ++q) host_rel[q] = r[q];
+        }
+        return HG_OK;
+    }
     if (host_ap) HG_HIP(hipMemcpyAsync(host_ap, c->ap.p, (size_t)Q * 8, hipMemcpyDeviceToHost, c->stream));
     std::vector<u32> rel;
     if (host_rel) {
