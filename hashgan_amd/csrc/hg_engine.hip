@@ -5,6 +5,7 @@
 #include "hg_real_kernels.hpp"
 #include "hg_select_mx.hpp"
 #include "hg_rank_lds.hpp"
+#include "hg_select_mx2.hpp"
 #include "../../include/hashgan_amd.h"
 
 #include <cmath>
@@ -130,6 +131,7 @@ struct hg_ctx {
     i64 opt_real_qpl = 1;      // real-valued path: queries per lane (1 or 2)
     i64 opt_rank_waves = 0;    // k_rank_fused wavefronts per query: 0 = by list length, else 4 or 16
     i64 opt_select_mfma = 1;   // optimistic select: 1 = matrix-core kernel (k_select_mx), 0 = vector-ALU k_select
+    i64 opt_select_packed = 1; // codes of <= 64 bits: k_select_mx2 (two distances per MFMA accumulator)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
     i64 opt_select_qt = 2;     // k_select_mx query tiles per wavefront (2: 4 wavefronts per SIMD, 4: 2)
 
@@ -148,6 +150,8 @@ struct hg_ctx {
     DevBuf db, dblab, qc, qlab;
     DevBuf dbx, qx;            // fp4 images of db / qc in MFMA fragment order for k_select_mx (built on first use)
     bool dbx_valid = false, qx_valid = false;
+    DevBuf dbx2, qx2;          // the same for k_select_mx2 (two rows per accumulator, codes of <= 64 bits)
+    bool dbx2_valid = false, qx2_valid = false;
     bool err_zeroed = false;   // the guess kernel of a one-shot bet already cleared err
     // pinned landing zone for a one-shot call's results: AP, hit counts and the lost-bet flag come back with the
     // call's single synchronisation instead of three blocking copies into pageable memory afterwards
@@ -236,8 +240,8 @@ void make_geometry(hg_ctx* c) {
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     i64 L = (c->N + S - 1) / S;
-    L = (L + 15) / 16 * 16;
-    if (L < 16) L = 16;
+    L = (L + 31) / 32 * 32;                            // k_select_mx2 walks segments in 32-row tiles
+    if (L < 32) L = 32;
     S = (c->N + L - 1) / L;
     if (S < 1) S = 1;
     if (c->opt_enable && c->opt_select_mfma && S >= 4) {
@@ -253,7 +257,7 @@ void make_geometry(hg_ctx* c) {
         if (S2 > maxS) S2 = maxS / 2 * 2;
         for (; S2 >= 4; S2 -= 2) {                 // rounding L up to 16 rows can drop segments: land on an even count
             i64 L2 = (c->N + S2 - 1) / S2;
-            L2 = (L2 + 15) / 16 * 16;
+            L2 = (L2 + 31) / 32 * 32;
             const i64 Sr = (c->N + L2 - 1) / L2;
             if (Sr * 4 < S * 3) break;             // too far from the target: keep the plain choice
             if (Sr % 2 == 0 && Sr * 4 <= S * 5 && (Sr / 2) * nQB <= slots * k) { S = Sr; L = L2; break; }
@@ -362,6 +366,51 @@ template <int NW, int LW, int QT> int launch_select_mx_q(hg_ctx* c) {
     return c->check_launch("k_select_mx");
 }
 
+// codes of <= 64 bits: two rows per accumulator (k_select_mx2); blocks = (pair of segments) x (256 queries)
+template <int NW, int LW> int launch_select_mx2_t(hg_ctx* c) {
+    if (!c->dbx2_valid) {
+        const i64 n32 = (c->N + 31) / 32 * 32;
+        HG_TRY(c->dbx2.reserve((size_t)(n32 > 0 ? n32 : 32) * NW * 16));
+        const i64 items = n32 * NW;
+        c->t_begin(KI_PACK);
+        if (items) hipLaunchKernelGGL(k_expand_db2, dim3(grid_for(items)), dim3(256), 0, c->stream, c->db.as<u32>(),
+                                      c->dbx2.as<uint4>(), (i64)c->N, n32, NW);
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_db2"));
+        c->dbx2_valid = true;
+    }
+    Geo g = c->geo;
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + 255) / 256;
+    if (!c->qx2_valid) {
+        const i64 qpad = (i64)nQB * 256;
+        HG_TRY(c->qx2.reserve((size_t)qpad * NW * 32));
+        const i64 items = qpad * NW;
+        c->t_begin(KI_PACK);
+        hipLaunchKernelGGL(k_expand_queries2, dim3(grid_for(items)), dim3(256), 0, c->stream, c->qc.as<u32>(), c->qx2.as<uint4>(),
+                           (i64)c->Q, qpad, NW);
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_queries2"));
+        c->qx2_valid = true;
+    }
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    const Mx2Lds L = mx2_lds_layout(NW, LW);
+    if (L.total > 64 * 1024)
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx2<NW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   L.total));
+    SelArgs a{c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
+              c->cap, c->crow, (int)c->opt_select_mfma, c->sstar.as<int>()};
+    c->t_begin(KI_SELECT_MX);
+    hipLaunchKernelGGL((k_select_mx2<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total, c->stream, c->qc.as<u32>(),
+                       c->qlab.as<u64>(), c->qx2.as<u8>(), c->db.as<u32>(), c->dbx2.as<u8>(), c->dblab.as<u64>(), a,
+                       c->cand.as<u64>(), g);
+    c->t_end();
+    return c->check_launch("k_select_mx2");
+}
+
 template <int NW, int LW> int launch_select_dense_t(hg_ctx* c) {
     const Geo& g = c->geo;
     SelArgs a{c->t.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
@@ -380,6 +429,16 @@ template <int NW> int launch_select_nw(hg_ctx* c) {
             case 1: return launch_select_dense_t<NW, 1>(c);
             case 2: return launch_select_dense_t<NW, 2>(c);
             default: return launch_select_dense_t<NW, 0>(c);
+        }
+    }
+    // two rows per accumulator: wins for one-word codes (half the MFMAs: 0.92 vs 1.02 ms at b = 32); for 33-64 bits
+    // its cheaper harvest (0.36 vs 0.44 ms) is eaten by the wider queue entries (select_packed = 2 forces it)
+    if (c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS) && c->geo.L % 32 == 0 &&
+        ((c->opt_select_packed == 1 && NW == 1) || (c->opt_select_packed == 2 && NW <= 2))) {
+        switch (lw) {
+            case 1: return launch_select_mx2_t<(NW <= 2 ? NW : 1), 1>(c);
+            case 2: return launch_select_mx2_t<(NW <= 2 ? NW : 1), 2>(c);
+            default: return launch_select_mx2_t<(NW <= 2 ? NW : 1), 0>(c);
         }
     }
     if (c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS)) {
@@ -556,7 +615,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2};
     for (auto* d : all) d->release();
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->pin) (void)hipHostFree(c->pin);
@@ -600,6 +659,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     HG_TRY(c->sync());
     c->stage = ST_DB;   // queries must be (re)set after the database: b, C may have changed
     c->dbx_valid = false;
+    c->dbx2_valid = false;
     return HG_OK;
 }
 
@@ -655,6 +715,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     HG_TRY(pack_on_device(c, host_x, host_labels, N, c->db, c->dblab, c->dbf, bad_codes, bad_labels));
     c->stage = ST_DB;
     c->dbx_valid = false;
+    c->dbx2_valid = false;
     return HG_OK;
 }
 
@@ -667,6 +728,7 @@ int hg_set_queries_f32(hg_ctx* c, const float* host_x, const int64_t* host_label
     HG_TRY(pack_on_device(c, host_x, host_labels, Q, c->qc, c->qlab, c->qf, bad_codes, bad_labels));
     c->stage = ST_DB | ST_Q;
     c->qx_valid = false;
+    c->qx2_valid = false;
     return HG_OK;
 }
 
@@ -692,6 +754,7 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     HG_TRY(c->sync());
     c->stage = ST_DB | ST_Q;
     c->qx_valid = false;
+    c->qx2_valid = false;
     return HG_OK;
 }
 
@@ -1525,6 +1588,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_waves")) {
         if (value != 0 && value != 4 && value != 16) return fail(HG_ERR_ARG, "rank_waves must be 0, 4 or 16");
         c->opt_rank_waves = value;
+    } else if (!strcmp(key, "select_packed")) {
+        c->opt_select_packed = value;
     } else if (!strcmp(key, "rank_lds")) {
         c->opt_rank_lds = value != 0;
     } else if (!strcmp(key, "select_mfma")) {
@@ -1570,7 +1635,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err,
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
-                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq};
+                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
         *value = total;

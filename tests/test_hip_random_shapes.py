@@ -81,11 +81,12 @@ def test_random_bet_shapes():
                 _, ap_ref, _, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
             ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
             ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
-            for mfma in (1, 0):
+            for mfma, packed in ((1, 1), (1, 2), (0, 1)):       # k_select_mx / k_select_mx2 by default rule, mx2 forced, vector ALU
                 ctx.set_option("select_mfma", mfma)
+                ctx.set_option("select_packed", packed)
                 r0 = ctx.get_stat("optimistic_runs")
                 ap, rel = ctx.map(R)
-                assert ctx.get_stat("optimistic_runs") == r0 + 1, (b, C, R, mfma)
+                assert ctx.get_stat("optimistic_runs") == r0 + 1, (b, C, R, mfma, packed)
                 assert ctx.get_stat("last_optimistic") == 1, (b, C, R, mfma)
                 assert np.array_equal(ap, ap_ref, equal_nan=True), (b, C, R, mfma)
                 ctx.topr(R)
@@ -114,6 +115,7 @@ def test_mx_select_segment_shapes():
             ctx.set_option("target_units", units)
             ctx.set_option("min_segment", minseg)
             ctx.set_option("select_qt", qt)
+            ctx.set_option("select_packed", 2 if qt == 2 else 0)     # both matrix-core kernels see these geometries
             ctx.set_option("optimistic", 1)
             ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
             ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
