@@ -39,7 +39,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MX_WT = 8;                // row tiles per window
 constexpr int MX_WROWS = 16 * MX_WT;    // rows per lane-half per window
-constexpr int mx_qcap(int QT) { return 64 * 4 * QT; }   // hit-queue entries (8 bytes) per wavefront: one per lane, query tile and mask word
+constexpr int mx_qcap(int QT) { return 64 * 2 * QT; }   // hit-queue entries (8 bytes) per wavefront: one per lane, query tile and mask word of HALF a window
 constexpr u32 MX_POS_BITS = 17;         // slice positions in a queue entry: cap < 2^17
 
 // 8 code bits -> 8 nibbles, bit j at bit 4 j
@@ -233,7 +233,8 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
     //          -- the positions fix the record order, so the queue order is free;
     //   emit   64 queue entries at a time, every lane busy: walk the word's bits (usually one), exact distance
     //          and match bit from the packed rows staged in LDS, one 8-byte store per hit.
-    // A window has at most 64 x 4 x 4 words, so the queue (MX_QCAP) cannot overflow, dense windows included.
+    // The queue is drained twice per window; half a window has at most 64 x QT x 2 words, so it (MX_QCAP) cannot overflow,
+    // dense windows included.
     u64* queue = (u64*)(mxlds + L.queue) + wave * MX_QCAP;
     u32 qfill = 0;                                                   // entries in the queue (wave-uniform)
     auto push = [&](const int t, const int w, const u32 word, u32& cntt, const u32 caplt, u32& droppedt) {
@@ -361,10 +362,13 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
             for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][3] == 0x1234567u) dropped[t]++;
         } else {
 #pragma unroll
-            for (int t = 0; t < QT; ++t)
+            for (int hw = 0; hw < 2; ++hw) {                         // two drains per window: half the queue, one block more per CU
 #pragma unroll
-                for (int w = 0; w < 4; ++w) push(t, w, m[t][w], cnt[t], capl[t], dropped[t]);
-            emit(win, st);
+                for (int t = 0; t < QT; ++t)
+#pragma unroll
+                    for (int w = 2 * hw; w < 2 * hw + 2; ++w) push(t, w, m[t][w], cnt[t], capl[t], dropped[t]);
+                emit(win, st);
+            }
         }
     }
 
