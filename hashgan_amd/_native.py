@@ -44,6 +44,7 @@ _SIGNATURES = {
     "hg_guess": [_p, _i64, _p, C.c_int, C.c_int],
     "hg_select_candidates": [_p],
     "hg_rank": [_p, _p, C.c_int, C.c_int, C.POINTER(C.c_int)],
+    "hg_bet_verdict": [_p, C.POINTER(C.c_int)],
     "hg_match": [_p],
     "hg_match_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
     "hg_merge_match": [_p, _p, C.c_int],
@@ -220,6 +221,11 @@ class Context:
     def rank(self, dev_hist_all=None, G=1, rank=0):
         lost = C.c_int()
         check(self._lib.hg_rank(self._h, _p(dev_hist_all) if dev_hist_all else None, int(G), int(rank), C.byref(lost)))
+        return None if lost.value < 0 else bool(lost.value)      # None: verdict deferred (option defer_verdict)
+
+    def bet_verdict(self):
+        lost = C.c_int()
+        check(self._lib.hg_bet_verdict(self._h, C.byref(lost)))
         return bool(lost.value)
 
     def match(self):

@@ -153,6 +153,9 @@ struct hg_ctx {
     DevBuf dbx2, qx2;          // the same for k_select_mx2 (two rows per accumulator, codes of <= 64 bits)
     bool dbx2_valid = false, qx2_valid = false;
     bool err_zeroed = false;   // the guess kernel of a one-shot bet already cleared err
+    i64 defer_verdict = 0;     // hg_rank does not wait for the bet's verdict; hg_bet_verdict reads it later
+    bool verdict_pending = false, verdict_known = false;
+    int verdict_flag = 0;
     // pinned landing zone for a one-shot call's results: AP, hit counts and the lost-bet flag come back with the
     // call's single synchronisation instead of three blocking copies into pageable memory afterwards
     void* pin = nullptr;
@@ -1159,6 +1162,32 @@ int hg_select_candidates(hg_ctx* c) {
     return c->stage_end();
 }
 
+static int ensure_pin(hg_ctx* c, size_t need_b) {
+    if (c->pin_cap >= need_b) return HG_OK;
+    if (c->pin) (void)hipHostFree(c->pin);
+    c->pin = nullptr; c->pin_cap = 0;
+    HG_HIP(hipHostMalloc(&c->pin, need_b, hipHostMallocDefault));
+    c->pin_cap = need_b;
+    return HG_OK;
+}
+
+// bookkeeping after the verdict of a staged bet is known
+static int settle_bet(hg_ctx* c, int flag) {
+    c->opt_runs++;
+    if (flag) {
+        c->opt_fallbacks++;
+        c->opt_consecutive_fail++;
+        c->stage = ST_DB | ST_Q;
+        return HG_OK;
+    }
+    c->opt_consecutive_fail = 0;
+    c->lists_valid = c->want_lists;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT;
+    if (c->LW <= 2) c->stage |= ST_MATCH;
+    else HG_TRY(do_match(c));
+    return c->sync();
+}
+
 int hg_rank(hg_ctx* c, const uint32_t* dev_hist_all, int G, int rank, int* bet_lost) {
     HG_TRY(need(c, ST_PLAN, "hg_rank", "hg_select_candidates"));
     if (!c->optimistic) return fail(HG_ERR_STATE, "hg_rank: no guess in force");
@@ -1178,22 +1207,40 @@ int hg_rank(hg_ctx* c, const uint32_t* dev_hist_all, int G, int rank, int* bet_l
     int nbits = 1;
     while ((1 << nbits) < g.NB) ++nbits;
     HG_TRY(launch_rank(c, 2, nbits));                // placement with the shared plan
+    if (c->defer_verdict) {
+        // the caller goes on as if the bet held (match bits, exchange, AP) and asks hg_bet_verdict at the end,
+        // together with its final download: no host round trip in the middle of the step
+        *bet_lost = -1;
+        c->verdict_pending = true;
+        c->verdict_known = false;
+        c->lists_valid = c->want_lists;
+        c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT;
+        if (c->LW <= 2) c->stage |= ST_MATCH;
+        else HG_TRY(do_match(c));
+        return c->stage_end();
+    }
     int flag = 0;
     HG_TRY(read_plan_flag(c, &flag));
     *bet_lost = flag;
+    return settle_bet(c, flag);
+}
+
+int hg_bet_verdict(hg_ctx* c, int* bet_lost) {
+    if (!c || !bet_lost) return fail(HG_ERR_ARG, "hg_bet_verdict: null argument");
+    if (!c->verdict_pending) return fail(HG_ERR_STATE, "hg_bet_verdict: no deferred hg_rank outstanding");
+    c->verdict_pending = false;
+    int flag = 0;
+    if (c->verdict_known) flag = c->verdict_flag;      // came over with hg_get_ap's download
+    else HG_TRY(read_plan_flag(c, &flag));
+    c->verdict_known = false;
+    *bet_lost = flag;
+    if (!flag) { c->opt_runs++; c->opt_consecutive_fail = 0; return HG_OK; }
     c->opt_runs++;
-    if (flag) {
-        c->opt_fallbacks++;
-        c->opt_consecutive_fail++;
-        c->stage = ST_DB | ST_Q;
-        return HG_OK;
-    }
-    c->opt_consecutive_fail = 0;
-    c->lists_valid = c->want_lists;
-    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT;
-    if (c->LW <= 2) c->stage |= ST_MATCH;
-    else HG_TRY(do_match(c));
-    return c->sync();
+    c->opt_fallbacks++;
+    c->opt_consecutive_fail++;
+    c->lists_valid = false;
+    c->stage = ST_DB | ST_Q;
+    return HG_OK;
 }
 
 // ---- one-shot forms: every stage enqueued back to back, one synchronisation ----
@@ -1330,12 +1377,7 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
         if (with_ap) {
             HG_TRY(do_ap(c));
             const size_t Q = (size_t)c->geo.Q, need_b = Q * 12 + 16;
-            if (c->pin_cap < need_b) {
-                if (c->pin) (void)hipHostFree(c->pin);
-                c->pin = nullptr; c->pin_cap = 0;
-                HG_HIP(hipHostMalloc(&c->pin, need_b, hipHostMallocDefault));
-                c->pin_cap = need_b;
-            }
+            HG_TRY(ensure_pin(c, need_b));
             char* pb = (char*)c->pin;                  // [flag 16 B][ap Q x 8][rel Q x 4]
             HG_HIP(hipMemcpyAsync(pb, c->err.p, 4, hipMemcpyDeviceToHost, c->stream));
             HG_HIP(hipMemcpyAsync(pb + 16, c->ap.p, Q * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1526,14 +1568,19 @@ int hg_get_ap(hg_ctx* c, double* host_ap, int64_t* host_rel) {
         }
         return HG_OK;
     }
-    if (host_ap) HG_HIP(hipMemcpyAsync(host_ap, c->ap.p, (size_t)Q * 8, hipMemcpyDeviceToHost, c->stream));
-    std::vector<u32> rel;
-    if (host_rel) {
-        rel.resize((size_t)Q);
-        HG_HIP(hipMemcpyAsync(rel.data(), c->rel.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
-    }
+    // one batch of copies into pinned memory, one synchronisation; a deferred verdict rides along
+    HG_TRY(ensure_pin(c, (size_t)Q * 12 + 16));
+    char* pb = (char*)c->pin;
+    if (c->verdict_pending) HG_HIP(hipMemcpyAsync(pb, c->err.p, 4, hipMemcpyDeviceToHost, c->stream));
+    if (host_ap) HG_HIP(hipMemcpyAsync(pb + 16, c->ap.p, (size_t)Q * 8, hipMemcpyDeviceToHost, c->stream));
+    if (host_rel) HG_HIP(hipMemcpyAsync(pb + 16 + (size_t)Q * 8, c->rel.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
     HG_TRY(c->sync());
-    if (host_rel) for (i64 q = 0; q < Q; ++q) host_rel[q] = rel[(size_t)q];
+    if (c->verdict_pending) { c->verdict_flag = *(const int*)pb; c->verdict_known = true; }
+    if (host_ap) memcpy(host_ap, pb + 16, (size_t)Q * 8);
+    if (host_rel) {
+        const u32* r = (const u32*)(pb + 16 + (size_t)Q * 8);
+        for (i64 q = 0; q < Q; ++q) host_rel[q] = r[q];
+    }
     return HG_OK;
 }
 
@@ -1588,6 +1635,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_waves")) {
         if (value != 0 && value != 4 && value != 16) return fail(HG_ERR_ARG, "rank_waves must be 0, 4 or 16");
         c->opt_rank_waves = value;
+    } else if (!strcmp(key, "defer_verdict")) {
+        c->defer_verdict = value != 0;
     } else if (!strcmp(key, "select_packed")) {
         c->opt_select_packed = value;
     } else if (!strcmp(key, "rank_lds")) {

@@ -119,6 +119,7 @@ class HipShardEngine:
             import torch
             ctx.set_stream(torch.cuda.current_stream(torch.device("cuda", ctx.device)).cuda_stream)
             ctx.set_option("stage_sync", 0)
+            ctx.set_option("defer_verdict", 1)      # the bet's verdict is read with the final download
 
     def hist(self):
         self.ctx.hist()
@@ -160,6 +161,10 @@ class HipShardEngine:
         self._keep.append(gathered)
         return self.ctx.rank(gathered.data_ptr() if gathered is not None else None, world, rank)
 
+    def verdict(self):
+        """True if a deferred bet (rank_candidates returned None) turned out lost."""
+        return self.ctx.bet_verdict()
+
     def finish(self, gathered_bits, world):
         if gathered_bits is not None:
             self._keep.append(gathered_bits)
@@ -195,12 +200,24 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
         # exact record histograms -> shared exact plan.  `lost` is the same on every rank.
         engine.guess(R, gather(engine.sample_hist(R)), comm.world, comm.rank)
         lost = engine.rank_candidates(gather(engine.select_candidates()), comm.world, comm.rank)
+        deferred = lost is None                      # engine does not wait for the verdict: carry on as if the bet held
         if not lost:
             bits = engine.match_bits()
+    else:
+        deferred = False
     if bits is None:                                 # exact two-pass sequence
         engine.plan(R, gather(engine.hist()), comm.world, comm.rank)
         bits = engine.select_match()
     B = gather(bits)
+    if deferred and not gather_topr:
+        ap, rel = engine.finish(B, comm.world)
+        if not engine.verdict():                     # the same on every rank (computed from gathered data)
+            return ap, rel
+        engine.plan(R, gather(engine.hist()), comm.world, comm.rank)      # lost after all: exact sequence
+        B = gather(engine.select_match())
+    elif deferred and engine.verdict():
+        engine.plan(R, gather(engine.hist()), comm.world, comm.rank)
+        B = gather(engine.select_match())
     lists = None
     if gather_topr:
         ti, td = engine.topr_tensors()

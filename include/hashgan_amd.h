@@ -124,6 +124,11 @@ int hg_sample_hist(hg_ctx* ctx, int64_t R);
 int hg_guess(hg_ctx* ctx, int64_t R, const uint32_t* dev_hist_all, int G, int rank);
 int hg_select_candidates(hg_ctx* ctx);
 int hg_rank(hg_ctx* ctx, const uint32_t* dev_hist_all, int G, int rank, int* bet_lost);
+/* With option "defer_verdict" = 1 hg_rank does not wait for the verdict (*bet_lost = -1): the caller carries on as
+ * if the bet held -- match bits, their exchange, hg_ap -- and asks here once, next to its final download; on
+ * *bet_lost = 1 it discards those results and runs the exact sequence.  Removes the only host round trip from
+ * the middle of a sharded step. */
+int hg_bet_verdict(hg_ctx* ctx, int* bet_lost);
 
 /* Ranked lists in global-position space: uint32 idx [Q][R] (HG_IDX_NONE where a
  * slot belongs to another shard), uint8 dist [Q][R] (0xFF there). */
