@@ -13,7 +13,7 @@ from hashgan_amd import _native, metric, sharded
 pytestmark = pytest.mark.gpu
 
 
-def _run_virtual(c, G, gather_topr):
+def _run_virtual(c, G, gather_topr, defer=False):
     N = c["dbbits"].shape[0]
     qw, ql = metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"])
     comms = sharded.LocalComm.create(G)
@@ -29,6 +29,8 @@ def _run_virtual(c, G, gather_topr):
                              c["b"], c["dblab"].shape[1], idx_base=base, n_total=N)
             ctx.set_queries(qw, ql)
             eng = sharded.HipShardEngine(ctx, want_lists=gather_topr)
+            if defer:
+                ctx.set_option("defer_verdict", 1)      # hg_rank does not wait; the verdict comes with the AP download
             results[r] = sharded.evaluate_shard(eng, comms[r], c["R"], gather_topr=gather_topr)
             stats[r] = (ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks"))
             ctx.close()
@@ -77,12 +79,13 @@ def test_virtual_shards_optimistic_sequence(name, G, case_cache):
     AP of the unmodified reference, and really have taken the one-pass route."""
     c = case_cache(name)
     g = cases.load_golden(name)
-    res = _run_virtual(c, G, gather_topr=False)
-    for r in range(G):
-        ap, rel = res[r]
-        assert np.array_equal(ap, g["ap"], equal_nan=True), (name, G, r)
-    assert sharded.mean_ap(*res[0]) == g["map"]
-    assert all(st == (1, 0) for st in _run_virtual.last_stats), _run_virtual.last_stats
+    for defer in (False, True):
+        res = _run_virtual(c, G, gather_topr=False, defer=defer)
+        for r in range(G):
+            ap, rel = res[r]
+            assert np.array_equal(ap, g["ap"], equal_nan=True), (name, G, r, defer)
+        assert sharded.mean_ap(*res[0]) == g["map"]
+        assert all(st == (1, 0) for st in _run_virtual.last_stats), _run_virtual.last_stats
 
 
 def test_virtual_shards_lost_bet_is_consistent():
@@ -100,8 +103,9 @@ def test_virtual_shards_lost_bet_is_consistent():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         _, ap_ref, *_ = O.map_from_codes(qb[:24], c["dbbits"], ql[:24], c["dblab"], R)
-    res = _run_virtual(c, 2, gather_topr=False)
-    for r in range(2):
-        assert np.array_equal(res[r][0][:24], ap_ref, equal_nan=True)
-    st = _run_virtual.last_stats
-    assert st[0] == st[1] and st[0][0] == 1, st          # both ranks took the bet, and agree on its outcome
+    for defer in (False, True):
+        res = _run_virtual(c, 2, gather_topr=False, defer=defer)
+        for r in range(2):
+            assert np.array_equal(res[r][0][:24], ap_ref, equal_nan=True)
+        st = _run_virtual.last_stats
+        assert st[0] == st[1] and st[0][0] == 1, st          # both ranks took the bet, and agree on its outcome
