@@ -128,3 +128,49 @@ def test_mx_select_segment_shapes():
             assert np.array_equal(idx, idx_ref) and np.array_equal(dist, dist_ref), key
     finally:
         ctx.close()
+
+
+def test_fuzz_bet_shapes():
+    """Random shapes in the bet's range (N >= 65536, R <= N / 8) through all three select kernels of the bet;
+    HG_RANDOM_ITERS scales the number of shapes (default 6)."""
+    iters = max(1, int(os.environ.get("HG_RANDOM_ITERS", "60")) // 10)
+    rng = np.random.default_rng(int(os.environ.get("HG_RANDOM_SEED", "2024")))
+    ctx = _native.Context(0)
+    try:
+        for it in range(iters):
+            b = int(rng.choice([1, 7, 16, 31, 32, 33, 48, 63, 64, 65, 96, 128, 129, 200, 256]))
+            C = int(rng.choice([1, 2, 10, 21, 64, 65, 128, 129]))
+            N = int(rng.integers(65536, 140000))
+            Q = int(rng.choice([1, 5, 31, 32, 33, 100, 257, 600]))
+            R = int(rng.choice([1, 3, 50, 1000, N // 64, N // 9]))
+            kind = ["iid", "fewvalues", "clustered"][it % 3]
+            if kind == "iid":
+                db = rng.integers(0, 2, (N, b), dtype=np.uint8)
+                qb = rng.integers(0, 2, (Q, b), dtype=np.uint8)
+            elif kind == "fewvalues":                                   # many exact duplicates: long tie runs at the cut
+                proto = rng.integers(0, 2, (37, b), dtype=np.uint8)
+                db = proto[rng.integers(0, 37, N)]
+                qb = proto[rng.integers(0, 37, Q)]
+            else:                                                      # noisy copies of a few centres
+                cen = rng.integers(0, 2, (11, b), dtype=np.uint8)
+                db = cen[rng.integers(0, 11, N)] ^ (rng.random((N, b)) < 0.08).astype(np.uint8)
+                qb = cen[rng.integers(0, 11, Q)] ^ (rng.random((Q, b)) < 0.08).astype(np.uint8)
+            dl = (rng.random((N, C)) < 0.3).astype(np.int8)
+            ql = (rng.random((Q, C)) < 0.3).astype(np.int8)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                _, ap_ref, _, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
+            ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
+            ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
+            for mfma, packed in ((1, 1), (1, 2), (0, 1)):
+                ctx.set_option("select_mfma", mfma)
+                ctx.set_option("select_packed", packed)
+                ctx.set_option("optimistic", 1)
+                key = (it, kind, b, C, N, Q, R, mfma, packed)
+                ap, rel = ctx.map(R)
+                assert np.array_equal(ap, ap_ref, equal_nan=True), key
+                ctx.topr(R)
+                idx, dist = ctx.get_topr()
+                assert np.array_equal(idx, idx_ref) and np.array_equal(dist, dist_ref), key
+    finally:
+        ctx.close()
