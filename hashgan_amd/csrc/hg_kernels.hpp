@@ -36,7 +36,7 @@ struct Geo {
     int NW, NB;         // 32-bit words per code, distance buckets (b + 1)
     int LW;             // 64-bit words per label row
     int S;              // segments of the shard
-    i64 N, L;           // shard rows, rows per segment (multiple of 16)
+    i64 N, L;           // shard rows, rows per segment (multiple of 32)
     i64 R;              // ranked-list length
     u32 idx_base;       // global index of shard row 0
     i64 nUnits;         // S * nQT
