@@ -131,7 +131,9 @@ struct hg_ctx {
     i64 opt_real_qpl = 1;      // real-valued path: queries per lane (1 or 2)
     i64 opt_rank_waves = 0;    // k_rank_fused wavefronts per query: 0 = by list length, else 4 or 16
     i64 opt_select_mfma = 1;   // optimistic select: 1 = matrix-core kernel (k_select_mx), 0 = vector-ALU k_select
+    i64 opt_probe = 0;         // measurement probes of the matrix-core select kernels (SelArgs::probe)
     i64 opt_select_packed = 1; // codes of <= 64 bits: k_select_mx2 (two distances per MFMA accumulator)
+    i64 opt_sample_ratio = 2;  // the sampled pass works on segments this many times longer than the select pass's
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
     i64 opt_select_qt = 2;     // k_select_mx query tiles per wavefront (2: 4 wavefronts per SIMD, 4: 2)
 
@@ -280,7 +282,7 @@ int padded_grid(int nBlk) { return (nBlk + 7) / 8 * 8; }
 Geo hist_geometry(const hg_ctx* c) {
     Geo g = c->geo;
     if (g.hist_stride > 1) {
-        const i64 L = g.L * 2;
+        const i64 L = g.L * c->opt_sample_ratio;
         g.L = L;
         g.S = (int)((g.N + L - 1) / L);
         g.nUnits = (i64)g.S * g.nQT;
@@ -308,7 +310,7 @@ template <int NW> int launch_hist_t(hg_ctx* c) {
 template <int NW, int LW, bool OPT> int launch_select_t(hg_ctx* c) {
     const Geo& g = c->geo;
     SelArgs a{c->optimistic ? c->tguess.as<int>() : c->t.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(),
-              c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, c->optimistic ? 1 : 0, c->sstar.as<int>()};
+              c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, c->optimistic ? 1 : 0, c->sstar.as<int>(), 0};
     c->t_begin(KI_SELECT);
     hipLaunchKernelGGL((k_select<NW, LW, OPT>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), a, c->cand.as<u64>(), g);
@@ -360,7 +362,7 @@ template <int NW, int LW, int QT> int launch_select_mx_q(hg_ctx* c) {
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx<NW, LW, QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    L.total));
     SelArgs a{c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
-              c->cap, c->crow, (int)c->opt_select_mfma, c->sstar.as<int>()};
+              c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
     c->t_begin(KI_SELECT_MX);
     hipLaunchKernelGGL((k_select_mx<NW, LW, QT>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx.as<u8>(), c->dblab.as<u64>(), a,
@@ -405,7 +407,7 @@ template <int NW, int LW> int launch_select_mx2_t(hg_ctx* c) {
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx2<NW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    L.total));
     SelArgs a{c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
-              c->cap, c->crow, (int)c->opt_select_mfma, c->sstar.as<int>()};
+              c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
     c->t_begin(KI_SELECT_MX);
     hipLaunchKernelGGL((k_select_mx2<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx2.as<u8>(), c->db.as<u32>(), c->dbx2.as<u8>(), c->dblab.as<u64>(), a,
@@ -417,7 +419,7 @@ template <int NW, int LW> int launch_select_mx2_t(hg_ctx* c) {
 template <int NW, int LW> int launch_select_dense_t(hg_ctx* c) {
     const Geo& g = c->geo;
     SelArgs a{c->t.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
-              c->cap, c->crow, 0, nullptr};
+              c->cap, c->crow, 0, nullptr, 0};
     c->t_begin(KI_SELECT);
     hipLaunchKernelGGL((k_select_dense<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), a, c->cand.as<u64>(), g);
@@ -482,10 +484,10 @@ int launch_hist(hg_ctx* c) { HG_DISPATCH_NW(launch_hist_t, c) }
 int launch_select(hg_ctx* c) { HG_DISPATCH_NW(launch_select_nw, c) }
 
 // rows k_hist visits with batch stride `stride` (mirrors its loop)
-template <int NW> i64 sampled_rows_t(Geo g, int stride) {
+template <int NW> i64 sampled_rows_t(Geo g, int stride, int ratio) {
     g.hist_stride = stride;
     {
-        const i64 L = g.L * 2;                      // mirrors hist_geometry()
+        const i64 L = g.L * ratio;                  // mirrors hist_geometry()
         g.L = L;
         g.S = (int)((g.N + L - 1) / L);
     }
@@ -500,14 +502,14 @@ template <int NW> i64 sampled_rows_t(Geo g, int stride) {
 }
 i64 sampled_rows(hg_ctx* c, int stride) {
     switch (c->NW) {
-        case 1: return sampled_rows_t<1>(c->geo, stride);
-        case 2: return sampled_rows_t<2>(c->geo, stride);
-        case 3: return sampled_rows_t<3>(c->geo, stride);
-        case 4: return sampled_rows_t<4>(c->geo, stride);
-        case 5: return sampled_rows_t<5>(c->geo, stride);
-        case 6: return sampled_rows_t<6>(c->geo, stride);
-        case 7: return sampled_rows_t<7>(c->geo, stride);
-        default: return sampled_rows_t<8>(c->geo, stride);
+        case 1: return sampled_rows_t<1>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 2: return sampled_rows_t<2>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 3: return sampled_rows_t<3>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 4: return sampled_rows_t<4>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 5: return sampled_rows_t<5>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 6: return sampled_rows_t<6>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 7: return sampled_rows_t<7>(c->geo, stride, (int)c->opt_sample_ratio);
+        default: return sampled_rows_t<8>(c->geo, stride, (int)c->opt_sample_ratio);
     }
 }
 
@@ -1635,6 +1637,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_waves")) {
         if (value != 0 && value != 4 && value != 16) return fail(HG_ERR_ARG, "rank_waves must be 0, 4 or 16");
         c->opt_rank_waves = value;
+    } else if (!strcmp(key, "sample_ratio")) {
+        if (value < 1 || value > 64) return fail(HG_ERR_ARG, "sample_ratio must be 1..64");
+        c->opt_sample_ratio = value;
     } else if (!strcmp(key, "defer_verdict")) {
         c->defer_verdict = value != 0;
     } else if (!strcmp(key, "select_packed")) {
@@ -1642,7 +1647,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_lds")) {
         c->opt_rank_lds = value != 0;
     } else if (!strcmp(key, "select_mfma")) {
-        c->opt_select_mfma = value;
+        c->opt_select_mfma = value != 0;
+    } else if (!strcmp(key, "probe_select")) {
+        c->opt_probe = value;
     } else if (!strcmp(key, "select_qt")) {
         c->opt_select_qt = value;
     } else if (!strcmp(key, "real_segment_bytes")) {

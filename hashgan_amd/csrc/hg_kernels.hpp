@@ -424,6 +424,8 @@ struct SelArgs {
     i64 crow;              // record-row stride
     int optimistic;
     const int* sstar;      // optimistic mode: [Qpad] last segment that still collects dist == T (k_guess)
+    int probe;             // measurement probes of the matrix-core kernels (option "probe_select"): 2 no drain,
+                           // 4 no record stores, 8 no emit -- each breaks the bet on purpose (exact rerun follows)
 };
 
 constexpr int sel_batch_rows(int nw) {          // rows per scalar-load batch: <= 64 SGPRs of code words, <= 32 rows

@@ -176,8 +176,9 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * "guess_sigma", "staged_lists" (0/1: hg_select materialises idx/dist lists),
  * "cand_budget_x10" (record budget of the bet per query, tenths of R), "rank_waves" (0 = auto, 4, 16),
  * "select_mfma" (1: the bet's select pass runs on the matrix cores -- fp4 MFMA distance tiles,
- * k_select_mx; 0: vector-ALU xor+popcount k_select; same records either way; values with bits 2/4/8 set
- * switch parts of the drain off for measurements and make the bet fail),
+ * k_select_mx; 0: vector-ALU xor+popcount k_select; same records either way), "probe_select" (measurement
+ * only: bits 2/4/8 switch parts of the matrix-core kernels' drain off; the bet then fails and the exact
+ * sequence runs, so results stay right),
  * "select_qt" (k_select_mx query tiles per wavefront: 2 or 4), "select_packed" (k_select_mx2, two rows per
  * MFMA accumulator: 1 = for codes of <= 32 bits, 2 = also for 33..64 bits, 0 = never), "rank_lds" (0/1),
  * "real_queries_per_lane", "real_segment_bytes" (real-valued path). */

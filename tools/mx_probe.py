@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-kernel timings of the one-shot binary path under engine options (experiments on k_select_mx).
+"""Per-kernel timings of the one-shot binary path under engine options (experiments on k_select_mx;
+probe_select=2 no drain, =5 no record stores, =9 no emit -- k_select_mx's own time is what to read then).
 usage: mx_probe.py [Q N b R] -- key=value[,key=value] ..."""
 import sys, time
 import numpy as np
