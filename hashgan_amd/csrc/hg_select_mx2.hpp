@@ -19,10 +19,11 @@
 // half staged through LDS by direct-to-LDS loads (image, packed codes, labels), the word-granular
 // push / dense emit drain, the same records, slices and counts.
 //
-// Bit layout of a 16-row mask word W (rows rho = 0..15 of the group, earliest row = highest bit):
+// Bit layout of a harvested 16-row mask (rows rho = 0..15 of the group, earliest row = highest bit):
 //     rho 0..7  <-> bits 25..18   (field 1: register 8u + 7 - rho,  second row of the accumulator)
 //     rho 8..15 <-> bits 14..7    (field 0: register 8u + 15 - rho, first row)
-// A 32-row tile gives two words (u = 0, 1: registers 0..7 and 8..15).
+// A 32-row tile gives two of them (u = 0, 1: registers 0..7 and 8..15); seven more ops squeeze them into one
+// 32-bit word with bit k <-> row 31 - k -- k_select_mx's convention, so push and emit are the same code.
 #pragma once
 #include "hg_select_mx.hpp"
 
@@ -31,8 +32,7 @@ namespace hg {
 constexpr int M2_QT = 2;                 // query tiles (of 32) per wavefront
 constexpr int M2_WT = 4;                 // 32-row tiles per window
 constexpr int M2_WROWS = 32 * M2_WT;     // rows per lane-half per window (= MX_WROWS)
-constexpr int M2_QCAP = 64 * M2_QT * M2_WT;   // queue entries (12 bytes) per wavefront: one per lane, query tile and row tile
-constexpr u32 M2_USED = 0x03FC7F80u;     // the 16 meaningful bits of a mask word
+constexpr int M2_QCAP = 64 * M2_QT * M2_WT / 2;   // queue entries (8 bytes) per wavefront: one per lane, query tile and row tile of HALF a window
 
 // row rho (0..31) of a 32-row group -> (register r, field f)
 __host__ __device__ inline void m2_place(int rho, int& r, int& f) {
@@ -83,13 +83,13 @@ __host__ __device__ inline Mx2Lds mx2_lds_layout(int NW, int LW) {
     l.qcodes = 2 * l.stage;
     l.qlabels = l.qcodes + WPB * 32 * M2_QT * NW * 4;
     l.queue = l.qlabels + WPB * 32 * M2_QT * LW * 8;
-    l.total = l.queue + WPB * M2_QCAP * 12;
+    l.total = l.queue + WPB * M2_QCAP * 8;
     return l;
 }
 
 // Geo as set by the launcher: g.nQT = query blocks (of 256 queries) per segment pair, g.nBlk = blocks; g.L % 32 == 0.
 template <int NW, int LW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))   // 52 KB of LDS: 3 blocks per CU anyway
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, const u8* __restrict__ qx,
                   const u32* __restrict__ db, const u8* __restrict__ dbx, const u64* __restrict__ dblab,
                   const SelArgs a, u64* __restrict__ cand, const Geo g) {
@@ -183,20 +183,17 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
         }
     };
 
-    // ---- drain: push (branch-free, one entry per lane, query tile and 32-row tile with a hit) + dense emit ----
-    u32* queue = (u32*)(mxlds + L.queue) + wave * M2_QCAP * 3;
+    // ---- drain: k_select_mx's push (branch-free, one 8-byte entry per lane, query tile and 32-row tile with a
+    // hit) + dense emit; the tile's mask word arrives compacted: bit k <-> row 31 - k of the tile ----
+    u64* queue = (u64*)(mxlds + L.queue) + wave * M2_QCAP;
     u32 qfill = 0;
-    auto push = [&](const int t, const int T, const u32 w0, const u32 w1, u32& cntt, const u32 caplt, u32& droppedt) {
-        const bool any = (w0 | w1) != 0u;
-        const u64 bal = __ballot(any);
+    auto push = [&](const int t, const int T, const u32 word, u32& cntt, const u32 caplt, u32& droppedt) {
+        const u64 bal = __ballot(word != 0u);
         const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-        if (any) {
-            u32* e = queue + slot * 3;
-            e[0] = cntt | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) | ((u32)T << (MX_POS_BITS + 7));
-            e[1] = w0;
-            e[2] = w1;
-        }
-        const u32 want = cntt + (u32)__builtin_popcount(w0) + (u32)__builtin_popcount(w1);
+        if (word != 0u)
+            queue[slot] = ((u64)word << 32) | (u64)(cntt | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
+                                                    ((u32)T << (MX_POS_BITS + 8)));
+        const u32 want = cntt + (u32)__builtin_popcount(word);
         const u32 got = want < caplt ? want : caplt;
         droppedt += want - got;
         cntt = got;
@@ -206,11 +203,11 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
         wave_lds_sync();
         const u32 n = (a.probe & 8) ? 0u : qfill;
         for (u32 i = lane; i < n; i += 64) {
-            const u32* e = queue + i * 3;
-            const u32 desc = e[0];
-            u32 w0 = e[1], w1 = e[2];
+            const u64 e = queue[i];
+            u32 word = (u32)(e >> 32);
+            const u32 desc = (u32)e;
             const u32 pos = desc & ((1u << MX_POS_BITS) - 1u), src = (desc >> MX_POS_BITS) & 63u;
-            const u32 t = (desc >> (MX_POS_BITS + 6)) & 1u, T = (desc >> (MX_POS_BITS + 7)) & 3u;
+            const u32 t = (desc >> (MX_POS_BITS + 6)) & 3u, T = (desc >> (MX_POS_BITS + 8)) & 3u;
             const u32 hs = src >> 5;
             const int ql = wave * WQ + (int)t * 32 + (int)(src & 31u);
             u32 qcw[NW];
@@ -225,13 +222,10 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
             u32 room = a.cap - pos;
             const u32 row0 = hs * M2_WROWS + T * 32;
             const u32 idx0 = g.idx_base + (u32)(seg * g.L + win * M2_WROWS) + T * 32;
-            while (w0 | w1) {
-                const bool in0 = w0 != 0u;
-                u32 cur = in0 ? w0 : w1;
-                const int k = 31 - __builtin_clz(cur);
-                cur ^= 1u << k;
-                if (in0) w0 = cur; else w1 = cur;
-                const u32 r = (in0 ? 0u : 16u) + (u32)(k >= 18 ? 25 - k : 22 - k);   // row inside the 32-row tile
+            while (word) {
+                const int k = 31 - __builtin_clz(word);
+                word ^= 1u << k;
+                const u32 r = 31 - k;                                 // highest bit = earliest row
                 const u32* rp = (const u32*)(st + L.codes + (row0 + r) * CB);
                 u32 d = 0;
 #pragma unroll
@@ -270,25 +264,19 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
         for (int w = 0; w < NW; ++w) af[w] = *(const i32x4*)(st + L.a + ((T * NW + w) * 64 + lane) * 16);
     };
     // 16 accumulators -> the two mask words of the tile: 16 v_and_or_b32 + 2 v_lshl_or_b32
-    auto harvest = [&](const f32x16& acc, u32& w0, u32& w1) {
+    auto harvest = [&](const f32x16& acc, u32& word) {
         u32 m[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const u32 K = (1u << (7 + (r & 3))) | (1u << (18 + (r & 3)));
             m[r >> 2] = (__float_as_uint(acc[r]) & K) | m[r >> 2];
         }
-        w0 = (m[1] << 4) | m[0];
-        w1 = (m[3] << 4) | m[2];
-        asm volatile("" : "+v"(w0), "+v"(w1));                       // pin here (pure ops would sink to the drain)
+        const u32 w0 = (m[1] << 4) | m[0], w1 = (m[3] << 4) | m[2];   // bits 25..18 = rows 0..7, bits 14..7 = rows 8..15
+        // compact each to 16 bits (bit k <-> row 15 - k) and join: bit k of the result <-> row 31 - k of the tile
+        const u32 c0 = ((w0 >> 7) & 0xFFu) | ((w0 >> 10) & 0xFF00u), c1 = ((w1 >> 7) & 0xFFu) | ((w1 >> 10) & 0xFF00u);
+        word = (c0 << 16) | c1;
+        asm volatile("" : "+v"(word));                               // pin here (pure ops would sink to the drain)
     };
-    // valid-row mask of a 16-row word holding v valid rows (rows past the segment's end never count)
-    auto keep16 = [](const i64 v) -> u32 {
-        if (v >= 16) return M2_USED;
-        if (v <= 0) return 0u;
-        const int v1 = (int)(v < 8 ? v : 8), v0 = (int)(v > 8 ? v - 8 : 0);
-        return (((0xFFu << (8 - v1)) & 0xFFu) << 18) | (((0xFFu << (8 - v0)) & 0xFFu) << 7);
-    };
-
     if (nwin > 0) stage_window(0, 0);
     for (i64 win = 0; win < nwin; ++win) {
         const int buf = (int)(win & 1);
@@ -297,7 +285,7 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
         if (win + 1 < nwin) stage_window(win + 1, buf ^ 1);
         const u8* st = mxlds + buf * L.stage;
 
-        u32 m[QT][M2_WT][2];
+        u32 m[QT][M2_WT];
         i32x4 acur[NW], anext[NW];
         load_a(acur, st, 0);
         f32x16 accn = issue(acur, 0);
@@ -309,7 +297,7 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
                 const f32x16 acc = accn;
                 if (t + 1 < QT) accn = issue(acur, t + 1);
                 else if (T + 1 < M2_WT) accn = issue(anext, 0);
-                harvest(acc, m[t][T][0], m[t][T][1]);
+                harvest(acc, m[t][T]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -318,23 +306,25 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
         const i64 left = mylen - win * M2_WROWS;                     // valid rows of this lane in the window
         if (left < M2_WROWS) {
 #pragma unroll
-            for (int T = 0; T < M2_WT; ++T)
+            for (int T = 0; T < M2_WT; ++T) {
+                const i64 v = left - 32 * T;                         // valid rows among the 32 of tile T
+                const u32 keep = v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ~(0xFFFFFFFFu >> (int)v));
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const u32 keep = keep16(left - (32 * T + 16 * u));
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) m[t][T][u] &= keep;
-                }
+                for (int t = 0; t < QT; ++t) m[t][T] &= keep;
+            }
         }
         if (a.probe & 2) {                                      // measurement probe: no drain
 #pragma unroll
-            for (int t = 0; t < QT; ++t) if (m[t][0][0] == 0x12345678u && m[t][3][1] == 0x1234567u) dropped[t]++;
+            for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][3] == 0x1234567u) dropped[t]++;
         } else {
 #pragma unroll
-            for (int t = 0; t < QT; ++t)
+            for (int hw = 0; hw < 2; ++hw) {                         // two drains per window: half the queue
 #pragma unroll
-                for (int T = 0; T < M2_WT; ++T) push(t, T, m[t][T][0], m[t][T][1], cnt[t], capl[t], dropped[t]);
-            emit(win, st);
+                for (int t = 0; t < QT; ++t)
+#pragma unroll
+                    for (int T = 2 * hw; T < 2 * hw + 2; ++T) push(t, T, m[t][T], cnt[t], capl[t], dropped[t]);
+                emit(win, st);
+            }
         }
     }
 
