@@ -134,6 +134,7 @@ struct hg_ctx {
     i64 opt_probe = 0;         // measurement probes of the matrix-core select kernels (SelArgs::probe)
     i64 opt_select_packed = 1; // codes of <= 64 bits: k_select_mx2 (two distances per MFMA accumulator)
     i64 opt_sample_ratio = 2;  // the sampled pass works on segments this many times longer than the select pass's
+    i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
     i64 opt_select_qt = 2;     // k_select_mx query tiles per wavefront (2: 4 wavefronts per SIMD, 4: 2)
 
@@ -1265,7 +1266,30 @@ static bool optimistic_eligible(hg_ctx* c, int64_t R, int* stride_out, u32* need
     return true;
 }
 
+// R = N on one shard: the layout of the record rows is known without looking at a single distance
+static int enqueue_all_rows(hg_ctx* c, int64_t R) {
+    make_geometry(c);
+    HG_TRY(set_R(c, R, 1, 0));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(c->t.reserve(qb)); HG_TRY(c->err.reserve(4));
+    HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
+    HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
+    HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+    c->t_begin(KI_SEG_LAYOUT);
+    hipLaunchKernelGGL(k_layout_all_rows, dim3(grid_for((i64)g.S * g.Qpad)), dim3(256), 0, c->stream, c->t.as<int>(),
+                       c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->tot.as<u32>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_layout_all_rows"));
+    c->optimistic = false;
+    c->crow = R;
+    c->cap = 0;
+    c->stage = ST_DB | ST_Q | ST_PLAN;
+    return do_select(c);
+}
+
 static int enqueue_exact(hg_ctx* c, int64_t R) {
+    if (c->N == c->n_total && R == c->N && c->opt_all_rows) return enqueue_all_rows(c, R);     // one-shot calls are single-shard
     HG_TRY(do_hist(c, 1));
     HG_TRY(do_plan(c, R, nullptr, 1, 0));
     return do_select(c);
@@ -1637,6 +1661,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_waves")) {
         if (value != 0 && value != 4 && value != 16) return fail(HG_ERR_ARG, "rank_waves must be 0, 4 or 16");
         c->opt_rank_waves = value;
+    } else if (!strcmp(key, "all_rows_shortcut")) {
+        c->opt_all_rows = value != 0;
     } else if (!strcmp(key, "sample_ratio")) {
         if (value < 1 || value > 64) return fail(HG_ERR_ARG, "sample_ratio must be 1..64");
         c->opt_sample_ratio = value;

@@ -1205,6 +1205,23 @@ __global__ __launch_bounds__(256) void k_move_rows(const u8* __restrict__ src, u
     }
 }
 
+// R = N (the reference's CIFAR-10 setting): every row is a member of every ranked list, so the record-row layout
+// needs no histogram -- segment s of every query starts at row s * L of its record row, nothing is a tie to ration.
+__global__ __launch_bounds__(256) void k_layout_all_rows(int* __restrict__ T, u32* __restrict__ sl_start, u32* __restrict__ sl_tie,
+                                                         u32* __restrict__ tot, const Geo g) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (i64)g.S * g.Qpad) return;
+    const i64 s = i / g.Qpad;
+    const i64 first = s * g.L;
+    sl_start[i] = (u32)(first < g.N ? first : g.N);
+    sl_tie[i] = 0xFFFFFFFFu;
+    if (s == 0) {
+        const int q = (int)i;
+        T[q] = g.NB;                                  // every distance is below the cut
+        tot[q] = q < g.Q ? (u32)g.N : 0u;
+    }
+}
+
 // fill helpers
 __global__ __launch_bounds__(256) void k_fill_u32(u32* __restrict__ p, u32 v, i64 n) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
