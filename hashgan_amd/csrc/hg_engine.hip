@@ -98,6 +98,21 @@ void build_shape(int n, ApShape& sh) {
         }
     } rec{sh};
     if (n > 0) rec.go(0, n);
+    // the same tree as a node table (k_ap evaluates it level by level): replay the postfix program on a stack of ids
+    int stack[64], sp = 0, height[2 * AP_LEAF] = {0};
+    for (int i = 0; i < sh.n_prog; ++i) {
+        const int op = sh.prog[i];
+        if (op >= 0) { stack[sp++] = op; continue; }
+        const int r = stack[--sp], l = stack[--sp];
+        const int k = sh.n_nodes++, id = sh.n_leaves + k;
+        sh.nl[k] = (short)l;
+        sh.nr[k] = (short)r;
+        const int hgt = 1 + (height[l] > height[r] ? height[l] : height[r]);
+        sh.nh[k] = (unsigned char)hgt;
+        height[id] = hgt;
+        if (hgt > sh.max_h) sh.max_h = hgt;
+        stack[sp++] = id;
+    }
 }
 
 }  // namespace

@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_min_topr(const u32* __restrict__ idx_al
 // as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail, halves split at
 // n/2 rounded down to a multiple of 8.  The split tree depends only on the
 // chunk length, so the host flattens it once per R into a leaf table and a
-// postfix program (ApShape); a thread evaluates one leaf, thread 0 the program.
+// node table (ApShape); a thread evaluates one leaf, then the internal nodes are summed level by level.
 // ----------------------------------------------------------------------------
 struct ApShape {               // tree of one chunk length (<= AP_CHUNK elements)
     int n;                     // chunk length
@@ -1061,7 +1061,13 @@ struct ApShape {               // tree of one chunk length (<= AP_CHUNK elements
     int n_prog;                // <= 255
     unsigned short leaf_start[AP_LEAF];
     unsigned short leaf_len[AP_LEAF];
-    short prog[2 * AP_LEAF];   // >= 0: push leaf, -1: add the two on top
+    short prog[2 * AP_LEAF];   // >= 0: push leaf, -1: add the two on top (the tree in postfix; kept for reference)
+    // the same tree by levels: node ids 0 .. n_leaves-1 are the leaves, internal node k has id n_leaves + k,
+    // children nl/nr (always left + right: the order of NumPy's additions), height nh = 1 + max(children)
+    int n_nodes;               // internal nodes = n_leaves - 1
+    int max_h;
+    short nl[AP_LEAF], nr[AP_LEAF];
+    unsigned char nh[AP_LEAF];
 };
 
 __device__ __forceinline__ u32 count_bits_below(const u64* cw, int e) {  // bits [0, e) of the chunk
@@ -1077,8 +1083,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
                                                    const ApShape* __restrict__ shapes,  // [0] full chunk, [1] last chunk
                                                    double* __restrict__ ap, u32* __restrict__ rel) {
     __shared__ u64 cw[AP_CHUNK / 64];
-    __shared__ double leafsum[AP_LEAF];
-    __shared__ double stk[16];
+    __shared__ double tree[2 * AP_LEAF];   // leaf sums, then the sums of the internal nodes
     __shared__ u32 s_before;
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
@@ -1122,17 +1127,18 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
                 res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
                 for (; i < ll; ++i) res += next();
             }
-            leafsum[tid] = res;
+            tree[tid] = res;
         }
         __syncthreads();
+        // the tree, level by level: all nodes of one height are independent (thread k owns internal node k);
+        // every addition is left + right exactly as in NumPy's recursion, only the schedule differs
+        for (int hgt = 1; hgt <= sh->max_h; ++hgt) {
+            if (tid < sh->n_nodes && sh->nh[tid] == hgt) tree[sh->n_leaves + tid] = tree[sh->nl[tid]] + tree[sh->nr[tid]];
+            __syncthreads();
+        }
         if (tid == 0) {
-            int sp = 0;
-            for (int i = 0; i < sh->n_prog; ++i) {
-                const int op = sh->prog[i];
-                if (op >= 0) stk[sp++] = leafsum[op];
-                else { --sp; stk[sp - 1] = stk[sp - 1] + stk[sp]; }
-            }
-            total = (c == 0) ? stk[0] : total + stk[0];
+            const double chunk_sum = tree[sh->n_leaves + sh->n_nodes - 1];    // the root is the last node (or the only leaf)
+            total = (c == 0) ? chunk_sum : total + chunk_sum;
             s_before = before + count_bits_below(cw, n);
         }
         __syncthreads();
