@@ -1084,7 +1084,8 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
                                                    double* __restrict__ ap, u32* __restrict__ rel) {
     __shared__ u64 cw[AP_CHUNK / 64];
     __shared__ double tree[2 * AP_LEAF];   // leaf sums, then the sums of the internal nodes
-    __shared__ u32 s_before;
+    __shared__ u32 wpre[AP_CHUNK / 64 + 1];   // matches in the chunk's words before word w
+    __shared__ u32 s_before, s_w0;
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const u64* __restrict__ row = mbits + (i64)q * RW;
@@ -1096,38 +1097,52 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
         const bool last = (c == n_chunks - 1);
         const ApShape* __restrict__ sh = shapes + ((last && (R - cb) != AP_CHUNK) ? 1 : 0);
         const int n = (int)(R - cb < AP_CHUNK ? R - cb : AP_CHUNK);
-        const i64 w = (cb >> 6) + tid;
-        cw[tid] = (w < RW) ? row[w] : 0ull;       // AP_THREADS == AP_CHUNK / 64
+        {   // load the chunk's words and prefix their popcounts (two wavefronts, 64 words each)
+            const i64 w = (cb >> 6) + tid;
+            const u64 word = (w < RW) ? row[w] : 0ull;        // AP_THREADS == AP_CHUNK / 64
+            cw[tid] = word;
+            u32 incl = (u32)__popcll(word);
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 v = (u32)__shfl_up((int)incl, off);
+                if ((tid & 63) >= off) incl += v;
+            }
+            if (tid == 63) s_w0 = incl;
+            wpre[tid + 1] = incl;                              // the second wave's values still lack the first's total
+            if (tid == 0) wpre[0] = 0u;
+        }
+        __syncthreads();
+        if (tid >= 64) wpre[tid + 1] += s_w0;
         __syncthreads();
         const u32 before = s_before;
-        if (tid < sh->n_leaves) {
-            const int ls = sh->leaf_start[tid], ll = sh->leaf_len[tid];
-            u32 cnt = before + count_bits_below(cw, ls);
-            int e = ls;                              // element index inside the chunk
-            // value of element e (elements are consumed in increasing order)
-            auto next = [&]() -> double {
-                const bool bit = (cw[e >> 6] >> (e & 63)) & 1ull;
-                double v = 0.0;
-                if (bit) { ++cnt; v = (double)cnt / (double)(cb + e + 1); }
-                ++e;
-                return v;
-            };
-            double res;
-            if (ll < 8) {
-                res = 0.0;
-                for (int i = 0; i < ll; ++i) res += next();
-            } else {
-                double r0 = next(), r1 = next(), r2 = next(), r3 = next();
-                double r4 = next(), r5 = next(), r6 = next(), r7 = next();
-                int i = 8;
-                for (; i < ll - (ll % 8); i += 8) {
-                    r0 += next(); r1 += next(); r2 += next(); r3 += next();
-                    r4 += next(); r5 += next(); r6 += next(); r7 += next();
-                }
-                res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-                for (; i < ll; ++i) res += next();
+        // value of element e of the chunk: (matches up to and including e) / (its 1-based rank), 0 without a match
+        auto val = [&](const int e) -> double {
+            const u64 word = cw[e >> 6];
+            const int bpos = e & 63;
+            if (!((word >> bpos) & 1ull)) return 0.0;
+            const u32 cnt = before + wpre[e >> 6] + (u32)__popcll(word & ((2ull << bpos) - 1ull));
+            return (double)cnt / (double)(cb + e + 1);
+        };
+        // Eight lanes per leaf: NumPy's leaf sum runs eight strided accumulators (element i -> r[i % 8], in order) and
+        // combines them as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Lane j of a leaf's group owns r_j; the xor butterfly
+        // 1, 2, 4 is exactly that tree (IEEE addition is commutative); lane 0 adds the < 8 tail elements in order.
+        const int nl = sh->n_leaves;
+        for (int l0 = 0; l0 < nl; l0 += AP_THREADS / 8) {
+            const int leaf = l0 + (tid >> 3), j = tid & 7;
+            const bool act = leaf < nl;
+            const int ls = act ? sh->leaf_start[leaf] : 0, ll = act ? sh->leaf_len[leaf] : 0;
+            const int body = ll - (ll % 8);
+            double r = 0.0;
+            if (ll >= 8)
+                for (int e = ls + j; e < ls + body; e += 8) r += val(e);      // 0.0 + v == v: the first add is exact
+            r += __shfl_xor(r, 1);
+            r += __shfl_xor(r, 2);
+            r += __shfl_xor(r, 4);
+            if (act && j == 0) {
+                double res = ll >= 8 ? r : 0.0;
+                for (int e = ls + (ll >= 8 ? body : 0); e < ls + ll; ++e) res += val(e);
+                tree[leaf] = res;
             }
-            tree[tid] = res;
         }
         __syncthreads();
         // the tree, level by level: all nodes of one height are independent (thread k owns internal node k);
@@ -1139,7 +1154,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
         if (tid == 0) {
             const double chunk_sum = tree[sh->n_leaves + sh->n_nodes - 1];    // the root is the last node (or the only leaf)
             total = (c == 0) ? chunk_sum : total + chunk_sum;
-            s_before = before + count_bits_below(cw, n);
+            s_before = before + wpre[n >> 6] + ((n & 63) ? (u32)__popcll(cw[n >> 6] & ((1ull << (n & 63)) - 1ull)) : 0u);
         }
         __syncthreads();
     }
