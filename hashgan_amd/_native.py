@@ -45,6 +45,8 @@ _SIGNATURES = {
     "hg_select_candidates": [_p],
     "hg_rank": [_p, _p, C.c_int, C.c_int, C.POINTER(C.c_int)],
     "hg_bet_verdict": [_p, C.POINTER(C.c_int)],
+    "hg_select_ranked": [_p],
+    "hg_merge_ranked": [_p, _p, _p, C.c_int, C.POINTER(C.c_int)],
     "hg_match": [_p],
     "hg_match_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
     "hg_merge_match": [_p, _p, C.c_int],
@@ -222,6 +224,15 @@ class Context:
         lost = C.c_int()
         check(self._lib.hg_rank(self._h, _p(dev_hist_all) if dev_hist_all else None, int(G), int(rank), C.byref(lost)))
         return None if lost.value < 0 else bool(lost.value)      # None: verdict deferred (option defer_verdict)
+
+    def select_ranked(self):
+        check(self._lib.hg_select_ranked(self._h))
+
+    def merge_ranked(self, dev_hist_all=None, dev_bits_all=None, G=1):
+        lost = C.c_int()
+        check(self._lib.hg_merge_ranked(self._h, _p(dev_hist_all) if dev_hist_all else None,
+                                        _p(dev_bits_all) if dev_bits_all else None, int(G), C.byref(lost)))
+        return None if lost.value < 0 else bool(lost.value)
 
     def bet_verdict(self):
         lost = C.c_int()

@@ -182,6 +182,8 @@ struct hg_ctx {
     DevBuf hist, hown, posbase, seglt, segtie;
     DevBuf t, tguess, sstar, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
+    DevBuf mbits2;             // hg_merge_ranked's output (swapped with mbits)
+    bool ranked_local = false; // mbits holds this shard's bitmap in LOCAL rank order (hg_select_ranked)
     DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
     int bpad = 0;              // feature count padded to a multiple of 16 (0: no float tables loaded)
@@ -636,7 +638,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2};
     for (auto* d : all) d->release();
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->pin) (void)hipHostFree(c->pin);
@@ -1178,6 +1180,72 @@ int hg_select_candidates(hg_ctx* c) {
     while ((1 << nbits) < g.NB) ++nbits;
     HG_TRY(launch_rank(c, 1, nbits));                // per-wave and shard histograms of the records
     return c->stage_end();
+}
+
+// Sharded bet, AP only: select, then rank THIS shard's records locally (rank kernels' mode 3).  What leaves the
+// shard is its per-distance record counts (hg_hist_buffer) and its match bitmap in local rank order
+// (hg_match_buffer); hg_merge_ranked stitches the global bitmap from the gathered pairs.  One exchange and one
+// pass over the records fewer than hg_select_candidates + hg_rank.
+int hg_select_ranked(hg_ctx* c) {
+    HG_TRY(need(c, ST_PLAN, "hg_select_ranked", "hg_guess"));
+    if (!c->optimistic) return fail(HG_ERR_STATE, "hg_select_ranked: no guess in force");
+    const Geo& g = c->geo;
+    c->want_lists = false;
+    HG_TRY(c->cand.reserve((size_t)g.Q * c->crow * 8));
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    HG_TRY(c->out_idx.reserve(16)); HG_TRY(c->out_dist.reserve(16));
+    HG_TRY(c->err.reserve(4));
+    HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+    HG_TRY(launch_select(c));
+    const size_t plane = (size_t)g.NB * g.Qpad * 4;
+    HG_HIP(hipMemsetAsync(c->hown.as<char>() + plane, 0, TAIL_WORDS * 4, c->stream));
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    HG_TRY(launch_rank(c, 3, nbits));
+    c->lists_valid = false;
+    c->ranked_local = true;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_MATCH;     // hg_match_buffer hands out the LOCAL bitmap until the merge
+    return c->stage_end();
+}
+
+int hg_merge_ranked(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, int* bet_lost) {
+    HG_TRY(need(c, ST_MATCH, "hg_merge_ranked", "hg_select_ranked"));
+    if (!c->ranked_local) return fail(HG_ERR_STATE, "hg_merge_ranked: hg_select_ranked has not run");
+    if (!bet_lost || G < 1 || G > 64 || (G > 1 && (!dev_hist_all || !dev_bits_all)))
+        return fail(HG_ERR_ARG, "hg_merge_ranked: bad argument (1 <= G <= 64, gathered buffers for G > 1)");
+    const Geo& g = c->geo;
+    HG_TRY(c->mbits2.reserve((size_t)g.Q * c->RW * 8));
+    HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
+    const u32* hall = G > 1 ? (const u32*)dev_hist_all : c->hown.as<u32>();
+    const u64* ball = G > 1 ? (const u64*)dev_bits_all : c->mbits.as<u64>();
+    c->t_begin(KI_MERGE);
+    hipLaunchKernelGGL(k_merge_ranked, dim3(grid_for(g.Q, WPB)), dim3(256), 0, c->stream, hall, ball, G, c->RW,
+                       c->mbits2.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_merge_ranked"));
+    std::swap(c->mbits, c->mbits2);                    // the global bitmap is what hg_ap and hg_get_match see
+    c->ranked_local = false;
+    c->G = G;
+    if (c->defer_verdict) {
+        *bet_lost = -1;
+        c->verdict_pending = true;
+        c->verdict_known = false;
+        c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
+        return c->stage_end();
+    }
+    int flag = 0;
+    HG_TRY(read_plan_flag(c, &flag));
+    *bet_lost = flag;
+    c->opt_runs++;
+    if (flag) {
+        c->opt_fallbacks++;
+        c->opt_consecutive_fail++;
+        c->stage = ST_DB | ST_Q;
+        return HG_OK;
+    }
+    c->opt_consecutive_fail = 0;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
+    return HG_OK;
 }
 
 static int ensure_pin(hg_ctx* c, size_t need_b) {
@@ -1732,7 +1800,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err,
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
-                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2};
+                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
         *value = total;

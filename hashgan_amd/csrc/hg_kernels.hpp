@@ -803,10 +803,10 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     if (a.only && !a.only[q]) return;
     if (a.fail[q]) {                                  // a slice of this query overflowed
         if (tid == 0) {
-            if (a.mode == 1) atomicOr(&a.hown[(i64)NB * g.Qpad], 1u);   // tail word 0: this shard lost the bet
+            if (a.mode == 1 || a.mode == 3) atomicOr(&a.hown[(i64)NB * g.Qpad], 1u);   // tail word 0: this shard lost the bet
             else { atomicExch(a.err, 1); a.qbad[q] = 1u; }
         }
-        if (a.mode == 1) for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = 0u;
+        if (a.mode == 1 || a.mode == 3) for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = 0u;
         return;
     }
     for (int i = tid; i < (nwav + 1) * NB + 8 + bmw; i += nthr) lds[i] = 0u;
@@ -883,6 +883,10 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
         for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = tot[d];
         return;
     }
+    if (a.mode == 3) {                                // counts for the merge, before the plan turns tot[] into starts
+        for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = tot[d];
+        __syncthreads();
+    }
     if (a.mode == 2) {
         if (tid == 0) {
             const int t = a.xt[q];
@@ -899,26 +903,39 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
             tot[d] = a.xposbase[(i64)d * g.Qpad + q];
         __syncthreads();
     }
-    if (a.mode == 0 && tid == 0) {
+    if ((a.mode == 0 || a.mode == 3) && tid == 0) {
+        // mode 3 (local ranking for k_merge_ranked): rank whatever this shard has, up to R -- never "lost" here
+        u64 want = (u64)g.R;
+        if (a.mode == 3) {
+            u64 have = 0;
+            for (int d = 0; d < NB; ++d) have += tot[d];
+            if (have < want) want = have;
+        }
         u64 cum = 0;
         int t = -1, dmin = -1;
-        for (int d = 0; d < NB; ++d) {
-            const u32 c = tot[d];
-            if (c && dmin < 0) dmin = d;
-            tot[d] = (u32)cum;                        // global start of bucket d
-            if (cum + c >= (u64)g.R) { t = d; break; }
-            cum += c;
-        }
+        if (want > 0)
+            for (int d = 0; d < NB; ++d) {
+                const u32 c = tot[d];
+                if (c && dmin < 0) dmin = d;
+                tot[d] = (u32)cum;                    // global start of bucket d
+                if (cum + c >= want) { t = d; break; }
+                cum += c;
+            }
         misc[0] = (u32)t;
         misc[1] = (u32)cum;                           // cnt_lt
-        misc[2] = (u32)((u64)g.R - cum);              // quota
+        misc[2] = (u32)(want - cum);                  // quota
         misc[3] = (u32)(dmin < 0 ? 0 : dmin);         // smallest distance present
-        if (t < 0) atomicExch(a.err, 1);              // the superset is too small: bet lost
-        a.qbad[q] = t < 0 ? 1u : 0u;
+        if (a.mode == 0) {
+            if (t < 0) atomicExch(a.err, 1);          // the superset is too small: bet lost
+            a.qbad[q] = t < 0 ? 1u : 0u;
+        }
     }
     __syncthreads();
     const int t = (int)misc[0];
-    if (t < 0) return;
+    if (t < 0) {
+        if (a.mode == 3) for (int w = tid; w < (int)(2 * a.RW); w += nthr) grow[w] = 0u;   // nothing to rank: an empty bitmap
+        return;
+    }
     const u32 tie0 = a.mode == 2 ? a.xtie_before[q] : 0u;    // ties owned by lower-ranked shards
     for (int d = tid; d <= t && d < NB; d += nthr) {  // per-wave starts: bucket start + records of earlier waves
         u32 run = d < t ? tot[d] : tie0;              // for d == t the "start" is the tie rank offset
@@ -992,6 +1009,82 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     if (a.bits_lds) {
         __syncthreads();
         for (int w = tid; w < bmw; w += nthr) grow[w] = bm[w];
+    }
+}
+
+// ----------------------------------------------------------------------------
+// K4m  merge of per-shard rankings (sharded bet, AP only).  Every shard has ranked its own records
+// (k_rank_lds / k_rank_fused mode 3): a match bitmap in LOCAL rank order -- distance ascending, index
+// ascending -- and its per-distance record counts.  Shards own contiguous index ranges, so the global order
+// is: for each distance d, shard 0's bucket d, then shard 1's, ...  One wavefront per query (lane r <->
+// shard r) derives the global cut from the gathered counts exactly like k_plan and stitches the global
+// bitmap together from bit ranges of the local ones.  A shard's records of global rank < R all have local
+// rank < R, so the local top-R lists suffice.  No second pass over the records, one exchange less.
+//   hall: [G][NB * Qpad + TAIL_WORDS] gathered counts (+ overflow flag in tail word 0)
+//   ball: [G][Q * RW] gathered local bitmaps (64-bit words)
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restrict__ hall, const u64* __restrict__ ball, int G,
+                                                      i64 RW, u64* __restrict__ out, int* __restrict__ err,
+                                                      u32* __restrict__ qbad, const Geo g) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (q >= g.Q) return;
+    const i64 plane = (i64)g.NB * g.Qpad + TAIL_WORDS;
+    const bool mine = lane < G;                                       // lane r speaks for shard r (G <= 64)
+    if (q == 0 && mine && hall[(i64)lane * plane + plane - TAIL_WORDS]) atomicExch(err, 1);   // a slice overflowed somewhere
+    const u32* __restrict__ hcol = hall + (mine ? (i64)lane * plane : 0) + q;
+    u64* __restrict__ orow = out + (i64)q * RW;
+    u64 acc = 0;                // output bits not yet written (wave-uniform), `fill` of them
+    int fill = 0;
+    i64 wi = 0;                 // next output word
+    u64 cum = 0;                // records of all shards closer than d
+    u32 loff = 0;               // this shard's records closer than d = where its bucket d starts in its bitmap
+    bool done = false;
+    for (int d = 0; d < g.NB && !done; ++d) {
+        const u32 c = mine ? hcol[(i64)d * g.Qpad] : 0u;
+        u32 tot = c, pre = c;                                          // wave sum and inclusive prefix over the shards
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 v = (u32)__shfl_up((int)pre, off);
+            if (lane >= off) pre += v;
+        }
+        tot = (u32)__shfl((int)pre, 63);
+        u32 take = c;
+        if (cum + tot >= (u64)g.R) {                                   // the cut falls into this distance: ties by (shard, index)
+            const u64 quota = (u64)g.R - cum;
+            const u64 before = (u64)(pre - c);
+            take = before >= quota ? 0u : (u32)((quota - before) < c ? (quota - before) : c);
+            done = true;
+        }
+        for (int r = 0; r < G; ++r) {                                  // append shard r's `take` bits of bucket d
+            const u32 n = (u32)__builtin_amdgcn_readlane((int)take, r);
+            const u32 so = (u32)__builtin_amdgcn_readlane((int)loff, r);
+            const u64* __restrict__ src = ball + ((i64)r * g.Q + q) * RW;
+            for (u32 k0 = 0; k0 < n; k0 += 64) {
+                const u32 k = k0 + lane;
+                const bool bit = k < n && ((src[(so + k) >> 6] >> ((so + k) & 63)) & 1ull);
+                const u64 chunk = __ballot(bit);
+                const int nv = (int)(n - k0 < 64 ? n - k0 : 64);
+                acc |= chunk << fill;
+                if (fill + nv >= 64) {
+                    if (lane == 0) orow[wi] = acc;
+                    ++wi;
+                    acc = fill ? chunk >> (64 - fill) : 0ull;
+                    fill = fill + nv - 64;
+                } else {
+                    fill += nv;
+                }
+            }
+        }
+        loff += c;
+        cum += tot;
+    }
+    if (fill && wi < RW) { if (lane == 0) orow[wi] = acc; ++wi; }
+    for (i64 w = wi + lane; w < RW; w += 64) orow[w] = 0ull;
+    if (lane == 0) {
+        const bool lost = cum < (u64)g.R;                              // fewer than R records over all shards: bet lost
+        qbad[q] = lost ? 1u : 0u;
+        if (lost) atomicExch(err, 1);
     }
 }
 

@@ -64,10 +64,10 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_lds(const u64* __restrict__ 
     else if (tid == 0) a.big[q] = 0u;
     if (a.fail[q]) {                                  // a slice of this query overflowed
         if (tid == 0) {
-            if (a.mode == 1) atomicOr(&a.hown[(i64)NB * g.Qpad], 1u);   // tail word 0: this shard lost the bet
+            if (a.mode == 1 || a.mode == 3) atomicOr(&a.hown[(i64)NB * g.Qpad], 1u);   // tail word 0: this shard lost the bet
             else { atomicExch(a.err, 1); a.qbad[q] = 1u; }
         }
-        if (a.mode == 1) for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = 0u;
+        if (a.mode == 1 || a.mode == 3) for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = 0u;
         return;
     }
     for (int i = tid; i < (NWAV + 1) * NB + 8 + NWAV + 8 + bmw; i += nthr) lds[i] = 0u;
@@ -158,6 +158,10 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_lds(const u64* __restrict__ 
         for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = tot[d];
         return;
     }
+    if (a.mode == 3) {                                // counts for the merge, before the plan turns tot[] into starts
+        for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = tot[d];
+        __syncthreads();
+    }
     if (a.mode == 2) {
         if (tid == 0) {
             const int t = a.xt[q];
@@ -173,26 +177,39 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_lds(const u64* __restrict__ 
         for (int d = tid; d < NB; d += nthr) tot[d] = a.xposbase[(i64)d * g.Qpad + q];   // my rows of bucket d start here
         __syncthreads();
     }
-    if (a.mode == 0 && tid == 0) {
+    if ((a.mode == 0 || a.mode == 3) && tid == 0) {
+        // mode 3 (local ranking for k_merge_ranked): rank whatever this shard has, up to R -- never "lost" here
+        u64 want = (u64)g.R;
+        if (a.mode == 3) {
+            u64 have = 0;
+            for (int d = 0; d < NB; ++d) have += tot[d];
+            if (have < want) want = have;
+        }
         u64 cum = 0;
         int t = -1, dmin = -1;
-        for (int d = 0; d < NB; ++d) {
-            const u32 c = tot[d];
-            if (c && dmin < 0) dmin = d;
-            tot[d] = (u32)cum;                        // global start of bucket d
-            if (cum + c >= (u64)g.R) { t = d; break; }
-            cum += c;
-        }
+        if (want > 0)
+            for (int d = 0; d < NB; ++d) {
+                const u32 c = tot[d];
+                if (c && dmin < 0) dmin = d;
+                tot[d] = (u32)cum;                    // global start of bucket d
+                if (cum + c >= want) { t = d; break; }
+                cum += c;
+            }
         misc[0] = (u32)t;
         misc[1] = (u32)cum;                           // cnt_lt
-        misc[2] = (u32)((u64)g.R - cum);              // quota
+        misc[2] = (u32)(want - cum);                  // quota
         misc[3] = (u32)(dmin < 0 ? 0 : dmin);         // smallest distance present
-        if (t < 0) atomicExch(a.err, 1);              // the superset is too small: bet lost
-        a.qbad[q] = t < 0 ? 1u : 0u;
+        if (a.mode == 0) {
+            if (t < 0) atomicExch(a.err, 1);          // the superset is too small: bet lost
+            a.qbad[q] = t < 0 ? 1u : 0u;
+        }
     }
     __syncthreads();
     const int t = (int)misc[0];
-    if (t < 0) return;
+    if (t < 0) {
+        if (a.mode == 3) for (int w = tid; w < (int)(2 * a.RW); w += nthr) grow[w] = 0u;   // nothing to rank: an empty bitmap
+        return;
+    }
     const u32 tie0 = a.mode == 2 ? a.xtie_before[q] : 0u;    // ties owned by lower-ranked shards
     for (int d = tid; d <= t && d < NB; d += nthr) {  // per-wave starts: bucket start + records of earlier waves
         u32 acc = d < t ? tot[d] : tie0;              // for d == t the "start" is the tie rank offset

@@ -161,6 +161,18 @@ class HipShardEngine:
         self._keep.append(gathered)
         return self.ctx.rank(gathered.data_ptr() if gathered is not None else None, world, rank)
 
+    def select_ranked(self):
+        """Select with the shared guess and rank this shard's records; -> (record counts, local match bitmap)."""
+        self.ctx.select_ranked()
+        ph, nh = self.ctx.hist_buffer()
+        pb, nb = self.ctx.match_buffer()
+        return _as_tensor(ph, nh, self.ctx.device), _as_tensor(pb, nb, self.ctx.device)
+
+    def merge_ranked(self, gathered_hist, gathered_bits, world):
+        self._keep += [gathered_hist, gathered_bits]
+        return self.ctx.merge_ranked(gathered_hist.data_ptr() if gathered_hist is not None else None,
+                                     gathered_bits.data_ptr() if gathered_bits is not None else None, world)
+
     def verdict(self):
         """True if a deferred bet (rank_candidates returned None) turned out lost."""
         return self.ctx.bet_verdict()
@@ -195,6 +207,18 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
     multi = comm.world > 1 or always_gather          # always_gather: exercise the collectives even with one rank
     gather = (lambda t: comm.all_gather(t)) if multi else (lambda t: None)
     bits = None
+    if (bet and not gather_topr and hasattr(engine, "select_ranked") and comm.world <= 64
+            and engine.bet_eligible(R, comm.world)):
+        # the bet with one record pass and one exchange after the guess: every shard ranks its own records, the
+        # global bitmap is stitched from the gathered local ones (hg_merge_ranked)
+        engine.guess(R, gather(engine.sample_hist(R)), comm.world, comm.rank)
+        h, b = engine.select_ranked()
+        lost = engine.merge_ranked(gather(h), gather(b), comm.world)
+        if not lost:                                  # held, or verdict deferred
+            ap, rel = engine.finish(None, comm.world)
+            if lost is not None or not engine.verdict():
+                return ap, rel
+        bet = False                                   # lost (the same on every rank): exact sequence below
     if bet and hasattr(engine, "bet_eligible") and engine.bet_eligible(R, comm.world):
         # one pass over the pairs: sampled histograms -> shared guess -> candidate records ->
         # exact record histograms -> shared exact plan.  `lost` is the same on every rank.

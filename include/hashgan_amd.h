@@ -129,6 +129,16 @@ int hg_rank(hg_ctx* ctx, const uint32_t* dev_hist_all, int G, int rank, int* bet
  * *bet_lost = 1 it discards those results and runs the exact sequence.  Removes the only host round trip from
  * the middle of a sharded step. */
 int hg_bet_verdict(hg_ctx* ctx, int* bet_lost);
+/* The bet with ONE record pass and ONE exchange after the guess (AP only, no ranked lists):
+ * hg_select_ranked   select with the shared guess, then rank this shard's own records.  Leaves the shard's
+ *                    per-distance record counts in hg_hist_buffer and its match bitmap in LOCAL rank order
+ *                    (metric.py:14,17-19 restricted to the shard) in hg_match_buffer -> all-gather both
+ * hg_merge_ranked    shards own contiguous index ranges, so the global order is, per distance, shard 0's rows,
+ *                    then shard 1's, ...: derives the cut from the gathered counts (metric.py:19's [0:R]) and
+ *                    stitches the global match bitmap from bit ranges of the local ones; then hg_ap.
+ *                    *bet_lost as in hg_rank (-1 with "defer_verdict"); G <= 64. */
+int hg_select_ranked(hg_ctx* ctx);
+int hg_merge_ranked(hg_ctx* ctx, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, int* bet_lost);
 
 /* Ranked lists in global-position space: uint32 idx [Q][R] (HG_IDX_NONE where a
  * slot belongs to another shard), uint8 dist [Q][R] (0xFF there). */
