@@ -69,3 +69,55 @@ class NumpyShardEngine:
             if a is not None:
                 ap[q] = a
         return ap, rel
+
+
+class NumpyRankedEngine(NumpyShardEngine):
+    """Adds the one-exchange form of the bet (HipShardEngine.select_ranked / merge_ranked): every shard ranks its
+    own rows, the global bitmap is stitched from the gathered local ones.  The "guess" here keeps every row,
+    which is a valid (if useless) superset; the merge is k_merge_ranked restated with Python loops."""
+
+    def bet_eligible(self, R, world):
+        return True
+
+    def sample_hist(self, R):
+        return self.hist()
+
+    def guess(self, R, gathered, world, rank):
+        self.R = R
+
+    def select_ranked(self):
+        Q, R = self.D.shape[0], self.R
+        bits = np.zeros((Q, R), dtype=bool)
+        for q in range(Q):
+            order = np.argsort(self.D[q], kind="stable")[:R]          # local rank order: distance, then index
+            bits[q, :len(order)] = [O.label_match(self.ql[q], self.dl[n:n + 1])[0] for n in order]
+        self.local_bits = bits
+        return torch.from_numpy(self.h.astype(np.int32)), torch.from_numpy(np.packbits(bits, axis=1, bitorder="little"))
+
+    def merge_ranked(self, gathered_hist, gathered_bits, world):
+        H = gathered_hist.numpy().astype(np.int64) if world > 1 else self.h[None]
+        B = gathered_bits.numpy() if world > 1 else np.packbits(self.local_bits, axis=1, bitorder="little")[None]
+        Q, R = self.D.shape[0], self.R
+        out = np.zeros((Q, R), dtype=bool)
+        lost = False
+        for q in range(Q):
+            loc = [np.unpackbits(B[r, q], bitorder="little")[:R].astype(bool) for r in range(H.shape[0])]
+            off = [0] * H.shape[0]
+            pos = 0
+            for d in range(self.NB):
+                for r in range(H.shape[0]):
+                    take = min(int(H[r, q, d]), R - pos)
+                    out[q, pos:pos + take] = loc[r][off[r]:off[r] + take]
+                    pos += take
+                    off[r] += int(H[r, q, d])
+                if pos >= R:
+                    break
+            lost = lost or pos < R
+        self.bits = out
+        return lost
+
+    def finish(self, gathered_bits, world):
+        if gathered_bits is None and world > 1:                       # merged already: nothing to OR
+            packed = np.packbits(self.bits, axis=1, bitorder="little")[None]
+            return NumpyShardEngine.finish(self, torch.from_numpy(packed), 1)
+        return NumpyShardEngine.finish(self, gathered_bits, world)

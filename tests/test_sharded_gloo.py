@@ -11,11 +11,11 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, name, out_dir):
+def _worker(rank, world, port, name, out_dir, ranked=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from tests import cases
-    from tests.numpy_shard_engine import NumpyShardEngine
+    from tests.numpy_shard_engine import NumpyShardEngine, NumpyRankedEngine
     from hashgan_amd import sharded
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -23,7 +23,8 @@ def _worker(rank, world, port, name, out_dir):
     c = cases.build_case(name)
     N = c["dbbits"].shape[0]
     base, rows = sharded.shard_bounds(N, world)[rank]
-    eng = NumpyShardEngine(c["qbits"], c["qlab"], c["dbbits"][base:base + rows], c["dblab"][base:base + rows], base)
+    cls = NumpyRankedEngine if ranked else NumpyShardEngine
+    eng = cls(c["qbits"], c["qlab"], c["dbbits"][base:base + rows], c["dblab"][base:base + rows], base)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ap, rel = sharded.evaluate_shard(eng, sharded.TorchComm(), c["R"])
@@ -43,6 +44,19 @@ def test_two_rank_gloo_matches_single_shard_oracle(name, tmp_path):
     r1 = np.load(tmp_path / "rank1.npz")
     assert np.array_equal(r0["ap"], r1["ap"], equal_nan=True)
     assert np.array_equal(r0["ap"], g["ap"], equal_nan=True)          # the unmodified reference's values
+
+
+@pytest.mark.parametrize("name", ["e_b8", "e_dups_alleq"])
+def test_two_rank_gloo_merged_local_rankings(name, tmp_path):
+    """The one-exchange form of the bet (select_ranked / merge_ranked branch of evaluate_shard) over gloo."""
+    from tests import cases
+    port = 29950 + (os.getpid() % 40)
+    mp.spawn(_worker, args=(2, port, name, str(tmp_path), True), nprocs=2, join=True)
+    g = cases.load_golden(name)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["ap"], r1["ap"], equal_nan=True)
+    assert np.array_equal(r0["ap"], g["ap"], equal_nan=True)
 
 
 def test_shard_bounds():
