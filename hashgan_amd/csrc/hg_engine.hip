@@ -1218,9 +1218,12 @@ int hg_merge_ranked(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev
     HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
     const u32* hall = G > 1 ? (const u32*)dev_hist_all : c->hown.as<u32>();
     const u64* ball = G > 1 ? (const u64*)dev_bits_all : c->mbits.as<u64>();
+    const size_t rows_lds = (size_t)WPB * G * c->RW * 8;       // the G local bitmap rows of a block's four queries
+    const int use_lds = rows_lds + (size_t)WPB * G * g.NB * 4 <= 64 * 1024;
     c->t_begin(KI_MERGE);
-    hipLaunchKernelGGL(k_merge_ranked, dim3(grid_for(g.Q, WPB)), dim3(256), 0, c->stream, hall, ball, G, c->RW,
-                       c->mbits2.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(), g);
+    hipLaunchKernelGGL(k_merge_ranked, dim3(grid_for(g.Q, WPB)), dim3(256),
+                       (use_lds ? rows_lds : 0) + (size_t)WPB * G * g.NB * 4, c->stream, hall, ball, G,
+                       c->RW, c->mbits2.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(), use_lds, g);
     c->t_end();
     HG_TRY(c->check_launch("k_merge_ranked"));
     std::swap(c->mbits, c->mbits2);                    // the global bitmap is what hg_ap and hg_get_match see

@@ -1023,16 +1023,33 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
 //   hall: [G][NB * Qpad + TAIL_WORDS] gathered counts (+ overflow flag in tail word 0)
 //   ball: [G][Q * RW] gathered local bitmaps (64-bit words)
 // ----------------------------------------------------------------------------
+// use_lds: the G local bitmap rows of the query are first copied into LDS with all loads in flight (the
+// stitching reads them bit range by bit range, one dependent load per 64 bits otherwise).
 __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restrict__ hall, const u64* __restrict__ ball, int G,
                                                       i64 RW, u64* __restrict__ out, int* __restrict__ err,
-                                                      u32* __restrict__ qbad, const Geo g) {
+                                                      u32* __restrict__ qbad, int use_lds, const Geo g) {
+    extern __shared__ __attribute__((aligned(16))) u64 mrows[];       // [WPB][G][RW] when use_lds
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (q >= g.Q) return;
+    const int wv = threadIdx.x >> 6;
+    u64* lrows = mrows + (i64)wv * G * RW;
+    // the query's record counts of all shards, [G][NB], fetched with every load in flight
+    u32* lcnt = (u32*)(mrows + (use_lds ? (i64)WPB * G * RW : 0)) + (i64)wv * G * g.NB;
+    for (int i = lane; i < G * g.NB; i += 64) {
+        const int r = i / g.NB, d = i - r * g.NB;
+        lcnt[i] = hall[(i64)r * ((i64)g.NB * g.Qpad + TAIL_WORDS) + (i64)d * g.Qpad + q];
+    }
+    if (use_lds) {
+        for (i64 i = lane; i < (i64)G * RW; i += 64) {
+            const i64 r = i / RW, w = i - r * RW;
+            lrows[i] = ball[(r * g.Q + q) * RW + w];
+        }
+    }
+    wave_lds_sync();
     const i64 plane = (i64)g.NB * g.Qpad + TAIL_WORDS;
     const bool mine = lane < G;                                       // lane r speaks for shard r (G <= 64)
     if (q == 0 && mine && hall[(i64)lane * plane + plane - TAIL_WORDS]) atomicExch(err, 1);   // a slice overflowed somewhere
-    const u32* __restrict__ hcol = hall + (mine ? (i64)lane * plane : 0) + q;
     u64* __restrict__ orow = out + (i64)q * RW;
     u64 acc = 0;                // output bits not yet written (wave-uniform), `fill` of them
     int fill = 0;
@@ -1041,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restrict__ ha
     u32 loff = 0;               // this shard's records closer than d = where its bucket d starts in its bitmap
     bool done = false;
     for (int d = 0; d < g.NB && !done; ++d) {
-        const u32 c = mine ? hcol[(i64)d * g.Qpad] : 0u;
+        const u32 c = mine ? lcnt[lane * g.NB + d] : 0u;
         u32 tot = c, pre = c;                                          // wave sum and inclusive prefix over the shards
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -1059,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restrict__ ha
         for (int r = 0; r < G; ++r) {                                  // append shard r's `take` bits of bucket d
             const u32 n = (u32)__builtin_amdgcn_readlane((int)take, r);
             const u32 so = (u32)__builtin_amdgcn_readlane((int)loff, r);
-            const u64* __restrict__ src = ball + ((i64)r * g.Q + q) * RW;
+            const u64* src = use_lds ? lrows + (i64)r * RW : ball + ((i64)r * g.Q + q) * RW;
             for (u32 k0 = 0; k0 < n; k0 += 64) {
                 const u32 k = k0 + lane;
                 const bool bit = k < n && ((src[(so + k) >> 6] >> ((so + k) & 63)) & 1ull);
