@@ -11,8 +11,9 @@
 // 32-row x 32-query tile of distances; the per-query constant popcount(q) - T - 1 rides in as
 // the C operand, so the SIGN of every accumulator IS the test dist <= T and the vector ALU is
 // left with ONE op per pair (v_alignbit: shift the lane's hit mask, append the sign) instead of
-// 2*NW + 1.  Everything after the hit masks -- the windowed drain, the 8-byte records, slices,
-// counts, overflow flags -- is k_select<OPT>'s, so the ranking stage cannot tell which kernel ran.
+// 2*NW + 1.  What leaves the kernel -- the 8-byte records in index order, the (segment, query)
+// slices, their counts and overflow flags -- is exactly k_select<OPT>'s, so the ranking stage
+// cannot tell which kernel ran.
 //
 // Mapping.  D[i][j] = sum_k A[i][k] B[k][j]: A rows = database rows, B columns = queries.  A
 // lane holds column j = lane & 31 of D, i.e. ONE query, and 16 of the tile's 32 rows:
@@ -23,11 +24,13 @@
 // The K order of an inner product is free as long as A and B agree: both images are produced
 // by the same expand_word() below.
 //
-// Data movement.  A block = 4 wavefronts = one segment pair x 512 queries (4 tiles of 32 per
-// wave).  The database streams through LDS in windows of 8 row tiles (128 rows per half): the
+// Data movement.  A block = 4 wavefronts = one segment pair x 128 QT queries (QT tiles of 32
+// per wave; QT = 2 by default, 4 for codes longer than 128 bits whose B fragments need the
+// registers).  The database streams through LDS in windows of 8 row tiles (128 rows per half): the
 // fp4 image of the rows (A fragments, lane-linear) plus their packed codes and labels (for the
 // drain's exact distance and match bit) are copied global -> LDS by direct-to-LDS loads, one
-// window ahead, shared by the four waves; one barrier per window.
+// window ahead, shared by the four waves; one barrier per window.  Hits leave through a
+// two-phase drain (push / emit, below) twice per window.
 #pragma once
 #include "hg_kernels.hpp"
 
