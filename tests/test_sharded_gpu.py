@@ -73,7 +73,7 @@ def test_virtual_shards_equal_single_shard(name, G, case_cache):
     assert (np.isnan(m) and np.isnan(g["map"])) or m == g["map"]
 
 
-@pytest.mark.parametrize("name,G", [("c2_q64", 4), ("c5_b128_q32", 2), ("c3_nus_q64", 2)])
+@pytest.mark.parametrize("name,G", [("c2_q64", 4), ("c2_q64", 8), ("c5_b128_q32", 2), ("c3_nus_q64", 2)])
 def test_virtual_shards_optimistic_sequence(name, G, case_cache):
     """Big enough for the sharded bet (sample -> guess -> candidates -> rank): must equal the golden
     AP of the unmodified reference, and really have taken the one-pass route."""
