@@ -1783,8 +1783,10 @@ int hg_trim(hg_ctx* c) {
     HG_TRY(c->use());
     HG_TRY(c->sync());
     DevBuf* work[] = {&c->hist, &c->seglt, &c->segtie, &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->cand, &c->out_idx,
-                      &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->scores};
+                      &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->scores, &c->bigq, &c->mbits2,
+                      &c->dbx, &c->qx, &c->dbx2, &c->qx2};   // the fp4 images are rebuilt on demand
     for (auto* d : work) d->release();
+    c->dbx_valid = c->qx_valid = c->dbx2_valid = c->qx2_valid = false;
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     c->stage &= (ST_DB | ST_Q);
     c->lists_valid = false;
