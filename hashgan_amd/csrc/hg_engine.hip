@@ -233,7 +233,7 @@ struct hg_ctx {
     }
     int sync() {
         HG_HIP(hipStreamSynchronize(stream));
-        t_collect();
+        if (pending.size() > 4096) t_collect();       // otherwise the elapsed times are read when somebody asks for them
         return HG_OK;
     }
     // end of a staged call that only enqueued work: synchronise unless the caller orders everything on
@@ -1826,12 +1826,16 @@ int hg_timing_enable(hg_ctx* c, int on) {
 
 int hg_timing_reset(hg_ctx* c) {
     if (!c) return fail(HG_ERR_ARG, "hg_timing_reset: null context");
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->t_collect();
     for (int i = 0; i < KI_COUNT; ++i) { c->t_ms[i] = 0; c->t_n[i] = 0; }
     return HG_OK;
 }
 
 int hg_timing_read(hg_ctx* c, int cap, const char** names, double* total_ms, int64_t* launches, int* n) {
     if (!c || !n) return fail(HG_ERR_ARG, "hg_timing_read: null argument");
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->t_collect();                                    // events recorded since the last read
     int k = 0;
     for (int i = 0; i < KI_COUNT && k < cap; ++i) {
         if (!c->t_n[i]) continue;
