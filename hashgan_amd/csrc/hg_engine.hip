@@ -170,6 +170,7 @@ struct hg_ctx {
     bool dbx_valid = false, qx_valid = false;
     DevBuf dbx2, qx2;          // the same for k_select_mx2 (two rows per accumulator, codes of <= 64 bits)
     bool dbx2_valid = false, qx2_valid = false;
+    bool direct_rank = false;  // R = N: k_rank_fused computes distance and match bit per row itself (no records)
     bool err_zeroed = false;   // the guess kernel of a one-shot bet already cleared err
     i64 defer_verdict = 0;     // hg_rank does not wait for the bet's verdict; hg_bet_verdict reads it later
     bool verdict_pending = false, verdict_known = false;
@@ -953,7 +954,8 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
     RankArgs ra{c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(),
                 mode, c->hwq.as<u32>(), c->hown.as<u32>(), c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(),
                 c->tie_before.as<u32>(), c->posbase.as<u32>(),
-                c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW, only};
+                c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW, only,
+                c->direct_rank ? 1 : 0, c->db.as<u32>(), c->dblab.as<u64>(), c->qc.as<u32>(), c->qlab.as<u64>()};
     const size_t lds_bytes = (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4;
     c->t_begin(mode == 1 ? KI_CAND_HIST : KI_RANK_FUSED);
     if (nwav == 16)
@@ -1352,30 +1354,38 @@ static bool optimistic_eligible(hg_ctx* c, int64_t R, int* stride_out, u32* need
     return true;
 }
 
-// R = N on one shard: the layout of the record rows is known without looking at a single distance
+// R = N on one shard (the reference's CIFAR-10 setting): every row is a member of every ranked list, so nothing
+// has to be selected or written down -- the ranking kernel walks the shard's rows directly, computing each row's
+// distance and match bit from the codes and labels in both of its passes (counting, then stable placement).
 static int enqueue_all_rows(hg_ctx* c, int64_t R) {
     make_geometry(c);
     HG_TRY(set_R(c, R, 1, 0));
     const Geo& g = c->geo;
     const size_t qb = (size_t)g.Qpad * 4;
-    HG_TRY(c->t.reserve(qb)); HG_TRY(c->err.reserve(4));
-    HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
-    HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
+    const size_t slots = (size_t)g.Q * g.R;
+    HG_TRY(c->err.reserve(4)); HG_TRY(c->failq.reserve(qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->sl_cnt.reserve(qb));
+    HG_TRY(c->cand.reserve(64));
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    HG_TRY(c->out_idx.reserve(c->want_lists ? slots * 4 : 16));
+    HG_TRY(c->out_dist.reserve(c->want_lists ? slots : 16));
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
-    c->t_begin(KI_SEG_LAYOUT);
-    hipLaunchKernelGGL(k_layout_all_rows, dim3(grid_for((i64)g.S * g.Qpad)), dim3(256), 0, c->stream, c->t.as<int>(),
-                       c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->tot.as<u32>(), g);
-    c->t_end();
-    HG_TRY(c->check_launch("k_layout_all_rows"));
     c->optimistic = false;
     c->crow = R;
     c->cap = 0;
-    c->stage = ST_DB | ST_Q | ST_PLAN;
-    return do_select(c);
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    c->direct_rank = true;
+    const int rc = launch_rank(c, 0, nbits);
+    c->direct_rank = false;
+    HG_TRY(rc);
+    c->lists_valid = c->want_lists;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
+    return HG_OK;
 }
 
 static int enqueue_exact(hg_ctx* c, int64_t R) {
-    if (c->N == c->n_total && R == c->N && c->opt_all_rows) return enqueue_all_rows(c, R);     // one-shot calls are single-shard
+    if (c->N == c->n_total && R == c->N && c->opt_all_rows && c->LW <= 2 && c->NW <= 8)
+        return enqueue_all_rows(c, R);                 // one-shot calls are single-shard
     HG_TRY(do_hist(c, 1));
     HG_TRY(do_plan(c, R, nullptr, 1, 0));
     return do_select(c);

@@ -780,6 +780,13 @@ struct RankArgs {
     int bits_lds;
     i64 RW;
     const u32* only;       // optional [Q]: handle only the flagged queries (the rest were ranked by k_rank_lds)
+    // direct mode (R = N on one shard): there are no records -- "record" i of a query is row i of the shard,
+    // its distance and match bit are computed from the codes and labels on the fly, in both passes
+    int direct;
+    const u32* db;         // [N][NW]
+    const u64* dblab;      // [N][LW]
+    const u32* qc;         // [Q][NW]
+    const u64* qlab;       // [Q][LW]
 };
 
 template <int NWAV>   // wavefronts per query: 4, or 16 for long lists
@@ -813,7 +820,7 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     __syncthreads();
     const u64* __restrict__ row = cand + (i64)q * a.crow;
     // slice mode: S slices of capacity cap; dense mode: the run of tot[q] records cut into chunks of cap
-    const u32 dense_tot = a.dense ? a.tot[q] : 0u;
+    const u32 dense_tot = a.direct ? (u32)g.N : (a.dense ? a.tot[q] : 0u);
     const int nsl = a.dense ? (int)((dense_tot + a.cap - 1) / a.cap) : g.S;
     const int s0 = (int)((i64)nsl * wave / nwav), s1 = (int)((i64)nsl * (wave + 1) / nwav);
     // A wave walks its slices 64 records per step.  Global-load latency, not work, bounds this
@@ -843,9 +850,25 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
         if (w.base >= a.cap || w.base >= w.cnt) { ++w.s; w.base = 0; w.cnt = slice_cnt(w.s); }
         return w;
     };
+    u32 dq[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};    // direct mode: the query's code and label words
+    u64 dl[2] = {0ull, 0ull};
+    if (a.direct) {
+        for (int w = 0; w < g.NW && w < 8; ++w) dq[w] = a.qc[(i64)q * g.NW + w];
+        for (int w = 0; w < g.LW && w < 2; ++w) dl[w] = a.qlab[(i64)q * g.LW + w];
+    }
     auto fetch = [&](const Walk& w) -> u64 {
         const u32 i = w.base + lane;
-        return (w.s < s1 && i < a.cap) ? row[(i64)w.s * a.cap + i] : 0ull;
+        if (!(w.s < s1 && i < a.cap)) return 0ull;
+        if (a.direct) {
+            const i64 n = (i64)w.s * a.cap + i;               // row of the shard
+            if (n >= g.N) return 0ull;
+            u32 d = 0;
+            for (int k = 0; k < g.NW && k < 8; ++k) d += (u32)__builtin_popcount(dq[k] ^ a.db[n * g.NW + k]);
+            u64 any = 0;
+            for (int k = 0; k < g.LW && k < 2; ++k) any |= dl[k] & a.dblab[n * g.LW + k];
+            return make_rec(g.idx_base + (u32)n, d, any != 0);
+        }
+        return row[(i64)w.s * a.cap + i];
     };
     // phase 1
     u32* myh = hw + wave * NB;
@@ -1333,23 +1356,6 @@ __global__ __launch_bounds__(256) void k_move_rows(const u8* __restrict__ src, u
         for (i64 k = threadIdx.x; k < rowbytes / 4; k += 256) d4[k] = s4[k];
     } else {
         for (i64 k = threadIdx.x; k < rowbytes; k += 256) d[k] = s[k];
-    }
-}
-
-// R = N (the reference's CIFAR-10 setting): every row is a member of every ranked list, so the record-row layout
-// needs no histogram -- segment s of every query starts at row s * L of its record row, nothing is a tie to ration.
-__global__ __launch_bounds__(256) void k_layout_all_rows(int* __restrict__ T, u32* __restrict__ sl_start, u32* __restrict__ sl_tie,
-                                                         u32* __restrict__ tot, const Geo g) {
-    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (i64)g.S * g.Qpad) return;
-    const i64 s = i / g.Qpad;
-    const i64 first = s * g.L;
-    sl_start[i] = (u32)(first < g.N ? first : g.N);
-    sl_tie[i] = 0xFFFFFFFFu;
-    if (s == 0) {
-        const int q = (int)i;
-        T[q] = g.NB;                                  // every distance is below the cut
-        tot[q] = q < g.Q ? (u32)g.N : 0u;
     }
 }
 
