@@ -1404,9 +1404,18 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     HG_TRY(c->sstar.reserve(qb));
     c->t_begin(KI_GUESS);
     const Geo gh = hist_geometry(c);                   // the sampled pass ran on coarser segments
-    hipLaunchKernelGGL(k_guess_direct, dim3(grid_for(g.Qpad, 64)), dim3(256), 0, c->stream, c->hist.as<u32>(), gh.S,
-                       (int)(gh.L / g.L), (double)c->opt_sigma, (i64)c->n_total, (u32)sampled_rows(c, stride),
-                       c->tguess.as<int>(), c->sstar.as<int>(), c->failq.as<u32>(), c->err.as<int>(), g);
+    {   // lanes per query by the number of sampled segments each has to sum
+        const int ratio = (int)(gh.L / g.L);
+        const u32 srows = (u32)sampled_rows(c, stride);
+#define HG_GUESS(P)                                                                                                     \
+        hipLaunchKernelGGL(k_guess_direct<P>, dim3(grid_for(g.Qpad, WPB * (64 / P))), dim3(256), 0, c->stream,          \
+                           c->hist.as<u32>(), gh.S, ratio, (double)c->opt_sigma, (i64)c->n_total, srows,                \
+                           c->tguess.as<int>(), c->sstar.as<int>(), c->failq.as<u32>(), c->err.as<int>(), g)
+        if (gh.S <= 64) HG_GUESS(4);
+        else if (gh.S <= 512) HG_GUESS(16);
+        else HG_GUESS(64);
+#undef HG_GUESS
+    }
     c->t_end();
     HG_TRY(c->check_launch("k_guess_direct"));
     c->err_zeroed = true;                              // launch_rank need not clear the lost-bet flag again

@@ -333,12 +333,14 @@ __global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, const
 // One-shot, single-shard form of k_hist_reduce + k_guess: sums the sampled pass's per-segment histograms
 // itself, bucket by bucket, and stops at the guessed cut -- a third of the planes at C2, no reduced copy,
 // one launch less.  Also clears the bet's per-query overflow flags and the lost-bet flag (two fills less).
+// PARTS lanes per query (4, 16 or 64 -- more when the sampled pass has many segments): 64 / PARTS queries per wavefront
+template <int PARTS>
 __global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hseg, int Sh, int ratio, double sigma,
                                                       i64 n_total, u32 sampled, int* __restrict__ T, int* __restrict__ sstar,
                                                       u32* __restrict__ failq, int* __restrict__ err, const Geo g) {
-    // 16 queries per wavefront, 4 lanes per query: lane part p sums segments [p * per, (p + 1) * per)
-    const int lane = threadIdx.x & 63, part = lane >> 4;
-    const int q = (blockIdx.x * WPB + (threadIdx.x >> 6)) * 16 + (lane & 15);
+    constexpr int QPW = 64 / PARTS;                    // lane = part * QPW + query-in-wave
+    const int lane = threadIdx.x & 63, part = lane / QPW;
+    const int q = (blockIdx.x * WPB + (threadIdx.x >> 6)) * QPW + (lane % QPW);
     if (part == 0 && q < g.Qpad) failq[q] = 0u;
     if (q == 0 && part == 0) *err = 0;
     const bool live = q < g.Q;
@@ -346,8 +348,8 @@ __global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hs
     const double fr = (double)g.R * (double)sampled / (double)n_total;
     const u64 need = (u64)ceil(fr + sigma * sqrt(fr) + 1.0);
     const i64 plane = (i64)g.NB * g.Qpad;
-    const int per = (Sh + 3) / 4;
-    const int s0 = part * per, s1 = s0 + per < Sh ? s0 + per : Sh;
+    const int per = (Sh + PARTS - 1) / PARTS;          // part p sums segments [p * per, (p + 1) * per)
+    const int s0 = part * per < Sh ? part * per : Sh, s1 = s0 + per < Sh ? s0 + per : Sh;
     u64 cum = 0, below = 0;
     int t = g.NB - 1;                                  // sample too thin: take everything
     bool found = false;
@@ -363,34 +365,37 @@ __global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hs
             for (int k = 0; k < 4; ++k) c += v[k];
         }
         for (; sh < s1; ++sh) c += col[(i64)sh * plane];
-        c += (u32)__shfl_xor((int)c, 16);
-        c += (u32)__shfl_xor((int)c, 32);
+#pragma unroll
+        for (int off = QPW; off < 64; off <<= 1) c += (u32)__shfl_xor((int)c, off);      // sum over the query's parts
         below = cum;
         cum += c;
         if (cum >= need) { t = d; found = true; break; }
     }
-    // all four parts of a query agree on t; a wave's queries may stop at different d: no shuffle after this point
-    // depends on lanes that left the loop early -- the ones below only pair lanes of the same query
+    // all parts of a query agree on t; a wave's queries may stop at different d: the shuffles below only pair
+    // lanes of the same query, which left the loop together
     int ss = g.S - 1;                                  // default: collect distance T everywhere
     if (found) {
         // {dist < T} everywhere + {dist == T} up to a segment: first segment (in order) where the count reaches need
         const u32* __restrict__ col = hseg + (i64)t * g.Qpad + qq;
         u32 mine = 0;
         for (int sh = s0; sh < s1; ++sh) mine += col[(i64)sh * plane];
-        // exclusive prefix over the four parts of the query
-        const u32 a1 = (u32)__shfl_xor((int)mine, 16);           // partner in the same pair
-        const u32 pair = mine + a1;
-        const u32 a2 = (u32)__shfl_xor((int)pair, 32);           // the other pair's total
-        u64 have = below + ((part & 1) ? a1 : 0u) + ((part & 2) ? a2 : 0u);
+        u32 incl = mine;                               // inclusive prefix over the query's parts (lanes QPW apart)
+#pragma unroll
+        for (int off = QPW; off < 64; off <<= 1) {
+            const u32 v = (u32)__shfl_up((int)incl, off);
+            if (lane >= off) incl += v;
+        }
+        u64 have = below + (u64)(incl - mine);
         int cand = 0x7FFFFFFF;
         for (int sh = s0; sh < s1; ++sh) {
             have += col[(i64)sh * plane];
             if (have >= need) { cand = sh; break; }
         }
-        int m = __shfl_xor(cand, 16);
-        cand = cand < m ? cand : m;
-        m = __shfl_xor(cand, 32);
-        cand = cand < m ? cand : m;
+#pragma unroll
+        for (int off = QPW; off < 64; off <<= 1) {
+            const int m = __shfl_xor(cand, off);
+            cand = cand < m ? cand : m;
+        }
         if (cand != 0x7FFFFFFF) ss = (cand + 1) * ratio - 1;
         if (ss > g.S - 1) ss = g.S - 1;
     }
