@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_lds(const u64* __restrict__ 
 
     // ---- copy the records into LDS: wave w takes slices w, w + NWAV, ...; two slices (four loads) in flight ----
     const u64* __restrict__ row = cand + (i64)q * a.crow;
-    constexpr int NSL = 4;                            // slices per iteration: 2 NSL loads in flight per wavefront
+    constexpr int NSL = 8;                            // slices per iteration: 2 NSL loads in flight per wavefront
     for (int s = wave; s < S; s += NSL * NWAV) {
         u32 p[NSL], c[NSL];
         u64 v0[NSL], v1[NSL];
