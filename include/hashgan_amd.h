@@ -40,7 +40,8 @@ extern "C" {
 #define HG_ERR_STATE (-3)  /* call sequence violated (e.g. hg_select before hg_plan) */
 #define HG_ERR_NOMEM (-4)  /* device allocation failed */
 
-#define HG_MAX_BITS 256        /* longest supported code */
+#define HG_MAX_BITS 255        /* longest supported code: a Hamming distance has to fit the 8 bits it gets in
+                                  the records and in the ranked lists (two 256-bit codes can be 256 apart) */
 #define HG_IDX_NONE 0xFFFFFFFFu /* ranked-list slot owned by another shard */
 
 typedef struct hg_ctx hg_ctx;

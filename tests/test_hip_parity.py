@@ -279,3 +279,32 @@ def test_state_and_argument_errors(ctx, case_cache):
     assert e.value.code == _native.HG_ERR_ARG
     with pytest.raises(_native.HashganNativeError):
         ctx.set_option("no_such_option", 1)
+
+
+def test_longest_code_and_largest_distance(ctx):
+    """b = 255 (HG_MAX_BITS), with rows that are the exact complement of a query: distance 255, the largest a
+    record or a ranked list has to hold; R = N ranks them (last).  A 256-bit code is refused: its complement
+    would be 256 away, one more than the 8-bit distance fields carry."""
+    rng = np.random.default_rng(3)
+    b, N, Q, C = 255, 300, 5, 4
+    db = rng.integers(0, 2, (N, b), dtype=np.uint8)
+    qb = rng.integers(0, 2, (Q, b), dtype=np.uint8)
+    db[7] = 1 - qb[0]
+    db[150] = 1 - qb[3]
+    dl = (rng.random((N, C)) < 0.4).astype(np.int8)
+    ql = (rng.random((Q, C)) < 0.4).astype(np.int8)
+    ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
+    ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
+    for R in (N, N - 1, 50):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, ap_ref, _, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
+        ap, rel = ctx.map(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True), R
+        ctx.topr(R)
+        idx, dist = ctx.get_topr()
+        assert np.array_equal(idx, idx_ref) and np.array_equal(dist, dist_ref), R
+    wide = rng.integers(0, 2, (N, 256), dtype=np.uint8)
+    with pytest.raises(_native.HashganNativeError) as e:
+        ctx.set_database(metric.pack_codes(wide), metric.pack_labels(dl), 256, C)
+    assert e.value.code == _native.HG_ERR_ARG

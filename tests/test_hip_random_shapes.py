@@ -50,7 +50,7 @@ def test_random_small_shapes():
     ctx = _native.Context(0)
     try:
         for it in range(iters):
-            b = int(rng.choice([1, 2, 5, 8, 16, 31, 32, 33, 48, 63, 64, 65, 96, 100, 128, 129, 200, 256]))
+            b = int(rng.choice([1, 2, 5, 8, 16, 31, 32, 33, 48, 63, 64, 65, 96, 100, 128, 129, 200, 255]))
             Q = int(rng.choice([1, 2, 63, 64, 65, 100, 130]))
             N = int(rng.choice([1, 2, 15, 16, 17, 255, 256, 257, 1000, 4097]))
             R = int(rng.choice([1, max(1, N // 7), max(1, N // 2), N]))
@@ -69,7 +69,7 @@ def test_random_bet_shapes():
     ctx = _native.Context(0)
     try:
         for b, C, R, Q in [(24, 5, 2000, 97), (64, 70, 3333, 97), (40, 130, 1000, 97), (100, 10, 5000, 97), (64, 10, 1, 97),
-                           (32, 3, 7, 97), (48, 10, 100, 97), (256, 10, 700, 40), (33, 2, 500, 300), (160, 65, 900, 31),
+                           (32, 3, 7, 97), (48, 10, 100, 97), (255, 10, 700, 40), (33, 2, 500, 300), (160, 65, 900, 31),
                            (64, 10, 8000, 520)]:
             N = 70000 + int(rng.integers(0, 999))
             qb = rng.integers(0, 2, (Q, b), dtype=np.uint8)
@@ -138,7 +138,7 @@ def test_fuzz_bet_shapes():
     ctx = _native.Context(0)
     try:
         for it in range(iters):
-            b = int(rng.choice([1, 7, 16, 31, 32, 33, 48, 63, 64, 65, 96, 128, 129, 200, 256]))
+            b = int(rng.choice([1, 7, 16, 31, 32, 33, 48, 63, 64, 65, 96, 128, 129, 200, 255]))
             C = int(rng.choice([1, 2, 10, 21, 64, 65, 128, 129]))
             N = int(rng.integers(65536, 140000))
             Q = int(rng.choice([1, 5, 31, 32, 33, 100, 257, 600]))

@@ -27,7 +27,7 @@ def run(Q, N, b, R, steps=5):
 
 if __name__ == "__main__":
     for (Q, N, b, R) in [(10000, 1000000, 64, 5000), (10000, 1000000, 64, 100), (10000, 1000000, 64, 50000), (10000, 1000000, 64, 500000),
-                         (10000, 1000000, 32, 5000), (10000, 1000000, 48, 5000), (10000, 1000000, 128, 5000), (10000, 1000000, 256, 5000),
+                         (10000, 1000000, 32, 5000), (10000, 1000000, 48, 5000), (10000, 1000000, 128, 5000), (10000, 1000000, 255, 5000),
                          (1000, 1000000, 64, 5000), (50000, 1000000, 64, 5000), (10000, 100000, 64, 5000), (10000, 10000000, 64, 5000),
                          (1000, 54000, 32, 54000), (2100, 190000, 48, 5000), (64, 10000000, 64, 5000)]:
         run(Q, N, b, R)
