@@ -5,7 +5,6 @@ fails to load, or finds no GPU, the error propagates (HashganNativeError).
 """
 import ctypes as C
 import os
-import sys
 
 import numpy as np
 
@@ -13,6 +12,7 @@ from . import build as _build
 
 HG_OK, HG_ERR_ARG, HG_ERR_HIP, HG_ERR_STATE, HG_ERR_NOMEM = 0, -1, -2, -3, -4
 IDX_NONE = 0xFFFFFFFF
+COMM_ID_BYTES = 128
 
 
 class HashganNativeError(RuntimeError):
@@ -62,6 +62,16 @@ _SIGNATURES = {
     "hg_get_match": [_p, _p],
     "hg_get_ap": [_p, _p, _p],
     "hg_get_hist": [_p, _p],
+    "hg_comm_unique_id": [_p],
+    "hg_comm_init": [_p, _p, C.c_int, C.c_int],
+    "hg_comm_destroy": [_p],
+    "hg_comm_info": [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "hg_allgather": [_p, C.c_int, _p, _i64, C.POINTER(_p)],
+    "hg_allgather_topr": [_p],
+    "hg_allreduce_max_f64": [_p, C.POINTER(C.c_double)],
+    "hg_barrier": [_p],
+    "hg_scratch": [_p, C.c_int, _i64, C.POINTER(_p)],
+    "hg_memcpy_dtod": [_p, _p, _p, _i64],
     "hg_set_stream": [_p, _p],
     "hg_set_option": [_p, C.c_char_p, _i64],
     "hg_get_stat": [_p, C.c_char_p, C.POINTER(_i64)],
@@ -76,7 +86,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB_PATH
+    """The production library, or the one HG_LIBRARY names (e.g. the probe build)."""
+    return os.environ.get("HG_LIBRARY") or _build.LIB_PATH
 
 
 def load():
@@ -84,17 +95,6 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    # PyTorch-ROCm ships its own copy of the HIP/HSA runtime.  Two runtimes in one process do not
-    # coexist (the second one finds no GPU), and the dynamic loader keeps whichever comes first.
-    # If the application has torch imported (sharded mode exchanges through torch.distributed),
-    # let torch bring its runtime up first; this library then binds to the same one.
-    torch = sys.modules.get("torch")
-    if torch is not None:
-        try:
-            if torch.cuda.is_available():
-                torch.cuda.init()
-        except Exception:      # noqa: BLE001 -- CPU-only torch, or no GPU: nothing to coordinate
-            pass
     path = library_path()
     if not os.path.exists(path):
         raise HashganNativeError(HG_ERR_STATE, "%s not built -- run `python -m hashgan_amd.build` "
@@ -312,9 +312,47 @@ class Context:
         check(self._lib.hg_get_hist(self._h, _ptr(h)))
         return h
 
+    # -- collectives (RCCL) -------------------------------------------------------
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        check(self._lib.hg_comm_init(self._h, buf, int(rank), int(world)))
+
+    def comm_destroy(self):
+        check(self._lib.hg_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        check(self._lib.hg_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def allgather(self, slot, dev_ptr, nbytes):
+        """-> device address of [world][nbytes], owned by the context (slot 0..3)."""
+        out = _p()
+        check(self._lib.hg_allgather(self._h, int(slot), _p(dev_ptr), int(nbytes), C.byref(out)))
+        return out.value
+
+    def allgather_topr(self):
+        check(self._lib.hg_allgather_topr(self._h))
+
+    def allreduce_max(self, x):
+        v = C.c_double(float(x))
+        check(self._lib.hg_allreduce_max_f64(self._h, C.byref(v)))
+        return v.value
+
+    def barrier(self):
+        check(self._lib.hg_barrier(self._h))
+
+    def scratch(self, slot, nbytes):
+        out = _p()
+        check(self._lib.hg_scratch(self._h, int(slot), int(nbytes), C.byref(out)))
+        return out.value
+
+    def memcpy_dtod(self, dst, src, nbytes):
+        check(self._lib.hg_memcpy_dtod(self._h, _p(dst), _p(src), int(nbytes)))
+
     # -- tuning / timing ----------------------------------------------------------
     def set_stream(self, stream_handle):
-        """Run on the caller's HIP stream (an int handle, e.g. torch.cuda.current_stream().cuda_stream); None = private."""
+        """Run on the caller's HIP stream (an int handle: a hipStream_t); None = back to a private one."""
         check(self._lib.hg_set_stream(self._h, _p(stream_handle) if stream_handle else None))
 
     def set_option(self, key, value):
@@ -345,6 +383,13 @@ class Context:
         n = C.c_int()
         check(self._lib.hg_timing_read(self._h, cap, names, ms, cnt, C.byref(n)))
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+
+def comm_unique_id():
+    """128 opaque bytes (ncclUniqueId) for rank 0 to hand to the other ranks; loads RCCL."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(load().hg_comm_unique_id(buf))
+    return bytes(buf)
 
 
 def device_count():

@@ -8,6 +8,9 @@
 #include "hg_select_mx2.hpp"
 #include "../../include/hashgan_amd.h"
 
+#include <rccl/rccl.h>     // types and enums only: the library itself is dlopen'ed by hg_comm_init (573 MB, not every process needs it)
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -68,10 +71,10 @@ struct DevBuf {
 
 enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_LAYOUT, KI_GUESS, KI_SELECT, KI_CAND_HIST,
                 KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_PACK, KI_REAL_SAMPLE, KI_REAL_GUESS, KI_REAL_SELECT,
-                KI_RADIX, KI_REAL_FINISH, KI_SELECT_MX, KI_RANK_LDS, KI_COUNT };
+                KI_RADIX, KI_REAL_FINISH, KI_SELECT_MX, KI_RANK_LDS, KI_COMM, KI_COUNT };
 const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_layout", "k_guess",
                                             "k_select", "k_rank_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge", "k_pack",
-                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish", "k_select_mx", "k_rank_lds"};
+                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish", "k_select_mx", "k_rank_lds", "rccl_allgather"};
 
 enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
 
@@ -115,6 +118,54 @@ void build_shape(int n, ApShape& sh) {
     }
 }
 
+
+// ---- RCCL, loaded on first use.  The product links no collective library: a single-GPU process never pays for it. ----
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+    if (g_rccl.handle) return HG_OK;
+    const char* cands[] = {getenv("HG_RCCL_LIBRARY"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    std::string tried;
+    for (const char* name : cands) {
+        if (!name || !*name) continue;
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+        const char* why = dlerror();
+        tried += std::string(name) + ": " + (why ? why : "?") + "; ";
+    }
+    if (!h) return fail(HG_ERR_STATE, "RCCL not found (%s)", tried.c_str());
+    RcclApi a;
+    a.handle = h;
+#define HG_SYM(field, name)                                                             \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));                      \
+    if (!a.field) { dlclose(h); return fail(HG_ERR_STATE, "RCCL: symbol %s missing", name); }
+    HG_SYM(GetUniqueId, "ncclGetUniqueId")
+    HG_SYM(CommInitRank, "ncclCommInitRank")
+    HG_SYM(CommDestroy, "ncclCommDestroy")
+    HG_SYM(AllGather, "ncclAllGather")
+    HG_SYM(AllReduce, "ncclAllReduce")
+    HG_SYM(GetErrorString, "ncclGetErrorString")
+#undef HG_SYM
+    g_rccl = a;
+    return HG_OK;
+}
+
+#define HG_NCCL(expr)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess)                                                                         \
+            return fail(HG_ERR_HIP, "%s: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
 }  // namespace
 
 struct hg_ctx {
@@ -160,7 +211,8 @@ struct hg_ctx {
     u32 cap = 0;               // optimistic slice capacity
     i64 crow = 0;              // record-row stride
     i64 opt_runs = 0, opt_fallbacks = 0, opt_requeried = 0;
-    int opt_consecutive_fail = 0;
+    int opt_consecutive_fail = 0;   // one-shot bets lost in a row (this context only)
+    int shard_bet_fail = 0;         // sharded bets lost in a row: identical on every rank by construction
     hg_ctx* sub = nullptr;     // child context (shares the database) that reruns single lost queries exactly
     bool is_sub = false;
 
@@ -188,8 +240,14 @@ struct hg_ctx {
     DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
     int bpad = 0;              // feature count padded to a multiple of 16 (0: no float tables loaded)
+    i64 census_db[3] = {0, 0, 0}, census_q[3] = {0, 0, 0};   // float tables as loaded: entries outside {-1,0,+1}, zeros, minus ones
     bool real_lists = false;
     i64 shapes_for_R = -1;
+
+    // collectives (RCCL over xGMI), one communicator per context; gathered[] are the landing zones of hg_allgather
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    DevBuf gathered[4], scratch[4], comm_tmp;
 
     // timing
     int timing = 0;            // 0 off, 1 the pair passes only (hist, select), 2 every kernel
@@ -641,6 +699,10 @@ int hg_destroy(hg_ctx* c) {
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
                      &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2};
     for (auto* d : all) d->release();
+    for (auto& d : c->gathered) d.release();
+    for (auto& d : c->scratch) d.release();
+    c->comm_tmp.release();
+    if (c->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
@@ -684,12 +746,13 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     c->stage = ST_DB;   // queries must be (re)set after the database: b, C may have changed
     c->dbx_valid = false;
     c->dbx2_valid = false;
+    c->opt_consecutive_fail = c->shard_bet_fail = 0;    // a new database: earlier lost bets say nothing about it
     return HG_OK;
 }
 
 // float32 features + int64 labels -> packed device tables (k_pack_sign_f32 / k_pack_labels_i64)
 static int pack_on_device(hg_ctx* c, const float* x, const int64_t* lab, i64 n, DevBuf& codes, DevBuf& labels,
-                          DevBuf& feats, int64_t* bad_codes, int64_t* bad_labels) {
+                          DevBuf& feats, int64_t* bad_codes, int64_t* bad_labels, i64 (&census)[3]) {
     const int b = c->b, C = c->C, NW = c->NW, LW = c->LW;
     // the float table stays resident, zero-padded to a multiple of 16 features: the real-valued
     // ranking (hg_map_real) streams it, and padding keeps its scalar loads 64-byte aligned
@@ -698,10 +761,10 @@ static int pack_on_device(hg_ctx* c, const float* x, const int64_t* lab, i64 n, 
     const size_t fb = (size_t)n * bpad * 4, lb = (size_t)n * C * 8;
     HG_TRY(feats.reserve(fb + 256));
     HG_TRY(c->stage_in.reserve(lb));
-    HG_TRY(c->badcnt.reserve(16));
+    HG_TRY(c->badcnt.reserve(32));
     HG_TRY(codes.reserve((size_t)n * NW * 4 + 64 * 4));
     HG_TRY(labels.reserve((size_t)n * LW * 8));
-    HG_HIP(hipMemsetAsync(c->badcnt.p, 0, 16, c->stream));
+    HG_HIP(hipMemsetAsync(c->badcnt.p, 0, 32, c->stream));
     if (bpad != b) HG_HIP(hipMemsetAsync(feats.p, 0, fb, c->stream));
     HG_HIP(hipMemcpy2DAsync(feats.p, (size_t)bpad * 4, x, (size_t)b * 4, (size_t)b * 4, (size_t)n, hipMemcpyHostToDevice, c->stream));
     c->t_begin(KI_PACK);
@@ -715,11 +778,12 @@ static int pack_on_device(hg_ctx* c, const float* x, const int64_t* lab, i64 n, 
                        labels.as<u64>(), n, C, LW, c->badcnt.as<unsigned long long>());
     c->t_end();
     HG_TRY(c->check_launch("k_pack_labels_i64"));
-    unsigned long long bad[2] = {0, 0};
-    HG_HIP(hipMemcpyAsync(bad, c->badcnt.p, 16, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long bad[4] = {0, 0, 0, 0};
+    HG_HIP(hipMemcpyAsync(bad, c->badcnt.p, 32, hipMemcpyDeviceToHost, c->stream));
     HG_TRY(c->sync());
     if (bad_codes) *bad_codes = (int64_t)bad[0];
     if (bad_labels) *bad_labels = (int64_t)bad[1];
+    census[0] = (i64)bad[0]; census[1] = (i64)bad[2]; census[2] = (i64)bad[3];
     return HG_OK;
 }
 
@@ -736,10 +800,11 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->N = N; c->b = b; c->C = C; c->n_total = n_total;
     c->NW = (b + 31) / 32; c->NB = b + 1; c->LW = (C + 63) / 64;
     c->idx_base = (u32)idx_base;
-    HG_TRY(pack_on_device(c, host_x, host_labels, N, c->db, c->dblab, c->dbf, bad_codes, bad_labels));
+    HG_TRY(pack_on_device(c, host_x, host_labels, N, c->db, c->dblab, c->dbf, bad_codes, bad_labels, c->census_db));
     c->stage = ST_DB;
     c->dbx_valid = false;
     c->dbx2_valid = false;
+    c->opt_consecutive_fail = c->shard_bet_fail = 0;
     return HG_OK;
 }
 
@@ -749,7 +814,7 @@ int hg_set_queries_f32(hg_ctx* c, const float* host_x, const int64_t* host_label
     if (Q < 1 || !host_x || !host_labels) return fail(HG_ERR_ARG, "hg_set_queries_f32: need Q >= 1 and data");
     if (Q > 0x7FFFFFC0ll) return fail(HG_ERR_ARG, "hg_set_queries_f32: Q too large");
     c->Q = Q;
-    HG_TRY(pack_on_device(c, host_x, host_labels, Q, c->qc, c->qlab, c->qf, bad_codes, bad_labels));
+    HG_TRY(pack_on_device(c, host_x, host_labels, Q, c->qc, c->qlab, c->qf, bad_codes, bad_labels, c->census_q));
     c->stage = ST_DB | ST_Q;
     c->qx_valid = false;
     c->qx2_valid = false;
@@ -1123,11 +1188,12 @@ static int auto_stride(hg_ctx* c, int64_t R) {
 
 int hg_bet_eligible(hg_ctx* c, int64_t R, int world, int* eligible) {
     if (!c || !eligible || world < 1) return fail(HG_ERR_ARG, "hg_bet_eligible: bad argument");
-    // only shard-independent quantities: every rank must reach the same verdict
+    // only quantities every rank shares: options, R, the size of the whole database, the world size -- and the count of
+    // consecutive SHARDED bets lost, which only hg_merge_ranked / hg_rank / hg_bet_verdict touch, with a verdict that is
+    // computed from gathered data and therefore the same on every rank (one-shot calls keep their own counter)
     const int stride = auto_stride(c, R);
     const i64 per_shard = c->n_total / world;
-    *eligible = c->opt_enable && c->opt_consecutive_fail < 2 && stride >= 2 && R * 8 <= c->n_total &&
-                per_shard >= 65536;
+    *eligible = c->opt_enable && c->shard_bet_fail < 2 && stride >= 2 && R * 8 <= c->n_total && per_shard >= 65536;
     return HG_OK;
 }
 
@@ -1192,10 +1258,15 @@ int hg_select_ranked(hg_ctx* c) {
     HG_TRY(need(c, ST_PLAN, "hg_select_ranked", "hg_guess"));
     if (!c->optimistic) return fail(HG_ERR_STATE, "hg_select_ranked: no guess in force");
     const Geo& g = c->geo;
-    c->want_lists = false;
+    // > 128 classes: the record pass leaves the match bit 0 (launch_select_nw instantiates LW = 0); the local bitmap
+    // then comes from k_match gathering the labels through the LOCAL ranked index list, so that list is kept
+    const bool wide = c->LW > 2;
+    c->want_lists = wide;
+    const size_t slots = (size_t)g.Q * g.R;
     HG_TRY(c->cand.reserve((size_t)g.Q * c->crow * 8));
     HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
-    HG_TRY(c->out_idx.reserve(16)); HG_TRY(c->out_dist.reserve(16));
+    HG_TRY(c->out_idx.reserve(wide ? slots * 4 : 16)); HG_TRY(c->out_dist.reserve(wide ? slots : 16));
+    if (wide) HG_HIP(hipMemsetAsync(c->out_idx.p, 0xFF, slots * 4, c->stream));    // slots past the shard's own records: IDX_NONE
     HG_TRY(c->err.reserve(4));
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     HG_TRY(launch_select(c));
@@ -1206,6 +1277,9 @@ int hg_select_ranked(hg_ctx* c) {
     HG_TRY(launch_rank(c, 3, nbits));
     c->lists_valid = false;
     c->ranked_local = true;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT;
+    if (wide) HG_TRY(do_match(c));                    // metric.py:17-19 through the local list
+    c->want_lists = false;
     c->stage = ST_DB | ST_Q | ST_PLAN | ST_MATCH;     // hg_match_buffer hands out the LOCAL bitmap until the merge
     return c->stage_end();
 }
@@ -1221,10 +1295,16 @@ int hg_merge_ranked(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev
     const u32* hall = G > 1 ? (const u32*)dev_hist_all : c->hown.as<u32>();
     const u64* ball = G > 1 ? (const u64*)dev_bits_all : c->mbits.as<u64>();
     const size_t rows_lds = (size_t)WPB * G * c->RW * 8;       // the G local bitmap rows of a block's four queries
-    const int use_lds = rows_lds + (size_t)WPB * G * g.NB * 4 <= 64 * 1024;
+    const size_t cnt_lds = (size_t)WPB * G * g.NB * 4;         // their per-distance counts: at most 4 * 64 * 256 * 4 = 256 KiB ...
+    const int use_lds = rows_lds + cnt_lds <= 64 * 1024;
+    const size_t merge_lds = (use_lds ? rows_lds : 0) + cnt_lds;
+    if (merge_lds > 160 * 1024)                                // ... which only many shards of long codes reach
+        return fail(HG_ERR_ARG, "hg_merge_ranked: G=%d shards of %d-bit codes need %zu bytes of LDS per block (160 KiB available): "
+                                "use the staged sequence (hg_select_candidates / hg_rank)", G, c->b, merge_lds);
+    if (merge_lds > 64 * 1024)
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_ranked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds));
     c->t_begin(KI_MERGE);
-    hipLaunchKernelGGL(k_merge_ranked, dim3(grid_for(g.Q, WPB)), dim3(256),
-                       (use_lds ? rows_lds : 0) + (size_t)WPB * G * g.NB * 4, c->stream, hall, ball, G,
+    hipLaunchKernelGGL(k_merge_ranked, dim3(grid_for(g.Q, WPB)), dim3(256), merge_lds, c->stream, hall, ball, G,
                        c->RW, c->mbits2.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(), use_lds, g);
     c->t_end();
     HG_TRY(c->check_launch("k_merge_ranked"));
@@ -1244,11 +1324,11 @@ int hg_merge_ranked(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev
     c->opt_runs++;
     if (flag) {
         c->opt_fallbacks++;
-        c->opt_consecutive_fail++;
+        c->shard_bet_fail++;
         c->stage = ST_DB | ST_Q;
         return HG_OK;
     }
-    c->opt_consecutive_fail = 0;
+    c->shard_bet_fail = 0;
     c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
     return HG_OK;
 }
@@ -1267,11 +1347,11 @@ static int settle_bet(hg_ctx* c, int flag) {
     c->opt_runs++;
     if (flag) {
         c->opt_fallbacks++;
-        c->opt_consecutive_fail++;
+        c->shard_bet_fail++;
         c->stage = ST_DB | ST_Q;
         return HG_OK;
     }
-    c->opt_consecutive_fail = 0;
+    c->shard_bet_fail = 0;
     c->lists_valid = c->want_lists;
     c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT;
     if (c->LW <= 2) c->stage |= ST_MATCH;
@@ -1325,10 +1405,10 @@ int hg_bet_verdict(hg_ctx* c, int* bet_lost) {
     else HG_TRY(read_plan_flag(c, &flag));
     c->verdict_known = false;
     *bet_lost = flag;
-    if (!flag) { c->opt_runs++; c->opt_consecutive_fail = 0; return HG_OK; }
+    if (!flag) { c->opt_runs++; c->shard_bet_fail = 0; return HG_OK; }
     c->opt_runs++;
     c->opt_fallbacks++;
-    c->opt_consecutive_fail++;
+    c->shard_bet_fail++;
     c->lists_valid = false;
     c->stage = ST_DB | ST_Q;
     return HG_OK;
@@ -1724,6 +1804,121 @@ int hg_get_hist(hg_ctx* c, uint32_t* host_hist) {
     return c->sync();
 }
 
+
+// ---- collectives: RCCL over xGMI, on the context's own stream (no PyTorch anywhere) ----------------------------
+int hg_comm_unique_id(uint8_t* id) {
+    if (!id) return fail(HG_ERR_ARG, "hg_comm_unique_id: null pointer");
+    HG_TRY(rccl_load());
+    ncclUniqueId u;
+    HG_NCCL(g_rccl.GetUniqueId(&u));
+    static_assert(sizeof u == HG_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, sizeof u);
+    return HG_OK;
+}
+
+int hg_comm_init(hg_ctx* c, const uint8_t* id, int rank, int world) {
+    if (!c || !id) return fail(HG_ERR_ARG, "hg_comm_init: null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(HG_ERR_ARG, "hg_comm_init: rank %d of %d", rank, world);
+    if (c->comm) return fail(HG_ERR_STATE, "hg_comm_init: the context already has a communicator (hg_comm_destroy first)");
+    HG_TRY(c->use());
+    HG_TRY(rccl_load());
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    HG_NCCL(g_rccl.CommInitRank(&c->comm, world, u, rank));
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return HG_OK;
+}
+
+int hg_comm_destroy(hg_ctx* c) {
+    if (!c) return fail(HG_ERR_ARG, "hg_comm_destroy: null context");
+    if (!c->comm) return HG_OK;
+    HG_TRY(c->use());
+    HG_TRY(c->sync());
+    ncclComm_t k = c->comm;
+    c->comm = nullptr;
+    c->comm_rank = 0; c->comm_world = 1;
+    HG_NCCL(g_rccl.CommDestroy(k));
+    return HG_OK;
+}
+
+int hg_comm_info(hg_ctx* c, int* rank, int* world) {
+    if (!c) return fail(HG_ERR_ARG, "hg_comm_info: null context");
+    if (rank) *rank = c->comm ? c->comm_rank : 0;
+    if (world) *world = c->comm ? c->comm_world : 0;      // 0: no communicator
+    return HG_OK;
+}
+
+int hg_allgather(hg_ctx* c, int slot, const void* dev_src, int64_t nbytes, void** dev_gathered) {
+    if (!c || !dev_src || !dev_gathered || nbytes < 1) return fail(HG_ERR_ARG, "hg_allgather: bad argument");
+    if (slot < 0 || slot >= 4) return fail(HG_ERR_ARG, "hg_allgather: slot %d outside 0..3", slot);
+    if (!c->comm) return fail(HG_ERR_STATE, "hg_allgather: no communicator (hg_comm_init)");
+    HG_TRY(c->use());
+    DevBuf& out = c->gathered[slot];
+    HG_TRY(out.reserve((size_t)nbytes * c->comm_world));
+    c->t_begin(KI_COMM);
+    HG_NCCL(g_rccl.AllGather(dev_src, out.p, (size_t)nbytes, ncclUint8, c->comm, c->stream));
+    c->t_end();
+    *dev_gathered = out.p;
+    return c->stage_end();
+}
+
+// The north star's exchange: every shard's ranked (dist, idx) lists all-gathered and merged (exactly one shard owns a
+// slot, the others hold HG_IDX_NONE / 0xFF there).  hg_get_topr then returns the global lists on every rank.
+int hg_allgather_topr(hg_ctx* c) {
+    HG_TRY(need(c, ST_SELECT, "hg_allgather_topr", "hg_select / hg_rank"));
+    if (!c->lists_valid) return fail(HG_ERR_STATE, "hg_allgather_topr: ranked lists were not materialised by the last call");
+    if (!c->comm) return fail(HG_ERR_STATE, "hg_allgather_topr: no communicator (hg_comm_init)");
+    const i64 n = (i64)c->geo.Q * c->geo.R;
+    const int G = c->comm_world;
+    HG_TRY(c->gathered[2].reserve((size_t)n * 4 * G));
+    HG_TRY(c->gathered[3].reserve((size_t)n * G));
+    c->t_begin(KI_COMM);
+    HG_NCCL(g_rccl.AllGather(c->out_idx.p, c->gathered[2].p, (size_t)n * 4, ncclUint8, c->comm, c->stream));
+    HG_NCCL(g_rccl.AllGather(c->out_dist.p, c->gathered[3].p, (size_t)n, ncclUint8, c->comm, c->stream));
+    c->t_end();
+    c->t_begin(KI_MERGE);
+    hipLaunchKernelGGL(k_min_topr, dim3(grid_for(n)), dim3(256), 0, c->stream, c->gathered[2].as<u32>(), c->gathered[3].as<u8>(),
+                       c->out_idx.as<u32>(), c->out_dist.as<u8>(), n, G);
+    c->t_end();
+    HG_TRY(c->check_launch("k_min_topr"));
+    return c->stage_end();
+}
+
+// max over the ranks of one host double (step times of a benchmark), and a barrier: both one tiny all-reduce
+int hg_allreduce_max_f64(hg_ctx* c, double* host_inout) {
+    if (!c || !host_inout) return fail(HG_ERR_ARG, "hg_allreduce_max_f64: null argument");
+    if (!c->comm) return fail(HG_ERR_STATE, "hg_allreduce_max_f64: no communicator (hg_comm_init)");
+    HG_TRY(c->use());
+    HG_TRY(c->comm_tmp.reserve(16));
+    HG_HIP(hipMemcpyAsync(c->comm_tmp.p, host_inout, 8, hipMemcpyHostToDevice, c->stream));
+    HG_NCCL(g_rccl.AllReduce(c->comm_tmp.p, c->comm_tmp.as<char>() + 8, 1, ncclFloat64, ncclMax, c->comm, c->stream));
+    HG_HIP(hipMemcpyAsync(host_inout, c->comm_tmp.as<char>() + 8, 8, hipMemcpyDeviceToHost, c->stream));
+    return c->sync();
+}
+
+int hg_barrier(hg_ctx* c) {
+    double x = 0.0;
+    return hg_allreduce_max_f64(c, &x);
+}
+
+// Context-owned device scratch (grows only) and a stream-ordered device-to-device copy: what an in-process
+// communicator (virtual shards of one GPU in the tests) needs to do hg_allgather's job without RCCL.
+int hg_scratch(hg_ctx* c, int slot, int64_t nbytes, void** dev_ptr) {
+    if (!c || !dev_ptr || nbytes < 1 || slot < 0 || slot >= 4) return fail(HG_ERR_ARG, "hg_scratch: bad argument");
+    HG_TRY(c->use());
+    HG_TRY(c->scratch[slot].reserve((size_t)nbytes));
+    *dev_ptr = c->scratch[slot].p;
+    return HG_OK;
+}
+
+int hg_memcpy_dtod(hg_ctx* c, void* dev_dst, const void* dev_src, int64_t nbytes) {
+    if (!c || !dev_dst || !dev_src || nbytes < 0) return fail(HG_ERR_ARG, "hg_memcpy_dtod: bad argument");
+    HG_TRY(c->use());
+    if (nbytes) HG_HIP(hipMemcpyAsync(dev_dst, dev_src, (size_t)nbytes, hipMemcpyDeviceToDevice, c->stream));
+    return c->stage_end();
+}
+
 int hg_set_stream(hg_ctx* c, void* stream) {
     if (!c) return fail(HG_ERR_ARG, "hg_set_stream: null context");
     HG_TRY(c->use());
@@ -1751,7 +1946,7 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->min_segment = value;
     } else if (!strcmp(key, "optimistic")) {
         c->opt_enable = value != 0;
-        c->opt_consecutive_fail = 0;
+        c->opt_consecutive_fail = c->shard_bet_fail = 0;
     } else if (!strcmp(key, "sample_stride")) {
         if (value < 0 || value > 1024) return fail(HG_ERR_ARG, "sample_stride must be 0 (auto) .. 1024");
         c->opt_stride = value;
@@ -1780,6 +1975,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "select_mfma")) {
         c->opt_select_mfma = value != 0;
     } else if (!strcmp(key, "probe_select")) {
+        if (value && !kProbes)
+            return fail(HG_ERR_ARG, "probe_select: this is the production build -- the probes live in libhashgan_amd_probe.so "
+                                    "(python -m hashgan_amd.build --probes, HG_LIBRARY=<path>)");
         c->opt_probe = value;
     } else if (!strcmp(key, "select_qt")) {
         c->opt_select_qt = value;
@@ -1805,6 +2003,8 @@ int hg_trim(hg_ctx* c) {
                       &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->scores, &c->bigq, &c->mbits2,
                       &c->dbx, &c->qx, &c->dbx2, &c->qx2};   // the fp4 images are rebuilt on demand
     for (auto* d : work) d->release();
+    for (auto& d : c->gathered) d.release();
+    for (auto& d : c->scratch) d.release();
     c->dbx_valid = c->qx_valid = c->dbx2_valid = c->qx2_valid = false;
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     c->stage &= (ST_DB | ST_Q);
@@ -1829,6 +2029,13 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
         *value = total;
     }
+    else if (!strcmp(key, "db_nonbinary")) *value = c->census_db[0];
+    else if (!strcmp(key, "db_zeros")) *value = c->census_db[1];
+    else if (!strcmp(key, "db_minus_ones")) *value = c->census_db[2];
+    else if (!strcmp(key, "q_nonbinary")) *value = c->census_q[0];
+    else if (!strcmp(key, "q_zeros")) *value = c->census_q[1];
+    else if (!strcmp(key, "q_minus_ones")) *value = c->census_q[2];
+    else if (!strcmp(key, "probe_build")) *value = kProbes ? 1 : 0;
     else if (!strcmp(key, "segments")) *value = c->geo.S;
     else if (!strcmp(key, "segment_rows")) *value = c->geo.L;
     else if (!strcmp(key, "slice_capacity")) *value = c->cap;

@@ -30,6 +30,13 @@ constexpr int AP_CHUNK = 8192;         // NumPy's reduction buffer (elements) --
 constexpr int AP_LEAF = 128;           // NumPy's pairwise-sum block
 constexpr int AP_THREADS = 128;
 constexpr int TAIL_WORDS = 64;         // words appended to an exported histogram: [0] overflow flag, [1] sampled rows
+// Measurement probes of the matrix-core select kernels (SelArgs::probe) exist only in the probe build
+// (`python -m hashgan_amd.build --probes` -> libhashgan_amd_probe.so, -DHG_PROBES=1); the production
+// kernels carry none of their branches.
+#ifndef HG_PROBES
+#define HG_PROBES 0
+#endif
+constexpr bool kProbes = HG_PROBES != 0;
 
 struct Geo {
     int Q, Qpad, nQT;   // queries, padded to 64, query tiles
@@ -1308,27 +1315,34 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
 // (main.py:151-158) hands float32 features [n][b] and integer labels [n][C]; the
 // reference never binarises (tanh outputs go straight into np.dot), the hashing
 // evaluation does: bit j = (x[j] > 0).  One wavefront per row, 64 columns per ballot.
-// Also counts entries outside {-1, 0, +1} (codes) / {0, 1} (labels) so the host can refuse
-// inputs that are not binary codes instead of silently ranking something else.
+// Also counts entries outside {-1, 0, +1}, zeros and minus ones (codes) / entries outside {0, 1} (labels), so
+// the host can tell +-1 codes from {0,1} bits from anything else (mixtures rank differently under np.dot than
+// under a Hamming distance -- metric.py:13) instead of silently ranking something else.
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_sign_f32(const float* __restrict__ x, i64 ld, u32* __restrict__ out, i64 n, int b,
                                                        int NW, unsigned long long* __restrict__ bad) {
     const int lane = threadIdx.x & 63;
     const i64 r = (i64)blockIdx.x * WPB + (threadIdx.x >> 6);
     if (r >= n) return;
-    u32 nbad = 0;
+    u32 nbad = 0, nzero = 0, nneg = 0;
     for (int c0 = 0; c0 < b; c0 += 64) {
         const int col = c0 + lane;
-        const float v = col < b ? x[r * ld + col] : 0.0f;     // ld: row pitch of the (zero-padded) feature table
+        const float v = col < b ? x[r * ld + col] : 1.0f;     // ld: row pitch of the (zero-padded) feature table
         nbad += !(v == 1.0f || v == -1.0f || v == 0.0f);
-        const u64 word = __ballot(v > 0.0f);
+        nzero += v == 0.0f;
+        nneg += v == -1.0f;
+        const u64 word = __ballot(col < b && v > 0.0f);
         const int w = c0 >> 5;
         if (lane == 0) {
             out[r * NW + w] = (u32)word;
             if (w + 1 < NW) out[r * NW + w + 1] = (u32)(word >> 32);
         }
     }
+    // bad[0]: entries outside {-1, 0, +1}; bad[2]: zeros; bad[3]: minus ones (bad[1] belongs to the labels).
+    // all +-1  <=>  bad[0] == 0 and bad[2] == 0;   all {0,1}  <=>  bad[0] == 0 and bad[3] == 0
     if (nbad) atomicAdd(bad, (unsigned long long)nbad);
+    if (nzero) atomicAdd(bad + 2, (unsigned long long)nzero);
+    if (nneg) atomicAdd(bad + 3, (unsigned long long)nneg);
 }
 
 __global__ __launch_bounds__(256) void k_pack_labels_i64(const long long* __restrict__ lab, u64* __restrict__ out, i64 n, int C,

@@ -254,7 +254,7 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
     };
     auto emit = [&](const i64 win, const u8* st) {
         wave_lds_sync();
-        const u32 n = (a.probe & 8) ? 0u : qfill;
+        const u32 n = (kProbes && (a.probe & 8)) ? 0u : qfill;
         for (u32 i = lane; i < n; i += 64) {
             const u64 e = queue[i];
             u32 word = (u32)(e >> 32);
@@ -290,7 +290,7 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
                     for (int c = 0; c < LWA; ++c) any |= lp[c] & qlw[c];
                 }
                 if (room) {
-                    if (!(a.probe & 4) || d == 0x7fffffffu) *out = make_rec(idx0 + r, d, any != 0);
+                    if (!(kProbes && (a.probe & 4)) || d == 0x7fffffffu) *out = make_rec(idx0 + r, d, any != 0);
                     ++out;
                     --room;
                 }
@@ -360,7 +360,7 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
                 for (int t = 0; t < QT; ++t) m[t][c] &= keep;
             }
         }
-        if (a.probe & 2) {                                      // measurement probe: no drain
+        if (kProbes && (a.probe & 2)) {                                      // measurement probe: no drain
 #pragma unroll
             for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][3] == 0x1234567u) dropped[t]++;
         } else {

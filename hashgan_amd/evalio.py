@@ -43,9 +43,15 @@ def stack_batches(outputs, labels, size, hash_dim, label_dim):
     return types.SimpleNamespace(output=out, label=lab)
 
 
-def evaluate(db, test, map_r, device=0, binarize=True):
-    """main.py:161-164 with the arrays already in hand: database first, then queries."""
-    return MAPs(map_r, device=device, binarize=binarize).get_maps_by_feature(db, test)
+def evaluate(db, test, map_r, device=0, binarize=False):
+    """main.py:161-164 with the arrays already in hand: database first, then queries.  Like the reference it
+    ranks the features as they are (main.py:164 hands the raw tanh outputs to np.dot); binarize=True is the
+    hashing evaluation proper -- sign() first, Hamming ranking."""
+    m = MAPs(map_r, device=device, binarize=binarize)
+    try:
+        return m.get_maps_by_feature(db, test)
+    finally:
+        m.close()
 
 
 def load_eval_config(yaml_path=None):

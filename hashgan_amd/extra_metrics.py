@@ -9,14 +9,15 @@ import numpy as np
 from . import metric
 
 
-def _load(device, q_codes, db_codes, q_labels, db_labels):
-    eng = metric._engine(device)
-    bad = eng.ctx.set_database_f32(np.asarray(db_codes), np.asarray(db_labels))
+def _load(eng, q_codes, db_codes, q_labels, db_labels):
+    """Binary codes only ({0,1} bits or +-1, the same spelling on both sides), like metric.MAP."""
+    metric._load_database(eng, np.asarray(db_codes), np.asarray(db_labels))
     qbad = eng.ctx.set_queries_f32(np.asarray(q_codes), np.asarray(q_labels))
-    if bad[1] or qbad[1]:
+    if qbad[1]:
         raise ValueError("labels must be {0,1} indicator matrices")
-    if bad[0] or qbad[0]:
-        raise ValueError("codes must be binary ({-1,+1} or {0,1})")
+    qk, dk = metric._kind(eng.ctx, 1), eng.db_kind
+    if not (qk == dk and qk in ("pm1", "bits")):
+        raise ValueError("codes must be binary: all {-1,+1} or all {0,1} (found %s queries, %s database)" % (qk, dk))
     return eng.ctx
 
 
@@ -28,9 +29,12 @@ def precision_recall_at_k(q_codes, db_codes, q_labels, db_labels, ks, device=0):
     N = np.asarray(db_codes).shape[0]
     if ks[0] < 1 or ks[-1] > N:
         raise ValueError("every k must be in 1..N")
-    ctx = _load(device, q_codes, db_codes, q_labels, db_labels)
-    ctx.topr(int(ks[-1]))
-    cum = np.cumsum(ctx.get_match().astype(np.int64), axis=1)           # [Q, kmax]
+    eng = metric._Shared.get(device)
+    with eng.lock:
+        ctx = _load(eng, q_codes, db_codes, q_labels, db_labels)
+        ctx.topr(int(ks[-1]))
+        match = ctx.get_match()
+    cum = np.cumsum(match.astype(np.int64), axis=1)                      # [Q, kmax]
     hits = cum[:, ks - 1]
     precision = (hits / ks[None, :]).mean(0)
     total_rel = ((np.asarray(q_labels) != 0).astype(np.int64) @ (np.asarray(db_labels) != 0).astype(np.int64).T > 0).sum(1)
@@ -43,15 +47,17 @@ def precision_within_radius(q_codes, db_codes, q_labels, db_labels, radius=2, de
     """Mean precision of Hamming-ball lookups: for every query, the fraction of database rows within
     `radius` that share a label with it; a query whose ball is empty contributes 0 (the usual
     convention).  -> (mean precision, per-query ball sizes)"""
-    ctx = _load(device, q_codes, db_codes, q_labels, db_labels)
-    ctx.hist()
-    ball = ctx.get_hist()[:radius + 1].astype(np.int64).sum(0)          # rows within the radius, per query
-    Q = ball.shape[0]
-    if ball.max() == 0:
-        return 0.0, ball
-    ctx.topr(int(ball.max()))                                            # every ball is a prefix of its ranked list
-    idx, dist = ctx.get_topr()
+    eng = metric._Shared.get(device)
+    with eng.lock:
+        ctx = _load(eng, q_codes, db_codes, q_labels, db_labels)
+        ctx.hist()
+        ball = ctx.get_hist()[:radius + 1].astype(np.int64).sum(0)      # rows within the radius, per query
+        if ball.max() == 0:
+            return 0.0, ball
+        ctx.topr(int(ball.max()))                                        # every ball is a prefix of its ranked list
+        idx, dist = ctx.get_topr()
+        match = ctx.get_match()
     inside = dist <= radius
-    hits = (ctx.get_match().astype(bool) & inside).sum(1)
+    hits = (match.astype(bool) & inside).sum(1)
     prec = np.where(ball > 0, hits / np.maximum(ball, 1), 0.0)
     return float(prec.mean()), ball

@@ -9,15 +9,16 @@ plus the spellings BASELINE.json's north star names (query first):
     MAP(query_codes, db_codes, query_labels, db_labels, R)
     calc_map(query_codes, db_codes, query_labels, db_labels, R)
 
-Binary codes (+-1 features or {0,1} bits) are ranked by Hamming distance with ties broken by
-ascending database index -- for +-1 codes exactly the order of np.argsort(-np.dot(q, db.T))
-once ties are broken by index.  Real-valued features (HashGAN's tanh outputs, what main.py
-feeds when nothing is binarised) are ranked by float32 inner product like metric.py:13-14
-(MAPs only; `binarize=True` applies sign() first instead).  Labels are {0,1} matrices.  All
-ranking work runs in the HIP kernels behind hashgan_amd._native; the host only checks
-arguments and takes the final mean (metric.py:24).
+MAPs ranks what the reference ranks: np.argsort(-np.dot(q, db.T)) (metric.py:13-14), ties broken
+by ascending database index.  For +-1 codes that is ascending Hamming distance and runs on the
+Hamming kernels; anything else -- HashGAN's real-valued tanh outputs, {0,1} bits (whose np.dot
+counts common ones: NOT a Hamming ranking), codes containing zeros -- is ranked by float32 inner
+product (`binarize=True` applies sign() first instead).  MAP / calc_map take binary codes only,
+{0,1} bits or +-1, and rank by Hamming distance.  Labels are {0,1} matrices.  All ranking work
+runs in the HIP kernels behind hashgan_amd._native; the host only checks arguments and takes the
+final mean (metric.py:24).
 """
-import warnings
+import threading
 
 import numpy as np
 
@@ -111,18 +112,36 @@ def mean_over_hits(ap, rel):
     return np.mean(np.array(ap[rel != 0]))
 
 
-_engines = {}
+# ------------------------------------------------------------------ engines
+class _Shared:
+    """One lazily created engine per device for the function spellings (MAP, calc_map, extra_metrics): a context
+    is not thread safe, so every use holds its lock.  MAPs objects own private engines instead."""
+    lock = threading.Lock()
+    engines = {}
+
+    @classmethod
+    def get(cls, device):
+        with cls.lock:
+            if device not in cls.engines:
+                e = RetrievalEngine(device)
+                e.lock = threading.RLock()
+                cls.engines[device] = e
+            return cls.engines[device]
+
+    @classmethod
+    def close_all(cls):
+        with cls.lock:
+            for e in cls.engines.values():
+                e.close()
+            cls.engines.clear()
 
 
-def _engine(device):
-    if device not in _engines:
-        _engines[device] = RetrievalEngine(device)
-    return _engines[device]
+def release_engines():
+    """Free the GPU contexts (and their device memory) behind MAP / calc_map / extra_metrics."""
+    _Shared.close_all()
 
 
-def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, binarize=False, real="rank"):
-    db_codes, q_codes = np.asarray(db_codes), np.asarray(q_codes)
-    db_labels, q_labels = np.asarray(db_labels), np.asarray(q_labels)
+def _check_shapes(q_codes, db_codes, q_labels, db_labels, R):
     if db_codes.ndim != 2 or q_codes.ndim != 2 or db_codes.shape[1] != q_codes.shape[1]:
         raise ValueError("query and database codes must be [n, b] with the same b")
     if db_labels.ndim != 2 or q_labels.ndim != 2 or db_labels.shape[1] != q_labels.shape[1]:
@@ -133,57 +152,158 @@ def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, binarize=False,
     if not 1 <= R <= N:
         # metric.py:21 fails the same way: a length-N px cannot be divided by arange(1, R+1)
         raise ValueError("R=%d must be in 1..N (N=%d database rows)" % (R, N))
-    eng = _engine(device)
-    # float32 features and int64 labels go to the GPU as they are; sign-binarise, bit packing and
-    # the "is this really a binary code / indicator label" check all run there (k_pack_*)
+
+
+def _kind(ctx, which):
+    """What hg_set_*_f32 found in a float table: 'ones' (every entry +1: reads as either spelling), 'pm1' (every
+    entry +-1), 'bits' (every entry 0/1), 'ternary' (-1/0/+1 mixed) or 'real'."""
+    p = "q_" if which else "db_"
+    other, zeros, neg = ctx.get_stat(p + "nonbinary"), ctx.get_stat(p + "zeros"), ctx.get_stat(p + "minus_ones")
+    if other:
+        return "real"
+    if not zeros:
+        return "pm1" if neg else "ones"
+    return "bits" if not neg else "ternary"
+
+
+def _load_database(eng, db_codes, db_labels):
     bad_c, bad_l = eng.ctx.set_database_f32(db_codes, db_labels)
-    eng.b, eng.C = db_codes.shape[1], db_labels.shape[1]
-    qbad_c, qbad_l = eng.ctx.set_queries_f32(q_codes, q_labels)
-    if bad_l or qbad_l:
+    if bad_l:
         raise ValueError("labels must be {0,1} indicator matrices")
-    if (bad_c or qbad_c) and not binarize:
-        # real-valued features (HashGAN's tanh outputs): rank by inner product like metric.py:13-14
-        if real == "error":
-            raise ValueError("features are not binary codes ({-1,+1} or {0,1}); binarise them first "
-                             "(np.sign), use binarize=True, or allow the inner-product ranking")
-        if db_codes.shape[1] > 128:
-            raise ValueError("inner-product ranking supports up to 128 features (have %d)" % db_codes.shape[1])
-        ap, rel = eng.ctx.map_real(R)
-    else:
-        ap, rel = eng.average_precisions(R)
+    eng.b, eng.C = db_codes.shape[1], db_labels.shape[1]
+    eng.db_kind = _kind(eng.ctx, 0)
+    eng.N = db_codes.shape[0]
+
+
+def _rank(eng, q_codes, q_labels, R, mode):
+    """Queries against the engine's resident database.  mode:
+       'reference'  MAPs: what np.dot ranks (metric.py:13-14).  +-1 codes on both sides -> Hamming kernels (the same
+                    order, ties by index); anything else -- real-valued tanh outputs, {0,1} bits (np.dot counts common
+                    ones, not a Hamming distance), codes with zeros -- goes through the float32 inner-product ranking;
+       'sign'       MAPs(binarize=True): sign() first, then Hamming;
+       'codes'      MAP / calc_map (north-star spelling): binary codes only, {0,1} bits or +-1, ranked by Hamming
+                    distance; anything else is an error."""
+    qbad_c, qbad_l = eng.ctx.set_queries_f32(q_codes, q_labels)
+    if qbad_l:
+        raise ValueError("labels must be {0,1} indicator matrices")
+    qk, dk = _kind(eng.ctx, 1), eng.db_kind
+    if mode == "sign" or {qk, dk} <= {"pm1", "ones"}:
+        return eng.average_precisions(R)
+    if mode == "codes":
+        if {qk, dk} <= {"bits", "ones"}:
+            return eng.average_precisions(R)
+        raise ValueError("codes must be binary -- all {0,1} or all {-1,+1}, the same spelling for queries and "
+                         "database (found %s queries, %s database); binarise first (np.sign), or hand real-valued "
+                         "features to MAPs.get_maps_by_feature, which ranks them by inner product like metric.py:13" % (qk, dk))
+    if q_codes.shape[1] > 128:
+        raise ValueError("inner-product ranking supports up to 128 features (have %d)" % q_codes.shape[1])
+    return eng.ctx.map_real(R)
+
+
+def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, mode):
+    db_codes, q_codes = np.asarray(db_codes), np.asarray(q_codes)
+    db_labels, q_labels = np.asarray(db_labels), np.asarray(q_labels)
+    _check_shapes(q_codes, db_codes, q_labels, db_labels, R)
+    eng = _Shared.get(device)
+    with eng.lock:
+        _load_database(eng, db_codes, db_labels)
+        ap, rel = _rank(eng, q_codes, q_labels, R, mode)
     return mean_over_hits(ap, rel), ap, rel
 
 
 # ------------------------------------------------------------------ reference surface
 class MAPs:
-    """Same constructor and method as lib/metric.py:4-24."""
+    """Same constructor and method as lib/metric.py:4-24.
+
+    The object owns one GPU context (created on first use, freed by close() / garbage collection) and a lock, so
+    several MAPs objects -- different R, different threads -- never share device state.  main.py:237-240 evaluates
+    the same database against fresh queries again and again; `set_database` keeps it packed on the GPU between
+    calls (explicit), and a database whose arrays are the SAME read-only objects as last time is reused
+    automatically (a writable array may have changed in place, so it is uploaded again)."""
 
     def __init__(self, r, device=0, binarize=False):
         self.R = r
         self.device = device
         self.binarize = binarize
+        self._eng = None
+        self._lock = threading.RLock()
+        self._resident = None          # (output array, label array) the engine holds, or ("explicit",)
 
+    # lib/metric.py:8-10 (unused by the reference; kept for surface parity)
     @staticmethod
     def distance(a, b):
-        """lib/metric.py:8-10 (unused by the reference; kept for surface parity)."""
         return np.dot(a, b)
 
+    def _engine(self):
+        if self._eng is None:
+            self._eng = RetrievalEngine(self.device)
+        return self._eng
+
+    def close(self):
+        with self._lock:
+            if self._eng is not None:
+                self._eng.close()
+                self._eng = None
+                self._resident = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass
+
+    def set_database(self, database):
+        """Upload + pack `database` (.output [N, b], .label [N, C]) once; get_maps_by_feature(None, query) -- or with
+        the same object -- then ranks against the resident copy."""
+        out, lab = np.asarray(database.output), np.asarray(database.label)
+        if out.ndim != 2 or lab.ndim != 2 or out.shape[0] != lab.shape[0]:
+            raise ValueError("database.output must be [N, b] and database.label [N, C]")
+        with self._lock:
+            _load_database(self._engine(), out, lab)
+            self._resident = ("explicit", database)
+
+    def _ensure_database(self, database):
+        if database is None:
+            if self._resident is None:
+                raise ValueError("no resident database: call set_database first")
+            return
+        if self._resident is not None and self._resident[0] == "explicit" and self._resident[1] is database:
+            return
+        out, lab = np.asarray(database.output), np.asarray(database.label)
+        if (self._resident is not None and self._resident[0] == "auto" and self._resident[1] is out
+                and self._resident[2] is lab and not out.flags.writeable and not lab.flags.writeable):
+            return                                     # the very same immutable arrays as last time
+        if out.ndim != 2 or lab.ndim != 2 or out.shape[0] != lab.shape[0]:
+            raise ValueError("database.output must be [N, b] and database.label [N, C]")
+        _load_database(self._engine(), out, lab)
+        self._resident = ("auto", out, lab)
+
     def get_maps_by_feature(self, database, query):
-        """database/query: objects with .output [n, b] and .label [n, C] (main.py:157)."""
-        m, _, _ = _evaluate(query.output, database.output, query.label, database.label, int(self.R), self.device,
-                            binarize=self.binarize)
-        return m
+        """database/query: objects with .output [n, b] and .label [n, C] (main.py:157); database first."""
+        q_codes, q_labels = np.asarray(query.output), np.asarray(query.label)
+        with self._lock:
+            self._ensure_database(database)
+            eng = self._engine()
+            if q_codes.ndim != 2 or q_codes.shape[1] != eng.b:
+                raise ValueError("query and database codes must be [n, b] with the same b")
+            if q_labels.ndim != 2 or q_labels.shape[1] != eng.C or q_labels.shape[0] != q_codes.shape[0]:
+                raise ValueError("query labels must be [Q, C] with the database's C")
+            R = int(self.R)
+            if not 1 <= R <= eng.N:
+                raise ValueError("R=%d must be in 1..N (N=%d database rows)" % (R, eng.N))
+            ap, rel = _rank(eng, q_codes, q_labels, R, "sign" if self.binarize else "reference")
+        return mean_over_hits(ap, rel)
 
 
 def MAP(query_codes, db_codes, query_labels, db_labels, R, device=0):
-    """mAP@R of binary codes, query-first argument order (BASELINE.json north star).  Codes must
-    be binary ({0,1} or +-1); real-valued features belong to MAPs.get_maps_by_feature."""
-    return _evaluate(query_codes, db_codes, query_labels, db_labels, int(R), device, real="error")[0]
+    """mAP@R of binary codes, query-first argument order (BASELINE.json north star).  Codes must be binary --
+    {0,1} bits or +-1, ranked by Hamming distance; real-valued features belong to MAPs.get_maps_by_feature."""
+    return _evaluate(query_codes, db_codes, query_labels, db_labels, int(R), device, "codes")[0]
 
 
 calc_map = MAP
 
 
 def MAP_per_query(query_codes, db_codes, query_labels, db_labels, R, device=0):
-    """(mAP, ap [Q] with nan for skipped queries, rel [Q])."""
-    return _evaluate(query_codes, db_codes, query_labels, db_labels, int(R), device)
+    """(mAP, ap [Q] with nan for skipped queries, rel [Q]); binary codes like MAP."""
+    return _evaluate(query_codes, db_codes, query_labels, db_labels, int(R), device, "codes")

@@ -1,63 +1,116 @@
 """Database-sharded evaluation: one shard per GPU, one process per GPU.
 
 The database is split into contiguous index ranges (shard r owns rows
-[base_r, base_r + N_r)); every rank holds all queries.  Exchange steps, both
-all-gathers of small per-query tables (RCCL over xGMI via torch.distributed
-when the tensors live on the GPU, gloo on CPU tensors in the tests):
+[base_r, base_r + N_r)); every rank holds all queries.  Exchange steps, all
+all-gathers of small per-query tables over RCCL/xGMI through the library's own
+C ABI (hg_comm_init / hg_allgather: no PyTorch in the process, collectives on the
+context's stream, ordered with its kernels):
 
   1. per-shard distance histograms  uint32 [b+1][Qpad]   (2.6 MB at C2)
      -> every rank derives the SAME global threshold t, tie quota, and the
         global rank positions of its own rows (k_plan): no comparison-based
         merge is ever needed, shards interleave by (distance, shard, index).
-  2. per-shard label-match bit rows in global position space, uint64
-     [Q][ceil(R/64)] (6.3 MB at C2), disjoint between shards -> OR -> AP.
+  2. per-shard label-match bit rows, uint64 [Q][ceil(R/64)] (6.3 MB at C2)
+     -> OR (global position space) or stitching (local rank order) -> AP.
 
 `gather_topr` additionally all-gathers the ranked (idx, dist) lists themselves
-(the exchange BASELINE.json's north star names) for callers that want them.
+(the exchange BASELINE.json's north star names, hg_allgather_topr) for callers
+that want them.
 
 The reference has no counterpart (lib/metric.py runs in one process); the
 result is bit-identical to the single-GPU path, which the tests check with
-virtual shards on one GPU.
+virtual shards on one GPU (LocalComm) and, for the orchestration, with a NumPy
+engine over a two-process gloo group on CPU (tests/torch_comm.py).
 """
+import collections
+import os
 import threading
+import time
 
 import numpy as np
 
+# A device allocation handed between an engine and a communicator: raw address + size.
+DevBuf = collections.namedtuple("DevBuf", "ptr nbytes")
+
 
 # ------------------------------------------------------------------ communicators
-class TorchComm:
-    """all_gather over a torch.distributed process group (nccl = RCCL, or gloo)."""
+class RcclComm:
+    """all_gather over the context's own RCCL communicator (hg_allgather).  Gathered buffers live in the
+    context (four rotating slots: the orchestration below keeps at most three alive at a time)."""
 
-    def __init__(self, group=None, host_sync=True):
-        """host_sync=False: the engine runs on torch's current stream (HipShardEngine(share_stream=True)),
-        collectives are stream-ordered with its kernels and nothing waits on the host."""
-        import torch.distributed as dist
-        self._dist = dist
-        self.group = group
-        self.host_sync = host_sync
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.rank, self.world = ctx.comm_info()
+        if self.world < 1:
+            raise RuntimeError("the context has no communicator: call init_rccl(ctx) first")
+        self._slot = 0
 
-    def all_gather(self, t):
-        import torch
-        flat = t.contiguous().view(-1)
-        if t.is_cuda and self._dist.get_backend(self.group) == "gloo":
-            # functional fallback (dry runs of the multi-rank path on one GPU): stage through the host
-            host = torch.empty(self.world * flat.numel(), dtype=t.dtype)
-            self._dist.all_gather_into_tensor(host, flat.cpu(), group=self.group)
-            return host.to(t.device).view((self.world,) + tuple(t.shape))
-        out = torch.empty(self.world * flat.numel(), dtype=t.dtype, device=t.device)
-        self._dist.all_gather_into_tensor(out, flat, group=self.group)
-        if t.is_cuda and self.host_sync:
-            torch.cuda.synchronize(t.device)       # the engine's own stream reads `out` next
-        return out.view((self.world,) + tuple(t.shape))
+    def all_gather(self, buf):
+        slot = self._slot
+        self._slot = (slot + 1) % 4
+        return DevBuf(self.ctx.allgather(slot, buf.ptr, buf.nbytes), buf.nbytes * self.world)
 
     def barrier(self):
-        self._dist.barrier(group=self.group)
+        self.ctx.barrier()
+
+
+def _id_file(world, port):
+    explicit = os.environ.get("HG_COMM_ID_FILE")
+    if explicit:
+        return explicit
+    # ranks of one launch are children of one launcher process: its pid (and the rendezvous port) name the launch
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "hashgan_amd_rccl_%d_%s_%d.id" % (os.getppid(), port, world))
+
+
+def init_rccl(ctx, rank=None, world=None, timeout=300.0):
+    """Create the context's RCCL communicator from the launcher's environment (RANK, WORLD_SIZE, MASTER_PORT as
+    `python -m torch.distributed.run` or any torchrun-like launcher sets them; one node).  Rank 0 draws the unique
+    id (hg_comm_unique_id) and publishes its 128 bytes in a file named after the launch (HG_COMM_ID_FILE
+    overrides the name); the other ranks pick it up.  -> RcclComm"""
+    from . import _native
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+    path = _id_file(world, os.environ.get("MASTER_PORT", "0"))
+    if rank == 0:
+        uid = _native.comm_unique_id()
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)                      # atomic: a reader sees no file or all 128 bytes
+    else:
+        t0 = time.time()
+        uid = None
+        while uid is None:
+            try:
+                # a file of an earlier launch with the same name (pid reuse) would be older than this process
+                if os.path.getmtime(path) >= _PROCESS_START - 120.0:
+                    with open(path, "rb") as f:
+                        data = f.read()
+                    if len(data) == _native.COMM_ID_BYTES:
+                        uid = data
+            except OSError:
+                pass
+            if uid is None:
+                if time.time() - t0 > timeout:
+                    raise RuntimeError("rank %d: no RCCL id from rank 0 in %s after %.0f s" % (rank, path, timeout))
+                time.sleep(0.02)
+    ctx.comm_init(uid, rank, world)
+    comm = RcclComm(ctx)
+    comm.barrier()                                 # everybody has read the id: rank 0 may remove the file
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return comm
+
+
+_PROCESS_START = time.time()
 
 
 class LocalComm:
-    """G virtual ranks inside one process (threads): shards of one GPU in the tests."""
+    """G virtual ranks inside one process (threads), each with its own context on the SAME GPU: the gather is G
+    device-to-device copies into the rank's own scratch (hg_scratch / hg_memcpy_dtod).  Tests only."""
 
     class _Shared:
         def __init__(self, world):
@@ -69,66 +122,54 @@ class LocalComm:
         self._s = shared
         self.rank = rank
         self.world = shared.world
+        self.ctx = None                # set by the owner: the context this rank copies with
+        self._slot = 0
 
     @classmethod
     def create(cls, world):
         sh = cls._Shared(world)
         return [cls(sh, r) for r in range(world)]
 
-    def all_gather(self, t):
-        import torch
-        self._s.slots[self.rank] = t
+    def all_gather(self, buf):
+        self._s.slots[self.rank] = buf          # the producing stage has synchronised (stage_sync = 1)
         self._s.barrier.wait()
-        out = torch.stack([x for x in self._s.slots])
-        self._s.barrier.wait()
-        return out
+        n = buf.nbytes
+        slot = self._slot
+        self._slot = (slot + 1) % 4
+        base = self.ctx.scratch(slot, n * self.world)
+        for r, src in enumerate(self._s.slots):
+            assert src.nbytes == n
+            self.ctx.memcpy_dtod(base + r * n, src.ptr, n)
+        self._s.barrier.wait()                  # every rank has copied: the sources may be overwritten
+        return DevBuf(base, n * self.world)
 
     def barrier(self):
         self._s.barrier.wait()
 
 
 # ------------------------------------------------------------------ HIP shard engine
-class _DevView:
-    """Expose a raw device allocation to torch (zero copy) via __cuda_array_interface__."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
-def _as_tensor(ptr, nbytes, device):
-    import torch
-    try:
-        return torch.as_tensor(_DevView(ptr, nbytes), device=torch.device("cuda", device))
-    except RuntimeError as e:
-        raise RuntimeError("torch cannot see the GPU this context runs on.  Import torch (and let it initialise "
-                           "CUDA/HIP) BEFORE creating the first hashgan_amd context: a process can host only one "
-                           "HIP runtime, and torch bundles its own.  (%s)" % e) from e
-
-
 class HipShardEngine:
-    """The staged C ABI of one context (one shard on one GPU), speaking torch tensors."""
+    """The staged C ABI of one context (one shard on one GPU), speaking raw device buffers."""
 
-    def __init__(self, ctx, want_lists=False, share_stream=False):
-        """share_stream: put the context on torch's current stream and stop synchronising per stage --
-        use with TorchComm(host_sync=False)."""
+    def __init__(self, ctx, want_lists=False, async_stages=False):
+        """async_stages: stop synchronising per stage -- kernels and RCCL collectives are ordered on the context's
+        one stream, and the bet's verdict is read with the final download.  Use with RcclComm."""
         self.ctx = ctx
         ctx.set_option("staged_lists", 1 if want_lists else 0)
-        self._keep = []                           # gathered tensors stay alive until the step's last kernel ran
-        if share_stream:
-            import torch
-            ctx.set_stream(torch.cuda.current_stream(torch.device("cuda", ctx.device)).cuda_stream)
+        if async_stages:
             ctx.set_option("stage_sync", 0)
             ctx.set_option("defer_verdict", 1)      # the bet's verdict is read with the final download
 
+    @staticmethod
+    def _ptr(buf):
+        return buf.ptr if buf is not None else None
+
     def hist(self):
         self.ctx.hist()
-        ptr, n = self.ctx.hist_buffer()
-        return _as_tensor(ptr, n, self.ctx.device)
+        return DevBuf(*self.ctx.hist_buffer())
 
     def plan(self, R, gathered, world, rank):
-        self._keep = [gathered]
-        self.ctx.plan(R, gathered.data_ptr() if (world > 1 and gathered is not None) else None, world, rank)
+        self.ctx.plan(R, self._ptr(gathered) if world > 1 else None, world, rank)
 
     def select_match(self):
         self.ctx.select()
@@ -136,42 +177,38 @@ class HipShardEngine:
 
     def match_bits(self):
         self.ctx.match()
-        ptr, n = self.ctx.match_buffer()
-        return _as_tensor(ptr, n, self.ctx.device)
+        return DevBuf(*self.ctx.match_buffer())
 
     # -- optimistic sequence (one pass over the pairs) --------------------------------
     def bet_eligible(self, R, world):
         return self.ctx.bet_eligible(R, world)
 
+    def ranked_merge_ok(self, world):
+        """hg_merge_ranked's limits (shard-independent): lane r <-> shard r, and the four queries of a block keep
+        their [G][b+1] record counts in LDS."""
+        return world <= 64 and 4 * world * (self.ctx.b + 1) * 4 <= 160 * 1024
+
     def sample_hist(self, R):
         self.ctx.sample_hist(R)
-        ptr, n = self.ctx.hist_buffer()
-        return _as_tensor(ptr, n, self.ctx.device)
+        return DevBuf(*self.ctx.hist_buffer())
 
     def guess(self, R, gathered, world, rank):
-        self._keep = [gathered]
-        self.ctx.guess(R, gathered.data_ptr() if gathered is not None else None, world, rank)
+        self.ctx.guess(R, self._ptr(gathered), world, rank)
 
     def select_candidates(self):
         self.ctx.select_candidates()
-        ptr, n = self.ctx.hist_buffer()
-        return _as_tensor(ptr, n, self.ctx.device)
+        return DevBuf(*self.ctx.hist_buffer())
 
     def rank_candidates(self, gathered, world, rank):
-        self._keep.append(gathered)
-        return self.ctx.rank(gathered.data_ptr() if gathered is not None else None, world, rank)
+        return self.ctx.rank(self._ptr(gathered), world, rank)
 
     def select_ranked(self):
         """Select with the shared guess and rank this shard's records; -> (record counts, local match bitmap)."""
         self.ctx.select_ranked()
-        ph, nh = self.ctx.hist_buffer()
-        pb, nb = self.ctx.match_buffer()
-        return _as_tensor(ph, nh, self.ctx.device), _as_tensor(pb, nb, self.ctx.device)
+        return DevBuf(*self.ctx.hist_buffer()), DevBuf(*self.ctx.match_buffer())
 
     def merge_ranked(self, gathered_hist, gathered_bits, world):
-        self._keep += [gathered_hist, gathered_bits]
-        return self.ctx.merge_ranked(gathered_hist.data_ptr() if gathered_hist is not None else None,
-                                     gathered_bits.data_ptr() if gathered_bits is not None else None, world)
+        return self.ctx.merge_ranked(self._ptr(gathered_hist), self._ptr(gathered_bits), world)
 
     def verdict(self):
         """True if a deferred bet (rank_candidates returned None) turned out lost."""
@@ -179,19 +216,16 @@ class HipShardEngine:
 
     def finish(self, gathered_bits, world):
         if gathered_bits is not None:
-            self._keep.append(gathered_bits)
-            self.ctx.merge_match(gathered_bits.data_ptr(), world)
+            self.ctx.merge_match(gathered_bits.ptr, world)
         self.ctx.ap()
-        out = self.ctx.get_ap()                   # synchronises
-        self._keep = []
-        return out
+        return self.ctx.get_ap()                  # synchronises
 
-    def topr_tensors(self):
+    def topr_buffers(self):
         pi, pd, n = self.ctx.topr_buffers()
-        return _as_tensor(pi, n * 4, self.ctx.device), _as_tensor(pd, n, self.ctx.device)
+        return DevBuf(pi, n * 4), DevBuf(pd, n)
 
     def merge_topr(self, gathered_idx, gathered_dist, world):
-        self.ctx.merge_topr(gathered_idx.data_ptr(), gathered_dist.data_ptr(), world)
+        self.ctx.merge_topr(gathered_idx.ptr, gathered_dist.ptr, world)
         return self.ctx.get_topr()
 
 
@@ -207,7 +241,7 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
     multi = comm.world > 1 or always_gather          # always_gather: exercise the collectives even with one rank
     gather = (lambda t: comm.all_gather(t)) if multi else (lambda t: None)
     bits = None
-    if (bet and not gather_topr and hasattr(engine, "select_ranked") and comm.world <= 64
+    if (bet and not gather_topr and hasattr(engine, "select_ranked") and engine.ranked_merge_ok(comm.world)
             and engine.bet_eligible(R, comm.world)):
         # the bet with one record pass and one exchange after the guess: every shard ranks its own records, the
         # global bitmap is stitched from the gathered local ones (hg_merge_ranked)
@@ -244,8 +278,11 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
         B = gather(engine.select_match())
     lists = None
     if gather_topr:
-        ti, td = engine.topr_tensors()
-        if multi:
+        if multi and isinstance(comm, RcclComm):
+            engine.ctx.allgather_topr()               # the north star's exchange, inside the library
+            lists = engine.ctx.get_topr()
+        elif multi:
+            ti, td = engine.topr_buffers()
             lists = engine.merge_topr(comm.all_gather(ti), comm.all_gather(td), comm.world)
         else:
             lists = engine.ctx.get_topr()

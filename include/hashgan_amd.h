@@ -15,7 +15,8 @@
  *   - a context owns one GPU stream; every call is complete (stream
  *     synchronised) when it returns; a context is not thread safe.
  *
- * Data layout (pinned by tests/test_pack.py):
+ * Data layout (pinned by tests/test_capi.py::test_pack_sign_matches_python_packing and
+ * tests/test_oracle_golden.py::test_pack_bits_layout):
  *   codes   uint64 [n][W], W = ceil(b/64); bit j of a code is bit (j % 64) of
  *           word j / 64; bit value = (feature[j] > 0); pad bits are zero.
  *   labels  uint64 [n][LW], LW = ceil(C/64), bit c set <=> label[c] != 0.
@@ -71,8 +72,8 @@ int hg_set_queries(hg_ctx* ctx, const uint64_t* host_codes, const uint64_t* host
 /* The same two calls fed with what forward_all() (main.py:151-158) actually returns: float32
  * features [n][b] and int64 labels [n][C].  Binarise (bit = x > 0) and pack run on the GPU.
  * *bad_codes counts feature entries outside {-1, 0, +1}, *bad_labels label entries outside
- * {0, 1}: the caller decides whether non-binary features are an error (the Python mirror raises
- * unless binarize=True). */
+ * {0, 1}: the caller decides what non-binary features mean (the Python mirror ranks them by inner product
+ * like metric.py:13-14 unless binarize=True); hg_get_stat has the finer census (zeros, minus ones). */
 int hg_set_database_f32(hg_ctx* ctx, const float* host_features, const int64_t* host_labels, int64_t N, int b, int C,
                         int64_t idx_base, int64_t n_total, int64_t* bad_codes, int64_t* bad_labels);
 int hg_set_queries_f32(hg_ctx* ctx, const float* host_features, const int64_t* host_labels, int64_t Q,
@@ -174,10 +175,38 @@ int hg_get_match(hg_ctx* ctx, uint8_t* host_imatch);                    /* [Q][R
 int hg_get_ap(hg_ctx* ctx, double* host_ap, int64_t* host_rel);         /* [Q]; ap = NaN where rel == 0 */
 int hg_get_hist(hg_ctx* ctx, uint32_t* host_hist);                      /* [b+1][Q] of this shard */
 
+/* ---- collectives: RCCL over xGMI, one process per GPU (the reference has no counterpart --
+ * main.py:260-263 only sets CUDA_VISIBLE_DEVICES) --------------------------------------------------------
+ * librccl.so.1 is dlopen'ed by the first hg_comm_* call (HG_RCCL_LIBRARY overrides the search); a single-GPU
+ * process never loads it.  Rank 0 obtains a unique id and hands its HG_COMM_ID_BYTES bytes to the other ranks out
+ * of band (hashgan_amd/sharded.py: a file next to the launcher's rendezvous), then every rank calls hg_comm_init.
+ * Collectives run on the context's own stream, ordered with its kernels; with "stage_sync" = 1 (default) a
+ * call is complete when it returns.
+ *   hg_allgather        every rank contributes nbytes from dev_src; *dev_gathered = [world][nbytes] in a buffer the
+ *                       context owns (slot 0..3: that many gathered buffers can be live at once), rank order.
+ *                       This is the exchange of every staged sequence above (histograms, match bitmaps).
+ *   hg_allgather_topr   the north star's exchange: the shards' ranked (idx, dist) lists all-gathered and merged
+ *                       (hg_merge_topr); hg_get_topr then returns the global lists on every rank.
+ *   hg_allreduce_max_f64 / hg_barrier   benchmark plumbing (max of the ranks' step times; barrier). */
+#define HG_COMM_ID_BYTES 128
+int hg_comm_unique_id(uint8_t* id);
+int hg_comm_init(hg_ctx* ctx, const uint8_t* id, int rank, int world);
+int hg_comm_destroy(hg_ctx* ctx);
+int hg_comm_info(hg_ctx* ctx, int* rank, int* world);          /* *world = 0: no communicator */
+int hg_allgather(hg_ctx* ctx, int slot, const void* dev_src, int64_t nbytes, void** dev_gathered);
+int hg_allgather_topr(hg_ctx* ctx);
+int hg_allreduce_max_f64(hg_ctx* ctx, double* host_inout);
+int hg_barrier(hg_ctx* ctx);
+/* Context-owned device scratch (slot 0..3, grows only) and a stream-ordered device-to-device copy: what an
+ * in-process communicator needs to do hg_allgather's job between several contexts of ONE process
+ * (virtual shards on one GPU: tests/test_sharded_gpu.py). */
+int hg_scratch(hg_ctx* ctx, int slot, int64_t nbytes, void** dev_ptr);
+int hg_memcpy_dtod(hg_ctx* ctx, void* dev_dst, const void* dev_src, int64_t nbytes);
+
 /* Run the context on a stream of the caller's (NULL: back to a private one).  With option
- * "stage_sync" = 0 the staged calls only enqueue; together this lets a sharded caller put every
- * stage and the collectives between them on ONE stream (torch's current stream) with no host
- * synchronisation except hg_rank's verdict and the final hg_get_*. */
+ * "stage_sync" = 0 the staged calls (hg_allgather included) only enqueue: every stage and the collectives
+ * between them then sit on ONE stream with no host synchronisation except the bet's verdict and the
+ * final hg_get_*. */
 int hg_set_stream(hg_ctx* ctx, void* hip_stream);
 
 /* ---- tuning and measurement -------------------------------------------------- */
@@ -187,16 +216,19 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * "guess_sigma", "staged_lists" (0/1: hg_select materialises idx/dist lists),
  * "cand_budget_x10" (record budget of the bet per query, tenths of R), "rank_waves" (0 = auto, 4, 16),
  * "select_mfma" (1: the bet's select pass runs on the matrix cores -- fp4 MFMA distance tiles,
- * k_select_mx; 0: vector-ALU xor+popcount k_select; same records either way), "probe_select" (measurement
- * only: bits 2/4/8 switch parts of the matrix-core kernels' drain off; the bet then fails and the exact
- * sequence runs, so results stay right),
+ * k_select_mx; 0: vector-ALU xor+popcount k_select; same records either way), "probe_select" (probe build only --
+ * python -m hashgan_amd.build --probes: bits 2/4/8 switch parts of the matrix-core kernels' drain off; the bet
+ * then fails and the exact sequence runs, so results stay right; the production library refuses the key),
  * "select_qt" (k_select_mx query tiles per wavefront: 2 or 4), "select_packed" (k_select_mx2, two rows per
  * MFMA accumulator: 1 = for codes of <= 32 bits, 2 = also for 33..64 bits, 0 = never), "rank_lds" (0/1),
  * "real_queries_per_lane", "real_segment_bytes" (real-valued path). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
 /* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
  * (single queries rerun exactly after losing their bet), "last_optimistic", "device_bytes", "segments",
- * "segment_rows", "slice_capacity", "record_row". */
+ * "segment_rows", "slice_capacity", "record_row"; census of the float tables loaded by hg_set_*_f32 --
+ * "db_nonbinary" / "q_nonbinary" (entries outside {-1,0,+1}), "db_zeros" / "q_zeros", "db_minus_ones" /
+ * "q_minus_ones" -- from which the caller tells +-1 codes, {0,1} bits and real-valued features apart;
+ * "probe_build". */
 int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
 /* Work buffers only grow; hg_trim frees everything except the resident code/label/feature tables
  * (stat "device_bytes" reports what the context holds). */

@@ -2,7 +2,7 @@
 
 This file is the checker, never the product: only tests/, __graft_entry__.smoke()
 and bench.py's `cpu_baseline` leg may import it.  hashgan_amd/ must never import
-anything under oracle/ (tests/test_layout.py enforces that).
+anything under oracle/ (tests/test_capi.py::test_product_never_imports_oracle enforces that).
 
 It restates /root/reference/lib/metric.py:4-24 (class MAPs) in NumPy:
 

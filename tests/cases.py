@@ -45,6 +45,10 @@ REAL_CASES = {
     "real_dups":   dict(Q=20, N=4000, b=16, R=1500, C=5, seed=0xF4, labels="onehot", dups=True),
     "real_b128":   dict(Q=16, N=5000, b=128, R=5000, C=10, seed=0xF5, labels="onehot"),
     "real_bet":    dict(Q=96, N=150000, b=64, R=3000, C=10, seed=0xF6, labels="onehot"),
+    # codes that are NOT +-1: np.dot (metric.py:13) does not rank them by Hamming distance -- {0,1} bits count common
+    # ones, zeros in a +-1 code contribute nothing -- so MAPs must route them through the inner-product ranking
+    "real_bits01":  dict(Q=40, N=6000, b=32, R=800, C=10, seed=0xF7, labels="onehot", feat="bits01"),
+    "real_ternary": dict(Q=40, N=6000, b=48, R=1500, C=10, seed=0xF8, labels="onehot", feat="ternary"),
 }
 
 
@@ -67,6 +71,15 @@ def build_real_case(name):
         x = np.tanh(0.8 * base + 0.9 * noise)
         return (np.round(x * 64) / 64).astype(np.float32)
     dbf, qf = feats(dblab, seed + 11), feats(qlab, seed + 12)
+    if c.get("feat") in ("bits01", "ternary"):
+        dbits, qbits = synth.planted_codes(seed, dblab, b, 0.25), synth.planted_codes(seed, qlab, b, 0.25, noise_seed=seed + 5)
+        if c["feat"] == "bits01":
+            dbf, qf = dbits.astype(np.float32), qbits.astype(np.float32)
+        else:                                           # +-1 codes with a quarter of the entries zeroed
+            dz = synth.random_bits(seed + 21, N, b) & synth.random_bits(seed + 22, N, b)
+            qz = synth.random_bits(seed + 23, Q, b) & synth.random_bits(seed + 24, Q, b)
+            dbf = ((dbits.astype(np.float32) * 2 - 1) * (1 - dz)).astype(np.float32)
+            qf = ((qbits.astype(np.float32) * 2 - 1) * (1 - qz)).astype(np.float32)
     if c.get("dups"):
         dbf[N // 2:] = dbf[:N - N // 2]               # the second half duplicates the first: exact ties
     return dict(qf=qf, dbf=dbf, qlab=qlab, dblab=dblab, R=c["R"], b=b, name=name)

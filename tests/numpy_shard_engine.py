@@ -79,6 +79,9 @@ class NumpyRankedEngine(NumpyShardEngine):
     def bet_eligible(self, R, world):
         return True
 
+    def ranked_merge_ok(self, world):
+        return True
+
     def sample_hist(self, R):
         return self.hist()
 

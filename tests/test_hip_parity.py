@@ -130,6 +130,44 @@ def test_python_surface_matches_golden(case_cache):
         MAP(c["qbits"], c["dbbits"], c["qlab"], c["dblab"], c["dbbits"].shape[0] + 1)
 
 
+def test_maps_objects_are_independent_and_keep_a_resident_database(case_cache):
+    """Two MAPs objects (own contexts) interleaved, from two threads; set_database / read-only arrays skip the
+    re-upload (main.py:237-240 evaluates the same database again and again)."""
+    import threading
+    import types
+    from hashgan_amd import MAPs
+    ca, cb = case_cache("e_ragged"), case_cache("e_b100")
+    ga, gb = cases.load_golden("e_ragged"), cases.load_golden("e_b100")
+
+    def ns(c, k):
+        return types.SimpleNamespace(output=c[k + "bits"].astype(np.float32) * 2 - 1, label=c[k + "lab"].astype(np.int64))
+    ma, mb = MAPs(ca["R"]), MAPs(cb["R"])
+    dba, dbb, qa, qb = ns(ca, "db"), ns(cb, "db"), ns(ca, "q"), ns(cb, "q")
+    out = {}
+
+    def work(key, m, db, q, n):
+        out[key] = [m.get_maps_by_feature(db, q) for _ in range(n)]
+    th = [threading.Thread(target=work, args=("a", ma, dba, qa, 3)), threading.Thread(target=work, args=("b", mb, dbb, qb, 3))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert out["a"] == [ga["map"]] * 3 and out["b"] == [gb["map"]] * 3
+    # explicit resident database
+    ma.set_database(dba)
+    bytes_before = ma._eng.ctx.get_stat("device_bytes")
+    assert ma.get_maps_by_feature(None, qa) == ga["map"]
+    assert ma.get_maps_by_feature(dba, qa) == ga["map"]            # the same object: no re-upload either
+    assert ma._eng.ctx.get_stat("device_bytes") == bytes_before
+    # automatic reuse needs read-only arrays; a writable one is uploaded again (it may have changed in place)
+    dbb.output.flags.writeable = False
+    dbb.label.flags.writeable = False
+    assert mb.get_maps_by_feature(dbb, qb) == gb["map"] and mb._resident[0] == "auto"
+    held = mb._resident
+    assert mb.get_maps_by_feature(dbb, qb) == gb["map"] and mb._resident is held
+    with pytest.raises(ValueError):
+        MAPs(5).get_maps_by_feature(None, qa)
+    ma.close(); mb.close()
+
+
 def test_device_pack_matches_host_pack(ctx):
     """k_pack_sign_f32 / k_pack_labels_i64 against the NumPy packing, bit for bit, including
     sign(0) -> 0, pad bits, odd word counts; and the non-binary detector."""

@@ -72,3 +72,28 @@ def test_python_surface_ranks_real_features_like_the_reference():
     assert MAPs(c["R"]).get_maps_by_feature(database, query) == g["map"]
     with pytest.raises(ValueError):
         MAP(c["qf"], c["dbf"], c["qlab"], c["dblab"], c["R"])          # MAP() is the binary-code spelling
+
+
+@pytest.mark.parametrize("name", ["real_bits01", "real_ternary"])
+def test_maps_ranks_non_pm1_codes_like_np_dot(name):
+    """{0,1} bits and +-1 codes with zeros: np.dot (metric.py:13) does NOT rank them by Hamming distance, so the
+    drop-in MAPs must not either (it once did).  Golden = the unmodified reference."""
+    from hashgan_amd import MAPs, MAP
+    c = cases.build_real_case(name)
+    g = cases.load_golden(name)
+    database = types.SimpleNamespace(output=c["dbf"], label=c["dblab"].astype(np.int64))
+    query = types.SimpleNamespace(output=c["qf"], label=c["qlab"].astype(np.int64))
+    m = MAPs(c["R"])
+    assert m.get_maps_by_feature(database, query) == g["map"]
+    m.close()
+    if name == "real_bits01":       # the north-star spelling takes {0,1} as BITS: Hamming ranking, a different number
+        from oracle import hamming_map as O
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mh, *_ = O.map_from_codes(c["qf"].astype(np.uint8), c["dbf"].astype(np.uint8), c["qlab"], c["dblab"], c["R"])
+        assert MAP(c["qf"], c["dbf"], c["qlab"], c["dblab"], c["R"]) == mh != g["map"]
+    else:                           # a ternary code is not a binary code
+        with pytest.raises(ValueError):
+            MAP(c["qf"], c["dbf"], c["qlab"], c["dblab"], c["R"])
+        with pytest.raises(ValueError):   # spellings must agree between queries and database
+            MAP((c["qf"] > 0).astype(np.float32), np.where(c["dbf"] > 0, 1.0, -1.0).astype(np.float32), c["qlab"], c["dblab"], c["R"])

@@ -35,7 +35,7 @@ def test_fma32_is_correctly_rounded():
         assert np.array_equal(r.view(np.uint32), ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("name", ["real_small", "real_b64", "real_multi", "real_dups", "real_b128"])
+@pytest.mark.parametrize("name", ["real_small", "real_b64", "real_multi", "real_dups", "real_b128", "real_bits01", "real_ternary"])
 def test_real_oracle_matches_reference_golden(name):
     c = cases.build_real_case(name)
     g = cases.load_golden(name)

@@ -17,6 +17,7 @@ def _worker(rank, world, port, name, out_dir, ranked=False):
     from tests import cases
     from tests.numpy_shard_engine import NumpyShardEngine, NumpyRankedEngine
     from hashgan_amd import sharded
+    from tests.torch_comm import TorchComm
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,7 +28,7 @@ def _worker(rank, world, port, name, out_dir, ranked=False):
     eng = cls(c["qbits"], c["qlab"], c["dbbits"][base:base + rows], c["dblab"][base:base + rows], base)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        ap, rel = sharded.evaluate_shard(eng, sharded.TorchComm(), c["R"])
+        ap, rel = sharded.evaluate_shard(eng, TorchComm(), c["R"])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ap=ap, rel=rel)
     dist.destroy_process_group()
 

@@ -6,7 +6,6 @@ import threading
 import warnings
 import numpy as np
 import pytest
-import torch  # noqa: F401  (imported before the native library loads: one HIP runtime per process, see _native.load)
 from tests import cases
 from hashgan_amd import _native, metric, sharded
 
@@ -28,6 +27,7 @@ def _run_virtual(c, G, gather_topr, defer=False):
             ctx.set_database(metric.pack_codes(c["dbbits"][base:base + rows]), metric.pack_labels(c["dblab"][base:base + rows]),
                              c["b"], c["dblab"].shape[1], idx_base=base, n_total=N)
             ctx.set_queries(qw, ql)
+            comms[r].ctx = ctx
             eng = sharded.HipShardEngine(ctx, want_lists=gather_topr)
             if defer:
                 ctx.set_option("defer_verdict", 1)      # hg_rank does not wait; the verdict comes with the AP download
@@ -51,7 +51,7 @@ def _run_virtual(c, G, gather_topr, defer=False):
 
 
 @pytest.mark.parametrize("name,G", [("e_ragged", 2), ("e_ragged", 3), ("e_b100", 4), ("e_dups_alleq", 8),
-                                    ("e_some_skipped", 2), ("e_r_eq_n", 5), ("c3_nus_q64", 8)])
+                                    ("e_some_skipped", 2), ("e_r_eq_n", 5), ("c3_nus_q64", 8), ("c4_n10m_q8", 8)])
 def test_virtual_shards_equal_single_shard(name, G, case_cache):
     c = case_cache(name)
     g = cases.load_golden(name)
@@ -73,7 +73,7 @@ def test_virtual_shards_equal_single_shard(name, G, case_cache):
     assert (np.isnan(m) and np.isnan(g["map"])) or m == g["map"]
 
 
-@pytest.mark.parametrize("name,G", [("c2_q64", 4), ("c2_q64", 8), ("c5_b128_q32", 2), ("c3_nus_q64", 2)])
+@pytest.mark.parametrize("name,G", [("c2_q64", 4), ("c2_q64", 8), ("c5_b128_q32", 2), ("c3_nus_q64", 2), ("c4_n10m_q8", 8)])
 def test_virtual_shards_optimistic_sequence(name, G, case_cache):
     """Big enough for the sharded bet (sample -> guess -> candidates -> rank): must equal the golden
     AP of the unmodified reference, and really have taken the one-pass route."""
@@ -109,3 +109,84 @@ def test_virtual_shards_lost_bet_is_consistent():
             assert np.array_equal(res[r][0][:24], ap_ref, equal_nan=True)
         st = _run_virtual.last_stats
         assert st[0] == st[1] and st[0][0] == 1, st          # both ranks took the bet, and agree on its outcome
+
+
+def test_virtual_shards_wide_labels_take_the_bet():
+    """More than 128 classes: the record pass cannot carry the match bit, so the merged-ranking bet builds its local
+    bitmaps with k_match through the local ranked lists (this path once produced all-zero bitmaps -> mAP nan)."""
+    from hashgan_amd import synth
+    from oracle import hamming_map as O
+    Q, N, b, R, C = 96, 262144, 32, 3000, 150
+    dl = synth.multihot_labels(91, N, C)
+    ql = synth.multihot_labels(92, Q, C)
+    db = synth.planted_codes(93, dl, b, 0.25)
+    qb = synth.planted_codes(93, ql, b, 0.25)
+    c = dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, R=R, b=b)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb[:32], db, ql[:32], dl, R)
+    assert np.isfinite(ap_ref).any()
+    for G in (1, 2, 3):
+        for defer in (False, True):
+            res = _run_virtual(c, G, gather_topr=False, defer=defer)
+            for r in range(G):
+                assert np.array_equal(res[r][0][:32], ap_ref, equal_nan=True), (G, r, defer)
+            assert all(st == (1, 0) for st in _run_virtual.last_stats), _run_virtual.last_stats
+
+
+def _one_rank_rccl(c, gather_topr, async_stages):
+    ctx = _native.Context(0)
+    try:
+        ctx.set_database(metric.pack_codes(c["dbbits"]), metric.pack_labels(c["dblab"]), c["b"], c["dblab"].shape[1])
+        ctx.set_queries(metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"]))
+        comm = sharded.init_rccl(ctx, rank=0, world=1)
+        assert (comm.rank, comm.world) == (0, 1)
+        eng = sharded.HipShardEngine(ctx, want_lists=gather_topr, async_stages=async_stages)
+        out = sharded.evaluate_shard(eng, comm, c["R"], gather_topr=gather_topr, always_gather=True)
+        stats = (ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks"))
+        ctx.comm_destroy()
+        return out, stats
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", ["c2_q64", "e_ragged", "c3_nus_q64"])
+def test_one_rank_native_rccl_matches_golden(name, case_cache):
+    """The collectives of every sequence through the library's own RCCL communicator (hg_comm_init / hg_allgather /
+    hg_allgather_topr) -- one rank, because a box has one GPU; no torch in the process."""
+    c = case_cache(name)
+    g = cases.load_golden(name)
+    for async_stages in (False, True):
+        (ap, rel), stats = _one_rank_rccl(c, False, async_stages)
+        assert np.array_equal(ap, g["ap"], equal_nan=True), (name, async_stages)
+        if name == "c2_q64":
+            assert stats == (1, 0), stats                  # the merged-ranking bet ran, over real collectives
+    (ap, rel, (idx, dist)), _ = _one_rank_rccl(c, True, False)
+    assert np.array_equal(ap, g["ap"], equal_nan=True)
+    if "idx" in g:
+        assert np.array_equal(idx, g["idx"])
+
+
+def test_sharded_product_path_is_torch_free():
+    """A fresh interpreter runs the sharded sequence over native RCCL; torch must never get imported."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests import cases\n"
+        "from hashgan_amd import _native, metric, sharded\n"
+        "c = cases.build_case('e_ragged'); g = cases.load_golden('e_ragged')\n"
+        "ctx = _native.Context(0)\n"
+        "ctx.set_database(metric.pack_codes(c['dbbits']), metric.pack_labels(c['dblab']), c['b'], c['dblab'].shape[1])\n"
+        "ctx.set_queries(metric.pack_codes(c['qbits']), metric.pack_labels(c['qlab']))\n"
+        "comm = sharded.init_rccl(ctx, rank=0, world=1)\n"
+        "eng = sharded.HipShardEngine(ctx, async_stages=True)\n"
+        "ap, rel = sharded.evaluate_shard(eng, comm, c['R'], always_gather=True)\n"
+        "assert np.array_equal(ap, g['ap'], equal_nan=True)\n"
+        "assert 'torch' not in sys.modules, sorted(m for m in sys.modules if m.startswith('torch'))[:5]\n"
+        "print('TORCH_FREE_OK')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TORCH_FREE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
