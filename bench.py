@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""Benchmark of the retrieval-evaluation hot path (BASELINE.json metric:
-queries/sec at Q=10k, N=1M, b=64, R=5000 -- config C2 -- on MI355X).
+"""Benchmark of the retrieval-evaluation hot path (BASELINE.json metric: queries/sec).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5|c1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5|c1|c4]
 
-One step = one full pass of the path over the query batch with codes and labels
-already resident in HBM: distance histogram -> threshold plan -> select ->
-order -> label match -> AP (all HIP) -> per-query AP to the host -> mean.
-N > 1 (launched by torch.distributed.run, one rank per GPU): the database is
-sharded, every rank holds `N` rows of it (weak scaling in database size), the
-shards exchange histograms and match bits over RCCL (see hashgan_amd/sharded.py).
+One step = one full pass of the path over the query batch with codes and labels already resident in HBM:
+sampled histogram -> threshold guess -> select -> verify + order + label match -> AP (all HIP) -> per-query AP to
+the host -> mean.  `value` = Q / step time: queries per second, whole job.
+
+  --gpus 1 (default)   C2 = BASELINE.json configs[1]: Q=10k, N=1M, b=64, R=5000 on one MI355X -- the configuration
+                       the metric is quoted on.
+  --gpus G > 1         C4 = configs[3]: the FIXED N=10M database sharded over the G GPUs of one node (contiguous
+                       index ranges, shard_bounds(10M, G)), Q=10k queries replicated; strong scaling.  One process per
+                       GPU, launched as `python -m torch.distributed.run --nproc-per-node G ... bench.py --gpus G`
+                       (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT from the environment); the exchanges are native
+                       RCCL all-gathers through the library's C ABI (hashgan_amd/sharded.py) -- no torch in the process.
+                       HG_BENCH_FORCE_SHARDED=1 runs this leg with one rank (`--workload c2` keeps its database small).
+  --workload c4 --gpus 1   C4 on a single GPU: the reference point for the scaling curve.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,13 +40,16 @@ VALU_PEAK_TLANEOPS = 39.3
 VALU_NOMINAL_FP32_TLANEOPS = 78.6
 HBM_PEAK_GBS = 8000.0         # HBM3E spec (6.3 TB/s achievable)
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense MX-fp4 MFMA peak (MI355X_MICROARCH.md: ~10 PF dense; 9.1 PF measured)
+METRIC = "queries/sec (mAP@R of Q queries vs N-code database, Hamming ranking)"
+DTYPE = "fp4 (E2M1 0/+-1) x fp4 -> f32 exact distances; u32 xor+popcount elsewhere; f64 AP"
 
 WORKLOADS = {
-    # name: (case in tests/cases.py whose seeds/shape we reuse, Q, golden anchor)
+    # name: the case in tests/cases.py whose seeds/shape we reuse, at full Q; `golden` = its committed reference outputs
     "c2": dict(Q=10000, N=1000000, b=64, R=5000, C=10, kind="planted", seed=0xC2, flip=0.30, golden="c2_q64"),
     "c5": dict(Q=10000, N=1000000, b=128, R=5000, C=10, kind="planted", seed=0xC5, flip=0.35, golden="c5_b128_q32"),
     "c3": dict(Q=2100, N=190000, b=48, R=5000, C=81, kind="multihot", seed=0xC3, flip=0.20, golden="c3_nus_q64"),
     "c1": dict(Q=1000, N=54000, b=32, R=54000, C=10, kind="cifar", seed=0xC1, flip=0.25, golden="c1_cifar_full"),
+    "c4": dict(Q=10000, N=10000000, b=64, R=5000, C=10, kind="iid", seed=0xC4, golden="c4_n10m_q8"),
 }
 
 
@@ -52,22 +63,46 @@ def build_inputs(spec):
         del cases.CASES["_bench"]
 
 
-def cpu_baseline(c, spec, budget_s=12.0, chunk=128):
+def build_packed(spec, base, rows):
+    """Packed query tables and rows [base, base + rows) of the packed database tables.  The iid workload (C4) draws
+    exactly its own rows from the seeded stream (hashgan_amd.synth, same arrays as tests/cases.py `iid`)."""
+    from hashgan_amd import metric, synth
+    if spec["kind"] == "iid":
+        seed, b, C = spec["seed"], spec["b"], spec["C"]
+        qw = synth.random_code_words(seed + 7, spec["Q"], b)
+        ql = synth.onehot_label_words(seed * 3 + 2, spec["Q"], C)
+        dw = synth.random_code_words(seed, rows, b, row_offset=base)
+        dl = synth.onehot_label_words(seed * 3 + 1, rows, C, row_offset=base)
+        return qw, ql, dw, dl
+    c = build_inputs(spec)
+    qw, ql = metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"])
+    sl = slice(base, base + rows)
+    return qw, ql, metric.pack_codes(c["dbbits"][sl]), metric.pack_labels(c["dblab"][sl])
+
+
+def unpack_bits(words, b):
+    return np.unpackbits(np.ascontiguousarray(words).view(np.uint8).reshape(words.shape[0], -1), axis=1, bitorder="little")[:, :b]
+
+
+def cpu_baseline(spec, packed, budget_s=12.0, chunk=128):
     """metric.py:12-24 as written (float32 np.dot -> np.argsort(-ips,1) -> Python
     loop; oracle.reference_as_written) on the GPU box's host cores, over query
     chunks (rows are independent; a chunk bounds the reference's 16 B/pair) until
     ~budget_s seconds of CPU work are done."""
     from oracle import hamming_map as O
-    Q = c["qbits"].shape[0]
-    dbf = c["dbbits"].astype(np.float32) * 2 - 1
-    dl = c["dblab"].astype(np.int64)
+    qw, ql, dw, dl = packed
+    b, C, R = spec["b"], spec["C"], spec["R"]
+    Q = qw.shape[0]
+    dbf = unpack_bits(dw, b).astype(np.float32) * 2 - 1
+    dlab = unpack_bits(dl, C).astype(np.int64)
+    qbits, qlab = unpack_bits(qw, b), unpack_bits(ql, C).astype(np.int64)
     chunk = max(1, min(chunk, int(2e9 // (16 * dbf.shape[0])) or 1))
     done, t0 = 0, time.perf_counter()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         while done < Q and time.perf_counter() - t0 < budget_s:
             sl = slice(done, min(Q, done + chunk))
-            O.reference_as_written(dbf, dl, c["qbits"][sl].astype(np.float32) * 2 - 1, c["qlab"][sl].astype(np.int64), c["R"])
+            O.reference_as_written(dbf, dlab, qbits[sl].astype(np.float32) * 2 - 1, qlab[sl], R)
             done = sl.stop
     dt = time.perf_counter() - t0
     try:
@@ -78,58 +113,115 @@ def cpu_baseline(c, spec, budget_s=12.0, chunk=128):
     return {"value": done / dt, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
             "sample": "%d of %d queries (chunks of %d) x full N=%d database in %.1f s; float32 +-1 features; np.dot on "
                       "BLAS threads %s, np.argsort and the per-query loop on 1 core; numpy %s"
-                      % (done, Q, chunk, c["dbbits"].shape[0], dt, blas, np.__version__)}
+                      % (done, Q, chunk, dbf.shape[0], dt, blas, np.__version__)}
+
+
+def kernel_sources_sha():
+    """Fingerprint of the device code: the committed PMC traffic figure is only quoted for the sources it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hashgan_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def traffic_from_profiles(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass
-    (profiles/latest_traffic.json, written by tools/pmc_traffic.py), or None."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass (profiles/latest_traffic.json, written by
+    tools/pmc_traffic.py from FETCH_SIZE / WRITE_SIZE passes of this same command) -- quoted only if that pass measured
+    the device code this run executes (same source fingerprint); else None plus the reason."""
     path = os.path.join(ROOT, "profiles", "latest_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+            d = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, "no PMC pass committed"
+    sha = d.get("_kernel_sources_sha")
+    if sha != kernel_sources_sha():
+        return None, "profiles/latest_traffic.json was measured on other kernel sources (%s); rerun tools/pmc_traffic.py" % sha
+    return d.get(kernel, {}).get("hbm_bytes_per_launch"), "rocprofv3 PMC pass of these sources (%s)" % d.get("_collected", "?")
 
 
-def kernel_rooflines(timing, steps, spec, geo_bytes):
-    """Per-kernel average launch time -> VALU and HBM fractions of the dominant one."""
-    Q, N, b = spec["Q"], spec["N"], spec["b"]
-    NW = (b + 31) // 32
-    pairs = Q * N
-    out = {}
-    for name, (ms, cnt) in timing.items():
-        out[name] = {"avg_ms": ms / max(cnt, 1), "launches": cnt}
-    dom = max(out, key=lambda k: out[k]["avg_ms"] * out[k]["launches"])
+def kernel_rooflines(timing, spec, rows, step_s):
+    """Per-kernel average launch time -> roofline of the dominant kernel.  `rows` = database rows this GPU holds."""
+    Q, b, C, R = spec["Q"], spec["b"], spec["C"], spec["R"]
+    NW, LW = (b + 31) // 32, (C + 63) // 64
+    pairs = Q * rows
+    code_bytes = (Q + rows) * NW * 4
+    alg_bytes = {   # algorithmic (compulsory) HBM bytes per launch, DESIGN.md section 4
+        "k_hist": code_bytes + (b + 1) * ((Q + 63) // 64 * 64) * 4,
+        "k_select": code_bytes + (Q + rows) * LW * 8 + Q * R * 8,       # codes + labels in, >= R records of 8 B out per query
+        # fp4 images of the codes (4 bits per code bit, 64-bit granules) + packed codes + labels in, records out
+        "k_select_mx": (Q + rows) * ((NW + 1) // 2) * 32 + code_bytes + (Q + rows) * LW * 8 + Q * R * 8,
+    }
+    out = {name: {"avg_ms": ms / max(cnt, 1), "launches": cnt} for name, (ms, cnt) in timing.items()}
+    pair_passes = {k: v for k, v in out.items() if k in alg_bytes}
+    dom = max(pair_passes or out, key=lambda k: out[k]["avg_ms"] * out[k]["launches"])
     t = out[dom]["avg_ms"] * 1e-3
-    alg_bytes = geo_bytes.get(dom, 0)
-    hbm = {"algorithmic_bytes": alg_bytes, "achieved": alg_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": alg_bytes / t / 1e9 / HBM_PEAK_GBS}
+    ab = alg_bytes.get(dom, 0)
+    hbm = {"algorithmic_bytes": ab, "achieved": ab / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / t / 1e9 / HBM_PEAK_GBS}
+    traffic, traffic_note = traffic_from_profiles(dom)
+    # SURVEY.md 8(d)'s own yardstick: the xor+popcount formulation's 4 W lane-ops per pair (W = ceil(b/64)) against the
+    # guide's 78.6 T lane-op/s, for the dominant kernel and for the whole step
+    W = (b + 63) // 64
+    valu_equiv = {"definition": "pairs * 4 * ceil(b/64) lane-ops / (t * 78.6e12)  (SURVEY.md 8d)",
+                  "kernel": pairs * 4 * W / t / (VALU_NOMINAL_FP32_TLANEOPS * 1e12),
+                  "step": pairs * 4 * W / step_s / (VALU_NOMINAL_FP32_TLANEOPS * 1e12)}
     if dom == "k_select_mx":
         # matrix-core select: one v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4) per 64 code bits and 32x32 tile of pairs
         K = 64 * ((NW + 1) // 2)
         flops = 2.0 * pairs * K
-        valu = pairs                                   # one v_alignbit_b32 per pair (sign of the accumulator -> hit mask)
         roof = {"bound": "mfma", "kernel": dom, "achieved": flops / t / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / t / 1e12 / MFMA_FP4_PEAK_TFLOPS, "traffic": traffic_from_profiles(dom),
+                "frac": flops / t / 1e12 / MFMA_FP4_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
                 "avg_launch_ms": out[dom]["avg_ms"], "algorithmic_flops": flops,
                 "note": "fp4 MFMA inner product over K=%d code bits per pair (2 flops per bit), against the dense fp4 peak; the "
-                        "kernel's other per-pair cost is one v_alignbit_b32, which on gfx950 does not overlap the MFMAs "
-                        "(profiles/r01_ubench_mx.txt): see 'valu'" % K,
-                "valu": {"algorithmic_laneops": valu, "achieved": valu / t / 1e12, "peak": VALU_PEAK_TLANEOPS,
-                         "unit": "Tlaneop/s", "frac": valu / t / 1e12 / VALU_PEAK_TLANEOPS},
-                "hbm": hbm}
+                        "kernel's other per-pair cost is the harvest of the accumulator signs on the vector ALU, which on gfx950 "
+                        "does not overlap the MFMAs (profiles/r01_ubench_mx.txt): see 'valu'" % K,
+                "valu": {"algorithmic_laneops": pairs, "achieved": pairs / t / 1e12, "peak": VALU_PEAK_TLANEOPS,
+                         "unit": "Tlaneop/s", "frac": pairs / t / 1e12 / VALU_PEAK_TLANEOPS},
+                "valu_equiv_frac": valu_equiv, "hbm": hbm}
         return roof, out
     laneops = pairs * 2 * NW                      # one v_xor_b32 + one v_bcnt_u32_b32 per 32-bit word per pair
     roof = {"bound": "valu", "kernel": dom, "achieved": laneops / t / 1e12, "peak": VALU_PEAK_TLANEOPS,
-            "unit": "Tlaneop/s", "frac": laneops / t / 1e12 / VALU_PEAK_TLANEOPS, "traffic": traffic_from_profiles(dom),
-            "avg_launch_ms": out[dom]["avg_ms"],
-            "algorithmic_laneops": laneops,
+            "unit": "Tlaneop/s", "frac": laneops / t / 1e12 / VALU_PEAK_TLANEOPS, "traffic": traffic, "traffic_source": traffic_note,
+            "avg_launch_ms": out[dom]["avg_ms"], "algorithmic_laneops": laneops,
             "note": "integer bit-count path: xor+popcount lane-ops (2 per 32-bit code word per pair) against the "
-                    "integer VALU issue peak (16 lanes/clk/SIMD); frac vs the 78.6 T packed-FP32 figure is %.3f"
-                    % (laneops / t / 1e12 / VALU_NOMINAL_FP32_TLANEOPS),
-            "hbm": hbm}
+                    "integer VALU issue peak (16 lanes/clk/SIMD)",
+            "valu_equiv_frac": valu_equiv, "hbm": hbm}
     return roof, out
+
+
+def h2d_inclusive(spec, packed, reps=3):
+    """The drop-in call itself, from HOST arrays as forward_all() returns them (float32 +-1 features, int64 labels):
+    MAPs(R).get_maps_by_feature(database, query) uploads 4 B per code bit over PCIe, binarises + packs on the GPU,
+    then runs the step.  Never `value`."""
+    import types
+    from hashgan_amd import MAPs
+    qw, ql, dw, dl = packed
+    b, C, R = spec["b"], spec["C"], spec["R"]
+    db = types.SimpleNamespace(output=unpack_bits(dw, b).astype(np.float32) * 2 - 1, label=unpack_bits(dl, C).astype(np.int64))
+    q = types.SimpleNamespace(output=unpack_bits(qw, b).astype(np.float32) * 2 - 1, label=unpack_bits(ql, C).astype(np.int64))
+    m = MAPs(R)
+    try:
+        val = m.get_maps_by_feature(db, q)              # first call: allocations
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            val = m.get_maps_by_feature(db, q)
+        full = (time.perf_counter() - t0) / reps
+        m.set_database(db)                              # main.py:237-240 re-evaluates one database: keep it resident
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            val2 = m.get_maps_by_feature(None, q)
+        resident = (time.perf_counter() - t0) / reps
+    finally:
+        m.close()
+    Q = qw.shape[0]
+    host_bytes = db.output.nbytes + db.label.nbytes + q.output.nbytes + q.label.nbytes
+    return {"call": "MAPs(R).get_maps_by_feature(database, query) from host float32 features + int64 labels",
+            "ms_per_call": full * 1e3, "queries_per_sec": Q / full, "host_bytes_uploaded": host_bytes,
+            "with_resident_database": {"call": "MAPs.set_database(database) once, then get_maps_by_feature(None, query)",
+                                       "ms_per_call": resident * 1e3, "queries_per_sec": Q / resident},
+            "map_equal_to_resident_path": bool(val == val2)}, float(val)
 
 
 def main():
@@ -137,14 +229,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--target-units", type=int, default=0)
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive MAPs(...) timing")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (hg_set_option), repeatable")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events (overhead probe)")
-    ap.add_argument("--kernel-timing", default="pair-passes", choices=["pair-passes", "all"],
-                    help="HIP events around the passes over the pairs only (the roofline kernel; default) or around every "
-                         "kernel (+0.04 ms per step: events keep kernels from being dispatched back to back)")
+    ap.add_argument("--kernel-timing", default="pair-passes", choices=["pair-passes", "all", "none"],
+                    help="HIP events around the passes over the pairs only (the roofline kernel; default), around every "
+                         "kernel (events keep kernels from being dispatched back to back), or none")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,41 +245,61 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    force = os.environ.get("HG_BENCH_FORCE_SHARDED") == "1"
+    sharded_leg = world > 1 or force
+    wl = args.workload or ("c4" if world > 1 else "c2")
+    spec = WORKLOADS[wl]
 
-    spec = WORKLOADS[args.workload]
-    from hashgan_amd import _native, metric
-    c = build_inputs(spec)
-    Q, N, R, b = c["qbits"].shape[0], c["dbbits"].shape[0], c["R"], c["b"]
-    qw, ql = metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"])
-    dw, dl = metric.pack_codes(c["dbbits"]), metric.pack_labels(c["dblab"])
+    from hashgan_amd import _native, metric, sharded
+    Q, N, R, b, C = spec["Q"], spec["N"], spec["R"], spec["b"], spec["C"]
+    base, rows = sharded.shard_bounds(N, world)[rank]
+    packed = build_packed(spec, base, rows)
+    qw, ql, dw, dl = packed
 
-    if world > 1 or os.environ.get("HG_BENCH_FORCE_SHARDED") == "1":
-        from bench_sharded import run_sharded
-        return run_sharded(args, spec, c, (qw, ql, dw, dl), rank, local_rank, world)
-
-    ctx = _native.Context(0)
-    if args.target_units:
-        ctx.set_option("target_units", args.target_units)
+    ctx = _native.Context(local_rank)
     for kv in args.opt:
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
-    ctx.set_database(dw, dl, b, spec["C"])           # inputs resident in HBM before the timed region
+    ctx.set_database(dw, dl, b, C, idx_base=base, n_total=N)    # inputs resident in HBM before the timed region
     ctx.set_queries(qw, ql)
 
-    def step():
-        a, r = ctx.map(R)
-        return metric.mean_over_hits(a, r), a
+    if sharded_leg:
+        comm = sharded.init_rccl(ctx, rank, world)
+        eng = sharded.HipShardEngine(ctx, want_lists=False, async_stages=True)   # one stream, no host waits between stages
+
+        def step():
+            a, r = sharded.evaluate_shard(eng, comm, R, always_gather=force)
+            return sharded.mean_ap(a, r), a
+
+        def fence():
+            ctx.barrier()                               # hipStreamSynchronize + a tiny all-reduce on every rank
+    else:
+        def step():
+            a, r = ctx.map(R)
+            return metric.mean_over_hits(a, r), a
+
+        def fence():
+            ctx.synchronize()                           # hipStreamSynchronize (every one-shot call also ends synchronised)
 
     for _ in range(args.warmup):
         m, a = step()
-    ctx.timing_enable(0 if args.no_kernel_timing else (2 if args.kernel_timing == "all" else 1))
+    ctx.timing_enable({"pair-passes": 1, "all": 2, "none": 0}[args.kernel_timing])
     ctx.timing_reset()
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         m, a = step()
+    fence()
     dt = time.perf_counter() - t0
-    timing = ctx.timing_read() or {"k_select": (dt * 1e3, args.steps)}
+    if sharded_leg:
+        dt = ctx.allreduce_max(dt)                      # the slowest rank's clock
+    timing = ctx.timing_read()
     ctx.timing_enable(False)
+    if rank != 0:
+        if sharded_leg:
+            ctx.barrier()
+            ctx.comm_destroy()
+        return
 
     # parity flag: the first queries are a golden case of the unmodified reference
     from tests import cases
@@ -196,34 +307,37 @@ def main():
     k = g["ap"].shape[0]
     parity = bool(np.array_equal(a[:k], g["ap"], equal_nan=True))
 
-    NW = (b + 31) // 32
-    NB = b + 1
-    Qpad = (Q + 63) // 64 * 64
-    code_bytes = (Q + N) * NW * 4
-    LW = (spec["C"] + 63) // 64
-    geo_bytes = {  # algorithmic (compulsory) HBM bytes per launch, DESIGN.md section 4
-        "k_hist": code_bytes + NB * Qpad * 4,
-        "k_select": code_bytes + (Q + N) * LW * 8 + Q * R * 8,      # codes + labels in, >= R records of 8 B out per query
-        # fp4 images of the codes (4 bits per code bit, 64-bit granules) + packed codes + labels in, records out
-        "k_select_mx": (Q + N) * ((NW + 1) // 2) * 32 + code_bytes + (Q + N) * LW * 8 + Q * R * 8,
-    }
-    roof, per_kernel = kernel_rooflines(timing, args.steps, spec, geo_bytes)
-    ms = dt / args.steps * 1e3
+    per_step = dt / args.steps
     out = {
-        "metric": "queries/sec (mAP@R of Q queries vs N-code database, Hamming ranking)",
-        "value": Q / (dt / args.steps), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp4 (E2M1 0/+-1) x fp4 -> f32 exact distances; u32 xor+popcount elsewhere; f64 AP", "data": "synthetic",
-        "config": {"workload": "%s: Q=%d N=%d b=%d R=%d C=%d, planted codes" % (args.workload.upper(), Q, N, b, R, spec["C"]),
-                   "parallelism": "1 GPU"},
+        "metric": METRIC, "value": Q / per_step, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True,
+        "scaling": "strong" if sharded_leg or wl == "c4" else "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": "%s: Q=%d N=%d b=%d R=%d C=%d, %s codes" % (wl.upper(), Q, N, b, R, C, spec["kind"]),
+                   "parallelism": ("database sharded over %d GPU%s (%d rows on rank 0); native RCCL all-gather of shard "
+                                   "histograms / record counts and match bitmaps" % (world, "s" if world > 1 else "", rows))
+                   if sharded_leg else "1 GPU"},
         "map": float(m), "parity_vs_reference_golden": parity,
         "optimistic_runs": ctx.get_stat("optimistic_runs"), "optimistic_fallbacks": ctx.get_stat("optimistic_fallbacks"),
-        "pairs_per_sec": Q * N / (dt / args.steps),
-        "roofline": roof,
-        "kernels": {k_: {"avg_ms": round(v["avg_ms"], 5), "launches": v["launches"]} for k_, v in per_kernel.items()},
+        "pairs_per_sec": Q * N / per_step,
     }
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(c, spec)
+    if sharded_leg:
+        out["value_definition"] = "Q queries ranked against the WHOLE %d-row database per step / step time (max over ranks)" % N
+        out["weak_scaling_equivalent"] = {"definition": "query x per-GPU-shard evaluations per second = value * n_gpus",
+                                          "value": Q * world / per_step}
+    if timing:
+        roof, per_kernel = kernel_rooflines(timing, spec, rows, per_step)
+        out["roofline"] = roof
+        out["kernels"] = {k_: {"avg_ms": round(v["avg_ms"], 5), "launches": v["launches"]} for k_, v in per_kernel.items()}
+    if sharded_leg:
+        ctx.barrier()
+        ctx.comm_destroy()
+    ctx.close()
+    if world == 1 and not force:
+        if not args.no_h2d:
+            out["h2d_inclusive"], m2 = h2d_inclusive(spec, packed)
+            out["h2d_inclusive"]["map_equal_to_timed_path"] = bool(m2 == out["map"])
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, packed)
     print(json.dumps(out))
 
 

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "hg_barrier": [_p],
     "hg_scratch": [_p, C.c_int, _i64, C.POINTER(_p)],
     "hg_memcpy_dtod": [_p, _p, _p, _i64],
+    "hg_synchronize": [_p],
     "hg_set_stream": [_p, _p],
     "hg_set_option": [_p, C.c_char_p, _i64],
     "hg_get_stat": [_p, C.c_char_p, C.POINTER(_i64)],
@@ -349,6 +350,9 @@ class Context:
 
     def memcpy_dtod(self, dst, src, nbytes):
         check(self._lib.hg_memcpy_dtod(self._h, _p(dst), _p(src), int(nbytes)))
+
+    def synchronize(self):
+        check(self._lib.hg_synchronize(self._h))
 
     # -- tuning / timing ----------------------------------------------------------
     def set_stream(self, stream_handle):

@@ -10,6 +10,7 @@
 
 #include <rccl/rccl.h>     // types and enums only: the library itself is dlopen'ed by hg_comm_init (573 MB, not every process needs it)
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -247,7 +248,7 @@ struct hg_ctx {
     // collectives (RCCL over xGMI), one communicator per context; gathered[] are the landing zones of hg_allgather
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
-    DevBuf gathered[4], scratch[4], comm_tmp;
+    DevBuf gathered[4], scratch[4], comm_tmp, gath_idx, gath_dist;
 
     // timing
     int timing = 0;            // 0 off, 1 the pair passes only (hist, select), 2 every kernel
@@ -701,7 +702,7 @@ int hg_destroy(hg_ctx* c) {
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
-    c->comm_tmp.release();
+    c->comm_tmp.release(); c->gath_idx.release(); c->gath_dist.release();
     if (c->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->pin) (void)hipHostFree(c->pin);
@@ -1824,7 +1825,15 @@ int hg_comm_init(hg_ctx* c, const uint8_t* id, int rank, int world) {
     HG_TRY(rccl_load());
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
-    HG_NCCL(g_rccl.CommInitRank(&c->comm, world, u, rank));
+    // RCCL prints a version banner on stdout when a communicator comes up; stdout belongs to the caller (bench.py's
+    // one JSON line): send whatever the library prints during the call to stderr instead
+    fflush(stdout);
+    const int saved = dup(1);
+    if (saved >= 0) (void)dup2(2, 1);
+    const ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    fflush(stdout);
+    if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
+    if (r != ncclSuccess) { c->comm = nullptr; return fail(HG_ERR_HIP, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
     c->comm_rank = rank;
     c->comm_world = world;
     return HG_OK;
@@ -1871,14 +1880,14 @@ int hg_allgather_topr(hg_ctx* c) {
     if (!c->comm) return fail(HG_ERR_STATE, "hg_allgather_topr: no communicator (hg_comm_init)");
     const i64 n = (i64)c->geo.Q * c->geo.R;
     const int G = c->comm_world;
-    HG_TRY(c->gathered[2].reserve((size_t)n * 4 * G));
-    HG_TRY(c->gathered[3].reserve((size_t)n * G));
+    HG_TRY(c->gath_idx.reserve((size_t)n * 4 * G));       // own landing zones: hg_allgather's slots may hold live data
+    HG_TRY(c->gath_dist.reserve((size_t)n * G));
     c->t_begin(KI_COMM);
-    HG_NCCL(g_rccl.AllGather(c->out_idx.p, c->gathered[2].p, (size_t)n * 4, ncclUint8, c->comm, c->stream));
-    HG_NCCL(g_rccl.AllGather(c->out_dist.p, c->gathered[3].p, (size_t)n, ncclUint8, c->comm, c->stream));
+    HG_NCCL(g_rccl.AllGather(c->out_idx.p, c->gath_idx.p, (size_t)n * 4, ncclUint8, c->comm, c->stream));
+    HG_NCCL(g_rccl.AllGather(c->out_dist.p, c->gath_dist.p, (size_t)n, ncclUint8, c->comm, c->stream));
     c->t_end();
     c->t_begin(KI_MERGE);
-    hipLaunchKernelGGL(k_min_topr, dim3(grid_for(n)), dim3(256), 0, c->stream, c->gathered[2].as<u32>(), c->gathered[3].as<u8>(),
+    hipLaunchKernelGGL(k_min_topr, dim3(grid_for(n)), dim3(256), 0, c->stream, c->gath_idx.as<u32>(), c->gath_dist.as<u8>(),
                        c->out_idx.as<u32>(), c->out_dist.as<u8>(), n, G);
     c->t_end();
     HG_TRY(c->check_launch("k_min_topr"));
@@ -1917,6 +1926,12 @@ int hg_memcpy_dtod(hg_ctx* c, void* dev_dst, const void* dev_src, int64_t nbytes
     HG_TRY(c->use());
     if (nbytes) HG_HIP(hipMemcpyAsync(dev_dst, dev_src, (size_t)nbytes, hipMemcpyDeviceToDevice, c->stream));
     return c->stage_end();
+}
+
+int hg_synchronize(hg_ctx* c) {
+    if (!c) return fail(HG_ERR_ARG, "hg_synchronize: null context");
+    HG_TRY(c->use());
+    return c->sync();
 }
 
 int hg_set_stream(hg_ctx* c, void* stream) {
@@ -2005,6 +2020,7 @@ int hg_trim(hg_ctx* c) {
     for (auto* d : work) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
+    c->gath_idx.release(); c->gath_dist.release();
     c->dbx_valid = c->qx_valid = c->dbx2_valid = c->qx2_valid = false;
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     c->stage &= (ST_DB | ST_Q);

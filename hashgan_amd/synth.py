@@ -15,10 +15,11 @@ import numpy as np
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-def splitmix64(seed, n):
-    """n uint64 draws of the splitmix64 generator started at `seed`."""
+def splitmix64(seed, n, offset=0):
+    """n uint64 draws of the splitmix64 generator started at `seed`, skipping the first `offset` (so a shard can
+    draw exactly its own rows of a global array)."""
     with np.errstate(over="ignore"):
-        i = np.arange(1, int(n) + 1, dtype=np.uint64)
+        i = np.arange(1 + int(offset), int(offset) + int(n) + 1, dtype=np.uint64)
         z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
@@ -28,6 +29,24 @@ def splitmix64(seed, n):
 def _uniform01(seed, n):
     """n doubles in [0, 1) with 53 random bits each."""
     return (splitmix64(seed, n) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def random_code_words(seed, n, b, row_offset=0):
+    """random_bits(seed, ...)[row_offset : row_offset + n] already packed: uint64 [n, ceil(b/64)], bit j of a code =
+    bit j % 64 of word j // 64, pad bits zero (hashgan_amd.metric.pack_codes of the bit matrix, without the detour)."""
+    words = (b + 63) // 64
+    raw = splitmix64(seed, n * words, offset=int(row_offset) * words).reshape(n, words)
+    if b % 64:
+        raw[:, -1] &= np.uint64((1 << (b % 64)) - 1)
+    return raw
+
+
+def onehot_label_words(seed, n, C, row_offset=0):
+    """onehot_labels(seed, ...)[row_offset : row_offset + n] packed like hashgan_amd.metric.pack_labels."""
+    cls = (splitmix64(seed, n, offset=row_offset) % np.uint64(C)).astype(np.int64)
+    out = np.zeros((n, (C + 63) // 64), dtype=np.uint64)
+    out[np.arange(n), cls // 64] = np.uint64(1) << (cls % 64).astype(np.uint64)
+    return out
 
 
 def random_bits(seed, n, b):

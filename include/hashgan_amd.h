@@ -203,6 +203,9 @@ int hg_barrier(hg_ctx* ctx);
 int hg_scratch(hg_ctx* ctx, int slot, int64_t nbytes, void** dev_ptr);
 int hg_memcpy_dtod(hg_ctx* ctx, void* dev_dst, const void* dev_src, int64_t nbytes);
 
+/* Wait until everything the context has enqueued is done (with "stage_sync" = 0 nothing else does). */
+int hg_synchronize(hg_ctx* ctx);
+
 /* Run the context on a stream of the caller's (NULL: back to a private one).  With option
  * "stage_sync" = 0 the staged calls (hg_allgather included) only enqueue: every stage and the collectives
  * between them then sit on ONE stream with no host synchronisation except the bet's verdict and the

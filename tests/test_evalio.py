@@ -54,4 +54,11 @@ def test_evaluate_like_main_py(case_cache):
                               c["dbbits"].shape[0], c["b"], c["dblab"].shape[1])
     test = evalio.stack_batches([np.tanh((c["qbits"].astype(np.float32) * 2 - 1) * 2)], [c["qlab"]],
                                 c["qbits"].shape[0], c["b"], c["qlab"].shape[1])
-    assert evalio.report(evalio.evaluate(db, test, c["R"])) == g["map"]
+    # the hashing evaluation proper: sign() first, Hamming ranking -> the golden of the +-1 codes
+    assert evalio.report(evalio.evaluate(db, test, c["R"], binarize=True)) == g["map"]
+    # the default ranks the raw tanh features by inner product, like main.py:164 does -- a different number
+    from hashgan_amd import MAPs
+    m = MAPs(c["R"])
+    raw = m.get_maps_by_feature(db, test)
+    m.close()
+    assert evalio.evaluate(db, test, c["R"]) == raw != g["map"]
