@@ -325,9 +325,15 @@ def main():
         out["weak_scaling_equivalent"] = {"definition": "query x per-GPU-shard evaluations per second = value * n_gpus",
                                           "value": Q * world / per_step}
     if timing:
+        span = timing.pop("step_gpu_span", None)
         roof, per_kernel = kernel_rooflines(timing, spec, rows, per_step)
         out["roofline"] = roof
         out["kernels"] = {k_: {"avg_ms": round(v["avg_ms"], 5), "launches": v["launches"]} for k_, v in per_kernel.items()}
+        if span:            # HIP events around the whole step on the GPU: what is left of the wall time is the host's
+            busy = span[0] / max(span[1], 1)
+            out["step_accounting"] = {"gpu_span_ms": round(busy, 5), "host_and_launch_ms": round(per_step * 1e3 - busy, 5),
+                                      "kernels_timed_ms": round(sum(v["avg_ms"] * v["launches"] for v in per_kernel.values()) / args.steps, 5),
+                                      "graph_replays": ctx.get_stat("graph_replays"), "graph_captures": ctx.get_stat("graph_captures")}
     if sharded_leg:
         ctx.barrier()
         ctx.comm_destroy()

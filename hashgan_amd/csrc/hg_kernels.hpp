@@ -795,6 +795,7 @@ struct RankArgs {
     // direct mode (R = N on one shard): there are no records -- "record" i of a query is row i of the shard,
     // its distance and match bit are computed from the codes and labels on the fly, in both passes
     int direct;
+    int rec8;              // records are one byte {match:1 | dist:7} (compact select) instead of 8 bytes
     const u32* db;         // [N][NW]
     const u64* dblab;      // [N][LW]
     const u32* qc;         // [Q][NW]
@@ -879,6 +880,10 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
             u64 any = 0;
             for (int k = 0; k < g.LW && k < 2; ++k) any |= dl[k] & a.dblab[n * g.LW + k];
             return make_rec(g.idx_base + (u32)n, d, any != 0);
+        }
+        if (a.rec8) {
+            const u32 m = ((const u8*)cand)[(i64)q * a.crow + (i64)w.s * a.cap + i];
+            return (u64)((m & 0x7Fu) | ((m >> 7) << 8)) << 32;
         }
         return row[(i64)w.s * a.cap + i];
     };

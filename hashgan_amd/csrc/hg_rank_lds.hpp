@@ -23,6 +23,7 @@ struct RankLdsArgs {
     u32 cap;
     i64 crow;
     int want_lists;
+    int rec8;              // records are one byte {match:1 | dist:7} (compact select, no lists) instead of 8-byte {idx, dist, match}
     i64 RW;
     int lds_recs;          // record capacity of the LDS arrays
     // several shards (k_rank_fused's modes): 0 fused; 1 histogram phase only (per-wave histograms -> hwq,
@@ -101,33 +102,65 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_lds(const u64* __restrict__ 
         return;
     }
 
-    // ---- copy the records into LDS: wave w takes slices w, w + NWAV, ...; two slices (four loads) in flight ----
+    // ---- copy the records into LDS: wave w takes slices w, w + NWAV, ...; many slices' loads in flight ----
     const u64* __restrict__ row = cand + (i64)q * a.crow;
-    constexpr int NSL = 8;                            // slices per iteration: 2 NSL loads in flight per wavefront
-    for (int s = wave; s < S; s += NSL * NWAV) {
-        u32 p[NSL], c[NSL];
-        u64 v0[NSL], v1[NSL];
+    if (a.rec8) {
+        // compact records, one byte {match:1 | dist:7} each: a lane fetches TWO (one 16-bit load covers 128 records of a
+        // slice; capacities are multiples of 16, so the odd byte past the count is still inside the slice)
+        const u8* __restrict__ row8 = (const u8*)cand + (i64)q * a.crow;
+        constexpr int NSL = 16;
+        for (int s = wave; s < S; s += NSL * NWAV) {
+            u32 p[NSL], c[NSL], v[NSL];
 #pragma unroll
-        for (int k = 0; k < NSL; ++k) {
-            const int sk = s + k * NWAV;
-            const bool ok = sk < S;
-            p[k] = ok ? pref[sk] : 0u;
-            c[k] = ok ? pref[sk + 1] - p[k] : 0u;
-            const u64* r = row + (i64)(ok ? sk : s) * a.cap;
-            v0[k] = (u32)lane < c[k] ? r[lane] : 0ull;
-            v1[k] = (u32)lane + 64 < c[k] ? r[lane + 64] : 0ull;
+            for (int k = 0; k < NSL; ++k) {
+                const int sk = s + k * NWAV;
+                const bool ok = sk < S;
+                p[k] = ok ? pref[sk] : 0u;
+                c[k] = ok ? pref[sk + 1] - p[k] : 0u;
+                const u8* r = row8 + (i64)(ok ? sk : s) * a.cap;
+                v[k] = 2u * (u32)lane < c[k] ? (u32)*(const unsigned short*)(r + 2 * lane) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) {
+                const u32 i0 = 2u * lane, m0 = v[k] & 0xFFu, m1 = v[k] >> 8;
+                if (i0 < c[k]) rec16[p[k] + i0] = (unsigned short)((m0 & 0x7Fu) | ((m0 >> 7) << 8));
+                if (i0 + 1 < c[k]) rec16[p[k] + i0 + 1] = (unsigned short)((m1 & 0x7Fu) | ((m1 >> 7) << 8));
+                if (c[k] > 128) {                     // long slices (rare)
+                    const u8* r = row8 + (i64)(s + k * NWAV) * a.cap;
+                    for (u32 i = lane + 128; i < c[k]; i += 64) {
+                        const u32 m = r[i];
+                        rec16[p[k] + i] = (unsigned short)((m & 0x7Fu) | ((m >> 7) << 8));
+                    }
+                }
+            }
         }
+    } else {
+        constexpr int NSL = 8;                        // slices per iteration: 2 NSL loads in flight per wavefront
+        for (int s = wave; s < S; s += NSL * NWAV) {
+            u32 p[NSL], c[NSL];
+            u64 v0[NSL], v1[NSL];
 #pragma unroll
-        for (int k = 0; k < NSL; ++k) {
-            const u32 i0 = lane, i1 = lane + 64;
-            if (i0 < c[k]) { rec16[p[k] + i0] = (unsigned short)(v0[k] >> 32); if (a.want_lists) idx32[p[k] + i0] = (u32)v0[k]; }
-            if (i1 < c[k]) { rec16[p[k] + i1] = (unsigned short)(v1[k] >> 32); if (a.want_lists) idx32[p[k] + i1] = (u32)v1[k]; }
-            if (c[k] > 128) {                         // long slices (rare)
-                const u64* r = row + (i64)(s + k * NWAV) * a.cap;
-                for (u32 i = lane + 128; i < c[k]; i += 64) {
-                    const u64 v = r[i];
-                    rec16[p[k] + i] = (unsigned short)(v >> 32);
-                    if (a.want_lists) idx32[p[k] + i] = (u32)v;
+            for (int k = 0; k < NSL; ++k) {
+                const int sk = s + k * NWAV;
+                const bool ok = sk < S;
+                p[k] = ok ? pref[sk] : 0u;
+                c[k] = ok ? pref[sk + 1] - p[k] : 0u;
+                const u64* r = row + (i64)(ok ? sk : s) * a.cap;
+                v0[k] = (u32)lane < c[k] ? r[lane] : 0ull;
+                v1[k] = (u32)lane + 64 < c[k] ? r[lane + 64] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) {
+                const u32 i0 = lane, i1 = lane + 64;
+                if (i0 < c[k]) { rec16[p[k] + i0] = (unsigned short)(v0[k] >> 32); if (a.want_lists) idx32[p[k] + i0] = (u32)v0[k]; }
+                if (i1 < c[k]) { rec16[p[k] + i1] = (unsigned short)(v1[k] >> 32); if (a.want_lists) idx32[p[k] + i1] = (u32)v1[k]; }
+                if (c[k] > 128) {                     // long slices (rare)
+                    const u64* r = row + (i64)(s + k * NWAV) * a.cap;
+                    for (u32 i = lane + 128; i < c[k]; i += 64) {
+                        const u64 v = r[i];
+                        rec16[p[k] + i] = (unsigned short)(v >> 32);
+                        if (a.want_lists) idx32[p[k] + i] = (u32)v;
+                    }
                 }
             }
         }

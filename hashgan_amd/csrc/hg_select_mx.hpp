@@ -33,6 +33,7 @@
 // two-phase drain (push / emit, below) twice per window.
 #pragma once
 #include "hg_kernels.hpp"
+#include "hg_mx_drain.hpp"
 
 namespace hg {
 
@@ -42,8 +43,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MX_WT = 8;                // row tiles per window
 constexpr int MX_WROWS = 16 * MX_WT;    // rows per lane-half per window
-constexpr int mx_qcap(int QT) { return 64 * 2 * QT; }   // hit-queue entries (8 bytes) per wavefront: one per lane, query tile and mask word of HALF a window
-constexpr u32 MX_POS_BITS = 17;         // slice positions in a queue entry: cap < 2^17
 
 // 8 code bits -> 8 nibbles, bit j at bit 4 j
 __device__ __forceinline__ u32 spread8(u32 y) {
@@ -97,10 +96,11 @@ struct MxLds {                 // byte offsets inside the block's dynamic LDS
     int a, codes, labels;      // inside one stage
     int stage;                 // stage size
     int qcodes, qlabels;       // query tables (after the two stages)
-    int queue;                 // per-wave hit queues (MX_QCAP entries of 8 bytes each)
+    int queue;                 // per-wave hit queues (mx_qcap entries of 8 bytes each)
+    int rings;                 // per-wave slice rings (compact records only)
     int total;
 };
-__host__ __device__ inline MxLds mx_lds_layout(int NW, int LW, int QT) {
+__host__ __device__ inline MxLds mx_lds_layout(int NW, int LW, int QT, bool compact) {
     const int QBLK = WPB * 32 * QT;            // queries per block
     const int NM = (NW + 1) / 2;
     MxLds l;
@@ -112,7 +112,8 @@ __host__ __device__ inline MxLds mx_lds_layout(int NW, int LW, int QT) {
     l.qcodes = 2 * l.stage;
     l.qlabels = l.qcodes + QBLK * NW * 4;
     l.queue = l.qlabels + QBLK * LW * 8;
-    l.total = l.queue + WPB * mx_qcap(QT) * 8;
+    l.rings = l.queue + WPB * mx_qcap(QT, compact) * 8;
+    l.total = l.rings + WPB * mx_ring_bytes(QT, compact);
     return l;
 }
 
@@ -123,18 +124,18 @@ __host__ __device__ inline MxLds mx_lds_layout(int NW, int LW, int QT) {
 // Geo as set by the launcher: g.nQT = query blocks (of 128 QT queries) per segment pair, g.nBlk = blocks.
 // QT: query tiles (of 32) per wavefront -- 4: 512 queries per block, ~180 VGPRs, 2 wavefronts per SIMD;
 //     2: 256 queries per block, 4 wavefronts per SIMD.
-template <int NW, int LW, int QT>
+// COMPACT: one-byte records through per-slice LDS rings (AP only -- hg_mx_drain.hpp); else 8-byte records with the index.
+template <int NW, int LW, int QT, bool COMPACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QT == 4 ? 2 : 4, QT == 4 ? 2 : 4)))
 void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const u8* __restrict__ qx,
                  const u32* __restrict__ db, const u8* __restrict__ dbx, const u64* __restrict__ dblab,
                  const SelArgs a, u64* __restrict__ cand, const Geo g) {
     extern __shared__ __attribute__((aligned(1024))) u8 mxlds[];
     constexpr int WQ = 32 * QT;                          // queries per wavefront
-    constexpr int MX_QCAP = mx_qcap(QT);
     constexpr int NM = (NW + 1) / 2;
     constexpr int CB = NW * 4, LB = LW * 8;
     constexpr int LWA = LW > 0 ? LW : 1;
-    const MxLds L = mx_lds_layout(NW, LW, QT);
+    const MxLds L = mx_lds_layout(NW, LW, QT, COMPACT);
 
     const int lb = logical_block(g.nBlk);
     if (lb < 0) return;                                   // whole block: no barrier is skipped by a part of it
@@ -175,25 +176,27 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
     }
     i32x4 bq[QT][NM];
     f32x16 biasv[QT];
-    u32 cnt[QT], dropped[QT];                                        // records in the lane's slices so far / lost to overflow
-    u32 capl[QT];                                                    // slice capacity (0: dead lane)
+    MxDrain<NW, LW, QT, MX_WROWS, COMPACT> dr;                        // slice cursors, hit queue, record rings
+    dr.init(mxlds, MxDrainLds{L.qcodes, L.qlabels, L.queue, L.rings, L.codes, L.labels}, wave, lane, qb, sp, a.cap, a.crow, a.probe,
+            g.idx_base, g.L, cand);
+    bool far[QT];                                                    // compact records hold 7-bit distances: a cut beyond 127 loses the bet
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = q0w + t * 32 + j;
-        const bool live = q < g.Q && seg_ok;
+        bool live = q < g.Q && seg_ok;
         int pop = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) pop += __builtin_popcount(q < g.Q ? qc[(i64)q * NW + w] : 0u);
 #pragma unroll
         for (int m = 0; m < NM; ++m) bq[t][m] = *(const i32x4*)(qx + (((i64)(q0w / 32 + t) * NM + m) * 64 + lane) * 16);
         // past the query's last tie-collecting segment only rows strictly closer than the guess are taken
-        const int T = live ? a.T[q] - (s > a.sstar[q] ? 1 : 0) : -1;
+        int T = live ? a.T[q] - (s > a.sstar[q] ? 1 : 0) : -1;
+        far[t] = COMPACT && NW >= 4 && T > 127;
+        if (far[t]) { live = false; T = -1; }
         const float bias = (float)(pop - T - 1);         // dist + (-T - 1) < 0  <=>  dist <= T;  dead lane: never
 #pragma unroll
         for (int r = 0; r < 16; ++r) biasv[t][r] = bias;
-        cnt[t] = 0;
-        capl[t] = live ? a.cap : 0u;
-        dropped[t] = 0;
+        dr.set_live(t, live);
     }
 
     // ---- window staging: global -> LDS, the four waves split the copy instructions ----
@@ -225,79 +228,6 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
             u8* dst = st + (is_lab ? L.labels : L.codes) + hh * MX_WROWS * rowb + piece * 1024;
             if (piece * 1024 + lane * 16 < MX_WROWS * rowb) HG_GLDS16(src, dst);
         }
-    };
-
-    // ---- drain, in two phases.  Hits are rare (~1 per lane, window and query tile) and unevenly spread over
-    // the lanes, so a loop in which every lane works off its own hit masks keeps most lanes idle and pays its
-    // ~40 instructions per round for the busiest lane's count.  Instead:
-    //   push   branch-free, per (query tile, 32-row mask word): every lane whose word is non-zero appends
-    //          {word | slice position of its first hit | lane | tile | word index} to the wavefront's queue in
-    //          LDS (slot = rank among the pushing lanes) and advances its slice cursor by the word's popcount
-    //          -- the positions fix the record order, so the queue order is free;
-    //   emit   64 queue entries at a time, every lane busy: walk the word's bits (usually one), exact distance
-    //          and match bit from the packed rows staged in LDS, one 8-byte store per hit.
-    // The queue is drained twice per window; half a window has at most 64 x QT x 2 words, so it (MX_QCAP) cannot overflow,
-    // dense windows included.
-    u64* queue = (u64*)(mxlds + L.queue) + wave * MX_QCAP;
-    u32 qfill = 0;                                                   // entries in the queue (wave-uniform)
-    auto push = [&](const int t, const int w, const u32 word, u32& cntt, const u32 caplt, u32& droppedt) {
-        const u64 bal = __ballot(word != 0u);
-        const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-        if (word != 0u)
-            queue[slot] = ((u64)word << 32) | (u64)(cntt | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
-                                                    ((u32)w << (MX_POS_BITS + 8)));
-        const u32 want = cntt + (u32)__builtin_popcount(word);
-        const u32 got = want < caplt ? want : caplt;                // the slice holds caplt records; the rest is lost
-        droppedt += want - got;
-        cntt = got;
-        qfill += (u32)__builtin_popcountll(bal);
-    };
-    auto emit = [&](const i64 win, const u8* st) {
-        wave_lds_sync();
-        const u32 n = (kProbes && (a.probe & 8)) ? 0u : qfill;
-        for (u32 i = lane; i < n; i += 64) {
-            const u64 e = queue[i];
-            u32 word = (u32)(e >> 32);
-            const u32 desc = (u32)e;
-            const u32 pos = desc & ((1u << MX_POS_BITS) - 1u), src = (desc >> MX_POS_BITS) & 63u;
-            const u32 t = (desc >> (MX_POS_BITS + 6)) & 3u, w = (desc >> (MX_POS_BITS + 8)) & 3u;
-            const u32 hs = src >> 5;                                  // the source lane's half = segment
-            const int ql = wave * WQ + (int)t * 32 + (int)(src & 31u);    // its query, block-local
-            u32 qcw[NW];
-            u64 qlw[LWA];
-#pragma unroll
-            for (int k = 0; k < NW; ++k) qcw[k] = ((const u32*)(mxlds + L.qcodes + ql * CB))[k];
-#pragma unroll
-            for (int k = 0; k < LWA; ++k) qlw[k] = LW > 0 ? ((const u64*)(mxlds + L.qlabels + ql * LB))[k] : 0ull;
-            const i64 q = (i64)qb * (WPB * WQ) + ql;
-            const i64 seg = 2 * sp + (int)hs;
-            u64* out = cand + q * a.crow + seg * a.cap + pos;
-            u32 room = a.cap - pos;
-            const u32 row0 = hs * MX_WROWS + w * 32;                  // first row of the word in the stage tables
-            const u32 idx0 = g.idx_base + (u32)(seg * g.L + win * MX_WROWS) + w * 32;
-            while (word) {
-                const int k = 31 - __builtin_clz(word);
-                word ^= 1u << k;
-                const u32 r = 31 - k;                                 // highest bit = earliest row
-                const u32* rp = (const u32*)(st + L.codes + (row0 + r) * CB);
-                u32 d = 0;
-#pragma unroll
-                for (int c = 0; c < NW; ++c) d += __builtin_popcount(qcw[c] ^ rp[c]);
-                u64 any = 0;
-                if (LW > 0) {
-                    const u64* lp = (const u64*)(st + L.labels + (row0 + r) * LB);
-#pragma unroll
-                    for (int c = 0; c < LWA; ++c) any |= lp[c] & qlw[c];
-                }
-                if (room) {
-                    if (!(kProbes && (a.probe & 4)) || d == 0x7fffffffu) *out = make_rec(idx0 + r, d, any != 0);
-                    ++out;
-                    --room;
-                }
-            }
-        }
-        wave_lds_sync();
-        qfill = 0;
     };
 
     const int scale1 = 0x7F7F7F7F;                                   // E8M0 block scales: 2^0
@@ -362,26 +292,26 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         }
         if (kProbes && (a.probe & 2)) {                                      // measurement probe: no drain
 #pragma unroll
-            for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][3] == 0x1234567u) dropped[t]++;
+            for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][3] == 0x1234567u) dr.flags |= 0x100u << t;
         } else {
-#pragma unroll
+#pragma unroll 1
             for (int hw = 0; hw < 2; ++hw) {                         // two drains per window: half the queue, one block more per CU
+                u32 wd[QT][2];
 #pragma unroll
-                for (int t = 0; t < QT; ++t)
-#pragma unroll
-                    for (int w = 2 * hw; w < 2 * hw + 2; ++w) push(t, w, m[t][w], cnt[t], capl[t], dropped[t]);
-                emit(win, st);
+                for (int t = 0; t < QT; ++t) { wd[t][0] = hw ? m[t][2] : m[t][0]; wd[t][1] = hw ? m[t][3] : m[t][1]; }
+                dr.drain(wd, 2 * hw, win, st);
             }
         }
     }
+    dr.finish();
 
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = q0w + t * 32 + j;
         if (seg_ok && q < g.Qpad) {
             const bool live = q < g.Q;
-            a.sl_cnt[(i64)s * g.Qpad + q] = live ? cnt[t] : 0u;
-            if (dropped[t] && live) a.fail[q] = 1u;
+            a.sl_cnt[(i64)s * g.Qpad + q] = live ? dr.cnt[t] : 0u;
+            if ((dr.lost(t) || far[t]) && live) a.fail[q] = 1u;
         }
     }
 }

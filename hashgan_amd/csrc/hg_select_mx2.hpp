@@ -32,7 +32,6 @@ namespace hg {
 constexpr int M2_QT = 2;                 // query tiles (of 32) per wavefront
 constexpr int M2_WT = 4;                 // 32-row tiles per window
 constexpr int M2_WROWS = 32 * M2_WT;     // rows per lane-half per window (= MX_WROWS)
-constexpr int M2_QCAP = 64 * M2_QT * M2_WT / 2;   // queue entries (8 bytes) per wavefront: one per lane, query tile and row tile of HALF a window
 
 // row rho (0..31) of a 32-row group -> (register r, field f)
 __host__ __device__ inline void m2_place(int rho, int& r, int& f) {
@@ -72,8 +71,8 @@ __global__ __launch_bounds__(256) void k_expand_queries2(const u32* __restrict__
     qx[base + 32] = o;
 }
 
-struct Mx2Lds { int a, codes, labels, stage, qcodes, qlabels, queue, total; };
-__host__ __device__ inline Mx2Lds mx2_lds_layout(int NW, int LW) {
+struct Mx2Lds { int a, codes, labels, stage, qcodes, qlabels, queue, rings, total; };
+__host__ __device__ inline Mx2Lds mx2_lds_layout(int NW, int LW, bool compact) {
     Mx2Lds l;
     l.a = 0;
     l.codes = M2_WT * NW * 1024;
@@ -83,12 +82,13 @@ __host__ __device__ inline Mx2Lds mx2_lds_layout(int NW, int LW) {
     l.qcodes = 2 * l.stage;
     l.qlabels = l.qcodes + WPB * 32 * M2_QT * NW * 4;
     l.queue = l.qlabels + WPB * 32 * M2_QT * LW * 8;
-    l.total = l.queue + WPB * M2_QCAP * 8;
+    l.rings = l.queue + WPB * mx_qcap(M2_QT, compact) * 8;
+    l.total = l.rings + WPB * mx_ring_bytes(M2_QT, compact);
     return l;
 }
 
 // Geo as set by the launcher: g.nQT = query blocks (of 256 queries) per segment pair, g.nBlk = blocks; g.L % 32 == 0.
-template <int NW, int LW>
+template <int NW, int LW, bool COMPACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, const u8* __restrict__ qx,
                   const u32* __restrict__ db, const u8* __restrict__ dbx, const u64* __restrict__ dblab,
@@ -98,7 +98,7 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
     constexpr int QT = M2_QT, WQ = 32 * QT;
     constexpr int CB = NW * 4, LB = LW * 8;
     constexpr int LWA = LW > 0 ? LW : 1;
-    const Mx2Lds L = mx2_lds_layout(NW, LW);
+    const Mx2Lds L = mx2_lds_layout(NW, LW, COMPACT);
 
     const int lb = logical_block(g.nBlk);
     if (lb < 0) return;                                   // whole block: no barrier is skipped by a part of it
@@ -136,7 +136,9 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
     }
     i32x4 bq[QT][NW];
     f32x16 biasv[QT];
-    u32 cnt[QT], dropped[QT], capl[QT];
+    MxDrain<NW, LW, QT, M2_WROWS, COMPACT> dr;                        // slice cursors, hit queue, record rings (hg_mx_drain.hpp)
+    dr.init(mxlds, MxDrainLds{L.qcodes, L.qlabels, L.queue, L.rings, L.codes, L.labels}, wave, lane, qb, sp, a.cap, a.crow, a.probe,
+            g.idx_base, g.L, cand);
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = q0w + t * 32 + j;
@@ -150,9 +152,7 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
         const float base = (float)(T - pop);             // T - dist = base + sum_k x_k s_k;  dead lane: T = -1, never >= 0
 #pragma unroll
         for (int r = 0; r < 16; ++r) biasv[t][r] = 8388608.0f + (base + (float)(128 << (r & 3))) * 2049.0f;
-        cnt[t] = 0;
-        capl[t] = live ? a.cap : 0u;
-        dropped[t] = 0;
+        dr.set_live(t, live);
     }
 
     // ---- window staging (k_select_mx's, with 32-row tiles) ----
@@ -181,70 +181,6 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
             u8* dst = st + (is_lab ? L.labels : L.codes) + hh * M2_WROWS * rowb + piece * 1024;
             if (piece * 1024 + lane * 16 < M2_WROWS * rowb) HG_GLDS16(src, dst);
         }
-    };
-
-    // ---- drain: k_select_mx's push (branch-free, one 8-byte entry per lane, query tile and 32-row tile with a
-    // hit) + dense emit; the tile's mask word arrives compacted: bit k <-> row 31 - k of the tile ----
-    u64* queue = (u64*)(mxlds + L.queue) + wave * M2_QCAP;
-    u32 qfill = 0;
-    auto push = [&](const int t, const int T, const u32 word, u32& cntt, const u32 caplt, u32& droppedt) {
-        const u64 bal = __ballot(word != 0u);
-        const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-        if (word != 0u)
-            queue[slot] = ((u64)word << 32) | (u64)(cntt | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
-                                                    ((u32)T << (MX_POS_BITS + 8)));
-        const u32 want = cntt + (u32)__builtin_popcount(word);
-        const u32 got = want < caplt ? want : caplt;
-        droppedt += want - got;
-        cntt = got;
-        qfill += (u32)__builtin_popcountll(bal);
-    };
-    auto emit = [&](const i64 win, const u8* st) {
-        wave_lds_sync();
-        const u32 n = (kProbes && (a.probe & 8)) ? 0u : qfill;
-        for (u32 i = lane; i < n; i += 64) {
-            const u64 e = queue[i];
-            u32 word = (u32)(e >> 32);
-            const u32 desc = (u32)e;
-            const u32 pos = desc & ((1u << MX_POS_BITS) - 1u), src = (desc >> MX_POS_BITS) & 63u;
-            const u32 t = (desc >> (MX_POS_BITS + 6)) & 3u, T = (desc >> (MX_POS_BITS + 8)) & 3u;
-            const u32 hs = src >> 5;
-            const int ql = wave * WQ + (int)t * 32 + (int)(src & 31u);
-            u32 qcw[NW];
-            u64 qlw[LWA];
-#pragma unroll
-            for (int k = 0; k < NW; ++k) qcw[k] = ((const u32*)(mxlds + L.qcodes + ql * CB))[k];
-#pragma unroll
-            for (int k = 0; k < LWA; ++k) qlw[k] = LW > 0 ? ((const u64*)(mxlds + L.qlabels + ql * LB))[k] : 0ull;
-            const i64 q = (i64)qb * (WPB * WQ) + ql;
-            const i64 seg = 2 * sp + (int)hs;
-            u64* out = cand + q * a.crow + seg * a.cap + pos;
-            u32 room = a.cap - pos;
-            const u32 row0 = hs * M2_WROWS + T * 32;
-            const u32 idx0 = g.idx_base + (u32)(seg * g.L + win * M2_WROWS) + T * 32;
-            while (word) {
-                const int k = 31 - __builtin_clz(word);
-                word ^= 1u << k;
-                const u32 r = 31 - k;                                 // highest bit = earliest row
-                const u32* rp = (const u32*)(st + L.codes + (row0 + r) * CB);
-                u32 d = 0;
-#pragma unroll
-                for (int c = 0; c < NW; ++c) d += __builtin_popcount(qcw[c] ^ rp[c]);
-                u64 any = 0;
-                if (LW > 0) {
-                    const u64* lp = (const u64*)(st + L.labels + (row0 + r) * LB);
-#pragma unroll
-                    for (int c = 0; c < LWA; ++c) any |= lp[c] & qlw[c];
-                }
-                if (room) {
-                    if (!(kProbes && (a.probe & 4)) || d == 0x7fffffffu) *out = make_rec(idx0 + r, d, any != 0);
-                    ++out;
-                    --room;
-                }
-            }
-        }
-        wave_lds_sync();
-        qfill = 0;
     };
 
     const int scale_b = 0x7F7F7F7F;                                  // E8M0 2^0
@@ -315,26 +251,26 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
         }
         if (kProbes && (a.probe & 2)) {                                      // measurement probe: no drain
 #pragma unroll
-            for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][3] == 0x1234567u) dropped[t]++;
+            for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][3] == 0x1234567u) dr.flags |= 0x100u << t;
         } else {
-#pragma unroll
+#pragma unroll 1
             for (int hw = 0; hw < 2; ++hw) {                         // two drains per window: half the queue
+                u32 wd[QT][2];
 #pragma unroll
-                for (int t = 0; t < QT; ++t)
-#pragma unroll
-                    for (int T = 2 * hw; T < 2 * hw + 2; ++T) push(t, T, m[t][T], cnt[t], capl[t], dropped[t]);
-                emit(win, st);
+                for (int t = 0; t < QT; ++t) { wd[t][0] = hw ? m[t][2] : m[t][0]; wd[t][1] = hw ? m[t][3] : m[t][1]; }
+                dr.drain(wd, 2 * hw, win, st);
             }
         }
     }
+    dr.finish();
 
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = q0w + t * 32 + j;
         if (seg_ok && q < g.Qpad) {
             const bool live = q < g.Q;
-            a.sl_cnt[(i64)s * g.Qpad + q] = live ? cnt[t] : 0u;
-            if (dropped[t] && live) a.fail[q] = 1u;
+            a.sl_cnt[(i64)s * g.Qpad + q] = live ? dr.cnt[t] : 0u;
+            if (dr.lost(t) && live) a.fail[q] = 1u;
         }
     }
 }

@@ -224,21 +224,28 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * then fails and the exact sequence runs, so results stay right; the production library refuses the key),
  * "select_qt" (k_select_mx query tiles per wavefront: 2 or 4), "select_packed" (k_select_mx2, two rows per
  * MFMA accumulator: 1 = for codes of <= 32 bits, 2 = also for 33..64 bits, 0 = never), "rank_lds" (0/1),
- * "real_queries_per_lane", "real_segment_bytes" (real-valued path). */
+ * "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
+ * {match, dist} through per-slice LDS rings instead of 8-byte {idx, dist, match} records),
+ * "real_queries_per_lane", "real_segment_bytes" (real-valued path), "step_graph" (1, default: hg_map captures its
+ * one-shot sequence into a hipGraph the second time it sees the same problem and replays it afterwards; 0: always
+ * enqueue kernel by kernel). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
 /* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
  * (single queries rerun exactly after losing their bet), "last_optimistic", "device_bytes", "segments",
  * "segment_rows", "slice_capacity", "record_row"; census of the float tables loaded by hg_set_*_f32 --
  * "db_nonbinary" / "q_nonbinary" (entries outside {-1,0,+1}), "db_zeros" / "q_zeros", "db_minus_ones" /
  * "q_minus_ones" -- from which the caller tells +-1 codes, {0,1} bits and real-valued features apart;
- * "probe_build". */
+ * "probe_build", "graph_captures", "graph_replays". */
 int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
 /* Work buffers only grow; hg_trim frees everything except the resident code/label/feature tables
  * (stat "device_bytes" reports what the context holds). */
 int hg_trim(hg_ctx* ctx);
 /* HIP-event timing of the kernels launched on the context's stream.  on = 2: every kernel; 1: only the
  * passes over the query x database pairs (k_hist, k_select, k_select_mx) -- two events per launch keep
- * consecutive kernels from being dispatched back to back, ~4 us each; 0: off. */
+ * consecutive kernels from being dispatched back to back, ~4 us each; 0: off.  Levels 1 and 2 also time the
+ * whole one-shot step on the GPU ("step_gpu_span": first enqueue to the last byte of the result download), so
+ * wall time per step - step_gpu_span = what the host adds.  Inside a captured step the events are event-record
+ * nodes of the graph. */
 int hg_timing_enable(hg_ctx* ctx, int on);
 int hg_timing_reset(hg_ctx* ctx);
 /* Fills up to cap entries; name[i] points to static strings. Returns count via *n. */

@@ -168,6 +168,91 @@ def test_maps_objects_are_independent_and_keep_a_resident_database(case_cache):
     ma.close(); mb.close()
 
 
+def test_bursts_of_hits_take_the_direct_route():
+    """Near-duplicates stored next to each other: a query's hits arrive ten and more to a 64-row half window, more than a
+    slice's 16-record ring takes between two flushes -- the compact-record drain must route such words straight to
+    global memory (hg_mx_drain.hpp) and still deliver every record, in order.  Checked against the 8-byte-record
+    kernels and the oracle."""
+    from hashgan_amd import synth
+    Q, N0, b, R, C, dup = 192, 8192, 64, 6000, 10, 24
+    dl0, _ = synth.onehot_labels(51, N0, C)
+    ql, _ = synth.onehot_labels(52, Q, C)
+    db0 = synth.planted_codes(53, dl0, b, 0.3)
+    qb = synth.planted_codes(53, ql, b, 0.3)
+    # every row followed by dup - 1 copies that differ in at most one bit: N = 196608 rows, bursts of 24 near-equal rows
+    db = np.repeat(db0, dup, axis=0)
+    dl = np.repeat(dl0, dup, axis=0)
+    flip = synth.splitmix64(54, db.shape[0]) % np.uint64(2 * b)
+    rows = np.nonzero(flip < b)[0]
+    db[rows, flip[rows].astype(np.int64)] ^= 1
+    c = dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, R=R, b=b)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb[:16], db, ql[:16], dl, R)
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, c)
+        ctx.set_option("step_graph", 0)
+        out = {}
+        for compact in (1, 0):
+            ctx.set_option("compact_records", compact)
+            ap, rel = ctx.map(R)
+            out[compact] = ap
+            assert np.array_equal(ap[:16], ap_ref, equal_nan=True), compact
+        assert np.array_equal(out[0], out[1], equal_nan=True)
+        assert ctx.get_stat("optimistic_runs") == 2 and ctx.get_stat("optimistic_fallbacks") == 0
+        # and with short codes (k_select_mx2's harvest feeding the same drain)
+        c32 = dict(c, qbits=qb[:, :32].copy(), dbbits=db[:, :32].copy(), b=32)
+        _load(ctx, c32)
+        res = []
+        for compact in (1, 0):
+            ctx.set_option("compact_records", compact)
+            res.append(ctx.map(R)[0])
+        assert np.array_equal(res[0], res[1], equal_nan=True)
+    finally:
+        ctx.close()
+
+
+def test_step_graph_replays_equal_eager_steps(case_cache):
+    """hg_map captures its one-shot bet into a hipGraph on the second identical call and replays it afterwards:
+    same AP bit for bit, with and without kernel timing, across a change of R and of the queries."""
+    c = case_cache("c2_q64")
+    g = cases.load_golden("c2_q64")
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, c)
+        ctx.set_option("step_graph", 1)                  # opt-in (off by default)
+        for timing in (0, 2, 1):
+            ctx.timing_enable(timing)
+            ctx.timing_reset()
+            before = ctx.get_stat("graph_replays")
+            for _ in range(4):
+                ap, rel = ctx.map(c["R"])
+                assert np.array_equal(ap, g["ap"], equal_nan=True), timing
+            if timing:                                   # kernel timing keeps the steps eager (events per launch)
+                assert ctx.get_stat("graph_replays") == before
+                t = ctx.timing_read()
+                assert t["k_select_mx"][1] == 4 and t["step_gpu_span"][1] == 4, t
+                assert 0 < t["k_select_mx"][0] < t["step_gpu_span"][0], t
+            else:
+                assert ctx.get_stat("graph_replays") - before >= 2
+        ctx.timing_enable(0)
+        ctx.set_option("step_graph", 0)
+        ap_eager, _ = ctx.map(c["R"] // 2)
+        ctx.set_option("step_graph", 1)
+        r0 = ctx.get_stat("graph_replays")
+        for _ in range(3):
+            ap2, _ = ctx.map(c["R"] // 2)                      # another R: a new capture, not the old graph
+            assert np.array_equal(ap2, ap_eager, equal_nan=True)
+        assert ctx.get_stat("graph_replays") > r0
+        ctx.set_queries(metric.pack_codes(c["qbits"][::-1].copy()), metric.pack_labels(c["qlab"][::-1].copy()))
+        for _ in range(3):
+            ap3, _ = ctx.map(c["R"])
+            assert np.array_equal(ap3, g["ap"][::-1], equal_nan=True)
+    finally:
+        ctx.close()
+
+
 def test_device_pack_matches_host_pack(ctx):
     """k_pack_sign_f32 / k_pack_labels_i64 against the NumPy packing, bit for bit, including
     sign(0) -> 0, pad bits, odd word counts; and the non-binary detector."""
