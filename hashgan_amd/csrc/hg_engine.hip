@@ -6,6 +6,7 @@
 #include "hg_mx_drain.hpp"
 #include "hg_select_mx.hpp"
 #include "hg_rank_lds.hpp"
+#include "hg_rank_cnt.hpp"
 #include "hg_select_mx2.hpp"
 #include "../../include/hashgan_amd.h"
 
@@ -211,6 +212,7 @@ struct hg_ctx {
     i64 opt_sample_ratio = 2;  // the sampled pass works on segments this many times longer than the select pass's
     i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
+    i64 opt_rank_cnt = 1;      // ... and ranks them with the per-thread counting sort (k_rank_cnt) where it applies
     i64 opt_select_qt = 2;     // k_select_mx query tiles per wavefront (2: 4 wavefronts per SIMD, 4: 2)
 
     // run state
@@ -1076,7 +1078,28 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
         c->err_zeroed = false;
     }
     const u32* only = nullptr;
-    if (use_lds) {
+    bool counted = false;
+    if (use_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
+        // per-thread counting sort (k_rank_cnt): byte counters for every distance + the records, <= 64 KiB per block
+        i64 r2 = recs;
+        RankCntLds L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0);
+        while (L.total > 64 * 1024 && r2 > 64) { r2 -= 64; L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0); }
+        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
+        if (L.total <= 64 * 1024 && (double)r2 >= 2.0 * (double)c->R * share && r2 < 65536) {
+            HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
+            RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
+                           c->cap, c->crow, c->want_lists ? 1 : 0, c->rec8 ? 1 : 0, c->RW, (int)r2, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
+                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>()};
+            c->t_begin(KI_RANK_LDS);
+            hipLaunchKernelGGL(k_rank_cnt, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, c->cand.as<u64>(), la, c->out_idx.as<u32>(),
+                               c->out_dist.as<u8>(), c->mbits.as<u32>(), g);
+            c->t_end();
+            HG_TRY(c->check_launch("k_rank_cnt"));
+            only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
+            counted = true;
+        }
+    }
+    if (use_lds && !counted) {
         {
             HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
             if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
@@ -2140,6 +2163,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_select_packed = value;
     } else if (!strcmp(key, "rank_lds")) {
         c->opt_rank_lds = value != 0;
+    } else if (!strcmp(key, "rank_cnt")) {
+        c->opt_rank_cnt = value != 0;
     } else if (!strcmp(key, "compact_records")) {
         c->opt_compact = value != 0;
     } else if (!strcmp(key, "lds_pad")) {

@@ -223,7 +223,8 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * python -m hashgan_amd.build --probes: bits 2/4/8 switch parts of the matrix-core kernels' drain off; the bet
  * then fails and the exact sequence runs, so results stay right; the production library refuses the key),
  * "select_qt" (k_select_mx query tiles per wavefront: 2 or 4), "select_packed" (k_select_mx2, two rows per
- * MFMA accumulator: 1 = for codes of <= 32 bits, 2 = also for 33..64 bits, 0 = never), "rank_lds" (0/1),
+ * MFMA accumulator: 1 = for codes of <= 32 bits, 2 = also for 33..64 bits, 0 = never), "rank_lds" (0/1), "rank_cnt" (0/1:
+ * the bet's rank stage as a per-thread counting sort, k_rank_cnt),
  * "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
  * {match, dist} through per-slice LDS rings instead of 8-byte {idx, dist, match} records),
  * "real_queries_per_lane", "real_segment_bytes" (real-valued path), "step_graph" (1, default: hg_map captures its
