@@ -198,6 +198,7 @@ struct hg_ctx {
     // options
     i64 target_units = 16384;
     i64 min_segment = 256;
+    i64 opt_max_segments = 2048;   // "max_segments"
     i64 opt_enable = 1;        // one-shot calls may bet on a sampled threshold (verified, exact fallback)
     i64 opt_stride = 0;        // sampling stride in row batches, 0 = auto
     i64 opt_sigma = 6;         // safety margin of the guess, in standard deviations of the sample count
@@ -379,6 +380,9 @@ void make_geometry(hg_ctx* c) {
     g.NW = c->NW; g.NB = c->NB; g.LW = c->LW;
     g.N = c->N; g.R = c->R; g.idx_base = c->idx_base;
     i64 S = (c->target_units + g.nQT - 1) / g.nQT;
+    // few queries: more segments than fill the GPU twice only make every query's record row longer to walk
+    // (Q = 64, N = 10M: 12500 slices per query cost the rank stage 3.4 ms; 2048 cost 0.1)
+    if (S > c->opt_max_segments) S = c->opt_max_segments;
     const i64 maxS = (c->N + c->min_segment - 1) / c->min_segment;
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
@@ -1059,7 +1063,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
     const size_t per_rec = c->want_lists ? 6 : 2;
     if (c->optimistic && c->opt_rank_lds) {
         const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);    // this shard's part of the list
-        recs = (i64)(2.5 * (double)c->R * share) + 256;
+        recs = (i64)(2.5 * (double)c->R * share) + 2048;   // small R: the guess's safety margin is relatively larger (R = 100 keeps ~4 R)
         const i64 fit = fixed < 64 * 1024 ? (i64)((64 * 1024 - fixed) / per_rec) : 0;
         if (recs > fit) recs = fit;
         recs = recs / 64 * 64;
@@ -1079,13 +1083,16 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
     }
     const u32* only = nullptr;
     bool counted = false;
-    if (use_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
-        // per-thread counting sort (k_rank_cnt): byte counters for every distance + the records, <= 64 KiB per block
-        i64 r2 = recs;
+    if (c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
+        // per-thread counting sort (k_rank_cnt): byte counters for every distance + a tile of the records, <= 64 KiB per
+        // block; lists longer than a tile are ranked tile by tile
+        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
+        i64 r2 = (i64)(2.5 * (double)c->R * share) + 256;         // a tile of the records: the usual list (1.3 - 2 R) in one
+        if (r2 < 4096) r2 = 4096;                                  // (small R: the guess's margin is relatively larger)
+        r2 = r2 / 64 * 64;
         RankCntLds L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0);
         while (L.total > 64 * 1024 && r2 > 64) { r2 -= 64; L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0); }
-        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
-        if (L.total <= 64 * 1024 && (double)r2 >= 2.0 * (double)c->R * share && r2 < 65536) {
+        if (L.total <= 64 * 1024 && r2 >= 4096) {
             HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
             RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
                            c->cap, c->crow, c->want_lists ? 1 : 0, c->rec8 ? 1 : 0, c->RW, (int)r2, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
@@ -2135,6 +2142,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "min_segment")) {
         if (value < 16) return fail(HG_ERR_ARG, "min_segment must be >= 16");
         c->min_segment = value;
+    } else if (!strcmp(key, "max_segments")) {
+        if (value < 1) return fail(HG_ERR_ARG, "max_segments must be >= 1");
+        c->opt_max_segments = value;
     } else if (!strcmp(key, "optimistic")) {
         c->opt_enable = value != 0;
         c->opt_consecutive_fail = c->shard_bet_fail = 0;

@@ -32,8 +32,8 @@ __host__ __device__ inline RankCntLds rank_cnt_layout(int NB, i64 RW, int S, int
     l.off = l.cnt + (NB < 128 ? NB : 128) * 256; // (distances beyond 127 never reach this path)   [RC_MAXB + 1][128] u32: 16-bit offset of thread 2 i + j = half j of dword i
     l.tot = l.off + (RC_MAXB + 1) * 512;         // [NB] u32   (offsets row RC_MAXB is a dummy: records beyond the cut add there)
     l.misc = l.tot + NB * 4;                     // [8] u32
-    l.wsum = l.misc + 32;                        // [8] u32
-    l.bm = l.wsum + 32;                          // [2 RW] u32
+    l.wsum = l.misc + 32;                        // [8] u32, then done[32] and tilecnt[32] (several tiles: per-bucket progress)
+    l.bm = l.wsum + 32 + 256;                    // [2 RW] u32
     l.pref = l.bm + (int)(2 * RW) * 4;           // [S + 2] u32
     l.rec = l.pref + ((S + 2) & ~1) * 4;         // [recs] u8 {match:1 | dist:7}
     l.idx = l.rec + ((recs + 7) & ~7);           // [recs] u32 (lists only)
@@ -60,6 +60,8 @@ __global__ __launch_bounds__(256) void k_rank_cnt(const u64* __restrict__ cand, 
     u32* tot = (u32*)(rlds + L.tot);
     u32* misc = (u32*)(rlds + L.misc);
     u32* wsum = (u32*)(rlds + L.wsum);
+    u32* done = wsum + 8;
+    u32* tilecnt = done + 32;
     u32* bm = (u32*)(rlds + L.bm);
     u32* pref = (u32*)(rlds + L.pref);
     u8* rec8 = rlds + L.rec;
@@ -101,90 +103,145 @@ __global__ __launch_bounds__(256) void k_rank_cnt(const u64* __restrict__ cand, 
     if (tid == nthr - 1) pref[S] = run;
     __syncthreads();
     const u32 n = pref[S];
-    if (n > (u32)a.lds_recs) {                        // too many records for the LDS: k_rank_fused takes this query
-        if (tid == 0) a.big[q] = 1u;
-        return;
-    }
-
-    // ---- copy the records into LDS, compacted in slice (= index) order ----
+    // The records are ranked in tiles of up to TC (they need not all fit the LDS): pass A counts every tile into the
+    // totals, the plan follows, pass B re-reads the tiles in order and places them, carrying per-bucket progress.
+    // One tile (the usual case, ~1.3 R records) is copied and counted once.
+    u32 TC = (u32)a.lds_recs & ~7u;
+    if (TC > 252u * nthr) TC = 252u * nthr;           // a thread's chunk must fit its byte counters
+    const u32 ntile = n ? (n + TC - 1) / TC : 1u;
     const u64* __restrict__ row = cand + (i64)q * a.crow;
-    if (a.rec8) {
-        const u8* __restrict__ row8 = (const u8*)cand + (i64)q * a.crow;
-        constexpr int NSL = 16;
-        for (int s = wave; s < S; s += NSL * NWAV) {
-            u32 p[NSL], c[NSL], v[NSL];
+    const u8* __restrict__ row8 = (const u8*)cand + (i64)q * a.crow;
+
+    // ---- copy records [T0, T0 + TC) of the query's list into LDS, compacted in slice (= index) order ----
+    auto copy_all = [&]() {                           // single tile: many slices' loads in flight per wavefront
+        if (a.rec8) {
+            constexpr int NSL = 16;
+            for (int s = wave; s < S; s += NSL * NWAV) {
+                u32 p[NSL], c[NSL], v[NSL];
 #pragma unroll
-            for (int k = 0; k < NSL; ++k) {
-                const int sk = s + k * NWAV;
-                const bool ok = sk < S;
-                p[k] = ok ? pref[sk] : 0u;
-                c[k] = ok ? pref[sk + 1] - p[k] : 0u;
-                const u8* r = row8 + (i64)(ok ? sk : s) * a.cap;
-                v[k] = 2u * (u32)lane < c[k] ? (u32)*(const unsigned short*)(r + 2 * lane) : 0u;
-            }
+                for (int k = 0; k < NSL; ++k) {
+                    const int sk = s + k * NWAV;
+                    const bool ok = sk < S;
+                    p[k] = ok ? pref[sk] : 0u;
+                    c[k] = ok ? pref[sk + 1] - p[k] : 0u;
+                    const u8* r = row8 + (i64)(ok ? sk : s) * a.cap;
+                    v[k] = 2u * (u32)lane < c[k] ? (u32)*(const unsigned short*)(r + 2 * lane) : 0u;
+                }
 #pragma unroll
-            for (int k = 0; k < NSL; ++k) {
-                const u32 i0 = 2u * lane;
-                if (i0 < c[k]) rec8[p[k] + i0] = (u8)v[k];
-                if (i0 + 1 < c[k]) rec8[p[k] + i0 + 1] = (u8)(v[k] >> 8);
-                if (c[k] > 128) {
-                    const u8* r = row8 + (i64)(s + k * NWAV) * a.cap;
-                    for (u32 i = lane + 128; i < c[k]; i += 64) rec8[p[k] + i] = r[i];
+                for (int k = 0; k < NSL; ++k) {
+                    const u32 j0 = 2u * lane;
+                    if (j0 < c[k]) rec8[p[k] + j0] = (u8)v[k];
+                    if (j0 + 1 < c[k]) rec8[p[k] + j0 + 1] = (u8)(v[k] >> 8);
+                    if (c[k] > 128) {
+                        const u8* r = row8 + (i64)(s + k * NWAV) * a.cap;
+                        for (u32 i = lane + 128; i < c[k]; i += 64) rec8[p[k] + i] = r[i];
+                    }
                 }
             }
-        }
-    } else {
-        constexpr int NSL = 8;
-        for (int s = wave; s < S; s += NSL * NWAV) {
-            u32 p[NSL], c[NSL];
-            u64 v0[NSL], v1[NSL];
+        } else {
+            constexpr int NSL = 8;
+            for (int s = wave; s < S; s += NSL * NWAV) {
+                u32 p[NSL], c[NSL];
+                u64 v0[NSL], v1[NSL];
 #pragma unroll
-            for (int k = 0; k < NSL; ++k) {
-                const int sk = s + k * NWAV;
-                const bool ok = sk < S;
-                p[k] = ok ? pref[sk] : 0u;
-                c[k] = ok ? pref[sk + 1] - p[k] : 0u;
-                const u64* r = row + (i64)(ok ? sk : s) * a.cap;
-                v0[k] = (u32)lane < c[k] ? r[lane] : 0ull;
-                v1[k] = (u32)lane + 64 < c[k] ? r[lane + 64] : 0ull;
-            }
+                for (int k = 0; k < NSL; ++k) {
+                    const int sk = s + k * NWAV;
+                    const bool ok = sk < S;
+                    p[k] = ok ? pref[sk] : 0u;
+                    c[k] = ok ? pref[sk + 1] - p[k] : 0u;
+                    const u64* r = row + (i64)(ok ? sk : s) * a.cap;
+                    v0[k] = (u32)lane < c[k] ? r[lane] : 0ull;
+                    v1[k] = (u32)lane + 64 < c[k] ? r[lane + 64] : 0ull;
+                }
 #pragma unroll
-            for (int k = 0; k < NSL; ++k) {
-                const u32 i0 = lane, i1 = lane + 64;
-                // 8-byte records {idx:32 | dist:8 | match:1} -> {match:1 | dist:7} (this path: b < 128, so a distance fits 7 bits)
-                if (i0 < c[k]) { rec8[p[k] + i0] = (u8)(((u32)(v0[k] >> 32) & 0x7Fu) | ((u32)(v0[k] >> 33) & 0x80u)); if (a.want_lists) idx32[p[k] + i0] = (u32)v0[k]; }
-                if (i1 < c[k]) { rec8[p[k] + i1] = (u8)(((u32)(v1[k] >> 32) & 0x7Fu) | ((u32)(v1[k] >> 33) & 0x80u)); if (a.want_lists) idx32[p[k] + i1] = (u32)v1[k]; }
-                if ((i0 < c[k] && ((u32)(v0[k] >> 32) & 0x80u)) || (i1 < c[k] && ((u32)(v1[k] >> 32) & 0x80u))) misc[7] = 1u;   // a distance beyond 127
-                if (c[k] > 128) {
-                    const u64* r = row + (i64)(s + k * NWAV) * a.cap;
-                    for (u32 i = lane + 128; i < c[k]; i += 64) {
-                        const u64 v = r[i];
-                        rec8[p[k] + i] = (u8)(((u32)(v >> 32) & 0x7Fu) | ((u32)(v >> 33) & 0x80u));
-                        if ((u32)(v >> 32) & 0x80u) misc[7] = 1u;
-                        if (a.want_lists) idx32[p[k] + i] = (u32)v;
+                for (int k = 0; k < NSL; ++k) {
+                    const u32 j0 = lane, j1 = lane + 64;
+                    // 8-byte records {idx:32 | dist:8 | match:1} -> {match:1 | dist:7}; a distance beyond 127 leaves this path
+                    if (j0 < c[k]) { rec8[p[k] + j0] = (u8)(((u32)(v0[k] >> 32) & 0x7Fu) | ((u32)(v0[k] >> 33) & 0x80u)); if (a.want_lists) idx32[p[k] + j0] = (u32)v0[k]; }
+                    if (j1 < c[k]) { rec8[p[k] + j1] = (u8)(((u32)(v1[k] >> 32) & 0x7Fu) | ((u32)(v1[k] >> 33) & 0x80u)); if (a.want_lists) idx32[p[k] + j1] = (u32)v1[k]; }
+                    if ((j0 < c[k] && ((u32)(v0[k] >> 32) & 0x80u)) || (j1 < c[k] && ((u32)(v1[k] >> 32) & 0x80u))) misc[7] = 1u;
+                    if (c[k] > 128) {
+                        const u64* r = row + (i64)(s + k * NWAV) * a.cap;
+                        for (u32 i = lane + 128; i < c[k]; i += 64) {
+                            const u64 v = r[i];
+                            rec8[p[k] + i] = (u8)(((u32)(v >> 32) & 0x7Fu) | ((u32)(v >> 33) & 0x80u));
+                            if ((u32)(v >> 32) & 0x80u) misc[7] = 1u;
+                            if (a.want_lists) idx32[p[k] + i] = (u32)v;
+                        }
                     }
                 }
             }
         }
-    }
-    __syncthreads();
-    if (misc[7]) {                                    // only codes of >= 128 bits ranked against far-away rows: the general kernel
-        if (tid == 0) a.big[q] = 1u;
-        return;
-    }
+    };
+    auto copy_tile = [&](const u32 T0, const u32 T1) {   // several tiles: slices are long; 4 slices x 4 loads in flight per wavefront
+        constexpr int NS = 4, NU = 4;
+        for (int s0 = wave; s0 < S; s0 += NS * NWAV) {
+            u32 p[NS], lo[NS], hi[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int s = s0 + k * NWAV;
+                const u32 pp = s < S ? pref[s] : 0u, e = s < S ? pref[s + 1] : 0u;
+                const bool in = e > T0 && pp < T1 && e > pp;
+                p[k] = pp;
+                lo[k] = in ? (pp > T0 ? pp : T0) - pp : 0u;          // the slice's records inside the tile: [lo, hi)
+                hi[k] = in ? (e < T1 ? e : T1) - pp : 0u;
+            }
+            if (a.rec8) {
+                u32 base[NS], more = 0;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) { base[k] = lo[k] & ~3u; more |= hi[k] > base[k] ? 1u : 0u; }
+                while (more) {                                        // wave-uniform: rounds of 1024 records per slice
+                    u32 v[NS][NU];
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const u8* r = row8 + (i64)(s0 + k * NWAV < S ? s0 + k * NWAV : 0) * a.cap;
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) {
+                            const u32 i4 = base[k] + 256u * u + 4u * lane;       // four records per load (slices start 16-byte aligned)
+                            v[k][u] = i4 < hi[k] ? *(const u32*)(r + i4) : 0u;
+                        }
+                    }
+                    more = 0;
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) {
+                            const u32 i4 = base[k] + 256u * u + 4u * lane;
+#pragma unroll
+                            for (u32 j = 0; j < 4; ++j) {
+                                const u32 i = i4 + j;
+                                if (i >= lo[k] && i < hi[k]) rec8[p[k] + i - T0] = (u8)(v[k][u] >> (8 * j));
+                            }
+                        }
+                        base[k] += 256u * NU;
+                        more |= hi[k] > base[k] ? 1u : 0u;
+                    }
+                    more = (u32)__any((int)more);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const u64* r = row + (i64)(s0 + k * NWAV < S ? s0 + k * NWAV : 0) * a.cap;
+                    for (u32 i = lo[k] + lane; i < hi[k]; i += 64) {
+                        const u64 v = r[i];
+                        rec8[p[k] + i - T0] = (u8)(((u32)(v >> 32) & 0x7Fu) | ((u32)(v >> 33) & 0x80u));
+                        if ((u32)(v >> 32) & 0x80u) misc[7] = 1u;
+                        if (a.want_lists) idx32[p[k] + i - T0] = (u32)v;
+                    }
+                }
+            }
+        }
+    };
 
-    // ---- count: thread `tid` owns records [i0, i1); chunk length = 4 (mod 8) bytes so that the 64 lanes of a wavefront
-    // read 64 different LDS banks (stride = chunk / 4 dwords, odd) and every chunk starts on a dword ----
-    u32 chunk = (n + nthr - 1) / nthr;
-    chunk += (4u - (chunk & 7u)) & 7u;
-    if (chunk > 252u) {                               // a byte counter could wrap: not this path's case
-        if (tid == 0) a.big[q] = 1u;
-        return;
-    }
-    const u32 i0 = (u32)tid * chunk < n ? (u32)tid * chunk : n;
-    const u32 i1 = i0 + chunk < n ? i0 + chunk : n;
-    const u32* rec32 = (const u32*)rec8;              // four records per read (i0 is a multiple of 4)
-    {
+    // per tile of m records: thread `tid` owns records [i0, i1) of the tile; chunk length = 4 (mod 8) bytes so that the 64 lanes
+    // of a wavefront read 64 different LDS banks (stride = chunk / 4 dwords, odd) and every chunk starts on a dword
+    const u32* rec32 = (const u32*)rec8;              // four records per read
+    u32 i0 = 0, i1 = 0;
+    auto count_tile = [&](const u32 m) {
+        u32 chunk = (m + nthr - 1) / nthr;
+        chunk += (4u - (chunk & 7u)) & 7u;
+        i0 = (u32)tid * chunk < m ? (u32)tid * chunk : m;
+        i1 = i0 + chunk < m ? i0 + chunk : m;
         const u32 one = 1u << (8 * (tid & 3));
 #pragma unroll 2
         for (u32 i = i0; i < i1; i += 4) {
@@ -195,21 +252,48 @@ __global__ __launch_bounds__(256) void k_rank_cnt(const u64* __restrict__ cand, 
                 if (i + j < i1 && d < (u32)NBc) atomicAdd(&cnt32[d * 64 + (tid >> 2)], one);
             }
         }
-    }
-    __syncthreads();
-    // ---- totals per distance: thread = (distance d, quarter j) sums 16 dwords of byte counters; 64 distances per round ----
-    for (int d0 = 0; d0 < NBc; d0 += 64) {
-        const int d = d0 + (tid >> 2), j = tid & 3;
-        u32 s = 0;
-        if (d < NBc) {
+    };
+    // totals per distance, added to tot[]: thread = (distance d, quarter j) sums 16 dwords of byte counters; 64 distances per round
+    auto add_totals = [&]() {
+        for (int d0 = 0; d0 < NBc; d0 += 64) {
+            const int d = d0 + (tid >> 2), j = tid & 3;
+            u32 sm = 0;
+            if (d < NBc) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s += __builtin_amdgcn_sad_u8(cnt32[d * 64 + j * 16 + k], 0u, 0u);
+                for (int k = 0; k < 16; ++k) sm += __builtin_amdgcn_sad_u8(cnt32[d * 64 + j * 16 + k], 0u, 0u);
+            }
+            sm += (u32)__shfl_xor((int)sm, 1);
+            sm += (u32)__shfl_xor((int)sm, 2);
+            if (d < NBc && j == 0) tot[d] += sm;
         }
-        s += (u32)__shfl_xor((int)s, 1);
-        s += (u32)__shfl_xor((int)s, 2);
-        if (d < NBc && j == 0) tot[d] = s;
+    };
+    auto zero_counters = [&]() {
+        for (int i = tid; i < NBc * 64; i += nthr) cnt32[i] = 0u;
+    };
+
+    // ---- pass A: totals ----
+    if (ntile == 1) {
+        copy_all();
+        __syncthreads();
+        if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }        // a distance beyond 127: the general kernel
+        count_tile(n);
+        __syncthreads();
+        add_totals();
+        __syncthreads();
+    } else {
+        for (u32 tl = 0; tl < ntile; ++tl) {
+            const u32 T0 = tl * TC, T1 = T0 + TC < n ? T0 + TC : n;
+            copy_tile(T0, T1);
+            __syncthreads();
+            if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }
+            count_tile(T1 - T0);
+            __syncthreads();
+            add_totals();
+            __syncthreads();
+            zero_counters();
+            __syncthreads();
+        }
     }
-    __syncthreads();
     if (a.mode == 3) {                                // counts for the merge, before the plan turns tot[] into starts
         for (int d = tid; d < NB; d += nthr) a.hown[(i64)d * g.Qpad + q] = tot[d];
         __syncthreads();
@@ -275,62 +359,78 @@ __global__ __launch_bounds__(256) void k_rank_cnt(const u64* __restrict__ cand, 
         if (tid == 0) { a.big[q] = 1u; if (a.mode == 0) a.qbad[q] = 0u; }
         return;
     }
-    // ---- scan: offsets of every thread inside each bucket [dmin, t] ----
-    for (int k = wave; k < nbk; k += NWAV) {
-        const u32 x = cnt32[(dmin + k) * 64 + lane];
-        const u32 s = __builtin_amdgcn_sad_u8(x, 0u, 0u);
-        u32 inc = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const u32 v = (u32)__shfl_up((int)inc, off);
-            if (lane >= off) inc += v;
+
+    // ---- pass B: per tile, offsets of every thread inside each bucket [dmin, t], then placement ----
+    u32* __restrict__ oi = out_idx + (i64)q * g.R;
+    u8* __restrict__ od = out_dist + (i64)q * g.R;
+    for (u32 tl = 0; tl < ntile; ++tl) {
+        const u32 T0 = tl * TC, T1 = T0 + TC < n ? T0 + TC : n;
+        if (ntile > 1) {                              // (one tile: records and counters are still in place)
+            copy_tile(T0, T1);
+            __syncthreads();
+            count_tile(T1 - T0);
+            __syncthreads();
         }
-        const u32 o0 = inc - s, o1 = o0 + (x & 0xFFu), o2 = o1 + ((x >> 8) & 0xFFu), o3 = o2 + ((x >> 16) & 0xFFu);
-        off32[k * 128 + 2 * lane] = o0 | (o1 << 16);                 // threads 4 lane, 4 lane + 1
-        off32[k * 128 + 2 * lane + 1] = o2 | (o3 << 16);             // threads 4 lane + 2, 4 lane + 3
-    }
-    __syncthreads();
-    // ---- place: four records per round -- their returning LDS adds are issued back to back (same-thread adds to one
-    // offset stay in order), so a round pays one LDS round trip, not four; records beyond the cut add to a dummy row ----
-    {
-        u32* __restrict__ oi = out_idx + (i64)q * g.R;
-        u8* __restrict__ od = out_dist + (i64)q * g.R;
-        const int sh = 16 * (tid & 1);
-        const u32 one = 1u << sh;
-        for (u32 i = i0; i < i1; i += 4) {
-            u32 meta[4], r[4], st[4];
-            const u32 v = rec32[i >> 2];
+        for (int k = wave; k < nbk; k += NWAV) {
+            const u32 x = cnt32[(dmin + k) * 64 + lane];
+            const u32 sm = __builtin_amdgcn_sad_u8(x, 0u, 0u);
+            u32 inc = sm;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {                             // -> {dist:8 | match at bit 8}; 0xFFFF: past the chunk
-                const u32 m = (v >> (8 * j)) & 0xFFu;
-                meta[j] = i + j < i1 ? (m & 0x7Fu) | ((m >> 7) << 8) : 0xFFFFu;
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 v = (u32)__shfl_up((int)inc, off);
+                if (lane >= off) inc += v;
             }
+            const u32 o0 = inc - sm, o1 = o0 + (x & 0xFFu), o2 = o1 + ((x >> 8) & 0xFFu), o3 = o2 + ((x >> 16) & 0xFFu);
+            off32[k * 128 + 2 * lane] = o0 | (o1 << 16);                 // threads 4 lane, 4 lane + 1
+            off32[k * 128 + 2 * lane + 1] = o2 | (o3 << 16);             // threads 4 lane + 2, 4 lane + 3
+            if (lane == 63) tilecnt[k] = inc;                            // the tile's records of this distance
+        }
+        __syncthreads();
+        // place: four records per round -- their returning LDS adds are issued back to back (same-thread adds to one
+        // offset stay in order), so a round pays one LDS round trip, not four; records beyond the cut add to a dummy row
+        {
+            const int sh = 16 * (tid & 1);
+            const u32 one = 1u << sh;
+            for (u32 i = i0; i < i1; i += 4) {
+                u32 meta[4], r[4], st[4];
+                const u32 v = rec32[i >> 2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int d = (int)(meta[j] & 0xFFu);
-                const bool in = d <= t && meta[j] != 0xFFFFu;
-                const int k = in ? d - dmin : RC_MAXB;
-                r[j] = atomicAdd(&off32[k * 128 + (tid >> 1)], one);
-                st[j] = tot[in ? d : 0];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int d = (int)(meta[j] & 0xFFu);
-                const bool in = d <= t && meta[j] != 0xFFFFu;
-                const u32 rk = (r[j] >> sh) & 0xFFFFu;
-                u32 pos = IDX_NONE;
-                if (in) {
-                    if (d < t) pos = st[j] + rk;
-                    else if (rk < quota) pos = cntlt + rk;
+                for (int j = 0; j < 4; ++j) {                             // -> {dist:8 | match at bit 8}; 0xFFFF: past the chunk
+                    const u32 m = (v >> (8 * j)) & 0xFFu;
+                    meta[j] = i + j < i1 ? (m & 0x7Fu) | ((m >> 7) << 8) : 0xFFFFu;
                 }
-                if (pos != IDX_NONE) {
-                    if (a.want_lists) { oi[pos] = idx32[i + j]; od[pos] = (u8)d; }
-                    if (meta[j] & 0x100u) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = (int)(meta[j] & 0xFFu);
+                    const bool in = d <= t && meta[j] != 0xFFFFu;
+                    const int k = in ? d - dmin : RC_MAXB;
+                    r[j] = atomicAdd(&off32[k * 128 + (tid >> 1)], one);
+                    st[j] = (in ? tot[d] : 0u) + done[in ? k : 0];           // bucket start + what earlier tiles placed there
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = (int)(meta[j] & 0xFFu);
+                    const bool in = d <= t && meta[j] != 0xFFFFu;
+                    const u32 rk = (r[j] >> sh) & 0xFFFFu;
+                    u32 pos = IDX_NONE;
+                    if (in) {
+                        if (d < t) pos = st[j] + rk;
+                        else if (st[j] - cntlt + rk < quota) pos = st[j] + rk;      // ties: st = cntlt + ties of earlier tiles
+                    }
+                    if (pos != IDX_NONE) {
+                        if (a.want_lists) { oi[pos] = idx32[i + j]; od[pos] = (u8)d; }
+                        if (meta[j] & 0x100u) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
+                    }
                 }
             }
         }
+        __syncthreads();
+        if (ntile > 1) {
+            if (tid < nbk) done[tid] += tilecnt[tid];
+            zero_counters();
+            __syncthreads();
+        }
     }
-    __syncthreads();
     for (int w = tid; w < bmw; w += nthr) grow[w] = bm[w];
 }
 

@@ -214,7 +214,7 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
 
 /* ---- tuning and measurement -------------------------------------------------- */
 /* key: "stage_sync" (see hg_set_stream), "target_units" (wavefront-sized units the pair passes are split into),
- * "min_segment" (rows), "optimistic" (0/1: one-shot calls may bet on a sampled
+ * "min_segment" (rows), "max_segments", "optimistic" (0/1: one-shot calls may bet on a sampled
  * threshold -- verified on device, exact fallback), "sample_stride" (0 = auto),
  * "guess_sigma", "staged_lists" (0/1: hg_select materialises idx/dist lists),
  * "cand_budget_x10" (record budget of the bet per query, tenths of R), "rank_waves" (0 = auto, 4, 16),

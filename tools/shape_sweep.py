@@ -22,7 +22,11 @@ def run(Q, N, b, R, steps=5):
     for _ in range(steps): ctx.map(R)
     dt = (time.perf_counter() - t) / steps
     path = "bet" if ctx.get_stat("last_optimistic") else "exact"
-    print("Q=%-6d N=%-9d b=%-3d R=%-7d %8.3f ms  %10.0f q/s  %6.2f Tpairs/s  %s" % (Q, N, b, R, dt * 1e3, Q / dt, Q * N / dt / 1e12, path), flush=True)
+    ctx.timing_enable(2); ctx.timing_reset()
+    for _ in range(3): ctx.map(R)
+    tm = ctx.timing_read(); ctx.timing_enable(0)
+    kern = " ".join("%s=%.3f" % (k.replace("k_", ""), v[0] / 3) for k, v in sorted(tm.items(), key=lambda kv: -kv[1][0]) if k != "step_gpu_span" and v[0] / 3 >= 0.005)
+    print("Q=%-6d N=%-9d b=%-3d R=%-7d %8.3f ms  %10.0f q/s  %6.2f Tpairs/s  %-5s S=%d | %s" % (Q, N, b, R, dt * 1e3, Q / dt, Q * N / dt / 1e12, path, ctx.get_stat("segments"), kern), flush=True)
     ctx.close()
 
 if __name__ == "__main__":
