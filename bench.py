@@ -142,8 +142,9 @@ def traffic_from_profiles(kernel):
     return d.get(kernel, {}).get("hbm_bytes_per_launch"), "rocprofv3 PMC pass of these sources (%s)" % d.get("_collected", "?")
 
 
-def kernel_rooflines(timing, spec, rows, step_s):
-    """Per-kernel average launch time -> roofline of the dominant kernel.  `rows` = database rows this GPU holds."""
+def kernel_rooflines(timing, spec, rows, step_s, rec_bytes=1):
+    """Per-kernel average launch time -> roofline of the dominant kernel.  `rows` = database rows this GPU holds;
+    rec_bytes: bytes per record the select pass writes (1: compact {match, dist}, hg_map's default; 8: with index)."""
     Q, b, C, R = spec["Q"], spec["b"], spec["C"], spec["R"]
     NW, LW = (b + 31) // 32, (C + 63) // 64
     pairs = Q * rows
@@ -152,7 +153,7 @@ def kernel_rooflines(timing, spec, rows, step_s):
         "k_hist": code_bytes + (b + 1) * ((Q + 63) // 64 * 64) * 4,
         "k_select": code_bytes + (Q + rows) * LW * 8 + Q * R * 8,       # codes + labels in, >= R records of 8 B out per query
         # fp4 images of the codes (4 bits per code bit, 64-bit granules) + packed codes + labels in, records out
-        "k_select_mx": (Q + rows) * ((NW + 1) // 2) * 32 + code_bytes + (Q + rows) * LW * 8 + Q * R * 8,
+        "k_select_mx": (Q + rows) * ((NW + 1) // 2) * 32 + code_bytes + (Q + rows) * LW * 8 + Q * R * rec_bytes,
     }
     out = {name: {"avg_ms": ms / max(cnt, 1), "launches": cnt} for name, (ms, cnt) in timing.items()}
     pair_passes = {k: v for k, v in out.items() if k in alg_bytes}
@@ -326,7 +327,8 @@ def main():
                                           "value": Q * world / per_step}
     if timing:
         span = timing.pop("step_gpu_span", None)
-        roof, per_kernel = kernel_rooflines(timing, spec, rows, per_step)
+        rec_bytes = 8 if any(kv.replace(" ", "") == "compact_records=0" for kv in args.opt) else 1
+        roof, per_kernel = kernel_rooflines(timing, spec, rows, per_step, rec_bytes)
         out["roofline"] = roof
         out["kernels"] = {k_: {"avg_ms": round(v["avg_ms"], 5), "launches": v["launches"]} for k_, v in per_kernel.items()}
         if span:            # HIP events around the whole step on the GPU: what is left of the wall time is the host's

@@ -4,16 +4,23 @@ per launch per kernel -> profiles/latest_traffic.json (read by bench.py's roofli
 
 usage: pmc_traffic.py fetch_results.db write_results.db out.json
 
-Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB... as
-reported by rocprofv3 on gfx950 they are multiples of 1024 B; FETCH_SIZE under-reports wide
-(16 B/lane) coalesced streaming reads by 2x.  The kernels here read through scalar loads and
-8-byte gathers, not wide streams, so NO doubling is applied; both raw counters are kept in the
-output so the reader can re-derive the figure.
+Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE come in KiB; on gfx950
+FETCH_SIZE reports HALF the bytes of wide (16 B per lane) coalesced streaming reads.  The matrix-core
+select kernels (k_select_mx*) stream the database image, codes and labels with 16-byte direct-to-LDS
+loads, so their FETCH_SIZE is doubled; the other kernels read through scalar loads, 1-8 byte gathers
+and LDS, and are left as reported.  WRITE_SIZE is uncalibrated (taken as reported).  Both raw counters
+stay in the output so the figure can be re-derived.  The file is stamped with a fingerprint of
+hashgan_amd/csrc (bench.py quotes it only for the sources it was measured on).
 """
 import json
+import os
 import re
 import sqlite3
 import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+WIDE_READERS = ("k_select_mx",)          # kernels whose reads are 16 B per lane streams
 
 
 def short(name):
@@ -37,12 +44,18 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, (0.0, 0))[0]
         w = write.get(k, (0.0, 0))[0]
-        out[k] = {"FETCH_SIZE_avg": f, "WRITE_SIZE_avg": w, "hbm_bytes_per_launch": (f + w) * 1024.0,
-                  "launches_sampled": fetch.get(k, (0, 0))[1]}
+        fx = 2.0 if k.startswith(WIDE_READERS) else 1.0
+        out[k] = {"FETCH_SIZE_avg_KiB": f, "WRITE_SIZE_avg_KiB": w, "fetch_correction": fx,
+                  "hbm_bytes_per_launch": (fx * f + w) * 1024.0, "launches_sampled": fetch.get(k, (0, 0))[1]}
+    from bench import kernel_sources_sha
+    out["_kernel_sources_sha"] = kernel_sources_sha()
+    out["_collected"] = time.strftime("%Y-%m-%d") + ", rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 10 --warmup 3` on MI355X"
     with open(sys.argv[3], "w") as fh:
         json.dump(out, fh, indent=1)
     for k, v in out.items():
-        print("%-16s fetch %12.1f KiB  write %12.1f KiB  -> %10.1f MB/launch" % (k, v["FETCH_SIZE_avg"], v["WRITE_SIZE_avg"], v["hbm_bytes_per_launch"] / 1e6))
+        if k.startswith("_"):
+            continue
+        print("%-16s fetch %12.1f KiB  write %12.1f KiB  -> %10.1f MB/launch" % (k, v["FETCH_SIZE_avg_KiB"], v["WRITE_SIZE_avg_KiB"], v["hbm_bytes_per_launch"] / 1e6))
 
 
 if __name__ == "__main__":
