@@ -237,6 +237,8 @@ struct hg_ctx {
     bool direct_rank = false;  // R = N: k_rank_fused computes distance and match bit per row itself (no records)
     bool rec8 = false;         // the record rows hold one-byte compact records (matrix-core select, no lists wanted)
     i64 opt_compact = 1;       // "compact_records": allow them
+    i64 opt_second_bet = 1;    // "second_bet": a lost one-shot bet is retried once with a wider margin before the exact sequence
+    i64 opt_rebets = 0;
     i64 opt_lds_pad = 0;       // "lds_pad": extra dynamic LDS per block of the matrix-core select (occupancy experiments)
     bool err_zeroed = false;   // the guess kernel of a one-shot bet already cleared err
     i64 defer_verdict = 0;     // hg_rank does not wait for the bet's verdict; hg_bet_verdict reads it later
@@ -1781,7 +1783,33 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
         bool handled = false;                      // some queries lost their bet
         HG_TRY(rerun_lost_queries(c, R, lists, with_ap, &handled));
         if (handled) { c->opt_consecutive_fail = 0; return HG_OK; }
-        c->opt_fallbacks++;                        // too many: exact path for all
+        // many queries lost.  Before paying for the exact two-pass sequence (3x the bet at C2), bet once more with
+        // twice the safety margin and twice the record budget -- the verification is what makes either bet exact
+        if (c->opt_second_bet) {
+            const i64 sigma0 = c->opt_sigma, budget0 = c->cand_budget_x10;
+            c->opt_sigma = 2 * sigma0 + 2;
+            c->cand_budget_x10 = 2 * budget0;
+            c->opt_rebets++;
+            c->want_lists = lists;
+            int rc;
+            if (with_ap) {
+                rc = enqueue_bet_with_ap(c, R, stride, need_cnt);
+                if (rc == HG_OK) rc = c->sync();
+                flag = *(const int*)c->pin;
+                c->ap_staged = rc == HG_OK && flag == 0;
+            } else {
+                rc = enqueue_optimistic(c, R, stride, need_cnt);
+                if (rc == HG_OK) rc = read_plan_flag(c, &flag);
+            }
+            c->opt_sigma = sigma0;
+            c->cand_budget_x10 = budget0;
+            HG_TRY(rc);
+            if (!flag) { c->opt_consecutive_fail = 0; return HG_OK; }
+            handled = false;
+            HG_TRY(rerun_lost_queries(c, R, lists, with_ap, &handled));
+            if (handled) { c->opt_consecutive_fail = 0; return HG_OK; }
+        }
+        c->opt_fallbacks++;                        // still too many: exact path for all
         c->opt_consecutive_fail++;
         c->want_lists = lists;
     }
@@ -2177,6 +2205,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_rank_cnt = value != 0;
     } else if (!strcmp(key, "compact_records")) {
         c->opt_compact = value != 0;
+    } else if (!strcmp(key, "second_bet")) {
+        c->opt_second_bet = value != 0;
     } else if (!strcmp(key, "lds_pad")) {
         if (value < 0 || value > 24 * 1024) return fail(HG_ERR_ARG, "lds_pad must be 0..24576");
         c->opt_lds_pad = value;
@@ -2227,6 +2257,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     if (!strcmp(key, "optimistic_runs")) *value = c->opt_runs;
     else if (!strcmp(key, "optimistic_fallbacks")) *value = c->opt_fallbacks;
     else if (!strcmp(key, "optimistic_requeried")) *value = c->opt_requeried;
+    else if (!strcmp(key, "optimistic_rebets")) *value = c->opt_rebets;
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
     else if (!strcmp(key, "device_bytes")) {
         DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,

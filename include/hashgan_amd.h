@@ -225,14 +225,15 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * "select_qt" (k_select_mx query tiles per wavefront: 2 or 4), "select_packed" (k_select_mx2, two rows per
  * MFMA accumulator: 1 = for codes of <= 32 bits, 2 = also for 33..64 bits, 0 = never), "rank_lds" (0/1), "rank_cnt" (0/1:
  * the bet's rank stage as a per-thread counting sort, k_rank_cnt),
- * "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
+ * "second_bet" (1, default: a one-shot bet that too many queries lost is retried once with twice the margin and record
+ * budget before the exact two-pass sequence runs), "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
  * {match, dist} through per-slice LDS rings instead of 8-byte {idx, dist, match} records),
  * "real_queries_per_lane", "real_segment_bytes" (real-valued path), "step_graph" (1, default: hg_map captures its
  * one-shot sequence into a hipGraph the second time it sees the same problem and replays it afterwards; 0: always
  * enqueue kernel by kernel). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
 /* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
- * (single queries rerun exactly after losing their bet), "last_optimistic", "device_bytes", "segments",
+ * (single queries rerun exactly after losing their bet), "optimistic_rebets" (second bets), "last_optimistic", "device_bytes", "segments",
  * "segment_rows", "slice_capacity", "record_row"; census of the float tables loaded by hg_set_*_f32 --
  * "db_nonbinary" / "q_nonbinary" (entries outside {-1,0,+1}), "db_zeros" / "q_zeros", "db_minus_ones" /
  * "q_minus_ones" -- from which the caller tells +-1 codes, {0,1} bits and real-valued features apart;

@@ -332,12 +332,16 @@ def test_failed_bet_falls_back_to_exact(ctx):
         ctx.set_option("optimistic", 1)              # also clears the consecutive-failure latch
         ctx.set_option("guess_sigma", sigma)
         r0 = ctx.get_stat("optimistic_runs")
-        f0, p0 = ctx.get_stat("optimistic_fallbacks"), ctx.get_stat("optimistic_requeried")
-        ap, rel = ctx.map(R)
-        assert ctx.get_stat("optimistic_runs") == r0 + 1
-        assert np.array_equal(ap[:32], ap_ref, equal_nan=True)
-        lost_some += (ctx.get_stat("optimistic_fallbacks") - f0) + (ctx.get_stat("optimistic_requeried") - p0)
+        f0, p0, b0 = ctx.get_stat("optimistic_fallbacks"), ctx.get_stat("optimistic_requeried"), ctx.get_stat("optimistic_rebets")
+        for second in (1, 0):                        # with and without the second, wider bet before the exact sequence
+            ctx.set_option("second_bet", second)
+            ap, rel = ctx.map(R)
+            assert np.array_equal(ap[:32], ap_ref, equal_nan=True), (sigma, second)
+        assert ctx.get_stat("optimistic_runs") == r0 + 2
+        lost_some += (ctx.get_stat("optimistic_fallbacks") - f0) + (ctx.get_stat("optimistic_requeried") - p0) + (
+            ctx.get_stat("optimistic_rebets") - b0)
     assert lost_some > 0                             # the scenario really exercised a fallback
+    ctx.set_option("second_bet", 1)
     ctx.set_option("guess_sigma", 6)
     ctx.set_option("optimistic", 1)
 
