@@ -8,6 +8,7 @@
 #include "hg_rank_lds.hpp"
 #include "hg_rank_cnt.hpp"
 #include "hg_select_mx2.hpp"
+#include "hg_real_mx.hpp"
 #include "../../include/hashgan_amd.h"
 
 #include <rccl/rccl.h>     // types and enums only: the library itself is dlopen'ed by hg_comm_init (573 MB, not every process needs it)
@@ -256,6 +257,9 @@ struct hg_ctx {
     bool ranked_local = false; // mbits holds this shard's bitmap in LOCAL rank order (hg_select_ranked)
     DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
+    DevBuf dbfx;               // float features of the database in MFMA A-fragment order (k_real_select_mx), built on first use
+    bool dbfx_valid = false;
+    i64 opt_real_mfma = 1;     // "real_mfma": the real-valued select pass runs on the matrix cores
     int bpad = 0;              // feature count padded to a multiple of 16 (0: no float tables loaded)
     i64 census_db[3] = {0, 0, 0}, census_q[3] = {0, 0, 0};   // float tables as loaded: entries outside {-1,0,+1}, zeros, minus ones
     bool real_lists = false;
@@ -716,6 +720,47 @@ template <int BP> int real_launch_select(hg_ctx* c) {
     if (BP <= 32 && c->opt_real_qpl == 2) return real_launch_select_q<BP, (BP <= 32 ? 2 : 1)>(c);
     return real_launch_select_q<BP, 1>(c);
 }
+// real-valued select on the matrix cores: blocks = (pair of segments) x (256 queries)
+template <int KP> int real_launch_select_mx(hg_ctx* c) {
+    if (!c->dbfx_valid) {
+        const i64 n16 = (c->N + 15) / 16 * 16;
+        HG_TRY(c->dbfx.reserve((size_t)n16 * KP * 4));
+        const i64 items = n16 * (KP / 4);
+        c->t_begin(KI_PACK);
+        hipLaunchKernelGGL(k_expand_dbf, dim3(grid_for(items)), dim3(256), 0, c->stream, c->dbf.as<float>(), c->dbfx.as<float4>(),
+                           (i64)c->N, n16, KP);
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_dbf"));
+        c->dbfx_valid = true;
+    }
+    Geo g = c->geo;
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + WPB * 32 * RMX_QT - 1) / (WPB * 32 * RMX_QT);
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
+    c->t_begin(KI_REAL_SELECT);
+    hipLaunchKernelGGL((k_real_select_mx<KP>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream,
+                       c->qf.as<float>(), c->dbfx.as<u8>(), a, c->cand.as<u64>(), g);
+    c->t_end();
+    return c->check_launch("k_real_select_mx");
+}
+int real_select_mx(hg_ctx* c) {
+    switch (c->bpad) {
+        case 16: return real_launch_select_mx<16>(c);
+        case 32: return real_launch_select_mx<32>(c);
+        case 48: return real_launch_select_mx<48>(c);
+        case 64: return real_launch_select_mx<64>(c);
+        case 80: return real_launch_select_mx<80>(c);
+        case 96: return real_launch_select_mx<96>(c);
+        case 112: return real_launch_select_mx<112>(c);
+        case 128: return real_launch_select_mx<128>(c);
+        default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 128 features (have %d)", c->b);
+    }
+}
+
 #define HG_DISPATCH_BP(fn, c, ...)                                  \
     switch ((c)->bpad / 2) {                                        \
         case 8: return fn<8>(c, ##__VA_ARGS__);                     \
@@ -729,7 +774,10 @@ template <int BP> int real_launch_select(hg_ctx* c) {
         default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 128 features (have %d)", (c)->b); \
     }
 int real_sample(hg_ctx* c, i64 M, i64 stride) { HG_DISPATCH_BP(real_launch_sample, c, M, stride) }
-int real_select(hg_ctx* c) { HG_DISPATCH_BP(real_launch_select, c) }
+int real_select(hg_ctx* c) {
+    if (c->opt_real_mfma && c->geo.L % 16 == 0) return real_select_mx(c);
+    HG_DISPATCH_BP(real_launch_select, c)
+}
 
 
 }  // namespace
@@ -777,7 +825,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -885,6 +933,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->stage = ST_DB;
     c->dbx_valid = false;
     c->dbx2_valid = false;
+    c->dbfx_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;
     c->cfg_epoch++;
     return HG_OK;
@@ -2219,6 +2268,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_probe = value;
     } else if (!strcmp(key, "select_qt")) {
         c->opt_select_qt = value;
+    } else if (!strcmp(key, "real_mfma")) {
+        c->opt_real_mfma = value != 0;
     } else if (!strcmp(key, "real_segment_bytes")) {
         if (value < 4096) return fail(HG_ERR_ARG, "real_segment_bytes must be >= 4096");
         c->opt_real_seg_bytes = value;
@@ -2239,8 +2290,9 @@ int hg_trim(hg_ctx* c) {
     HG_TRY(c->sync());
     DevBuf* work[] = {&c->hist, &c->seglt, &c->segtie, &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->cand, &c->out_idx,
                       &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->scores, &c->bigq, &c->mbits2,
-                      &c->dbx, &c->qx, &c->dbx2, &c->qx2};   // the fp4 images are rebuilt on demand
+                      &c->dbx, &c->qx, &c->dbx2, &c->qx2, &c->dbfx};   // the images are rebuilt on demand
     for (auto* d : work) d->release();
+    c->dbfx_valid = false;
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
     c->gath_idx.release(); c->gath_dist.release();

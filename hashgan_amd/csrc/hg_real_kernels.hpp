@@ -4,8 +4,8 @@
 // features in VGPRs), database rows wave-uniform through scalar loads, hit masks + drain.
 //
 // Arithmetic (fixed, restated exactly by oracle/real_map.py):
-//   ip = ((c0 + c1) + (c2 + c3)) + 0.0, c_j = float32 fma chain over k = j mod 4, k ascending;
-// two v_pk_fma_f32 accumulators carry the four chains.  Ranking: ip descending, database index ascending.
+//   ip = (one float32 fma chain from +0.0 over k ascending) + 0.0
+// -- the order of the matrix cores' float32 MFMA (hg_real_mx.hpp).  Ranking: ip descending, database index ascending.
 // Sortable record: (~mono(ip) << 32) | idx, mono() = the usual order-preserving map of float
 // bits to unsigned; ascending records = descending ip, ascending index.
 #pragma once
@@ -26,15 +26,15 @@ __device__ __forceinline__ float mono_inv(u32 k) {
 
 template <int BP>   // BP = padded feature count / 2 (a multiple of 8)
 __device__ __forceinline__ float ip_row(const f2 (&q)[BP], const f2* __restrict__ row) {
-    // four float32 fma chains, k mod 4 (two independent v_pk_fma_f32 accumulators: half the dependent
-    // chain length of a single one), combined as ((c0 + c1) + (c2 + c3)) + 0.0
-    f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
+    // ONE float32 fma chain from +0.0 over k ascending: bitwise what the chained v_mfma_f32_32x32x2_f32 of
+    // k_real_select_mx computes (hg_real_mx.hpp), so every kernel of this path yields the same scores
+    float acc = 0.0f;
 #pragma unroll
-    for (int p = 0; p < BP; p += 2) {
-        a = __builtin_elementwise_fma(q[p], row[p], a);
-        b = __builtin_elementwise_fma(q[p + 1], row[p + 1], b);
+    for (int p = 0; p < BP; ++p) {
+        acc = __builtin_fmaf(q[p].x, row[p].x, acc);
+        acc = __builtin_fmaf(q[p].y, row[p].y, acc);
     }
-    return ((a.x + a.y) + (b.x + b.y)) + 0.0f;
+    return acc + 0.0f;
 }
 
 // ----------------------------------------------------------------------------

@@ -161,8 +161,8 @@ int hg_map(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel);
 /* ---- real-valued features (what main.py feeds when nothing is binarised) ----
  * Ranking by float32 inner product, lib/metric.py:13-14 as written, on the float tables kept by
  * hg_set_database_f32 / hg_set_queries_f32 (b <= 128, one shard).  Order: inner product descending,
- * database index ascending.  The product's summation order is fixed (even-k and odd-k float32 fma
- * chains, then their sum) and restated exactly by oracle/real_map.py; it equals the reference's
+ * database index ascending.  The product's summation order is fixed (one float32 fma chain in feature
+ * order: what the chained v_mfma_f32_32x32x2_f32 computes) and restated exactly by oracle/real_map.py; it equals the reference's
  * np.dot wherever float32 rounding does not reorder near-equal products, exactly so on inputs
  * whose arithmetic is exact.  hg_map_real = ranking + label match + AP; hg_topr_real = ranking only. */
 int hg_map_real(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel);
@@ -228,6 +228,7 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * "second_bet" (1, default: a one-shot bet that too many queries lost is retried once with twice the margin and record
  * budget before the exact two-pass sequence runs), "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
  * {match, dist} through per-slice LDS rings instead of 8-byte {idx, dist, match} records),
+ * "real_mfma" (1, default: the real-valued select pass on the float32 matrix-core instruction; 0: vector ALU),
  * "real_queries_per_lane", "real_segment_bytes" (real-valued path), "step_graph" (1, default: hg_map captures its
  * one-shot sequence into a hipGraph the second time it sees the same problem and replays it afterwards; 0: always
  * enqueue kernel by kernel). */

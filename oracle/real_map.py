@@ -5,12 +5,12 @@ metric.py:13-14 ranks by float32 inner products, `np.argsort(-np.dot(q, db.T), 1
 GEMM's rounding depends on its summation order (OpenBLAS's is not the GPU's), so the build fixes
 one order and this file restates it exactly:
 
-    ip(q, d) = ((c0 + c1) + (c2 + c3)) + 0.0                               all in float32,
-               c_j = fma chain over k = j (mod 4): acc = fma(q[k], d[k], acc), k ascending, from +0.0
+    ip(q, d) = acc + 0.0,   acc = fma(q[k], d[k], acc) for k = 0, 1, ..., from +0.0            all in float32
                (features zero-padded to a multiple of 16)
 
-(two `v_pk_fma_f32` accumulators on the GPU carry the four chains; the final `+ 0.0` folds -0.0
-into +0.0 so that equal values compare equal as bit patterns).  Ranking: ip descending, database
+-- ONE fma chain in feature order: measured on the MI355X (tools/mfma_f32_probe.hip), that is bit for bit what the
+chained `v_mfma_f32_32x32x2_f32` instructions of the select kernel compute per (query, row) pair (the final `+ 0.0`
+folds -0.0 into +0.0 so that equal values compare equal as bit patterns).  Ranking: ip descending, database
 index ascending.  AP/mAP: the expressions of metric.py:17-24, via oracle.hamming_map.
 
 Parity pin: on features whose products and partial sums are exactly representable in float32
@@ -58,10 +58,10 @@ def inner_products(qf, dbf):
     dbf = np.ascontiguousarray(dbf, dtype=np.float32)
     Q, b = qf.shape
     N = dbf.shape[0]
-    acc = [np.zeros((Q, N), np.float32) for _ in range(4)]
+    acc = np.zeros((Q, N), np.float32)
     for k in range(b):
-        acc[k & 3] = fma32(np.broadcast_to(qf[:, k][:, None], (Q, N)), np.broadcast_to(dbf[:, k][None, :], (Q, N)), acc[k & 3])
-    return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + np.float32(0.0)
+        acc = fma32(np.broadcast_to(qf[:, k][:, None], (Q, N)), np.broadcast_to(dbf[:, k][None, :], (Q, N)), acc)
+    return acc + np.float32(0.0)
 
 
 def map_from_features(qf, dbf, qlabels, dblabels, R):
