@@ -1,6 +1,6 @@
-"""BASELINE.json's headline configuration at FULL size (C2: Q=10k, N=1M, b=64,
-R=5000), where the oracle would take hours: size-independent properties of the
-HIP result plus a golden anchor on the first 64 queries."""
+"""BASELINE.json's single-GPU configurations at FULL size (C2: Q=10k, N=1M, b=64, R=5000; C3: Q=2.1k, N=190k,
+b=48, 81 multi-hot classes; C5: b=128), where the oracle would take hours: size-independent properties of the
+HIP result plus a golden anchor on the first queries."""
 import numpy as np
 import pytest
 from tests import cases
@@ -10,24 +10,26 @@ from hashgan_amd import _native, metric
 pytestmark = pytest.mark.gpu
 
 
-def test_c2_full_properties():
-    spec = dict(cases.CASES["c2_q64"])
+@pytest.mark.parametrize("name", ["c2_q64", "c3_nus_q64", "c5_b128_q32"])
+def test_full_size_properties(name):
+    spec = dict(cases.CASES[name])
     spec.pop("q_take")
-    cases.CASES["_c2_full"] = spec
+    cases.CASES["_full"] = spec
     try:
-        c = cases.build_case("_c2_full")
+        c = cases.build_case("_full")
     finally:
-        del cases.CASES["_c2_full"]
+        del cases.CASES["_full"]
     Q, N, R, b = c["qbits"].shape[0], c["dbbits"].shape[0], c["R"], c["b"]
     ctx = _native.Context(0)
     qw, dw = metric.pack_codes(c["qbits"]), metric.pack_codes(c["dbbits"])
-    ctx.set_database(dw, metric.pack_labels(c["dblab"]), b, 10)
+    ctx.set_database(dw, metric.pack_labels(c["dblab"]), b, c["dblab"].shape[1])
     ctx.set_queries(qw, metric.pack_labels(c["qlab"]))
     ap, rel = ctx.map(R)                              # one-shot (sampled-threshold bet)
     assert ctx.get_stat("last_optimistic") == 1
-    g = cases.load_golden("c2_q64")
-    # anchor: the first 64 queries are exactly the golden case
-    assert np.array_equal(ap[:64], g["ap"], equal_nan=True)
+    g = cases.load_golden(name)
+    # anchor: the first queries are exactly the golden case
+    k = g["ap"].shape[0]
+    assert np.array_equal(ap[:k], g["ap"], equal_nan=True)
     # staged exact path: full histogram -> plan -> select; must agree with the one-shot result
     ctx.hist(); ctx.plan(R); ctx.select(); ctx.ap()
     ap2, rel2 = ctx.get_ap()
@@ -48,11 +50,13 @@ def test_c2_full_properties():
     assert ((dist < t[:, None]).sum(1) == closer).all()
     # distances are the Hamming distances of the listed rows (sampled queries)
     for q in range(0, Q, 997):
-        d = np.bitwise_count(dw[idx[q].astype(np.int64), 0] ^ qw[q, 0])
+        d = np.bitwise_count(dw[idx[q].astype(np.int64)] ^ qw[q][None, :]).sum(1)
         assert np.array_equal(d, dist[q])
     # AP recomputed on the host from the device's match bits, NumPy expressions of metric.py:20-23
     m = ctx.get_match().astype(bool)
     for q in range(0, Q, 499):
         a, r = O.average_precision(m[q], R)
         assert r == rel[q] and (a == ap[q] or (a is None and np.isnan(ap[q])))
+        # ... and the match bits themselves against the labels (metric.py:17-19)
+        assert np.array_equal(m[q], O.label_match(c["qlab"][q], c["dblab"][idx[q].astype(np.int64)]))
     ctx.close()

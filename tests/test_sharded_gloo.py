@@ -64,3 +64,47 @@ def test_shard_bounds():
     from hashgan_amd import sharded
     assert sharded.shard_bounds(10, 3) == [(0, 4), (4, 3), (7, 3)]
     assert sharded.shard_bounds(8, 8) == [(i, 1) for i in range(8)]
+
+
+def _id_worker(rank, world, port, out_dir):
+    """hashgan_amd.sharded.init_rccl's rendezvous without RCCL: rank 0 draws an id, the file carries it to the others."""
+    sys.path.insert(0, ROOT)
+    from hashgan_amd import _native, sharded
+    os.environ["MASTER_PORT"] = str(port)
+
+    class FakeCtx:                       # the three calls init_rccl makes on a context
+        def comm_init(self, uid, r, w):
+            self.uid, self.r, self.w = bytes(uid), r, w
+
+        def comm_info(self):
+            return self.r, self.w
+
+        def barrier(self):               # the real one is an all-reduce; here: wait until every rank has written its result
+            open(os.path.join(out_dir, "arrived%d" % self.r), "w").close()
+            import time
+            t0 = time.time()
+            while not all(os.path.exists(os.path.join(out_dir, "arrived%d" % k)) for k in range(self.w)):
+                assert time.time() - t0 < 60
+                time.sleep(0.01)
+
+    _native.comm_unique_id = lambda: bytes([(7 * i + os.getpid()) % 251 for i in range(_native.COMM_ID_BYTES)])
+    ctx = FakeCtx()
+    comm = sharded.init_rccl(ctx, rank, world, timeout=60)
+    assert (comm.rank, comm.world) == (rank, world)
+    with open(os.path.join(out_dir, "id%d" % rank), "wb") as f:
+        f.write(ctx.uid)
+
+
+def test_rccl_id_rendezvous_between_processes(tmp_path):
+    """Three sibling processes (as a launcher starts them): every rank ends up with rank 0's 128 bytes, the
+    rendezvous file is gone afterwards, and a stale file of an earlier launch is not mistaken for the id."""
+    from hashgan_amd import sharded
+    port = 31000 + (os.getpid() % 500)
+    stale = sharded._id_file(3, str(port)).replace("_%d_" % os.getppid(), "_%d_" % os.getpid())   # the name the children will use
+    with open(stale, "wb") as f:
+        f.write(b"\0" * 128)
+    os.utime(stale, (1, 1))                              # ancient
+    mp.spawn(_id_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    ids = [open(tmp_path / ("id%d" % r), "rb").read() for r in range(3)]
+    assert ids[0] == ids[1] == ids[2] and len(ids[0]) == 128 and ids[0] != b"\0" * 128
+    assert not os.path.exists(stale)
