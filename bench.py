@@ -194,8 +194,8 @@ def kernel_rooflines(timing, spec, rows, step_s, rec_bytes=1):
 
 def h2d_inclusive(spec, packed, reps=3):
     """The drop-in call itself, from HOST arrays as forward_all() returns them (float32 +-1 features, int64 labels):
-    MAPs(R).get_maps_by_feature(database, query) uploads 4 B per code bit over PCIe, binarises + packs on the GPU,
-    then runs the step.  Never `value`."""
+    MAPs(R).get_maps_by_feature(database, query) packs them with a pool of host threads (hg_host_pack.hpp), uploads
+    the packed tables over PCIe, then runs the step.  Never `value`."""
     import types
     from hashgan_amd import MAPs
     qw, ql, dw, dl = packed
@@ -219,7 +219,8 @@ def h2d_inclusive(spec, packed, reps=3):
     Q = qw.shape[0]
     host_bytes = db.output.nbytes + db.label.nbytes + q.output.nbytes + q.label.nbytes
     return {"call": "MAPs(R).get_maps_by_feature(database, query) from host float32 features + int64 labels",
-            "ms_per_call": full * 1e3, "queries_per_sec": Q / full, "host_bytes_uploaded": host_bytes,
+            "ms_per_call": full * 1e3, "queries_per_sec": Q / full, "host_array_bytes": host_bytes,
+            "bytes_over_pcie": int(dw.nbytes + dl.nbytes + qw.nbytes + ql.nbytes),
             "with_resident_database": {"call": "MAPs.set_database(database) once, then get_maps_by_feature(None, query)",
                                        "ms_per_call": resident * 1e3, "queries_per_sec": Q / resident},
             "map_equal_to_resident_path": bool(val == val2)}, float(val)

@@ -9,6 +9,7 @@
 #include "hg_rank_cnt.hpp"
 #include "hg_select_mx2.hpp"
 #include "hg_real_mx.hpp"
+#include "hg_host_pack.hpp"
 #include "../../include/hashgan_amd.h"
 
 #include <rccl/rccl.h>     // types and enums only: the library itself is dlopen'ed by hg_comm_init (573 MB, not every process needs it)
@@ -261,7 +262,14 @@ struct hg_ctx {
     bool dbfx_valid = false;
     i64 opt_real_mfma = 1;     // "real_mfma": the real-valued select pass runs on the matrix cores
     int bpad = 0;              // feature count padded to a multiple of 16 (0: no float tables loaded)
-    i64 census_db[3] = {0, 0, 0}, census_q[3] = {0, 0, 0};   // float tables as loaded: entries outside {-1,0,+1}, zeros, minus ones
+    i64 census_db[3] = {0, 0, 0}, census_q[3] = {0, 0, 0};
+    // hand-over of float32 / int64 arrays: packed on the host by a thread pool before the upload (hg_host_pack.hpp)
+    i64 opt_host_pack = 1;     // "host_pack": 0 = upload the raw arrays and pack on the GPU (k_pack_*)
+    i64 opt_keep_floats = 2;   // "keep_floats": database float table on the GPU -- 0 never, 1 always, 2 only if it is not a +-1 code
+    i64 opt_pack_threads = 0;  // "pack_threads": 0 = up to 32
+    void* hpk = nullptr;       // pinned staging for the packed tables
+    size_t hpk_cap = 0;
+    bool dbf_resident = false, qf_resident = false;   // float tables as loaded: entries outside {-1,0,+1}, zeros, minus ones
     bool real_lists = false;
     i64 shapes_for_R = -1;
 
@@ -833,6 +841,7 @@ int hg_destroy(hg_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->pin) (void)hipHostFree(c->pin);
+    if (c->hpk) (void)hipHostFree(c->hpk);
     if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
     delete c;
     return HG_OK;
@@ -867,6 +876,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     c->NW = (b + 31) / 32; c->NB = b + 1; c->LW = (C + 63) / 64;
     c->idx_base = (u32)idx_base;
     c->bpad = 0;                                       // packed input: no float tables for the real-valued path
+    c->dbf_resident = false;
     HG_TRY(upload_codes(c, c->db, codes, N, (b + 63) / 64, c->NW));
     HG_TRY(c->dblab.reserve((size_t)(N > 0 ? N : 1) * c->LW * 8));
     if (N) HG_HIP(hipMemcpyAsync(c->dblab.p, labels, (size_t)N * c->LW * 8, hipMemcpyHostToDevice, c->stream));
@@ -879,12 +889,12 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     return HG_OK;
 }
 
-// float32 features + int64 labels -> packed device tables (k_pack_sign_f32 / k_pack_labels_i64)
+// float32 features + int64 labels -> packed device tables, packed ON THE GPU (k_pack_sign_f32 / k_pack_labels_i64)
 static int pack_on_device(hg_ctx* c, const float* x, const int64_t* lab, i64 n, DevBuf& codes, DevBuf& labels,
                           DevBuf& feats, int64_t* bad_codes, int64_t* bad_labels, i64 (&census)[3]) {
     const int b = c->b, C = c->C, NW = c->NW, LW = c->LW;
     // the float table stays resident, zero-padded to a multiple of 16 features: the real-valued
-    // ranking (hg_map_real) streams it, and padding keeps its scalar loads 64-byte aligned
+    // ranking (hg_map_real) streams it, and padding keeps its rows 64-byte aligned
     const int bpad = (b + 15) / 16 * 16;
     c->bpad = bpad;
     const size_t fb = (size_t)n * bpad * 4, lb = (size_t)n * C * 8;
@@ -916,6 +926,47 @@ static int pack_on_device(hg_ctx* c, const float* x, const int64_t* lab, i64 n, 
     return HG_OK;
 }
 
+// The same hand-over with the packing done by host threads BEFORE the upload (hg_host_pack.hpp): 16 MB instead of 339 MB
+// cross PCIe at C2.  The float table follows only when somebody will rank by inner product (`floats`: 0 no, 1 yes,
+// 2 = iff the table is not a +-1 code).  *has_floats tells what happened.
+static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, DevBuf& codes, DevBuf& labels,
+                        DevBuf& feats, int floats, bool* has_floats, int64_t* bad_codes, int64_t* bad_labels, i64 (&census)[3]) {
+    const int b = c->b, C = c->C, NW = c->NW, LW = c->LW;
+    const size_t cb = (size_t)n * NW * 4, lbytes = (size_t)n * LW * 8;
+    const size_t need_b = ((cb + 63) & ~(size_t)63) + lbytes;
+    if (c->hpk_cap < need_b) {
+        HG_TRY(c->sync());
+        if (c->hpk) (void)hipHostFree(c->hpk);
+        c->hpk = nullptr; c->hpk_cap = 0;
+        HG_HIP(hipHostMalloc(&c->hpk, need_b, hipHostMallocDefault));
+        c->hpk_cap = need_b;
+    }
+    u32* hc = (u32*)c->hpk;
+    u64* hl = (u64*)((char*)c->hpk + ((cb + 63) & ~(size_t)63));
+    HostPackCensus cs;
+    host_pack(x, lab, n, b, C, hc, hl, &cs, (int)c->opt_pack_threads);
+    HG_TRY(codes.reserve(cb + 64 * 4));
+    HG_TRY(labels.reserve(lbytes));
+    HG_HIP(hipMemcpyAsync(codes.p, hc, cb, hipMemcpyHostToDevice, c->stream));
+    HG_HIP(hipMemcpyAsync(labels.p, hl, lbytes, hipMemcpyHostToDevice, c->stream));
+    const bool pm1 = cs.nonbinary == 0 && cs.zeros == 0;
+    const bool up = floats == 1 || (floats == 2 && !pm1);
+    if (up) {
+        const int bpad = (b + 15) / 16 * 16;
+        c->bpad = bpad;
+        const size_t fb = (size_t)n * bpad * 4;
+        HG_TRY(feats.reserve(fb + 256));
+        if (bpad != b) HG_HIP(hipMemsetAsync(feats.p, 0, fb, c->stream));
+        HG_HIP(hipMemcpy2DAsync(feats.p, (size_t)bpad * 4, x, (size_t)b * 4, (size_t)b * 4, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
+    *has_floats = up;
+    HG_TRY(c->sync());                                 // the pinned staging is reused by the next call
+    if (bad_codes) *bad_codes = (int64_t)cs.nonbinary;
+    if (bad_labels) *bad_labels = (int64_t)cs.bad_labels;
+    census[0] = cs.nonbinary; census[1] = cs.zeros; census[2] = cs.minus_ones;
+    return HG_OK;
+}
+
 int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labels, int64_t N, int b, int C,
                         int64_t idx_base, int64_t n_total, int64_t* bad_codes, int64_t* bad_labels) {
     if (!c) return fail(HG_ERR_ARG, "hg_set_database_f32: null context");
@@ -929,7 +980,14 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->N = N; c->b = b; c->C = C; c->n_total = n_total;
     c->NW = (b + 31) / 32; c->NB = b + 1; c->LW = (C + 63) / 64;
     c->idx_base = (u32)idx_base;
-    HG_TRY(pack_on_device(c, host_x, host_labels, N, c->db, c->dblab, c->dbf, bad_codes, bad_labels, c->census_db));
+    if (c->opt_host_pack) {
+        HG_TRY(pack_on_host(c, host_x, host_labels, N, c->db, c->dblab, c->dbf, (int)c->opt_keep_floats, &c->dbf_resident,
+                            bad_codes, bad_labels, c->census_db));
+    } else {
+        HG_TRY(pack_on_device(c, host_x, host_labels, N, c->db, c->dblab, c->dbf, bad_codes, bad_labels, c->census_db));
+        c->dbf_resident = true;
+    }
+    if (!c->dbf_resident) c->bpad = 0;
     c->stage = ST_DB;
     c->dbx_valid = false;
     c->dbx2_valid = false;
@@ -945,7 +1003,16 @@ int hg_set_queries_f32(hg_ctx* c, const float* host_x, const int64_t* host_label
     if (Q < 1 || !host_x || !host_labels) return fail(HG_ERR_ARG, "hg_set_queries_f32: need Q >= 1 and data");
     if (Q > 0x7FFFFFC0ll) return fail(HG_ERR_ARG, "hg_set_queries_f32: Q too large");
     c->Q = Q;
-    HG_TRY(pack_on_device(c, host_x, host_labels, Q, c->qc, c->qlab, c->qf, bad_codes, bad_labels, c->census_q));
+    if (c->opt_host_pack) {
+        // the query table is small: its floats follow whenever the database's are there (the inner-product ranking needs both)
+        const int saved_bpad = c->bpad;
+        HG_TRY(pack_on_host(c, host_x, host_labels, Q, c->qc, c->qlab, c->qf, c->dbf_resident ? 1 : 0, &c->qf_resident,
+                            bad_codes, bad_labels, c->census_q));
+        if (!c->qf_resident) c->bpad = saved_bpad;
+    } else {
+        HG_TRY(pack_on_device(c, host_x, host_labels, Q, c->qc, c->qlab, c->qf, bad_codes, bad_labels, c->census_q));
+        c->qf_resident = true;
+    }
     c->stage = ST_DB | ST_Q;
     c->qx_valid = false;
     c->qx2_valid = false;
@@ -976,6 +1043,7 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     c->stage = ST_DB | ST_Q;
     c->qx_valid = false;
     c->qx2_valid = false;
+    c->qf_resident = false;                            // packed input: no float table
     c->cfg_epoch++;
     return HG_OK;
 }
@@ -1966,8 +2034,9 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
 }
 
 static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
-    if (!c->bpad || !c->dbf.p || !c->qf.p)
-        return fail(HG_ERR_STATE, "real-valued ranking needs float features: load them with hg_set_database_f32 / hg_set_queries_f32");
+    if (!c->bpad || !c->dbf.p || !c->qf.p || !c->dbf_resident || !c->qf_resident)
+        return fail(HG_ERR_STATE, "real-valued ranking needs the float features on the GPU: load them with hg_set_database_f32 / "
+                                  "hg_set_queries_f32 (option keep_floats = 1 if the database is a +-1 code)");
     if (c->n_total != c->N) return fail(HG_ERR_STATE, "real-valued ranking is single-shard");
     if (R < 1 || R > c->N) return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->N);
     int lost = 0;
@@ -2252,6 +2321,14 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_rank_lds = value != 0;
     } else if (!strcmp(key, "rank_cnt")) {
         c->opt_rank_cnt = value != 0;
+    } else if (!strcmp(key, "host_pack")) {
+        c->opt_host_pack = value != 0;
+    } else if (!strcmp(key, "keep_floats")) {
+        if (value < 0 || value > 2) return fail(HG_ERR_ARG, "keep_floats must be 0, 1 or 2");
+        c->opt_keep_floats = value;
+    } else if (!strcmp(key, "pack_threads")) {
+        if (value < 0 || value > 1024) return fail(HG_ERR_ARG, "pack_threads must be 0..1024");
+        c->opt_pack_threads = value;
     } else if (!strcmp(key, "compact_records")) {
         c->opt_compact = value != 0;
     } else if (!strcmp(key, "second_bet")) {
@@ -2328,6 +2405,8 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "q_zeros")) *value = c->census_q[1];
     else if (!strcmp(key, "q_minus_ones")) *value = c->census_q[2];
     else if (!strcmp(key, "probe_build")) *value = kProbes ? 1 : 0;
+    else if (!strcmp(key, "db_floats")) *value = c->dbf_resident ? 1 : 0;
+    else if (!strcmp(key, "q_floats")) *value = c->qf_resident ? 1 : 0;
     else if (!strcmp(key, "graph_replays")) *value = c->graph_replays;
     else if (!strcmp(key, "graph_captures")) *value = c->graph_captures;
     else if (!strcmp(key, "segments")) *value = c->geo.S;

@@ -1,0 +1,148 @@
+// hashgan_amd -- host side of the hand-over of forward_all()'s arrays (main.py:151-158): float32 features [n][b] and
+// int64 labels [n][C] become packed code / label words BEFORE they cross PCIe.  339 MB of raw arrays at C2 cost 17 ms
+// of upload; their packed form is 16 MB.  A pool of host threads streams the arrays once (AVX-512 compares give 16
+// sign bits per load), producing the device layout directly -- codes uint32 [n][ceil(b/32)], labels uint64
+// [n][ceil(C/64)] -- plus the census the caller needs to tell +-1 codes, {0,1} bits and real-valued features apart.
+// Same bits as k_pack_sign_f32 / k_pack_labels_i64 (bit = x > 0, bit = label != 0): tests/test_hip_parity.py.
+#pragma once
+#include <stdint.h>
+
+namespace hg {
+
+struct HostPackCensus {
+    long long nonbinary = 0;     // feature entries outside {-1, 0, +1} (NaN included)
+    long long zeros = 0;
+    long long minus_ones = 0;
+    long long bad_labels = 0;    // label entries outside {0, 1}
+};
+
+// x may be null (labels only) and lab may be null (codes only).  threads <= 0: pick from the hardware.
+void host_pack(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,
+               HostPackCensus* census, int threads);
+
+}  // namespace hg
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+namespace hg {
+namespace hostpack {
+
+inline void rows_scalar(const float* x, const int64_t* lab, long long r0, long long r1, int b, int C, uint32_t* codes,
+                        uint64_t* labels, HostPackCensus& cs) {
+    const int NW = (b + 31) / 32, LW = (C + 63) / 64;
+    for (long long r = r0; r < r1; ++r) {
+        if (x) {
+            const float* row = x + r * b;
+            for (int w = 0; w < NW; ++w) {
+                uint32_t v = 0;
+                const int hi = b - w * 32 < 32 ? b - w * 32 : 32;
+                for (int j = 0; j < hi; ++j) {
+                    const float f = row[w * 32 + j];
+                    v |= (uint32_t)(f > 0.0f) << j;
+                    cs.zeros += f == 0.0f;
+                    cs.minus_ones += f == -1.0f;
+                    cs.nonbinary += !(f == 1.0f || f == -1.0f || f == 0.0f);
+                }
+                codes[r * NW + w] = v;
+            }
+        }
+        if (lab) {
+            const int64_t* row = lab + r * C;
+            for (int w = 0; w < LW; ++w) {
+                uint64_t v = 0;
+                const int hi = C - w * 64 < 64 ? C - w * 64 : 64;
+                for (int j = 0; j < hi; ++j) {
+                    const int64_t l = row[w * 64 + j];
+                    v |= (uint64_t)(l != 0) << j;
+                    cs.bad_labels += !(l == 0 || l == 1);
+                }
+                labels[r * LW + w] = v;
+            }
+        }
+    }
+}
+
+__attribute__((target("avx512f,avx512bw,avx512vl,popcnt")))
+inline void rows_avx512(const float* x, const int64_t* lab, long long r0, long long r1, int b, int C, uint32_t* codes,
+                        uint64_t* labels, HostPackCensus& cs) {
+    const int NW = (b + 31) / 32, LW = (C + 63) / 64;
+    const __m512 zero = _mm512_setzero_ps(), one = _mm512_set1_ps(1.0f), mone = _mm512_set1_ps(-1.0f);
+    long long nz = 0, nm = 0, np = 0, nbad = 0;
+    for (long long r = r0; r < r1; ++r) {
+        if (x) {
+            const float* row = x + r * b;
+            for (int w = 0; w < NW; ++w) {
+                uint32_t v = 0;
+                for (int half = 0; half < 2; ++half) {
+                    const int k = w * 32 + half * 16;
+                    if (k >= b) break;
+                    const int left = b - k;
+                    const __mmask16 m = left >= 16 ? (__mmask16)0xFFFF : (__mmask16)((1u << left) - 1u);
+                    const __m512 f = _mm512_maskz_loadu_ps(m, row + k);
+                    v |= (uint32_t)_mm512_mask_cmp_ps_mask(m, f, zero, _CMP_GT_OQ) << (16 * half);
+                    nz += _mm_popcnt_u32(_mm512_mask_cmp_ps_mask(m, f, zero, _CMP_EQ_OQ));
+                    nm += _mm_popcnt_u32(_mm512_mask_cmp_ps_mask(m, f, mone, _CMP_EQ_OQ));
+                    np += _mm_popcnt_u32(_mm512_mask_cmp_ps_mask(m, f, one, _CMP_EQ_OQ));
+                }
+                codes[r * NW + w] = v;
+            }
+        }
+        if (lab) {
+            const int64_t* row = lab + r * C;
+            const __m512i z = _mm512_setzero_si512(), o = _mm512_set1_epi64(1);
+            for (int w = 0; w < LW; ++w) {
+                uint64_t v = 0;
+                for (int e = 0; e < 8; ++e) {
+                    const int k = w * 64 + e * 8;
+                    if (k >= C) break;
+                    const int left = C - k;
+                    const __mmask8 m = left >= 8 ? (__mmask8)0xFF : (__mmask8)((1u << left) - 1u);
+                    const __m512i l = _mm512_maskz_loadu_epi64(m, row + k);
+                    const __mmask8 nzm = _mm512_mask_cmpneq_epi64_mask(m, l, z);
+                    v |= (uint64_t)nzm << (8 * e);
+                    nbad += _mm_popcnt_u32(_mm512_mask_cmpneq_epi64_mask(nzm, l, o));
+                }
+                labels[r * LW + w] = v;
+            }
+        }
+    }
+    cs.zeros += nz;
+    cs.minus_ones += nm;
+    cs.bad_labels += nbad;
+    if (x) cs.nonbinary += (r1 - r0) * (long long)b - nz - nm - np;
+}
+
+}  // namespace hostpack
+
+inline void host_pack(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,
+                      HostPackCensus* census, int threads) {
+    const bool wide = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+    if (threads <= 0) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        threads = (int)std::min<unsigned>(hw ? hw : 1u, 32u);         // the pass is memory bound well before 32 threads
+    }
+    const long long bytes = n * ((long long)(x ? b * 4 : 0) + (lab ? C * 8 : 0));
+    threads = (int)std::max<long long>(1, std::min<long long>(threads, bytes >> 20));    // at least ~1 MB of input per thread
+    std::vector<HostPackCensus> part((size_t)threads);
+    auto work = [&](int t) {
+        const long long r0 = n * t / threads, r1 = n * (t + 1) / threads;
+        if (wide) hostpack::rows_avx512(x, lab, r0, r1, b, C, codes, labels, part[(size_t)t]);
+        else hostpack::rows_scalar(x, lab, r0, r1, b, C, codes, labels, part[(size_t)t]);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    HostPackCensus tot;
+    for (const auto& p : part) {
+        tot.nonbinary += p.nonbinary; tot.zeros += p.zeros; tot.minus_ones += p.minus_ones; tot.bad_labels += p.bad_labels;
+    }
+    if (census) *census = tot;
+}
+
+}  // namespace hg
+#endif

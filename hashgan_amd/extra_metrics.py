@@ -11,7 +11,7 @@ from . import metric
 
 def _load(eng, q_codes, db_codes, q_labels, db_labels):
     """Binary codes only ({0,1} bits or +-1, the same spelling on both sides), like metric.MAP."""
-    metric._load_database(eng, np.asarray(db_codes), np.asarray(db_labels))
+    metric._load_database(eng, np.asarray(db_codes), np.asarray(db_labels), "codes")
     qbad = eng.ctx.set_queries_f32(np.asarray(q_codes), np.asarray(q_labels))
     if qbad[1]:
         raise ValueError("labels must be {0,1} indicator matrices")

@@ -166,13 +166,18 @@ def _kind(ctx, which):
     return "bits" if not neg else "ternary"
 
 
-def _load_database(eng, db_codes, db_labels):
+def _load_database(eng, db_codes, db_labels, mode="reference", floats=None):
+    """Pack on the host, upload (hg_set_database_f32).  The float table itself goes to the GPU only when it may be ranked
+    by inner product: never for the spellings that binarise or insist on binary codes, and in 'reference' mode only if
+    the database is not a +-1 code (a +-1 database meeting real-valued queries is uploaded again with it, below)."""
+    eng.ctx.set_option("keep_floats", floats if floats is not None else (2 if mode == "reference" else 0))
     bad_c, bad_l = eng.ctx.set_database_f32(db_codes, db_labels)
     if bad_l:
         raise ValueError("labels must be {0,1} indicator matrices")
     eng.b, eng.C = db_codes.shape[1], db_labels.shape[1]
     eng.db_kind = _kind(eng.ctx, 0)
     eng.N = db_codes.shape[0]
+    eng.db_src = (db_codes, db_labels)                # for that second upload
 
 
 def _rank(eng, q_codes, q_labels, R, mode):
@@ -197,6 +202,9 @@ def _rank(eng, q_codes, q_labels, R, mode):
                          "features to MAPs.get_maps_by_feature, which ranks them by inner product like metric.py:13" % (qk, dk))
     if q_codes.shape[1] > 128:
         raise ValueError("inner-product ranking supports up to 128 features (have %d)" % q_codes.shape[1])
+    if not eng.ctx.get_stat("db_floats"):             # a +-1 database whose floats stayed on the host: bring them over now
+        _load_database(eng, eng.db_src[0], eng.db_src[1], floats=1)
+        eng.ctx.set_queries_f32(q_codes, q_labels)
     return eng.ctx.map_real(R)
 
 
@@ -206,7 +214,7 @@ def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, mode):
     _check_shapes(q_codes, db_codes, q_labels, db_labels, R)
     eng = _Shared.get(device)
     with eng.lock:
-        _load_database(eng, db_codes, db_labels)
+        _load_database(eng, db_codes, db_labels, mode)
         ap, rel = _rank(eng, q_codes, q_labels, R, mode)
     return mean_over_hits(ap, rel), ap, rel
 
@@ -259,7 +267,7 @@ class MAPs:
         if out.ndim != 2 or lab.ndim != 2 or out.shape[0] != lab.shape[0]:
             raise ValueError("database.output must be [N, b] and database.label [N, C]")
         with self._lock:
-            _load_database(self._engine(), out, lab)
+            _load_database(self._engine(), out, lab, "sign" if self.binarize else "reference")
             self._resident = ("explicit", database)
 
     def _ensure_database(self, database):
@@ -275,7 +283,7 @@ class MAPs:
             return                                     # the very same immutable arrays as last time
         if out.ndim != 2 or lab.ndim != 2 or out.shape[0] != lab.shape[0]:
             raise ValueError("database.output must be [N, b] and database.label [N, C]")
-        _load_database(self._engine(), out, lab)
+        _load_database(self._engine(), out, lab, "sign" if self.binarize else "reference")
         self._resident = ("auto", out, lab)
 
     def get_maps_by_feature(self, database, query):

@@ -70,7 +70,10 @@ int hg_set_database(hg_ctx* ctx, const uint64_t* host_codes, const uint64_t* hos
 int hg_set_queries(hg_ctx* ctx, const uint64_t* host_codes, const uint64_t* host_labels, int64_t Q);
 
 /* The same two calls fed with what forward_all() (main.py:151-158) actually returns: float32
- * features [n][b] and int64 labels [n][C].  Binarise (bit = x > 0) and pack run on the GPU.
+ * features [n][b] and int64 labels [n][C].  Binarise (bit = x > 0) and pack run on a pool of host threads BEFORE the
+ * upload (16 MB instead of 339 MB cross PCIe at C2; option "host_pack" = 0: upload raw, pack on the GPU).  The float
+ * table itself follows only if it will be ranked by inner product: option "keep_floats" = 2 (default) uploads it iff the
+ * database is not a +-1 code, 1 always, 0 never; the queries' floats follow the database's.
  * *bad_codes counts feature entries outside {-1, 0, +1}, *bad_labels label entries outside
  * {0, 1}: the caller decides what non-binary features mean (the Python mirror ranks them by inner product
  * like metric.py:13-14 unless binarize=True); hg_get_stat has the finer census (zeros, minus ones). */
@@ -225,7 +228,7 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * "select_qt" (k_select_mx query tiles per wavefront: 2 or 4), "select_packed" (k_select_mx2, two rows per
  * MFMA accumulator: 1 = for codes of <= 32 bits, 2 = also for 33..64 bits, 0 = never), "rank_lds" (0/1), "rank_cnt" (0/1:
  * the bet's rank stage as a per-thread counting sort, k_rank_cnt),
- * "second_bet" (1, default: a one-shot bet that too many queries lost is retried once with twice the margin and record
+ * "host_pack", "keep_floats", "pack_threads" (hg_set_*_f32, see there), "second_bet" (1, default: a one-shot bet that too many queries lost is retried once with twice the margin and record
  * budget before the exact two-pass sequence runs), "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
  * {match, dist} through per-slice LDS rings instead of 8-byte {idx, dist, match} records),
  * "real_mfma" (1, default: the real-valued select pass on the float32 matrix-core instruction; 0: vector ALU),
@@ -238,7 +241,7 @@ int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
  * "segment_rows", "slice_capacity", "record_row"; census of the float tables loaded by hg_set_*_f32 --
  * "db_nonbinary" / "q_nonbinary" (entries outside {-1,0,+1}), "db_zeros" / "q_zeros", "db_minus_ones" /
  * "q_minus_ones" -- from which the caller tells +-1 codes, {0,1} bits and real-valued features apart;
- * "probe_build", "graph_captures", "graph_replays". */
+ * "db_floats" / "q_floats" (the float tables are on the GPU), "probe_build", "graph_captures", "graph_replays". */
 int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
 /* Work buffers only grow; hg_trim frees everything except the resident code/label/feature tables
  * (stat "device_bytes" reports what the context holds). */

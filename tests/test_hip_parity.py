@@ -254,26 +254,69 @@ def test_step_graph_replays_equal_eager_steps(case_cache):
 
 
 def test_device_pack_matches_host_pack(ctx):
-    """k_pack_sign_f32 / k_pack_labels_i64 against the NumPy packing, bit for bit, including
-    sign(0) -> 0, pad bits, odd word counts; and the non-binary detector."""
+    """The two ways float32 features / int64 labels become packed tables -- a pool of host threads before the upload
+    (hg_host_pack.hpp, the default) and k_pack_sign_f32 / k_pack_labels_i64 on the GPU -- against the NumPy packing, bit
+    for bit, including sign(0) -> 0, pad bits, odd word counts; and the census (non-binary entries, zeros, minus ones)."""
     rng = np.random.default_rng(5)
-    for b, C in [(1, 1), (31, 10), (32, 64), (33, 65), (48, 81), (64, 10), (65, 128), (100, 3), (128, 200)]:
-        n = 777
-        x = rng.choice(np.array([-1.0, 1.0], np.float32), size=(n, b))
-        lab = (rng.random((n, C)) < 0.2).astype(np.int64)
-        bad = ctx.set_database_f32(x, lab)
-        assert bad == (0, 0)
-        codes, labels = ctx.get_packed(0)
-        ref = metric.pack_codes(x).view(np.uint32).reshape(n, -1)[:, :(b + 31) // 32]
-        assert np.array_equal(codes, ref), (b, C)
-        assert np.array_equal(labels, metric.pack_labels(lab)), (b, C)
-        x01 = (x > 0).astype(np.float32)                       # {0,1} spelling packs to the same words
-        assert ctx.set_database_f32(x01, lab) == (0, 0)
-        assert np.array_equal(ctx.get_packed(0)[0], ref)
-    x = rng.standard_normal((50, 16)).astype(np.float32)
-    lab = np.zeros((50, 3), np.int64); lab[7, 1] = 2
-    bad_c, bad_l = ctx.set_database_f32(x, lab)
-    assert bad_c == 50 * 16 and bad_l == 1
+    try:
+        for host_pack in (1, 0):
+            ctx.set_option("host_pack", host_pack)
+            for b, C in [(1, 1), (31, 10), (32, 64), (33, 65), (48, 81), (64, 10), (65, 128), (100, 3), (128, 200), (255, 7)]:
+                n = 777
+                x = rng.choice(np.array([-1.0, 1.0], np.float32), size=(n, b))
+                lab = (rng.random((n, C)) < 0.2).astype(np.int64)
+                bad = ctx.set_database_f32(x, lab)
+                assert bad == (0, 0)
+                assert ctx.get_stat("db_zeros") == 0 and ctx.get_stat("db_minus_ones") == int((x == -1).sum())
+                assert ctx.get_stat("db_floats") == (0 if host_pack else 1)          # a +-1 code: its floats stay on the host
+                codes, labels = ctx.get_packed(0)
+                ref = metric.pack_codes(x).view(np.uint32).reshape(n, -1)[:, :(b + 31) // 32]
+                assert np.array_equal(codes, ref), (b, C, host_pack)
+                assert np.array_equal(labels, metric.pack_labels(lab)), (b, C, host_pack)
+                x01 = (x > 0).astype(np.float32)                       # {0,1} spelling packs to the same words
+                assert ctx.set_database_f32(x01, lab) == (0, 0)
+                assert np.array_equal(ctx.get_packed(0)[0], ref)
+                assert ctx.get_stat("db_zeros") == int((x01 == 0).sum()) and ctx.get_stat("db_minus_ones") == 0
+                assert ctx.get_stat("db_floats") == 1                                # not a +-1 code: np.dot would not rank it by Hamming distance
+            x = rng.standard_normal((50, 16)).astype(np.float32)
+            x[3, 3] = np.nan
+            lab = np.zeros((50, 3), np.int64); lab[7, 1] = 2
+            bad_c, bad_l = ctx.set_database_f32(x, lab)
+            assert bad_c == 50 * 16 and bad_l == 1
+            n = 300001                                                 # enough rows for several host threads, ragged split
+            x = rng.choice(np.array([-1.0, 0.0, 1.0, 0.5], np.float32), size=(n, 48))
+            lab = (rng.random((n, 10)) < 0.1).astype(np.int64)
+            assert ctx.set_database_f32(x, lab) == (int((x == 0.5).sum()), 0)
+            codes, labels = ctx.get_packed(0)
+            assert np.array_equal(codes, metric.pack_codes(x).view(np.uint32).reshape(n, -1)[:, :2])
+            assert np.array_equal(labels, metric.pack_labels(lab))
+            assert ctx.get_stat("db_zeros") == int((x == 0).sum()) and ctx.get_stat("db_minus_ones") == int((x == -1).sum())
+    finally:
+        ctx.set_option("host_pack", 1)
+
+
+def test_pm1_database_meets_real_valued_queries():
+    """A +-1 database keeps its floats on the host; when queries turn out real-valued, MAPs must rank by inner product all
+    the same (metric.py:13): the database's float table is then brought over."""
+    import types
+    from hashgan_amd import MAPs
+    from oracle import real_map as RM
+    rng = np.random.default_rng(11)
+    N, Q, b, R, C = 5000, 30, 32, 700, 6
+    dbf = rng.choice(np.array([-1.0, 1.0], np.float32), size=(N, b))
+    qf = (np.round(np.tanh(rng.standard_normal((Q, b))) * 64) / 64).astype(np.float32)      # grid values: exact arithmetic
+    dl = (rng.random((N, C)) < 0.3).astype(np.int64)
+    ql = (rng.random((Q, C)) < 0.3).astype(np.int64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m_ref, *_ = RM.map_from_features(qf, dbf, ql, dl, R)
+    m = MAPs(R)
+    db = types.SimpleNamespace(output=dbf, label=dl)
+    assert m.get_maps_by_feature(db, types.SimpleNamespace(output=np.where(qf > 0, 1.0, -1.0).astype(np.float32), label=ql)) is not None
+    assert m._eng.ctx.get_stat("db_floats") == 0                     # +-1 on both sides: Hamming, no float table
+    assert m.get_maps_by_feature(db, types.SimpleNamespace(output=qf, label=ql)) == m_ref
+    assert m._eng.ctx.get_stat("db_floats") == 1
+    m.close()
 
 
 def test_python_surface_rejects_non_binary(case_cache):
