@@ -203,7 +203,8 @@ struct hg_ctx {
     i64 opt_max_segments = 2048;   // "max_segments"
     i64 opt_enable = 1;        // one-shot calls may bet on a sampled threshold (verified, exact fallback)
     i64 opt_stride = 0;        // sampling stride in row batches, 0 = auto
-    i64 opt_sigma = 6;         // safety margin of the guess, in standard deviations of the sample count
+    i64 opt_sigma = 5;         // safety margin of the guess, in standard deviations of the sample count (5: a query loses its bet
+                               // about once in 3 million -- it is then rerun alone; 6 -> 5 keeps ~4 % fewer surplus records)
     i64 staged_lists = 1;      // staged hg_select materialises the idx/dist lists
     i64 cand_budget_x10 = 40;  // optimistic record budget per query, in tenths of R
     i64 opt_real_seg_bytes = 512 * 1024;   // real-valued path: bytes of feature rows per segment

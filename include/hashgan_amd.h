@@ -118,7 +118,7 @@ int hg_ap(hg_ctx* ctx);
 /* ---- staged optimistic sequence (R << N): one pass over the pairs instead of two ----
  * hg_bet_eligible      same verdict on every rank (uses only R, n_total, world, options)
  * hg_sample_hist       histogram of every k-th row batch            -> hg_hist_buffer -> all-gather
- * hg_guess             threshold guess from the G sample histograms (6 sigma high)
+ * hg_guess             threshold guess from the G sample histograms ("guess_sigma" = 5 standard deviations high)
  * hg_select_candidates ONE pass over the pairs: superset of the members as records, plus the
  *                      exact histogram of those records              -> hg_hist_buffer -> all-gather
  * hg_rank              exact plan from the G record histograms + ordering + match bits.
