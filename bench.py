@@ -258,7 +258,10 @@ def main():
     packed = build_packed(spec, base, rows)
     qw, ql, dw, dl = packed
 
-    ctx = _native.Context(local_rank)
+    # HG_BENCH_FILECOMM=<dir>: functional dry run of the N > 1 leg on a ONE-GPU box -- every rank a process on GPU 0, the
+    # exchanges through files (tests/file_comm.py).  Never a measurement; the JSON line says so.
+    dry_dir = os.environ.get("HG_BENCH_FILECOMM")
+    ctx = _native.Context(0 if dry_dir else local_rank)
     for kv in args.opt:
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
@@ -266,15 +269,20 @@ def main():
     ctx.set_queries(qw, ql)
 
     if sharded_leg:
-        comm = sharded.init_rccl(ctx, rank, world)
-        eng = sharded.HipShardEngine(ctx, want_lists=False, async_stages=True)   # one stream, no host waits between stages
+        if dry_dir:
+            from tests.file_comm import FileComm
+            comm = FileComm(dry_dir, rank, world, ctx)
+            eng = sharded.HipShardEngine(ctx, want_lists=False)
+        else:
+            comm = sharded.init_rccl(ctx, rank, world)
+            eng = sharded.HipShardEngine(ctx, want_lists=False, async_stages=True)   # one stream, no host waits between stages
 
         def step():
             a, r = sharded.evaluate_shard(eng, comm, R, always_gather=force)
             return sharded.mean_ap(a, r), a
 
         def fence():
-            ctx.barrier()                               # hipStreamSynchronize + a tiny all-reduce on every rank
+            comm.barrier()                              # hipStreamSynchronize + a tiny all-reduce on every rank
     else:
         def step():
             a, r = ctx.map(R)
@@ -294,13 +302,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if sharded_leg:
-        dt = ctx.allreduce_max(dt)                      # the slowest rank's clock
+        dt = comm.allreduce_max(dt)                     # the slowest rank's clock
     timing = ctx.timing_read()
     ctx.timing_enable(False)
     if rank != 0:
         if sharded_leg:
-            ctx.barrier()
-            ctx.comm_destroy()
+            comm.barrier()
+            if not dry_dir:
+                ctx.comm_destroy()
         return
 
     # parity flag: the first queries are a golden case of the unmodified reference
@@ -337,9 +346,12 @@ def main():
             out["step_accounting"] = {"gpu_span_ms": round(busy, 5), "host_and_launch_ms": round(per_step * 1e3 - busy, 5),
                                       "kernels_timed_ms": round(sum(v["avg_ms"] * v["launches"] for v in per_kernel.values()) / args.steps, 5),
                                       "graph_replays": ctx.get_stat("graph_replays"), "graph_captures": ctx.get_stat("graph_captures")}
+    if dry_dir:
+        out["dry_run_not_a_measurement"] = "ranks share GPU 0 and exchange through files (HG_BENCH_FILECOMM)"
     if sharded_leg:
-        ctx.barrier()
-        ctx.comm_destroy()
+        comm.barrier()
+        if not dry_dir:
+            ctx.comm_destroy()
     ctx.close()
     if world == 1 and not force:
         if not args.no_h2d:

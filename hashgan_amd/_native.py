@@ -72,6 +72,8 @@ _SIGNATURES = {
     "hg_barrier": [_p],
     "hg_scratch": [_p, C.c_int, _i64, C.POINTER(_p)],
     "hg_memcpy_dtod": [_p, _p, _p, _i64],
+    "hg_memcpy_dtoh": [_p, _p, _p, _i64],
+    "hg_memcpy_htod": [_p, _p, _p, _i64],
     "hg_synchronize": [_p],
     "hg_set_stream": [_p, _p],
     "hg_set_option": [_p, C.c_char_p, _i64],
@@ -350,6 +352,12 @@ class Context:
 
     def memcpy_dtod(self, dst, src, nbytes):
         check(self._lib.hg_memcpy_dtod(self._h, _p(dst), _p(src), int(nbytes)))
+
+    def memcpy_dtoh(self, host_array, src, nbytes):
+        check(self._lib.hg_memcpy_dtoh(self._h, _ptr(host_array), _p(src), int(nbytes)))
+
+    def memcpy_htod(self, dst, host_array, nbytes):
+        check(self._lib.hg_memcpy_htod(self._h, _p(dst), _ptr(host_array), int(nbytes)))
 
     def synchronize(self):
         check(self._lib.hg_synchronize(self._h))

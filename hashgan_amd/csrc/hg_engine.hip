@@ -2254,6 +2254,22 @@ int hg_memcpy_dtod(hg_ctx* c, void* dev_dst, const void* dev_src, int64_t nbytes
     return c->stage_end();
 }
 
+// device <-> host copies of raw device addresses, complete on return (a stand-in communicator that goes through the
+// host -- tests/file_comm.py, for multi-process dry runs on one GPU -- is their only user)
+int hg_memcpy_dtoh(hg_ctx* c, void* host_dst, const void* dev_src, int64_t nbytes) {
+    if (!c || !host_dst || !dev_src || nbytes < 0) return fail(HG_ERR_ARG, "hg_memcpy_dtoh: bad argument");
+    HG_TRY(c->use());
+    if (nbytes) HG_HIP(hipMemcpyAsync(host_dst, dev_src, (size_t)nbytes, hipMemcpyDeviceToHost, c->stream));
+    return c->sync();
+}
+
+int hg_memcpy_htod(hg_ctx* c, void* dev_dst, const void* host_src, int64_t nbytes) {
+    if (!c || !dev_dst || !host_src || nbytes < 0) return fail(HG_ERR_ARG, "hg_memcpy_htod: bad argument");
+    HG_TRY(c->use());
+    if (nbytes) HG_HIP(hipMemcpyAsync(dev_dst, host_src, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    return c->sync();
+}
+
 int hg_synchronize(hg_ctx* c) {
     if (!c) return fail(HG_ERR_ARG, "hg_synchronize: null context");
     HG_TRY(c->use());

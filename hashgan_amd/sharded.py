@@ -53,6 +53,10 @@ class RcclComm:
     def barrier(self):
         self.ctx.barrier()
 
+    def allreduce_max(self, x):
+        """max over the ranks of one host number (a benchmark's step time)."""
+        return self.ctx.allreduce_max(x)
+
 
 def _id_file(world, port):
     explicit = os.environ.get("HG_COMM_ID_FILE")

@@ -205,6 +205,10 @@ int hg_barrier(hg_ctx* ctx);
  * (virtual shards on one GPU: tests/test_sharded_gpu.py). */
 int hg_scratch(hg_ctx* ctx, int slot, int64_t nbytes, void** dev_ptr);
 int hg_memcpy_dtod(hg_ctx* ctx, void* dev_dst, const void* dev_src, int64_t nbytes);
+/* The same between a device address and host memory, complete on return (a communicator that goes through the host,
+ * for multi-process dry runs on ONE GPU: tests/file_comm.py). */
+int hg_memcpy_dtoh(hg_ctx* ctx, void* host_dst, const void* dev_src, int64_t nbytes);
+int hg_memcpy_htod(hg_ctx* ctx, void* dev_dst, const void* host_src, int64_t nbytes);
 
 /* Wait until everything the context has enqueued is done (with "stage_sync" = 0 nothing else does). */
 int hg_synchronize(hg_ctx* ctx);

@@ -190,3 +190,33 @@ def test_sharded_product_path_is_torch_free():
         "print('TORCH_FREE_OK')\n" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "TORCH_FREE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("world,workload", [(2, "c3"), (3, "c3")])
+def test_bench_multi_rank_control_flow(world, workload, tmp_path):
+    """bench.py --gpus G as the driver launches it (one process per rank, RANK / WORLD_SIZE / LOCAL_RANK in the
+    environment), dry-run on ONE GPU with the file communicator standing in for RCCL: rendezvous of the processes, shard
+    bounds, the orchestration over real process boundaries, max-over-ranks clock, only rank 0 prints -- one JSON line
+    whose AP matches the reference's golden.  (world 2: the merged-ranking bet; world 3: shards too small, exact sequence.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29871", HG_BENCH_FILECOMM=str(tmp_path / "comm"))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--workload", workload,
+                                       "--steps", "2", "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    assert all(outs[r][0].strip() == "" for r in range(1, world)), "only rank 0 prints"
+    lines = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert len(lines) == 1, outs[0][0][-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["unit"] == "queries/s"
+    assert d["parity_vs_reference_golden"] is True
+    assert abs(d["value"] - 2100 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # raw queries per second
+    assert d["optimistic_runs"] == (3 if world == 2 else 0) and d["optimistic_fallbacks"] == 0
+    assert "dry_run_not_a_measurement" in d and "cpu_baseline" not in d
