@@ -238,6 +238,8 @@ struct hg_ctx {
     DevBuf dbx2, qx2;          // the same for k_select_mx2 (two rows per accumulator, codes of <= 64 bits)
     bool dbx2_valid = false, qx2_valid = false;
     bool direct_rank = false;  // R = N: k_rank_fused computes distance and match bit per row itself (no records)
+    bool exact_mx = false;     // the matrix-core select runs with the EXACT threshold (hg_hist + k_plan) instead of a guess
+    i64 opt_exact_mfma = 1;    // "exact_mfma": the one-shot exact sequence selects on the matrix cores when R << N
     bool rec8 = false;         // the record rows hold one-byte compact records (matrix-core select, no lists wanted)
     i64 opt_compact = 1;       // "compact_records": allow them
     i64 opt_second_bet = 1;    // "second_bet": a lost one-shot bet is retried once with a wider margin before the exact sequence
@@ -523,8 +525,8 @@ template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c
                                    hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
         lds_set = L.total;
     }
-    SelArgs a{c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
-              c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
+    SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
+              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
     c->t_begin(KI_SELECT_MX);
     hipLaunchKernelGGL((k_select_mx<NW, LW, QT, COMPACT>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total + (size_t)c->opt_lds_pad, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx.as<u8>(), c->dblab.as<u64>(), a,
@@ -572,8 +574,8 @@ template <int NW, int LW, bool COMPACT> int launch_select_mx2_c(hg_ctx* c) {
     if (L.total > 64 * 1024)
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx2<NW, LW, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    L.total));
-    SelArgs a{c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
-              c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
+    SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
+              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
     c->t_begin(KI_SELECT_MX);
     hipLaunchKernelGGL((k_select_mx2<NW, LW, COMPACT>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx2.as<u8>(), c->db.as<u32>(), c->dbx2.as<u8>(), c->dblab.as<u64>(), a,
@@ -1127,6 +1129,7 @@ static int do_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, in
     HG_TRY(c->seglt.reserve((size_t)g.S * qb)); HG_TRY(c->segtie.reserve((size_t)g.S * qb));
     HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
     HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
+    HG_TRY(c->sstar.reserve(qb));
     c->t_begin(KI_SEG_COUNTS);
     hipLaunchKernelGGL(k_seg_counts, dim3(grid_for((i64)g.S * g.Qpad)), dim3(256), 0, c->stream, c->hist.as<u32>(),
                        c->t.as<int>(), c->seglt.as<u32>(), c->segtie.as<u32>(), g);
@@ -1135,7 +1138,7 @@ static int do_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, in
     c->t_begin(KI_SEG_LAYOUT);
     hipLaunchKernelGGL(k_seg_layout, dim3(grid_for(g.Qpad)), dim3(256), 0, c->stream, c->seglt.as<u32>(),
                        c->segtie.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->sl_start.as<u32>(),
-                       c->sl_tie.as<u32>(), c->tot.as<u32>(), g);
+                       c->sl_tie.as<u32>(), c->tot.as<u32>(), c->sstar.as<int>(), g);
     c->t_end();
     HG_TRY(c->check_launch("k_seg_layout"));
     c->optimistic = false;
@@ -1700,6 +1703,32 @@ static int enqueue_exact(hg_ctx* c, int64_t R) {
     return do_select(c);
 }
 
+// The exact sequence with its second pass on the matrix cores (one shard, R << N): full histogram -> plan (exact
+// threshold t, and sstar = the last segment whose ties at t are still inside the quota) -> k_select_mx with T = t,
+// fixed-capacity slices -> the bet's rank stage, which cuts the ties at the quota.  Nothing is guessed, so the only way
+// this can fail is a slice overflowing its capacity (clustered rows): *err then, and the caller runs enqueue_exact.
+static bool exact_mx_applies(const hg_ctx* c, int64_t R) {
+    return c->opt_exact_mfma && c->opt_select_mfma && c->N == c->n_total && R * 8 <= c->N && c->N >= 65536 && !c->is_sub;
+}
+static int enqueue_exact_mx(hg_ctx* c, int64_t R) {
+    HG_TRY(do_hist(c, 1));
+    HG_TRY(do_plan(c, R, nullptr, 1, 0));              // c->t, c->sstar; leaves optimistic = false, crow = R
+    const Geo& g = c->geo;
+    // in all the slices hold R records + the ties of one segment beyond the quota, but unevenly: segments up to sstar carry
+    // ALL their rows at distance t (the cut bucket is typically the fullest), later ones none -- budget like the bet does
+    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)R / (double)g.S;
+    u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
+    cap = (cap + 15u) & ~15u;
+    c->optimistic = true;
+    c->exact_mx = true;
+    c->cap = cap;
+    c->crow = (i64)g.S * cap;
+    HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
+    const int rc = do_select(c);
+    c->exact_mx = false;
+    return rc;
+}
+
 static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     (void)need_cnt;
     HG_TRY(do_hist(c, stride, false));
@@ -1930,6 +1959,16 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
         c->opt_fallbacks++;                        // still too many: exact path for all
         c->opt_consecutive_fail++;
         c->want_lists = lists;
+    }
+    if (exact_mx_applies(c, R)) {
+        c->want_lists = lists;
+        c->t_step_begin();
+        HG_TRY(enqueue_exact_mx(c, R));
+        if (with_ap) HG_TRY(do_ap(c));
+        c->t_step_end();
+        HG_TRY(read_plan_flag(c, &flag));
+        if (!flag) return HG_OK;
+        c->want_lists = lists;                         // a slice overflowed: the vector-ALU select with exact-sized slices
     }
     c->t_step_begin();
     HG_TRY(enqueue_exact(c, R));
@@ -2353,6 +2392,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "lds_pad")) {
         if (value < 0 || value > 24 * 1024) return fail(HG_ERR_ARG, "lds_pad must be 0..24576");
         c->opt_lds_pad = value;
+    } else if (!strcmp(key, "exact_mfma")) {
+        c->opt_exact_mfma = value != 0;
     } else if (!strcmp(key, "select_mfma")) {
         c->opt_select_mfma = value != 0;
     } else if (!strcmp(key, "probe_select")) {

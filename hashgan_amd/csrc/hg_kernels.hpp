@@ -260,12 +260,13 @@ __global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ hist
 __global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ seglt, const u32* __restrict__ segtie,
                                                     const u32* __restrict__ quota, const u32* __restrict__ tie_before,
                                                     u32* __restrict__ sl_start, u32* __restrict__ sl_tie,
-                                                    u32* __restrict__ tot, const Geo g) {
+                                                    u32* __restrict__ tot, int* __restrict__ sstar, const Geo g) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= g.Qpad) return;
     u32 pos = 0;
     u64 tierank = q < g.Q ? tie_before[q] : 0;
     const u64 qt = q < g.Q ? quota[q] : 0;
+    int last = -1;                                      // last segment that still contributes ties at the cut
     for (int s = 0; s < g.S; ++s) {
         const i64 o = (i64)s * g.Qpad + q;
         const u32 lt = seglt[o], tie = segtie[o];
@@ -273,10 +274,12 @@ __global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ segl
         const u32 keep = tie < room ? tie : (u32)room;
         sl_start[o] = pos;
         sl_tie[o] = keep;
+        if (keep) last = s;
         pos += lt + keep;
         tierank += tie;
     }
     tot[q] = pos;
+    if (sstar && q < g.Q) sstar[q] = last;              // the matrix-core select collects distance t up to here (its `sstar`)
 }
 
 // K2e  optimistic plan: threshold guess from SAMPLED histograms (this shard's, or the G
