@@ -9,6 +9,7 @@
 #include "hg_rank_cnt.hpp"
 #include "hg_select_mx2.hpp"
 #include "hg_real_mx.hpp"
+#include "hg_hist_mx.hpp"
 #include "hg_host_pack.hpp"
 #include "../../include/hashgan_amd.h"
 
@@ -238,6 +239,8 @@ struct hg_ctx {
     DevBuf dbx2, qx2;          // the same for k_select_mx2 (two rows per accumulator, codes of <= 64 bits)
     bool dbx2_valid = false, qx2_valid = false;
     bool direct_rank = false;  // R = N: k_rank_fused computes distance and match bit per row itself (no records)
+    i64 opt_hist_mfma = 1;     // "hist_mfma": histograms (sampled pass; full pass of the one-shot exact sequence) on the matrix cores
+    bool hist_pairs = false;   // the last FULL histogram pass ran per segment pair (k_hist_mx)
     bool exact_mx = false;     // the matrix-core select runs with the EXACT threshold (hg_hist + k_plan) instead of a guess
     i64 opt_exact_mfma = 1;    // "exact_mfma": the one-shot exact sequence selects on the matrix cores when R << N
     bool rec8 = false;         // the record rows hold one-byte compact records (matrix-core select, no lists wanted)
@@ -440,8 +443,8 @@ int padded_grid(int nBlk) { return (nBlk + 7) / 8 * 8; }
 // histogram array (and its reduction) shrinks with the work.
 Geo hist_geometry(const hg_ctx* c) {
     Geo g = c->geo;
-    if (g.hist_stride > 1) {
-        const i64 L = g.L * c->opt_sample_ratio;
+    if (g.hist_stride > 1 || c->hist_pairs) {
+        const i64 L = g.L * (c->hist_pairs ? 2 : c->opt_sample_ratio);
         g.L = L;
         g.S = (int)((g.N + L - 1) / L);
         g.nUnits = (i64)g.S * g.nQT;
@@ -479,16 +482,9 @@ template <int NW, int LW, bool OPT> int launch_select_t(hg_ctx* c) {
 
 // matrix-core optimistic select: units = (pair of segments) x (group of 32 QT queries)
 // matrix-core optimistic select: blocks = (pair of segments) x (block of 512 queries)
-template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c);
-template <int NW, int LW> int launch_select_mx_t(hg_ctx* c) {
-    // long codes need the registers of the 2-waves-per-SIMD variant (B fragments: 4 per query tile and 64 bits)
-    const bool qt2 = NW <= 4 && c->opt_select_qt == 2;
-    if (c->rec8) return qt2 ? launch_select_mx_q<NW, LW, (NW <= 4 ? 2 : 4), true>(c) : launch_select_mx_q<NW, LW, 4, true>(c);
-    return qt2 ? launch_select_mx_q<NW, LW, (NW <= 4 ? 2 : 4), false>(c) : launch_select_mx_q<NW, LW, 4, false>(c);
-}
-template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c) {
+// the fp4 images of the codes in MFMA fragment order (k_select_mx, k_hist_mx), built on first use
+template <int NW> int ensure_mx_images(hg_ctx* c) {
     constexpr int NM = (NW + 1) / 2;
-    constexpr int QBLK = WPB * 32 * QT;                // queries per block
     if (!c->dbx_valid) {
         const i64 n16 = (c->N + 15) / 16 * 16;
         HG_TRY(c->dbx.reserve((size_t)(n16 > 0 ? n16 : 16) * NM * 32));
@@ -500,9 +496,6 @@ template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c
         HG_TRY(c->check_launch("k_expand_db"));
         c->dbx_valid = true;
     }
-    Geo g = c->geo;
-    const int nSP = (g.S + 1) / 2;
-    const int nQB = (g.Q + QBLK - 1) / QBLK;           // query blocks
     if (!c->qx_valid) {
         const i64 qpad = ((i64)c->Q + 511) / 512 * 512;
         HG_TRY(c->qx.reserve((size_t)qpad * NM * 32));
@@ -514,6 +507,54 @@ template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c
         HG_TRY(c->check_launch("k_expand_queries"));
         c->qx_valid = true;
     }
+    return HG_OK;
+}
+
+// histogram on the matrix cores: blocks = (pair of segments) x (256 queries); stride in tiles of 16 rows
+bool hist_mx_applies(const hg_ctx* c, int stride, bool pairs_ok) {
+    if (!c->opt_hist_mfma || !c->opt_select_mfma || c->NW > 8 || c->is_sub) return false;
+    return stride > 1 ? c->opt_sample_ratio == 2 : pairs_ok;
+}
+template <int NW> int launch_hist_mx_t(hg_ctx* c) {
+    HG_TRY(ensure_mx_images<NW>(c));
+    Geo g = c->geo;                                    // fine geometry; the kernel pairs the segments itself
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + 255) / 256;
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    const i64 tiles_per_half = ((g.L + 15) / 16 + g.hist_stride - 1) / g.hist_stride;      // visited by one lane-half
+    const i64 visited_per_pair = 2 * tiles_per_half * 16;
+    const bool pack16 = visited_per_pair < 65536;
+    const size_t lds = (size_t)WPB * (pack16 ? 1 : 2) * g.NB * 32 * 4;
+    c->t_begin(KI_HIST);
+    if (pack16) {
+        hipLaunchKernelGGL((k_hist_mx<NW, true>), dim3(padded_grid(g.nBlk)), dim3(256), lds, c->stream, c->qc.as<u32>(), c->qx.as<u8>(),
+                           c->dbx.as<u8>(), c->hist.as<u32>(), g);
+    } else {
+        if (lds > 64 * 1024)
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist_mx<NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_hist_mx<NW, false>), dim3(padded_grid(g.nBlk)), dim3(256), lds, c->stream, c->qc.as<u32>(), c->qx.as<u8>(),
+                           c->dbx.as<u8>(), c->hist.as<u32>(), g);
+    }
+    c->t_end();
+    return c->check_launch("k_hist_mx");
+}
+
+template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c);
+template <int NW, int LW> int launch_select_mx_t(hg_ctx* c) {
+    // long codes need the registers of the 2-waves-per-SIMD variant (B fragments: 4 per query tile and 64 bits)
+    const bool qt2 = NW <= 4 && c->opt_select_qt == 2;
+    if (c->rec8) return qt2 ? launch_select_mx_q<NW, LW, (NW <= 4 ? 2 : 4), true>(c) : launch_select_mx_q<NW, LW, 4, true>(c);
+    return qt2 ? launch_select_mx_q<NW, LW, (NW <= 4 ? 2 : 4), false>(c) : launch_select_mx_q<NW, LW, 4, false>(c);
+}
+template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c) {
+    constexpr int QBLK = WPB * 32 * QT;                // queries per block
+    HG_TRY(ensure_mx_images<NW>(c));
+    Geo g = c->geo;
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + QBLK - 1) / QBLK;           // query blocks
     g.nQT = nQB;
     g.nUnits = (i64)nSP * nQB;
     g.wpb = WPB;
@@ -652,6 +693,7 @@ template <int NW> int launch_select_nw(hg_ctx* c) {
     }
 
 int launch_hist(hg_ctx* c) { HG_DISPATCH_NW(launch_hist_t, c) }
+int launch_hist_mx(hg_ctx* c) { HG_DISPATCH_NW(launch_hist_mx_t, c) }
 int launch_select(hg_ctx* c) { HG_DISPATCH_NW(launch_select_nw, c) }
 
 // rows k_hist visits with batch stride `stride` (mirrors its loop)
@@ -672,6 +714,7 @@ template <int NW> i64 sampled_rows_t(Geo g, int stride, int ratio) {
     return total;
 }
 i64 sampled_rows(hg_ctx* c, int stride) {
+    if (hist_mx_applies(c, stride, false)) return hist_mx_sampled_rows(c->geo, stride);
     switch (c->NW) {
         case 1: return sampled_rows_t<1>(c->geo, stride, (int)c->opt_sample_ratio);
         case 2: return sampled_rows_t<2>(c->geo, stride, (int)c->opt_sample_ratio);
@@ -1051,9 +1094,11 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     return HG_OK;
 }
 
-static int do_hist(hg_ctx* c, int stride, bool reduce = true) {
+static int do_hist(hg_ctx* c, int stride, bool reduce = true, bool pairs_ok = false) {
     make_geometry(c);
     c->geo.hist_stride = stride;
+    const bool mx = hist_mx_applies(c, stride, pairs_ok);
+    c->hist_pairs = mx && stride == 1;                 // full pass per segment pair: the plan's per-segment steps follow suit
     const Geo& g = c->geo;
     const size_t plane = (size_t)g.NB * g.Qpad * 4;
     HG_TRY(c->hist.reserve(plane * g.S));
@@ -1066,7 +1111,7 @@ static int do_hist(hg_ctx* c, int stride, bool reduce = true) {
         }
         HG_HIP(hipMemcpyAsync(c->hown.as<char>() + plane, c->tail_host, sizeof c->tail_host, hipMemcpyHostToDevice, c->stream));
     }
-    HG_TRY(launch_hist(c));
+    HG_TRY(mx ? launch_hist_mx(c) : launch_hist(c));
     if (!reduce) { c->stage = ST_DB | ST_Q; return HG_OK; }      // the caller reads the per-segment histograms itself
     const Geo gh = hist_geometry(c);
     c->t_begin(KI_HIST_REDUCE);
@@ -1130,15 +1175,17 @@ static int do_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, in
     HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
     HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
     HG_TRY(c->sstar.reserve(qb));
+    const Geo gp = hist_geometry(c);                   // per segment -- or per segment pair after k_hist_mx (then only sstar is used)
+    const int ratio = (int)(gp.L / g.L);
     c->t_begin(KI_SEG_COUNTS);
-    hipLaunchKernelGGL(k_seg_counts, dim3(grid_for((i64)g.S * g.Qpad)), dim3(256), 0, c->stream, c->hist.as<u32>(),
-                       c->t.as<int>(), c->seglt.as<u32>(), c->segtie.as<u32>(), g);
+    hipLaunchKernelGGL(k_seg_counts, dim3(grid_for((i64)gp.S * g.Qpad)), dim3(256), 0, c->stream, c->hist.as<u32>(),
+                       c->t.as<int>(), c->seglt.as<u32>(), c->segtie.as<u32>(), gp);
     c->t_end();
     HG_TRY(c->check_launch("k_seg_counts"));
     c->t_begin(KI_SEG_LAYOUT);
     hipLaunchKernelGGL(k_seg_layout, dim3(grid_for(g.Qpad)), dim3(256), 0, c->stream, c->seglt.as<u32>(),
                        c->segtie.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->sl_start.as<u32>(),
-                       c->sl_tie.as<u32>(), c->tot.as<u32>(), c->sstar.as<int>(), g);
+                       c->sl_tie.as<u32>(), c->tot.as<u32>(), c->sstar.as<int>(), ratio, gp);
     c->t_end();
     HG_TRY(c->check_launch("k_seg_layout"));
     c->optimistic = false;
@@ -1711,7 +1758,7 @@ static bool exact_mx_applies(const hg_ctx* c, int64_t R) {
     return c->opt_exact_mfma && c->opt_select_mfma && c->N == c->n_total && R * 8 <= c->N && c->N >= 65536 && !c->is_sub;
 }
 static int enqueue_exact_mx(hg_ctx* c, int64_t R) {
-    HG_TRY(do_hist(c, 1));
+    HG_TRY(do_hist(c, 1, true, true));                 // per segment pair on the matrix cores where that applies
     HG_TRY(do_plan(c, R, nullptr, 1, 0));              // c->t, c->sstar; leaves optimistic = false, crow = R
     const Geo& g = c->geo;
     // in all the slices hold R records + the ties of one segment beyond the quota, but unevenly: segments up to sstar carry
@@ -2392,6 +2439,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "lds_pad")) {
         if (value < 0 || value > 24 * 1024) return fail(HG_ERR_ARG, "lds_pad must be 0..24576");
         c->opt_lds_pad = value;
+    } else if (!strcmp(key, "hist_mfma")) {
+        c->opt_hist_mfma = value != 0;
     } else if (!strcmp(key, "exact_mfma")) {
         c->opt_exact_mfma = value != 0;
     } else if (!strcmp(key, "select_mfma")) {

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ hist
 __global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ seglt, const u32* __restrict__ segtie,
                                                     const u32* __restrict__ quota, const u32* __restrict__ tie_before,
                                                     u32* __restrict__ sl_start, u32* __restrict__ sl_tie,
-                                                    u32* __restrict__ tot, int* __restrict__ sstar, const Geo g) {
+                                                    u32* __restrict__ tot, int* __restrict__ sstar, int ratio, const Geo g) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= g.Qpad) return;
     u32 pos = 0;
@@ -279,7 +279,8 @@ __global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ segl
         tierank += tie;
     }
     tot[q] = pos;
-    if (sstar && q < g.Q) sstar[q] = last;              // the matrix-core select collects distance t up to here (its `sstar`)
+    // the matrix-core select collects distance t up to here (its `sstar`); `ratio` select segments per segment of this pass
+    if (sstar && q < g.Q) sstar[q] = last < 0 ? -1 : (last + 1) * ratio - 1;
 }
 
 // K2e  optimistic plan: threshold guess from SAMPLED histograms (this shard's, or the G

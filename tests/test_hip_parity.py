@@ -168,6 +168,32 @@ def test_maps_objects_are_independent_and_keep_a_resident_database(case_cache):
     ma.close(); mb.close()
 
 
+def test_matrix_core_histogram_is_exact(case_cache):
+    """k_hist_mx (fp4 MFMA distances -> LDS counters, per segment pair): the full pass of the one-shot exact sequence must
+    produce the oracle's histogram -- including ragged segment ends, an unpaired last segment and both counter layouts
+    (16-bit halves shared by the two query tiles / one dword per tile for long segments)."""
+    c = case_cache("c2_q64")
+    Dref = None
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, c)
+        ctx.set_option("optimistic", 0)
+        g = cases.load_golden("c2_q64")
+        for units, maxseg in [(16384, 2048), (3, 2048), (16384, 7)]:        # S = 2048-ish, 3 long segments (dword counters), 7
+            ctx.set_option("target_units", units)
+            ctx.set_option("max_segments", maxseg)
+            ap, rel = ctx.map(c["R"])
+            assert np.array_equal(ap, g["ap"], equal_nan=True), (units, maxseg)
+            h = ctx.get_hist().astype(np.int64)                      # [b + 1][Q] from the pass that just ran
+            if Dref is None:
+                D = O.hamming_matrix(O.pack_bits(c["qbits"]), O.pack_bits(c["dbbits"]))
+                Dref = np.stack([np.bincount(D[i], minlength=c["b"] + 1) for i in range(D.shape[0])]).T
+            assert np.array_equal(h, Dref), (units, maxseg)
+            assert ctx.get_stat("optimistic_fallbacks") == 0
+    finally:
+        ctx.close()
+
+
 def test_bursts_of_hits_take_the_direct_route():
     """Near-duplicates stored next to each other: a query's hits arrive ten and more to a 64-row half window, more than a
     slice's 16-record ring takes between two flushes -- the compact-record drain must route such words straight to
