@@ -21,6 +21,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -990,7 +991,11 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
     u32* hc = (u32*)c->hpk;
     u64* hl = (u64*)((char*)c->hpk + ((cb + 63) & ~(size_t)63));
     HostPackCensus cs;
-    host_pack(x, lab, n, b, C, hc, hl, &cs, (int)c->opt_pack_threads);
+    try {
+        host_pack(x, lab, n, b, C, hc, hl, &cs, (int)c->opt_pack_threads);
+    } catch (const std::exception& e) {               // no exception crosses the C ABI (thread creation can fail)
+        return fail(HG_ERR_NOMEM, "host-side packing failed: %s", e.what());
+    }
     HG_TRY(codes.reserve(cb + 64 * 4));
     HG_TRY(labels.reserve(lbytes));
     HG_HIP(hipMemcpyAsync(codes.p, hc, cb, hipMemcpyHostToDevice, c->stream));
@@ -1213,6 +1218,9 @@ static int check_plan_flag(hg_ctx* c) {
 
 int hg_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
     HG_TRY(need(c, ST_HIST, "hg_plan", "hg_hist"));
+    // a one-shot exact call may have left histograms per segment PAIR (k_hist_mx); the staged select lays its slices out
+    // per segment
+    if (c->hist_pairs) return fail(HG_ERR_STATE, "hg_plan called before hg_hist (the last histogram pass belonged to a one-shot call)");
     HG_TRY(do_plan(c, R, dev_hist_all, G, rank));
     // the device flag says "R exceeds the rows in the gathered histograms"; R <= n_total was checked on
     // the host already, so an unsynchronised caller loses nothing by skipping the read-back
