@@ -415,7 +415,7 @@ void make_geometry(hg_ctx* c) {
     if (c->opt_enable && c->opt_select_mfma && S >= 4) {
         // k_select_mx runs (S / 2) x ceil(Q / 256 or 512) equal blocks, 4 or 2 resident per CU: pick the S near the
         // target that fills a whole number of such rounds, so the last round is not a nearly empty one
-        const bool qt2 = c->NW <= 4 && c->opt_select_qt == 2;       // mirrors launch_select_mx_t
+        const bool qt2 = c->NW <= 4;                                // mirrors launch_select_mx_t
         const i64 qblk = qt2 ? 256 : 512;
         const i64 nQB = (c->Q + qblk - 1) / qblk;
         const i64 slots = (i64)c->n_cu * (qt2 ? 4 : 2);
@@ -545,10 +545,10 @@ template <int NW> int launch_hist_mx_t(hg_ctx* c) {
 
 template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c);
 template <int NW, int LW> int launch_select_mx_t(hg_ctx* c) {
-    // long codes need the registers of the 2-waves-per-SIMD variant (B fragments: 4 per query tile and 64 bits)
-    const bool qt2 = NW <= 4 && c->opt_select_qt == 2;
-    if (c->rec8) return qt2 ? launch_select_mx_q<NW, LW, (NW <= 4 ? 2 : 4), true>(c) : launch_select_mx_q<NW, LW, 4, true>(c);
-    return qt2 ? launch_select_mx_q<NW, LW, (NW <= 4 ? 2 : 4), false>(c) : launch_select_mx_q<NW, LW, 4, false>(c);
+    // codes of up to 128 bits: two query tiles per wavefront, 4 wavefronts per SIMD; longer codes need the registers of the
+    // 2-waves-per-SIMD variant (B fragments: 4 per query tile and 64 bits) and take four tiles
+    constexpr int QT = NW <= 4 ? 2 : 4;
+    return c->rec8 ? launch_select_mx_q<NW, LW, QT, true>(c) : launch_select_mx_q<NW, LW, QT, false>(c);
 }
 template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c) {
     constexpr int QBLK = WPB * 32 * QT;                // queries per block
@@ -2459,7 +2459,7 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
                                     "(python -m hashgan_amd.build --probes, HG_LIBRARY=<path>)");
         c->opt_probe = value;
     } else if (!strcmp(key, "select_qt")) {
-        c->opt_select_qt = value;
+        (void)value;                                   // retired (round 1 experiment): the tile count follows the code length
     } else if (!strcmp(key, "real_mfma")) {
         c->opt_real_mfma = value != 0;
     } else if (!strcmp(key, "real_segment_bytes")) {
