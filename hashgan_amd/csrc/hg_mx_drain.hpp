@@ -165,7 +165,6 @@ struct MxDrain {
             const i64 seg = 2 * sp + (int)hs;
             const i64 slice0 = COMPACT ? 0 : q * crow + seg * cap;   // first record of the slice (compact: computed on the rare direct route)
             u8* ring = rings + (t * 64 + src) * MX_RING;
-            u32 room = cap - pos;
             const u32 row0 = hs * WROWS + w * 32;                     // first row of the word in the stage tables
             const u32 idx0 = idx_base + (u32)(seg * segL + win * WROWS) + w * 32;
             while (word) {
@@ -182,19 +181,16 @@ struct MxDrain {
 #pragma unroll
                     for (int c = 0; c < LWA; ++c) any |= lp[c] & qlw[c];
                 }
-                if (room) {
-                    if (!(kProbes && (probe & 4)) || d == 0x7fffffffu) {
-                        if (COMPACT) {
-                            const u8 rec = make_rec8(d, any != 0);
-                            if (__builtin_expect(direct, 0)) cand8[q * crow + seg * cap + pos] = rec;
-                            else ring[pos & (MX_RING - 1)] = rec;
-                        } else {
-                            ((u64*)cand8)[slice0 + pos] = make_rec(idx0 + r, d, any != 0);
-                        }
+                if (!(kProbes && (probe & 4)) || d == 0x7fffffffu) {      // (the push trimmed the word to what the slice holds)
+                    if (COMPACT) {
+                        const u8 rec = make_rec8(d, any != 0);
+                        if (__builtin_expect(direct, 0)) cand8[q * crow + seg * cap + pos] = rec;
+                        else ring[pos & (MX_RING - 1)] = rec;
+                    } else {
+                        ((u64*)cand8)[slice0 + pos] = make_rec(idx0 + r, d, any != 0);
                     }
-                    ++pos;
-                    --room;
                 }
+                ++pos;
             }
         }
         wave_lds_sync();
@@ -203,6 +199,13 @@ struct MxDrain {
             flush_all_pieces();
             wave_lds_sync();                                          // ring reads done before the next emit overwrites slots
         }
+    }
+
+    // the n earliest rows (highest bits) of a hit mask, n < popcount(word): what still fits a full slice
+    __device__ __forceinline__ static u32 first_hits(const u32 word, u32 n) {
+        u32 m = 0;
+        while (n--) m |= 0x80000000u >> __builtin_clz(word ^ m);
+        return m;
     }
 
     template <class T> __device__ __forceinline__ static T pick(const T (&arr)[QT], const int t) {   // arr[t], t not a constant
@@ -247,12 +250,15 @@ struct MxDrain {
                     const u32 word = wd[t][i];
                     const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(bal[t][i] >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal[t][i], 0u));
                     const u32 want = cnt[t] + (u32)__builtin_popcount(word);
-                    const u32 capl = (flags >> t) & 1u ? cap : 0u;          // a dead lane's slice holds nothing
-                    const u32 got = want < capl ? want : capl;              // the slice holds `cap` records; the rest is lost
-                    if (word != 0u)
-                        queue[slot] = ((u64)word << 32) | (u64)(cnt[t] | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
+                    const u32 got = want < cap ? want : cap;                // the slice holds `cap` records; the rest is lost
+                    u32 kept = word;                                        // (dead lanes never hit: their bias keeps every accumulator >= 0)
+                    if (__builtin_expect(want != got, 0)) {                 // full slice: the word's first got - cnt hits only
+                        flags |= 0x100u << t;
+                        kept = first_hits(word, got - cnt[t]);
+                    }
+                    if (word != 0u)                                         // (an entry even when nothing is kept: the slot is counted)
+                        queue[slot] = ((u64)kept << 32) | (u64)(cnt[t] | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
                                                                 ((u32)(w0 + i) << (MX_POS_BITS + 8)));
-                    flags |= want != got ? 0x100u << t : 0u;
                     cnt[t] = got;
                     qfill += (u32)__builtin_popcountll(bal[t][i]);
                 }
@@ -275,8 +281,8 @@ struct MxDrain {
             const u64 bal = __ballot(word != 0u);
             const u32 c0 = pick(cnt, t);
             const u32 want = c0 + (u32)__builtin_popcount(word);
-            const u32 capl = (flags >> t) & 1u ? cap : 0u;
-            const u32 got = want < capl ? want : capl;
+            const u32 got = want < cap ? want : cap;
+            const u32 kept = want != got ? first_hits(word, got - c0) : word;
             bool direct = false;
             if (COMPACT) {
                 const u32 f = pick(flushed, t);
@@ -290,7 +296,7 @@ struct MxDrain {
             }
             const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
             if (word != 0u)
-                queue[slot] = ((u64)word << 32) | (u64)(c0 | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
+                queue[slot] = ((u64)kept << 32) | (u64)(c0 | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
                                                         ((u32)(w0 + i) << (MX_POS_BITS + 8)) | ((direct ? 1u : 0u) << (MX_POS_BITS + 10)));
             flags |= want != got ? 0x100u << t : 0u;
             put(cnt, t, got);
