@@ -142,7 +142,9 @@ struct MxDrain {
         for (u32 p = fl + lo; p < cnt[t]; ++p) out[p] = ring[p & (MX_RING - 1)];
     }
 
-    __device__ __forceinline__ void emit(const i64 win, const u8* st) {
+    // DIRECT: the queue may hold direct-routed entries (only drain_slow makes them); the common instantiation carries
+    // none of their address arithmetic
+    template <bool DIRECT> __device__ __forceinline__ void emit(const i64 win, const u8* st) {
         wave_lds_sync();
         const u32 n = (kProbes && (probe & 8)) ? 0u : qfill;
         for (u32 i = lane; i < n; i += 64) {
@@ -152,7 +154,7 @@ struct MxDrain {
             u32 pos = desc & ((1u << MX_POS_BITS) - 1u);
             const u32 src = (desc >> MX_POS_BITS) & 63u;
             const u32 t = (desc >> (MX_POS_BITS + 6)) & 3u, w = (desc >> (MX_POS_BITS + 8)) & 3u;
-            const bool direct = COMPACT && ((desc >> (MX_POS_BITS + 10)) & 1u);
+            const bool direct = COMPACT && DIRECT && ((desc >> (MX_POS_BITS + 10)) & 1u);
             const u32 hs = src >> 5;                                  // the source lane's half = segment
             const int ql = wave * WQ + (int)t * 32 + (int)(src & 31u);    // its query, block-local
             u32 qcw[NW];
@@ -184,7 +186,7 @@ struct MxDrain {
                 if (!(kProbes && (probe & 4)) || d == 0x7fffffffu) {      // (the push trimmed the word to what the slice holds)
                     if (COMPACT) {
                         const u8 rec = make_rec8(d, any != 0);
-                        if (__builtin_expect(direct, 0)) cand8[q * crow + seg * cap + pos] = rec;
+                        if (DIRECT && __builtin_expect(direct, 0)) cand8[q * crow + seg * cap + pos] = rec;
                         else ring[pos & (MX_RING - 1)] = rec;
                     } else {
                         ((u64*)cand8)[slice0 + pos] = make_rec(idx0 + r, d, any != 0);
@@ -219,9 +221,68 @@ struct MxDrain {
         for (int k = 0; k < QT; ++k) arr[k] = t == k ? v : arr[k];
     }
 
-    // One drain = the hit masks of HALF a window: wd[t][i] = the lane's mask word w0 + i of query tile t.
-    // Whether the queue could overflow (compact: 128 entries) or a slice's ring could (see the header) is decided once
-    // for the whole drain; the common case then runs four check-free pushes and one emit.
+    // One queue entry for the lane's mask word `word` (query tile t, word index w of the window), if it has hits.
+    __device__ __forceinline__ void push(const u32 word, const u64 bal, const int t, const int w) {
+        const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+        const u32 want = cnt[t] + (u32)__builtin_popcount(word);
+        const u32 got = want < cap ? want : cap;                // the slice holds `cap` records; the rest is lost
+        u32 kept = word;                                        // (dead lanes never hit: their bias keeps every accumulator >= 0)
+        if (__builtin_expect(want != got, 0)) {                 // full slice: the word's first got - cnt hits only
+            flags |= 0x100u << t;
+            kept = first_hits(word, got - cnt[t]);
+        }
+        if (word != 0u)                                         // (an entry even when nothing is kept: the slot is counted)
+            queue[slot] = ((u64)kept << 32) | (u64)(cnt[t] | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
+                                                    ((u32)w << (MX_POS_BITS + 8)));
+        cnt[t] = got;
+        qfill += (u32)__builtin_popcountll(bal);
+    }
+
+    // The hit masks of a window: m[t][w] = the lane's mask word w (32 rows) of query tile t.  Sparse windows -- the
+    // case the kernel is tuned for, ~58 non-zero words per wavefront at C2 -- drain in one go: eight check-free pushes
+    // and ONE emit with most lanes busy.  Whether that is safe (queue: QCAP entries; compact: a slice's ring takes up
+    // to 16 - 7 new records, see the header) is decided once, wave-uniformly; otherwise the window drains in two halves,
+    // each with its own decision between the check-free form and the word-by-word one.
+    __device__ __forceinline__ void drain_window(const u32 (&m)[QT][4], const i64 win, const u8* st) {
+        u64 bal[QT][4];
+        u32 nz = 0;
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                bal[t][w] = __ballot(m[t][w] != 0u);
+                nz += (u32)__builtin_popcountll(bal[t][w]);
+            }
+        bool whole = nz <= (u32)QCAP;
+        if (COMPACT) {
+            bool over = false;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                u32 want = cnt[t];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) want += (u32)__builtin_popcount(m[t][w]);
+                over |= (want < cap ? want : cap) - (flushed[t] & ~7u) > (u32)MX_RING;
+            }
+            whole = whole && __any(over) == 0;
+        }
+        if (__builtin_expect(whole, 1)) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) push(m[t][w], bal[t][w], t, w);
+            emit<false>(win, st);
+            return;
+        }
+#pragma unroll 1
+        for (int hw = 0; hw < 2; ++hw) {
+            u32 wd[QT][2];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) { wd[t][0] = hw ? m[t][2] : m[t][0]; wd[t][1] = hw ? m[t][3] : m[t][1]; }
+            drain(wd, 2 * hw, win, st);
+        }
+    }
+
+    // Half a window: wd[t][i] = the lane's mask word w0 + i of query tile t.
     __device__ __forceinline__ void drain(const u32 (&wd)[QT][2], const int w0, const i64 win, const u8* st) {
         u64 bal[QT][2];
         u32 nz = 0;
@@ -246,23 +307,8 @@ struct MxDrain {
 #pragma unroll
             for (int t = 0; t < QT; ++t)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const u32 word = wd[t][i];
-                    const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(bal[t][i] >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal[t][i], 0u));
-                    const u32 want = cnt[t] + (u32)__builtin_popcount(word);
-                    const u32 got = want < cap ? want : cap;                // the slice holds `cap` records; the rest is lost
-                    u32 kept = word;                                        // (dead lanes never hit: their bias keeps every accumulator >= 0)
-                    if (__builtin_expect(want != got, 0)) {                 // full slice: the word's first got - cnt hits only
-                        flags |= 0x100u << t;
-                        kept = first_hits(word, got - cnt[t]);
-                    }
-                    if (word != 0u)                                         // (an entry even when nothing is kept: the slot is counted)
-                        queue[slot] = ((u64)kept << 32) | (u64)(cnt[t] | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
-                                                                ((u32)(w0 + i) << (MX_POS_BITS + 8)));
-                    cnt[t] = got;
-                    qfill += (u32)__builtin_popcountll(bal[t][i]);
-                }
-            emit(win, st);
+                for (int i = 0; i < 2; ++i) push(wd[t][i], bal[t][i], t, w0 + i);
+            emit<false>(win, st);
         } else {
             drain_slow(wd, w0, win, st);
         }
@@ -301,7 +347,7 @@ struct MxDrain {
             flags |= want != got ? 0x100u << t : 0u;
             put(cnt, t, got);
             qfill += (u32)__builtin_popcountll(bal);
-            emit(win, st);
+            emit<true>(win, st);
         }
     }
 

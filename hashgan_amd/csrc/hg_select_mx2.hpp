@@ -253,13 +253,7 @@ void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
 #pragma unroll
             for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][3] == 0x1234567u) dr.flags |= 0x100u << t;
         } else {
-#pragma unroll 1
-            for (int hw = 0; hw < 2; ++hw) {                         // two drains per window: half the queue
-                u32 wd[QT][2];
-#pragma unroll
-                for (int t = 0; t < QT; ++t) { wd[t][0] = hw ? m[t][2] : m[t][0]; wd[t][1] = hw ? m[t][3] : m[t][1]; }
-                dr.drain(wd, 2 * hw, win, st);
-            }
+            dr.drain_window(m, win, st);
         }
     }
     dr.finish();
