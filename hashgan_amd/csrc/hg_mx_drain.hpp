@@ -18,7 +18,8 @@
 //          owns a 16-record ring in LDS, the emit writes record `pos` to ring slot pos & 15, and after the emit the
 //          OWNER lane of a slice flushes each completed 8-record piece with one aligned 8-byte store.  1/8 of
 //          the store instructions, 1/8 of the bytes, no partial-line rewrites.
-//          Ring invariant: between drains a slice has < 8 unflushed records; a drain may add up to 16 - 7.  A
+//          Ring invariant: a slice never has more than 16 unflushed records; the checked paths flush after every
+//          emit (< 8 pending at their start, a drain may add up to 16 - 7), the sparse-window path only on demand.  A
 //          push that would break it (>= 10 hits of one query in <= 64 rows: clustered duplicates) first drains
 //          what is pending, then routes that word's records directly to global memory (entry flag), after the
 //          owner has written the ring's leftovers out byte by byte -- rare, slow, exact.
@@ -144,7 +145,8 @@ struct MxDrain {
 
     // DIRECT: the queue may hold direct-routed entries (only drain_slow makes them); the common instantiation carries
     // none of their address arithmetic
-    template <bool DIRECT> __device__ __forceinline__ void emit(const i64 win, const u8* st) {
+    // FLUSH: write the completed pieces out right away (the paths that need < 8 pending records per slice at their start)
+    template <bool DIRECT, bool FLUSH = true> __device__ __forceinline__ void emit(const i64 win, const u8* st) {
         wave_lds_sync();
         const u32 n = (kProbes && (probe & 8)) ? 0u : qfill;
         for (u32 i = lane; i < n; i += 64) {
@@ -197,7 +199,7 @@ struct MxDrain {
         }
         wave_lds_sync();
         qfill = 0;
-        if (COMPACT) {
+        if (COMPACT && FLUSH) {
             flush_all_pieces();
             wave_lds_sync();                                          // ring reads done before the next emit overwrites slots
         }
@@ -239,47 +241,61 @@ struct MxDrain {
     }
 
     // The hit masks of a window: m[t][w] = the lane's mask word w (32 rows) of query tile t.  Sparse windows -- the
-    // case the kernel is tuned for, ~58 non-zero words per wavefront at C2 -- drain in one go: eight check-free pushes
-    // and ONE emit with most lanes busy.  Whether that is safe (queue: QCAP entries; compact: a slice's ring takes up
-    // to 16 - 7 new records, see the header) is decided once, wave-uniformly; otherwise the window drains in two halves,
-    // each with its own decision between the check-free form and the word-by-word one.
+    // case the kernel is tuned for, ~100 non-zero words per wavefront at C2 -- drain in one go: eight check-free pushes
+    // and one emit.  What makes that safe is decided once, wave-uniformly: the queue takes the window's entries; no
+    // slice fills up (nothing to trim); compact: every slice's ring takes its new records on top of what is pending.
+    // Windows that do not fit drain in two halves, each with its own decision between the checked pushes and the
+    // word-by-word form.  (Flushing pieces lazily -- only when a ring could not take the next window -- was tried: with
+    // 128 slices per wavefront some ring is nearly always close to full, it saved nothing.)
     __device__ __forceinline__ void drain_window(const u32 (&m)[QT][4], const i64 win, const u8* st) {
         u64 bal[QT][4];
-        u32 nz = 0;
+        u32 nz = 0, want[QT];
 #pragma unroll
-        for (int t = 0; t < QT; ++t)
+        for (int t = 0; t < QT; ++t) {
+            want[t] = cnt[t];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 bal[t][w] = __ballot(m[t][w] != 0u);
                 nz += (u32)__builtin_popcountll(bal[t][w]);
+                want[t] += (u32)__builtin_popcount(m[t][w]);
             }
-        bool whole = nz <= (u32)QCAP;
-        if (COMPACT) {
-            bool over = false;
+        }
+        auto fits = [&]() {
+            bool bad = false;
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                u32 want = cnt[t];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) want += (u32)__builtin_popcount(m[t][w]);
-                over |= (want < cap ? want : cap) - (flushed[t] & ~7u) > (u32)MX_RING;
+                bad |= want[t] > cap;
+                if (COMPACT) bad |= want[t] - (flushed[t] & ~7u) > (u32)MX_RING;
             }
-            whole = whole && __any(over) == 0;
-        }
-        if (__builtin_expect(whole, 1)) {
+            return __any(bad) == 0;
+        };
+        if (__builtin_expect(!(nz <= (u32)QCAP && fits()), 0)) {
+#pragma unroll 1
+            for (int hw = 0; hw < 2; ++hw) {
+                u32 wd[QT][2];
 #pragma unroll
-            for (int t = 0; t < QT; ++t)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) push(m[t][w], bal[t][w], t, w);
-            emit<false>(win, st);
+                for (int t = 0; t < QT; ++t) { wd[t][0] = hw ? m[t][2] : m[t][0]; wd[t][1] = hw ? m[t][3] : m[t][1]; }
+                drain(wd, 2 * hw, win, st);
+            }
             return;
         }
-#pragma unroll 1
-        for (int hw = 0; hw < 2; ++hw) {
-            u32 wd[QT][2];
 #pragma unroll
-            for (int t = 0; t < QT; ++t) { wd[t][0] = hw ? m[t][2] : m[t][0]; wd[t][1] = hw ? m[t][3] : m[t][1]; }
-            drain(wd, 2 * hw, win, st);
+        for (int t = 0; t < QT; ++t) {
+            u32 pos = cnt[t];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const u32 word = m[t][w];
+                const u64 b = bal[t][w];
+                const u32 slot = qfill + __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));
+                if (word != 0u)
+                    queue[slot] = ((u64)word << 32) | (u64)(pos | ((u32)lane << MX_POS_BITS) | ((u32)t << (MX_POS_BITS + 6)) |
+                                                            ((u32)w << (MX_POS_BITS + 8)));
+                pos += (u32)__builtin_popcount(word);
+                qfill += (u32)__builtin_popcountll(b);
+            }
+            cnt[t] = want[t];
         }
+        emit<false>(win, st);
     }
 
     // Half a window: wd[t][i] = the lane's mask word w0 + i of query tile t.
@@ -355,6 +371,7 @@ struct MxDrain {
     __device__ __forceinline__ void finish() {
         if (!COMPACT) return;
         wave_lds_sync();
+        flush_all_pieces();                                           // (lazy flushes: up to two pieces may be pending)
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const u32 f = flushed[t];
