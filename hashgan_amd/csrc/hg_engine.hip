@@ -9,6 +9,7 @@
 #include "hg_rank_cnt.hpp"
 #include "hg_select_mx2.hpp"
 #include "hg_real_mx.hpp"
+#include "hg_real_bf.hpp"
 #include "hg_hist_mx.hpp"
 #include "hg_host_pack.hpp"
 #include "../../include/hashgan_amd.h"
@@ -83,10 +84,10 @@ struct DevBuf {
 
 enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_LAYOUT, KI_GUESS, KI_SELECT, KI_CAND_HIST,
                 KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_PACK, KI_REAL_SAMPLE, KI_REAL_GUESS, KI_REAL_SELECT,
-                KI_RADIX, KI_REAL_FINISH, KI_SELECT_MX, KI_RANK_LDS, KI_COMM, KI_STEP, KI_COUNT };
+                KI_RADIX, KI_REAL_FINISH, KI_SELECT_MX, KI_RANK_LDS, KI_COMM, KI_STEP, KI_REAL_RESCORE, KI_COUNT };
 const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_layout", "k_guess",
                                             "k_select", "k_rank_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge", "k_pack",
-                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish", "k_select_mx", "k_rank_lds", "rccl_allgather", "step_gpu_span"};
+                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish", "k_select_mx", "k_rank_lds", "rccl_allgather", "step_gpu_span", "k_real_rescore"};
 
 enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
 
@@ -267,7 +268,11 @@ struct hg_ctx {
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
     DevBuf dbfx;               // float features of the database in MFMA A-fragment order (k_real_select_mx), built on first use
     bool dbfx_valid = false;
-    i64 opt_real_mfma = 1;     // "real_mfma": the real-valued select pass runs on the matrix cores
+    DevBuf dbfb, thr2, xmax2;  // filter + rescore path (hg_real_bf.hpp): bf16 image of the database, lowered cuts, max row norm^2
+    bool dbfb_valid = false;
+    i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit
+    bool real_filtered = false;   // the last real_select left unscored candidates that k_real_rescore completed
+    i64 opt_real_mfma = 2;     // "real_mfma": 2 = bf16 filter on the matrix cores + exact rescoring of the survivors, 1 = exact float32 MFMA pass, 0 = vector ALU
     int bpad = 0;              // feature count padded to a multiple of 16 (0: no float tables loaded)
     i64 census_db[3] = {0, 0, 0}, census_q[3] = {0, 0, 0};
     // hand-over of float32 / int64 arrays: packed on the host by a thread pool before the upload (hg_host_pack.hpp)
@@ -802,6 +807,64 @@ template <int KP> int real_launch_select_mx(hg_ctx* c) {
     c->t_end();
     return c->check_launch("k_real_select_mx");
 }
+// filter + rescore (hg_real_bf.hpp): bf16 pair pass with a rigorous margin, then the exact chain for the survivors
+template <int KP> int real_launch_select_bf(hg_ctx* c) {
+    if (!c->dbfb_valid) {
+        const i64 n16 = (c->N + 15) / 16 * 16;
+        HG_TRY(c->dbfb.reserve((size_t)n16 * KP * 2));
+        HG_TRY(c->xmax2.reserve(4));
+        HG_HIP(hipMemsetAsync(c->xmax2.p, 0, 4, c->stream));
+        c->t_begin(KI_PACK);
+        hipLaunchKernelGGL(k_expand_dbf_bf16, dim3(grid_for(n16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
+                           c->dbfb.as<uint4>(), (i64)c->N, n16, KP);
+        hipLaunchKernelGGL(k_row_norm_max, dim3(grid_for(c->N)), dim3(256), 0, c->stream, c->dbf.as<float>(), (i64)c->N, KP, c->xmax2.as<u32>());
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_dbf_bf16"));
+        c->dbfb_valid = true;
+    }
+    Geo g = c->geo;
+    HG_TRY(c->thr2.reserve((size_t)g.Qpad * 4));
+    c->t_begin(KI_REAL_GUESS);
+    hipLaunchKernelGGL(k_real_thr2, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->qf.as<float>(), c->thr.as<float>(),
+                       c->xmax2.as<u32>(), c->thr2.as<float>(), g.Q, KP);
+    c->t_end();
+    HG_TRY(c->check_launch("k_real_thr2"));
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + WPB * 64 - 1) / (WPB * 64);
+    Geo gs = g;
+    gs.nQT = nQB;
+    gs.nUnits = (i64)nSP * nQB;
+    gs.wpb = WPB;
+    gs.nBlk = (int)gs.nUnits;
+    RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
+    c->t_begin(KI_REAL_SELECT);
+    hipLaunchKernelGGL((k_real_select_bf<KP>), dim3(padded_grid(gs.nBlk)), dim3(256), 0, c->stream,
+                       c->qf.as<float>(), c->dbfb.as<u8>(), c->thr2.as<float>(), a, c->cand.as<u64>(), gs);
+    c->t_end();
+    HG_TRY(c->check_launch("k_real_select_bf"));
+    constexpr int SG = 4;
+    const i64 waves = (i64)((g.S + SG - 1) / SG) * g.Q;
+    c->t_begin(KI_REAL_RESCORE);
+    HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_rescore<KP, SG>), hipFuncAttributeMaxDynamicSharedMemorySize, rescore_lds_bytes()));
+    hipLaunchKernelGGL((k_real_rescore<KP, SG>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(),
+                       c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(), c->sl_cnt.as<u32>(), g);
+    c->t_end();
+    c->real_filtered = true;
+    return c->check_launch("k_real_rescore");
+}
+int real_select_bf(hg_ctx* c) {
+    switch (c->bpad) {
+        case 16: return real_launch_select_bf<16>(c);
+        case 32: return real_launch_select_bf<32>(c);
+        case 48: return real_launch_select_bf<48>(c);
+        case 64: return real_launch_select_bf<64>(c);
+        case 80: return real_launch_select_bf<80>(c);
+        case 96: return real_launch_select_bf<96>(c);
+        case 112: return real_launch_select_bf<112>(c);
+        case 128: return real_launch_select_bf<128>(c);
+        default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 128 features (have %d)", c->b);
+    }
+}
 int real_select_mx(hg_ctx* c) {
     switch (c->bpad) {
         case 16: return real_launch_select_mx<16>(c);
@@ -830,6 +893,8 @@ int real_select_mx(hg_ctx* c) {
     }
 int real_sample(hg_ctx* c, i64 M, i64 stride) { HG_DISPATCH_BP(real_launch_sample, c, M, stride) }
 int real_select(hg_ctx* c) {
+    c->real_filtered = false;
+    if (c->opt_real_mfma == 2 && c->geo.L % 16 == 0) return real_select_bf(c);
     if (c->opt_real_mfma && c->geo.L % 16 == 0) return real_select_mx(c);
     HG_DISPATCH_BP(real_launch_select, c)
 }
@@ -880,7 +945,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -1043,6 +1108,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->dbx_valid = false;
     c->dbx2_valid = false;
     c->dbfx_valid = false;
+    c->dbfb_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;
     c->cfg_epoch++;
     return HG_OK;
@@ -2096,6 +2162,33 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         return fail(HG_ERR_NOMEM, "real-valued ranking: %zu GB of records needed (Q=%d, %lld per query)", rows * 3 >> 30, g.Q, (long long)c->crow);
     HG_TRY(c->cand.reserve(rows)); HG_TRY(c->sortA.reserve(rows)); HG_TRY(c->sortB.reserve(rows));
     HG_TRY(real_select(c));
+    const size_t slots = (size_t)g.Q * g.R;
+    HG_TRY(c->out_idx.reserve(slots * 4));
+    HG_TRY(c->scores.reserve(slots * 4));
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    if (c->real_filtered && bet && c->opt_real_sort_lds && g.S <= RK_SMAX && R <= RK_RMAX) {
+        // a query's records fit the LDS of one workgroup: copy + select + counting passes + ranked list in one kernel
+        constexpr int NA = 14336;
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_rank_lds<NA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)real_rank_lds_bytes<NA>()));
+        c->t_begin(KI_RADIX);
+        hipLaunchKernelGGL(k_real_rank_lds<NA>, dim3(g.Q), dim3(1024), real_rank_lds_bytes<NA>(), c->stream, c->cand.as<u64>(), c->crow, c->cap,
+                           c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->thr.as<float>(), c->out_idx.as<u32>(), c->scores.as<float>(),
+                           c->err.as<int>(), c->qbad.as<u32>(), g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_real_rank_lds"));
+        int flag = 0;
+        HG_TRY(read_plan_flag(c, &flag));
+        if (!(flag & 2)) {
+            *lost = flag & 1;
+            c->stage = ST_DB | ST_Q | ST_SELECT;
+            if (*lost) return HG_OK;
+            HG_TRY(do_match(c));
+            if (with_ap) HG_TRY(do_ap(c));
+            return c->sync();
+        }
+        HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));    // some query's records exceed the LDS: the global-memory passes rank them all
+    }
     const int nwav = c->crow >= 16384 ? 16 : 4;
     const size_t lds = (size_t)(nwav + 1) * 256 * 4;
     u64* bufs[2] = {c->sortA.as<u64>(), c->sortB.as<u64>()};
@@ -2110,15 +2203,12 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         HG_TRY(c->check_launch("k_radix_pass"));
         in = out;
     }
-    const size_t slots = (size_t)g.Q * g.R;
-    HG_TRY(c->out_idx.reserve(slots * 4));
-    HG_TRY(c->scores.reserve(slots * 4));
-    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
     c->t_begin(KI_REAL_FINISH);
     const i64 nKB = grid_for(g.R);
     if (nKB * g.Q > 0x7FFFFFFFll) return fail(HG_ERR_ARG, "real-valued ranking: Q*R too large for one launch");
     hipLaunchKernelGGL(k_real_finish, dim3((unsigned)(nKB * g.Q)), dim3(256), 0, c->stream, in, c->crow, c->tot.as<u32>(),
-                       c->out_idx.as<u32>(), c->scores.as<float>(), c->err.as<int>(), c->qbad.as<u32>(), (int)nKB, g);
+                       c->out_idx.as<u32>(), c->scores.as<float>(), c->err.as<int>(), c->qbad.as<u32>(), (int)nKB,
+                       c->real_filtered ? c->thr.as<float>() : nullptr, g);
     c->t_end();
     HG_TRY(c->check_launch("k_real_finish"));
     c->stage = ST_DB | ST_Q | ST_SELECT;
@@ -2461,7 +2551,10 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "select_qt")) {
         (void)value;                                   // retired (round 1 experiment): the tile count follows the code length
     } else if (!strcmp(key, "real_mfma")) {
-        c->opt_real_mfma = value != 0;
+        if (value < 0 || value > 2) return fail(HG_ERR_ARG, "real_mfma must be 0, 1 or 2");
+        c->opt_real_mfma = value;
+    } else if (!strcmp(key, "real_sort_lds")) {
+        c->opt_real_sort_lds = value != 0;
     } else if (!strcmp(key, "real_segment_bytes")) {
         if (value < 4096) return fail(HG_ERR_ARG, "real_segment_bytes must be >= 4096");
         c->opt_real_seg_bytes = value;
@@ -2482,9 +2575,10 @@ int hg_trim(hg_ctx* c) {
     HG_TRY(c->sync());
     DevBuf* work[] = {&c->hist, &c->seglt, &c->segtie, &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->cand, &c->out_idx,
                       &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->scores, &c->bigq, &c->mbits2,
-                      &c->dbx, &c->qx, &c->dbx2, &c->qx2, &c->dbfx};   // the images are rebuilt on demand
+                      &c->dbx, &c->qx, &c->dbx2, &c->qx2, &c->dbfx, &c->dbfb};   // the images are rebuilt on demand
     for (auto* d : work) d->release();
     c->dbfx_valid = false;
+    c->dbfb_valid = false;
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
     c->gath_idx.release(); c->gath_dist.release();

@@ -1,0 +1,467 @@
+// hashgan_amd -- the real-valued select pass as FILTER + RESCORE.
+//
+// lib/metric.py:13 is a float32 GEMM whose every element the ranking needs in ONE fixed arithmetic (the float32 fma
+// chain, k ascending: oracle/real_map.py) -- but only for the ~R rows per query that can reach the top R.  The float32
+// MFMA computes that chain for all Q x N pairs at the vector fma rate (k_real_select_mx: 12 ms at the C2 shape, 78 % of
+// what the instruction allows).  Here the pair pass runs in bfloat16 on the matrix cores (16x the float32 rate) and
+// only decides, with a rigorous error bound, which pairs CAN qualify; the survivors -- ~1.3 R per query -- get the exact
+// chain from the float32 rows:
+//
+//   filter    approx = sum_k bf16(q_k) bf16(x_k), float32 accumulation.  With u = 2^-8 covering either rounding of the
+//             conversions,  |approx - chain| <= sum_k |q_k x_k| (2u + u^2 + (K + 2) 2^-21)  <=  |q|_2 max_rows |x|_2 c
+//             (Cauchy-Schwarz; the K 2^-21 term covers the float32 roundings of both accumulations, any order).
+//             A pair is kept when approx > thr2[q] = thr[q] - eps[q] (k_real_thr2): a superset of {chain > thr[q]}.
+//             The test is the sign of the accumulator itself: C = thr2, B = -bf16(q)  ->  acc = thr2 - approx.
+//   rescore   k_real_rescore: every kept (query, row) gets the exact chain from the float32 tables; those with
+//             chain > thr[q] become the same sortable record {~mono(ip) | idx} the exact kernels write, compacted to the
+//             front of their slice, and the slice counts shrink accordingly -- from here on the records are exactly what
+//             the exact kernels would have left.
+//
+// Mapping of the filter: k_real_select_mx's (lane = query column j and 16 rows of segment 2 sp + h per tile, records in
+// index order into the (segment, query) slice, written by the owning lane).
+#pragma once
+#include "hg_kernels.hpp"
+#include "hg_real_kernels.hpp"
+#include "hg_select_mx.hpp"
+
+namespace hg {
+
+typedef unsigned short u16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32 pack_bf16x2(float lo, float hi) {      // v_cvt_pk_bf16_f32 (round to nearest even)
+    const f2 v = {lo, hi};
+    const bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return *(const u32*)&r;
+}
+
+// Database image in A-fragment order of v_mfma_f32_32x32x16_bf16: groups of 16 rows; chunk (group G, MFMA m, k-half
+// hh, row r) = 16 bytes at (((G * (KP/16) + m) * 2 + hh) * 16 + r) * 16 holding bf16 features 16 m + 8 hh .. + 7 of
+// row 16 G + r.
+__global__ __launch_bounds__(256) void k_expand_dbf_bf16(const float* __restrict__ dbf, uint4* __restrict__ img, i64 N, i64 n16, int KP) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = KP / 8;
+    if (i >= n16 * per_row) return;
+    const i64 row = i / per_row;
+    const int c = (int)(i - row * per_row), m = c >> 1, hh = c & 1;
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (row < N) {
+        const float4* f = (const float4*)(dbf + row * KP + 16 * m + 8 * hh);
+        const float4 a = f[0], b = f[1];
+        v.x = pack_bf16x2(a.x, a.y); v.y = pack_bf16x2(a.z, a.w);
+        v.z = pack_bf16x2(b.x, b.y); v.w = pack_bf16x2(b.z, b.w);
+    }
+    img[(((row >> 4) * (KP / 16) + m) * 2 + hh) * 16 + (row & 15)] = v;
+}
+
+// max over the rows of |x|_2^2 (float32 sum of squares; the caller inflates it), as float bits (non-negative floats
+// order like unsigned integers).  out must be zeroed.
+__global__ __launch_bounds__(256) void k_row_norm_max(const float* __restrict__ dbf, i64 N, int KP, u32* __restrict__ out) {
+    const i64 row = (i64)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.0f;
+    if (row < N) {
+        const float4* f = (const float4*)(dbf + row * KP);
+        for (int k = 0; k < KP / 4; ++k) { const float4 v = f[k]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    }
+    u32 b = __float_as_uint(s);
+    if (s != s) b = 0x7F800000u;                                  // NaN features: no bound holds; +inf keeps every pair
+    for (int o = 32; o > 0; o >>= 1) { const u32 t = (u32)__shfl_xor((int)b, o); b = t > b ? t : b; }
+    if ((threadIdx.x & 63) == 0 && b) atomicMax(out, b);
+}
+
+// thr2[q] = thr[q] - eps[q], rounded down (see the header).  One thread per query, double arithmetic.
+__global__ __launch_bounds__(256) void k_real_thr2(const float* __restrict__ qf, const float* __restrict__ thr, const u32* __restrict__ xmax2,
+                                                   float* __restrict__ thr2, int Q, int KP) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q) return;
+    const float t = thr[q];
+    if (!(t > -INFINITY && t < INFINITY)) { thr2[q] = t; return; }   // -inf: everything qualifies; +inf: nothing
+    double qq = 0.0;
+    for (int k = 0; k < KP; ++k) { const double v = (double)qf[(i64)q * KP + k]; qq += v * v; }
+    const double xx = (double)__uint_as_float(*xmax2) * 1.0001;       // the float32 sum of squares, inflated
+    const double u = 1.0 / 256.0;
+    const double c = 2.0 * u + u * u + (double)(KP + 2) * 4.76837158203125e-07;   // 2^-21
+    const double eps = 1.0001 * c * sqrt(qq * xx) + (double)(KP + 2) * 4.76837158203125e-07 * fabs((double)t) + 1e-30;
+    const double want = (double)t - eps;
+    float r = (float)want;
+    if ((double)r > want) r = __uint_as_float(r > 0.0f ? __float_as_uint(r) - 1u : (r < 0.0f ? __float_as_uint(r) + 1u : 0x80000001u));
+    thr2[q] = r;
+}
+
+template <int KP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, KP <= 64 ? 4 : 2)))
+void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, const float* __restrict__ thr2, const RealSelArgs a,
+                      u64* __restrict__ cand, const Geo g) {
+    constexpr int QT = 2, WQ = 32 * QT;
+    constexpr int NM = KP / 16;                              // MFMAs (and 16-byte A chunks per lane) per tile
+
+    const int lb = logical_block(g.nBlk);
+    if (lb < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nQB = g.nQT;
+    const int sp = lb / nQB, qb = lb - sp * nQB;
+    const int h = lane >> 5, j = lane & 31;
+    const int s = 2 * sp + h;                                // this lane's segment
+    const bool seg_ok = s < g.S;
+    const i64 lo0 = (i64)(2 * sp) * g.L, lo1 = lo0 + g.L;
+    const i64 len0 = (lo0 + g.L < g.N ? g.L : g.N - lo0);
+    const i64 len1 = lo1 >= g.N ? 0 : (lo1 + g.L < g.N ? g.L : g.N - lo1);
+    const i64 mylen = h ? len1 : len0;
+    const i64 ntile = ((len0 > len1 ? len0 : len1) + 15) / 16;
+    const i64 NG = (g.N + 15) >> 4;
+
+    // ---- queries: B fragments (-bf16 of features 16 m + 8 h .. + 7 of query j), cut, slice cursors ----
+    const int q0w = (qb * WPB + wave) * WQ;
+    bf16x8 bq[QT][NM];
+    float cut[QT];
+    u32 cnt[QT], room[QT], dropped[QT];
+    u64* wp[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = q0w + t * 32 + j;
+        const bool live = q < g.Q && seg_ok;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            u32 w[4] = {0u, 0u, 0u, 0u};
+            if (q < g.Q) {
+                const float4* f = (const float4*)(qf + (i64)q * KP + 16 * m + 8 * h);
+                const float4 x = f[0], y = f[1];
+                w[0] = pack_bf16x2(-x.x, -x.y); w[1] = pack_bf16x2(-x.z, -x.w);
+                w[2] = pack_bf16x2(-y.x, -y.y); w[3] = pack_bf16x2(-y.z, -y.w);
+            }
+            bq[t][m] = *(const bf16x8*)w;
+        }
+        cut[t] = live ? thr2[q] : __uint_as_float(0x7F800000u);      // +inf: nothing qualifies
+        cnt[t] = 0; room[t] = live ? a.cap : 0u; dropped[t] = 0;
+        wp[t] = cand + (i64)(q < g.Q ? q : 0) * a.crow + (i64)(seg_ok ? s : 0) * a.cap;
+    }
+
+    // ---- A fragments straight from the image into registers, one tile ahead (k_real_select_mx's scheme) ----
+    const int ah = (j >> 2) & 1;                             // lane-half (segment) that A row j feeds
+    const int ar = (j & 3) + 4 * (j >> 3);                   // its row inside that half's 16
+    const i64 ag0 = (ah ? lo1 : lo0) >> 4;
+    auto chunk = [&](const i64 T, const int m) -> bf16x8 {
+        i64 G = ag0 + T;
+        G = G < NG ? G : NG - 1;                             // past the end: any valid group (masked later)
+        return *(const bf16x8*)(img + ((((G * NM + m) * 2 + h) * 16 + ar) * 16));
+    };
+    bf16x8 av[NM];
+    if (ntile > 0) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) av[m] = chunk(0, m);
+    }
+    for (i64 T = 0; T < ntile; ++T) {
+        const i64 left = mylen - T * 16;                     // valid rows of this lane in the tile
+        const u32 keep = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : (1u << (int)left) - 1u);
+        const i64 Tn = T + 1 < ntile ? T + 1 : T;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = cut[t];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bq[t][m], acc, 0, 0, 0);
+                if (t == QT - 1) av[m] = chunk(Tn, m);
+            }
+            // harvest: bit r <-> row 16 T + r of the lane's segment may qualify (thr2 - approx < 0)
+            u32 mask = 0;
+#pragma unroll
+            for (int r = 15; r >= 0; --r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(acc[r]), 31);
+            mask &= keep;
+            // drain: the owning lane writes the row numbers of its hits, lowest row first; the score comes later
+            while (__any(mask != 0u)) {
+                if (mask != 0u) {
+                    const int r = __builtin_ctz(mask);
+                    mask &= mask - 1u;
+                    if (room[t]) {
+                        wp[t][cnt[t]] = (u64)(g.idx_base + (u32)((i64)s * g.L + T * 16 + r));
+                        ++cnt[t];
+                        --room[t];
+                    } else {
+                        ++dropped[t];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = q0w + t * 32 + j;
+        if (seg_ok && q < g.Qpad) {
+            const bool live = q < g.Q;
+            a.sl_cnt[(i64)s * g.Qpad + q] = live ? cnt[t] : 0u;
+            if (dropped[t] && live) a.fail[q] = 1u;
+        }
+    }
+}
+
+// Rescore: wavefront = (group of SG consecutive slices, query); lane = one kept row.  The query's features are
+// wave-uniform (scalar loads); consecutive wavefronts take consecutive queries of the SAME segment group, whose rows
+// (SG x real_segment_bytes) stay in the L2 while all queries pass.  The 64 rows of a round are fetched COALESCED --
+// 16 lanes per row, 4 rows per load instruction, whole cache lines -- and turned through LDS (rows padded to 272 bytes)
+// so that every lane then walks its own row in feature order: one float32 fma chain, k ascending.
+constexpr int RS_ROWB = 272;                                 // bytes per staged row: 64 floats + 16 (bank spread)
+constexpr int rescore_lds_bytes() { return WPB * 64 * RS_ROWB; }
+
+template <int KP, int SG>
+__global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ qf, const float* __restrict__ dbf, const u32* sl_cnt,
+                                                      u64* __restrict__ cand, u32 cap, i64 crow, const float* __restrict__ thr,
+                                                      u32* sl_cnt_out, const Geo g) {      // (sl_cnt_out may be sl_cnt)
+    extern __shared__ __attribute__((aligned(16))) u8 rlds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const i64 unit = (i64)blockIdx.x * WPB + wave;
+    const int nG = (g.S + SG - 1) / SG;
+    if (unit >= (i64)nG * g.Q) return;
+    const int sg = __builtin_amdgcn_readfirstlane((int)(unit / g.Q));
+    const int q = __builtin_amdgcn_readfirstlane((int)(unit - (i64)sg * g.Q));
+    const int s0 = sg * SG;
+    u32 pre[SG + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int k = 0; k < SG; ++k) pre[k + 1] = pre[k] + (s0 + k < g.S ? sl_cnt[(i64)(s0 + k) * g.Qpad + q] : 0u);
+    const u32 total = pre[SG];
+    const float* __restrict__ qrow = qf + (i64)q * KP;
+    const float cutq = thr[q];
+    u64* __restrict__ rows = cand + (i64)q * crow + (i64)s0 * cap;
+    u8* st = rlds + wave * 64 * RS_ROWB;
+    u32 kept[SG];                                            // records of each slice that score above the cut, so far
+#pragma unroll
+    for (int x = 0; x < SG; ++x) kept[x] = 0;
+    const u64 below = (1ull << lane) - 1ull;
+    const int pr = lane >> 4, pp = lane & 15;                // staging role: row 4 e + pr of the round, piece pp
+    for (u32 base = 0; base < total; base += 64) {
+        const u32 i = base + lane;
+        const bool valid = i < total;
+        int k = 0;
+#pragma unroll
+        for (int x = 1; x < SG; ++x) k += i >= pre[x] ? 1 : 0;
+        u32 off = i;
+#pragma unroll
+        for (int x = 1; x < SG; ++x) off = k == x ? i - pre[x] : off;
+        u64* p = rows + (i64)k * cap + off;
+        const u32 idx = valid ? (u32)*p : g.idx_base;        // idle lanes: any valid row
+        const u32 local = idx - g.idx_base;
+        float acc = 0.0f;
+#pragma unroll 1
+        for (int c0 = 0; c0 < KP; c0 += 64) {                // 64 features at a time
+            constexpr int CH = KP < 64 ? KP : 64;            // (KP > 64: the last chunk may be shorter, guarded below)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const u32 ridx = (u32)__shfl((int)local, 4 * e + pr);
+                if (c0 + 4 * pp < KP)
+                    *(float4*)(st + (4 * e + pr) * RS_ROWB + pp * 16) = *(const float4*)(dbf + (i64)ridx * KP + c0 + 4 * pp);
+            }
+            wave_lds_sync();
+            float4 v[CH / 4];
+#pragma unroll
+            for (int e = 0; e < CH / 4; ++e) v[e] = *(const float4*)(st + lane * RS_ROWB + e * 16);
+            wave_lds_sync();
+#pragma unroll
+            for (int e = 0; e < CH / 4; ++e) {
+                if (c0 + 4 * e < KP) {
+                    acc = __builtin_fmaf(qrow[c0 + 4 * e + 0], v[e].x, acc);
+                    acc = __builtin_fmaf(qrow[c0 + 4 * e + 1], v[e].y, acc);
+                    acc = __builtin_fmaf(qrow[c0 + 4 * e + 2], v[e].z, acc);
+                    acc = __builtin_fmaf(qrow[c0 + 4 * e + 3], v[e].w, acc);
+                }
+            }
+        }
+        // Only rows that score above the cut stay (the filter's margin let others through): they move to the front of
+        // their slice, in index order -- every read of this round is done, and a record never moves to the right.
+        const float ipv = acc + 0.0f;
+        const bool pass = valid && !(ipv <= cutq);
+        const u64 bal = __ballot(pass);
+        u64 mine = 0;
+        u32 before = 0;
+#pragma unroll
+        for (int x = 0; x < SG; ++x) {
+            const u64 m = __ballot(valid && k == x);
+            if (k == x) { mine = m; before = kept[x]; }
+            kept[x] += (u32)__popcll(bal & m);
+        }
+        if (pass) rows[(i64)k * cap + before + (u32)__popcll(bal & mine & below)] = ((u64)(~mono_key(ipv)) << 32) | (u64)idx;
+    }
+#pragma unroll
+    for (int x = 0; x < SG; ++x)
+        if (lane == x && s0 + x < g.S) sl_cnt_out[(i64)(s0 + x) * g.Qpad + q] = kept[x];
+}
+
+// Rank + finish in one kernel, one block of 1024 threads per query (replaces 4 x k_radix_pass + k_real_finish when a
+// query's records fit the LDS): everything after the one coalesced copy of the records happens in LDS --
+//   1  slice offsets (scan of the slice counts), records copied in index order: A[0 .. n)
+//   2  radix select (11 + 11 + 10 bits of the key half) of K, the R-th smallest key, and of how many records with
+//      key == K belong to the first R; the query is flagged if that record does not score above thr (see k_real_finish)
+//   3  ordered compaction IN PLACE: the R chosen records, still in index order, A[0 .. R)
+//   4  four stable counting passes over 16-bit positions P[0 .. R) by the bytes of the key (per-wave digit counters,
+//      ballot matching inside a 64-record batch: k_radix_pass's scheme, but LDS to LDS)
+//   5  the ranked list: idx and score of A[P[k]].
+// A query whose records exceed NA sets bit 1 of *err (the host then ranks with the global-memory passes); one whose
+// cut was too high or whose slices overflowed sets bit 0 (a lost bet).
+constexpr int RK_SMAX = 4096;                                // slices per query the offsets array takes
+constexpr int RK_RMAX = 6144;                                // ranked-list length the position arrays take
+template <int NA> constexpr size_t real_rank_lds_bytes() { return (size_t)NA * 8 + (size_t)RK_RMAX * 4 + (RK_SMAX + 1) * 4; }
+
+__device__ __forceinline__ u32 block_excl_scan_1024(const u32 v, u32* s_w, u32& total) {   // 1024 threads; s_w: 16 dwords
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    u32 wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const u32 x = s_w[w]; wbase += w < wave ? x : 0u; tot += x; }
+    __syncthreads();
+    total = tot;
+    return wbase + inc - v;
+}
+
+template <int NA>
+__global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ cand, i64 crow, u32 cap, const u32* __restrict__ sl_cnt,
+                                                        const u32* __restrict__ fail, const float* __restrict__ thr,
+                                                        u32* __restrict__ out_idx, float* __restrict__ scores,
+                                                        int* __restrict__ err, u32* __restrict__ qbad, const Geo g) {
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    u64* A = smem;                                           // [NA] records
+    u16* P0 = (u16*)(A + NA);                                // [RK_RMAX] positions, ping
+    u16* P1 = P0 + RK_RMAX;                                  // [RK_RMAX] pong
+    u32* hw = (u32*)(P1 + RK_RMAX);                          // [16][256] per-wave digit counters / [2048] select histogram ...
+    u32* off = hw;                                           // ... / [S + 1] slice offsets (step 1 only)
+    __shared__ u32 s_w[16];
+    __shared__ u32 s_prefix, s_need;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 R = (u32)g.R;
+
+    // ---- 1: offsets, copy ----
+    u32 n = 0;
+    for (int sb = 0; sb < g.S; sb += 1024) {
+        const int s = sb + tid;
+        const u32 c = s < g.S ? sl_cnt[(i64)s * g.Qpad + q] : 0u;
+        u32 tot;
+        const u32 ex = block_excl_scan_1024(c, s_w, tot);
+        if (s < g.S) off[s] = n + ex;
+        n += tot;
+    }
+    if (tid == 0) off[g.S] = n;
+    __syncthreads();
+    const bool over = n > (u32)NA;
+    bool bad = fail[q] != 0u || over || n < R;
+    if (!bad) {
+        const u64* __restrict__ row = cand + (i64)q * crow;
+        for (int sb = 0; sb < g.S; sb += 64) {
+            const int s = sb + (tid >> 4);
+            if (s < g.S) {
+                const u32 o = off[s], c = off[s + 1] - o;
+                for (u32 i = tid & 15; i < c; i += 16) A[o + i] = row[(i64)s * cap + i];
+            }
+        }
+        __syncthreads();
+        // ---- 2: K = the R-th smallest key ----
+        if (tid == 0) { s_prefix = 0u; s_need = R; }
+        u32 mask = 0;
+        const int shifts[3] = {21, 10, 0};
+        const int widths[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            hw[tid] = 0u; hw[tid + 1024] = 0u;
+            __syncthreads();
+            const u32 prefix = s_prefix, need = s_need, bins = 1u << widths[pass];
+            for (u32 i = tid; i < n; i += 1024) {
+                const u32 k = (u32)(A[i] >> 32);
+                if ((k & mask) == prefix) atomicAdd(&hw[(k >> shifts[pass]) & (bins - 1u)], 1u);
+            }
+            __syncthreads();
+            const u32 c0 = 2u * tid < bins ? hw[2 * tid] : 0u, c1 = 2u * tid + 1u < bins ? hw[2 * tid + 1] : 0u;
+            u32 tot;
+            const u32 ex = block_excl_scan_1024(c0 + c1, s_w, tot);
+            if (ex < need && need <= ex + c0) { s_prefix = prefix | ((2u * tid) << shifts[pass]); s_need = need - ex; }
+            else if (ex + c0 < need && need <= ex + c0 + c1) { s_prefix = prefix | ((2u * tid + 1u) << shifts[pass]); s_need = need - ex - c0; }
+            __syncthreads();
+            mask |= (bins - 1u) << shifts[pass];
+        }
+        const u32 K = s_prefix, need_eq = s_need;
+        bad = !(K < ~mono_key(thr[q]));                      // the R-th record must score above thr
+        if (!bad) {
+            // ---- 3: the chosen R records, in index order, compacted in place (all reads, barrier, all writes) ----
+            constexpr int CH = (NA + 1023) / 1024;
+            const u32 chunk = (n + 1023u) / 1024u;
+            const u32 lo = tid * chunk < n ? tid * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+            u64 mine[CH];
+            u32 lt = 0, eq = 0;
+#pragma unroll
+            for (int x = 0; x < CH; ++x) {
+                mine[x] = lo + x < hi ? A[lo + x] : ~0ull;
+                const u32 k = (u32)(mine[x] >> 32);
+                lt += lo + x < hi && k < K ? 1u : 0u; eq += lo + x < hi && k == K ? 1u : 0u;
+            }
+            u32 t0, t1;
+            const u32 lt_ex = block_excl_scan_1024(lt, s_w, t0);     // (its barriers separate the reads above from the writes below)
+            u32 e = block_excl_scan_1024(eq, s_w, t1);
+            u32 pos = lt_ex + (e < need_eq ? e : need_eq);
+#pragma unroll
+            for (int x = 0; x < CH; ++x) {
+                if (lo + x < hi) {
+                    const u32 k = (u32)(mine[x] >> 32);
+                    if (k < K) A[pos++] = mine[x];
+                    else if (k == K) { if (e < need_eq) A[pos++] = mine[x]; ++e; }
+                }
+            }
+            for (u32 i = tid; i < R; i += 1024) P0[i] = (u16)i;
+            __syncthreads();
+            // ---- 4: stable counting passes by key byte ----
+            u16* Pin = P0;
+            u16* Pout = P1;
+            const u32 wlo = (u32)((u64)R * wave / 16), whi = (u32)((u64)R * (wave + 1) / 16);
+            const u64 below = (1ull << lane) - 1ull;
+            for (int pass = 0; pass < 4; ++pass) {
+                const int sh = 8 * pass;
+                for (int i = tid; i < 16 * 256; i += 1024) hw[i] = 0u;
+                __syncthreads();
+                u32* myh = hw + wave * 256;
+                for (u32 i = wlo + lane; i < whi; i += 64) atomicAdd(&myh[((u32)(A[Pin[i]] >> 32) >> sh) & 0xFFu], 1u);
+                __syncthreads();
+                u32 dsum = 0;
+                if (tid < 256) for (int w = 0; w < 16; ++w) dsum += hw[w * 256 + tid];
+                u32 tot;
+                u32 run = block_excl_scan_1024(tid < 256 ? dsum : 0u, s_w, tot);
+                if (tid < 256) for (int w = 0; w < 16; ++w) { const u32 x = hw[w * 256 + tid]; hw[w * 256 + tid] = run; run += x; }
+                __syncthreads();
+                for (u32 base = wlo; base < whi; base += 64) {
+                    const u32 i = base + lane;
+                    const bool valid = i < whi;
+                    const u32 p = valid ? Pin[i] : 0u;
+                    const u32 d = ((u32)(A[p] >> 32) >> sh) & 0xFFu;
+                    u64 peers = __ballot(valid);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool bit = (d >> k) & 1u;
+                        const u64 m = __ballot(valid && bit);
+                        peers &= bit ? m : ~m;
+                    }
+                    if (valid) {
+                        const u32 rank = (u32)__popcll(peers & below), npeer = (u32)__popcll(peers);
+                        const u32 start = myh[d];
+                        Pout[start + rank] = (u16)p;
+                        if (rank == npeer - 1) myh[d] = start + npeer;
+                    }
+                    wave_lds_sync();
+                }
+                __syncthreads();
+                u16* t = Pin; Pin = Pout; Pout = t;
+            }
+            // ---- 5: the ranked list ----
+            for (u32 k = tid; k < R; k += 1024) {
+                const u64 rec = A[Pin[k]];
+                out_idx[(i64)q * g.R + k] = (u32)rec;
+                if (scores) scores[(i64)q * g.R + k] = mono_inv(~(u32)(rec >> 32));
+            }
+        }
+    }
+    if (tid == 0) { qbad[q] = bad ? 1u : 0u; if (bad) atomicOr(err, over ? 2 : 1); }
+}
+
+}  // namespace hg

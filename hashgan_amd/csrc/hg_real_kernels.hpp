@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_real_sample(const float* __restrict__ q
 __global__ __launch_bounds__(256) void k_real_guess(const float* __restrict__ samp, i64 M, u32 rank_s,
                                                     float* __restrict__ thr) {
     __shared__ u32 hist[2048];
-    __shared__ u32 s_prefix, s_rank;
+    __shared__ u32 s_prefix, s_rank, s_wsum[4];
     const int q = blockIdx.x, tid = threadIdx.x;
     const float* __restrict__ col = samp + (i64)q * M;
     if (rank_s > (u32)M) {
@@ -100,16 +100,26 @@ __global__ __launch_bounds__(256) void k_real_guess(const float* __restrict__ sa
             if ((k & mask) == prefix) atomicAdd(&hist[(k >> shifts[pass]) & (bins - 1)], 1u);
         }
         __syncthreads();
-        if (tid == 0) {                                       // walk the digits from the largest down
-            u32 need = s_rank, dgt = bins - 1;
-            for (;; --dgt) {
-                const u32 c = hist[dgt];
-                if (c >= need) break;
-                need -= c;
-                if (dgt == 0) break;
+        {   // the digit that holds the rank, counted from the largest digit down: 8 bins per thread, block scan of the sums
+            const u32 need = s_rank;
+            u32 c[8], sum = 0;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) { const u32 d = bins - 1u - (8u * tid + x); c[x] = 8u * tid + x < bins ? hist[d] : 0u; sum += c[x]; }
+            u32 inc = sum;
+            const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
+            if (lane == 63) s_wsum[wave] = inc;
+            __syncthreads();
+            u32 ex = inc - sum;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) ex += w < wave ? s_wsum[w] : 0u;
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                if (ex < need && need <= ex + c[x]) { s_rank = need - ex; s_prefix = prefix | ((bins - 1u - (8u * tid + x)) << shifts[pass]); }
+                ex += c[x];
             }
-            s_rank = need;
-            s_prefix = prefix | (dgt << shifts[pass]);
         }
         __syncthreads();
         mask |= ((1u << widths[pass]) - 1u) << shifts[pass];
@@ -305,14 +315,18 @@ __global__ __launch_bounds__(NWAV * 64) void k_radix_pass(const u64* __restrict_
 }
 
 // R5  finish: the first R sorted records of every query -> ranked idx list and scores; a query with
-// fewer than R records (guess too high) or an overflowed slice is flagged for the host.
+// fewer than R records (guess too high) or an overflowed slice is flagged for the host.  thr (filter + rescore path,
+// hg_real_bf.hpp): the records are a superset of the rows scoring above thr[q], so the first R are the top R of all rows
+// only if the R-th still scores above it.
 __global__ __launch_bounds__(256) void k_real_finish(const u64* __restrict__ sorted, i64 crow, const u32* __restrict__ tot,
                                                      u32* __restrict__ out_idx, float* __restrict__ scores,
-                                                     int* __restrict__ err, u32* __restrict__ qbad, int nKB, const Geo g) {
+                                                     int* __restrict__ err, u32* __restrict__ qbad, int nKB, const float* __restrict__ thr,
+                                                     const Geo g) {
     const int q = (int)(blockIdx.x / (u32)nKB);                  // nKB = ceil(R / 256) blocks per query
     const i64 k = (i64)(blockIdx.x - (u32)q * (u32)nKB) * 256 + threadIdx.x;
     const u32 n = tot[q];
-    const bool bad = n == 0xFFFFFFFFu || (i64)n < g.R;
+    bool bad = n == 0xFFFFFFFFu || (i64)n < g.R;
+    if (!bad && thr) bad = !(mono_inv(~(u32)(sorted[(i64)q * crow + g.R - 1] >> 32)) > thr[q]);
     if (k == 0) { qbad[q] = bad ? 1u : 0u; if (bad) atomicExch(err, 1); }
     if (bad || k >= g.R) return;
     const u64 rec = sorted[(i64)q * crow + k];
