@@ -272,6 +272,8 @@ struct hg_ctx {
     bool dbfb_valid = false;
     i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit
     bool real_filtered = false;   // the last real_select left unscored candidates that k_real_rescore completed
+    i64 real_attempts = 0;        // statistics of the last real-valued ranking: attempts made (1 = the first bet held) ...
+    i64 real_lds_ranked = 0;      // ... and whether the LDS-resident rank kernel produced its lists
     i64 opt_real_mfma = 2;     // "real_mfma": 2 = bf16 filter on the matrix cores + exact rescoring of the survivors, 1 = exact float32 MFMA pass, 0 = vector ALU
     int bpad = 0;              // feature count padded to a multiple of 16 (0: no float tables loaded)
     i64 census_db[3] = {0, 0, 0}, census_q[3] = {0, 0, 0};
@@ -838,16 +840,25 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     gs.nBlk = (int)gs.nUnits;
     RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
     c->t_begin(KI_REAL_SELECT);
-    hipLaunchKernelGGL((k_real_select_bf<KP>), dim3(padded_grid(gs.nBlk)), dim3(256), 0, c->stream,
+    if (real_bf_lds_bytes(KP) > 64 * 1024)
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_select_bf<KP>), hipFuncAttributeMaxDynamicSharedMemorySize, real_bf_lds_bytes(KP)));
+    hipLaunchKernelGGL((k_real_select_bf<KP>), dim3(padded_grid(gs.nBlk)), dim3(256), real_bf_lds_bytes(KP), c->stream,
                        c->qf.as<float>(), c->dbfb.as<u8>(), c->thr2.as<float>(), a, c->cand.as<u64>(), gs);
     c->t_end();
     HG_TRY(c->check_launch("k_real_select_bf"));
-    constexpr int SG = 4;
+    // slices per wavefront of the rescoring pass: about one round of 64 kept rows (the filter keeps ~2 R per query)
+    const double per_slice = 2.0 * (double)c->R / (double)g.S;
+    const int SG = per_slice * 8 <= 60 ? 8 : per_slice * 4 <= 60 ? 4 : per_slice * 3 <= 60 ? 3 : per_slice * 2 <= 60 ? 2 : 1;
     const i64 waves = (i64)((g.S + SG - 1) / SG) * g.Q;
     c->t_begin(KI_REAL_RESCORE);
-    HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_rescore<KP, SG>), hipFuncAttributeMaxDynamicSharedMemorySize, rescore_lds_bytes()));
-    hipLaunchKernelGGL((k_real_rescore<KP, SG>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(),
-                       c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(), c->sl_cnt.as<u32>(), g);
+#define HG_RESCORE(sg)                                                                                                                   \
+    case sg:                                                                                                                             \
+        hipLaunchKernelGGL((k_real_rescore<KP, sg>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(), \
+                           c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(),               \
+                           c->sl_cnt.as<u32>(), g);                                                                                      \
+        break;
+    switch (SG) { HG_RESCORE(8) HG_RESCORE(4) HG_RESCORE(3) HG_RESCORE(2) HG_RESCORE(1) }
+#undef HG_RESCORE
     c->t_end();
     c->real_filtered = true;
     return c->check_launch("k_real_rescore");
@@ -2112,6 +2123,8 @@ int hg_map(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
 // ---- real-valued ranking: sample -> guess -> select -> 4-pass radix sort -> finish ----
 // one attempt; *lost = some query came up short of R records or overflowed a slice (bet mode only)
 static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double budget, bool with_ap, int* lost) {
+    ++c->real_attempts;
+    c->real_lds_ranked = 0;
     make_geometry(c);
     {   // Float rows are 4*bpad bytes (32x a 64-bit code): keep a segment's rows within ~512 KB so the few
         // segments an XCD works on at a time stay in its 4 MiB L2 while all query tiles pass over them.
@@ -2180,6 +2193,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         int flag = 0;
         HG_TRY(read_plan_flag(c, &flag));
         if (!(flag & 2)) {
+            c->real_lds_ranked = 1;
             *lost = flag & 1;
             c->stage = ST_DB | ST_Q | ST_SELECT;
             if (*lost) return HG_OK;
@@ -2225,6 +2239,7 @@ static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
     if (c->n_total != c->N) return fail(HG_ERR_STATE, "real-valued ranking is single-shard");
     if (R < 1 || R > c->N) return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->N);
     int lost = 0;
+    c->real_attempts = 0;
     if (R * 8 <= c->N && c->N >= 65536) {              // bet on a sampled cut; retry once deeper, then give up betting
         HG_TRY(real_attempt(c, R, true, 6.0, 3.0, with_ap, &lost));
         if (!lost) { c->real_lists = true; return HG_OK; }
@@ -2597,6 +2612,9 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "optimistic_requeried")) *value = c->opt_requeried;
     else if (!strcmp(key, "optimistic_rebets")) *value = c->opt_rebets;
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
+    else if (!strcmp(key, "real_attempts")) *value = c->real_attempts;
+    else if (!strcmp(key, "real_filtered")) *value = c->real_filtered ? 1 : 0;
+    else if (!strcmp(key, "real_lds_ranked")) *value = c->real_lds_ranked;
     else if (!strcmp(key, "device_bytes")) {
         DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
                          &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err,

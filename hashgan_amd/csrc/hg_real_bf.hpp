@@ -89,10 +89,14 @@ __global__ __launch_bounds__(256) void k_real_thr2(const float* __restrict__ qf,
     thr2[q] = r;
 }
 
+constexpr int RB_WT = 4;                                     // row tiles per staged window
+constexpr int real_bf_lds_bytes(int KP) { return 2 * RB_WT * (KP / 16) * 1024; }
+
 template <int KP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, KP <= 64 ? 4 : 2)))
 void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, const float* __restrict__ thr2, const RealSelArgs a,
                       u64* __restrict__ cand, const Geo g) {
+    extern __shared__ __attribute__((aligned(16))) u8 blds[];
     constexpr int QT = 2, WQ = 32 * QT;
     constexpr int NM = KP / 16;                              // MFMAs (and 16-byte A chunks per lane) per tile
 
@@ -138,51 +142,78 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
         wp[t] = cand + (i64)(q < g.Q ? q : 0) * a.crow + (i64)(seg_ok ? s : 0) * a.cap;
     }
 
-    // ---- A fragments straight from the image into registers, one tile ahead (k_real_select_mx's scheme) ----
+    // ---- A fragments: windows of RB_WT tiles staged global -> LDS (k_select_mx's scheme), shared by the four
+    // wavefronts of the block -- every wavefront copies a quarter of a window and reads all of it, lane-linear, so a
+    // lane gets back exactly the 16-byte chunks the MFMA wants from it.  Double-buffered: one barrier per window.
     const int ah = (j >> 2) & 1;                             // lane-half (segment) that A row j feeds
     const int ar = (j & 3) + 4 * (j >> 3);                   // its row inside that half's 16
     const i64 ag0 = (ah ? lo1 : lo0) >> 4;
-    auto chunk = [&](const i64 T, const int m) -> bf16x8 {
-        i64 G = ag0 + T;
-        G = G < NG ? G : NG - 1;                             // past the end: any valid group (masked later)
-        return *(const bf16x8*)(img + ((((G * NM + m) * 2 + h) * 16 + ar) * 16));
+    const i64 nwin = (ntile + RB_WT - 1) / RB_WT;
+    constexpr int STAGE = RB_WT * NM * 1024;
+    auto stage_window = [&](const i64 win, const int buf) {
+        for (int c = wave; c < RB_WT * NM; c += WPB) {
+            const int T = c / NM, m = c - T * NM;
+            i64 G = ag0 + win * RB_WT + T;
+            G = G < NG ? G : NG - 1;                         // past the end: any valid group (masked later)
+            HG_GLDS16(img + ((((G * NM + m) * 2 + h) * 16 + ar) * 16), blds + buf * STAGE + c * 1024);
+        }
     };
-    bf16x8 av[NM];
-    if (ntile > 0) {
+    if (nwin > 0) stage_window(0, 0);
+    for (i64 win = 0; win < nwin; ++win) {
+        const int buf = (int)(win & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my copies have landed; after the barrier everybody's have
+        __syncthreads();                                     // ... and nobody still reads the other buffer
+        if (win + 1 < nwin) stage_window(win + 1, buf ^ 1);
+        const u8* st = blds + buf * STAGE;
+#pragma unroll 1
+        for (int Tw = 0; Tw < RB_WT; ++Tw) {
+            const i64 T = win * RB_WT + Tw;
+            if (T >= ntile) break;
+            const i64 left = mylen - T * 16;                 // valid rows of this lane in the tile
+            const u32 keep = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : (1u << (int)left) - 1u);
+            bf16x8 av[NM];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) av[m] = chunk(0, m);
-    }
-    for (i64 T = 0; T < ntile; ++T) {
-        const i64 left = mylen - T * 16;                     // valid rows of this lane in the tile
-        const u32 keep = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : (1u << (int)left) - 1u);
-        const i64 Tn = T + 1 < ntile ? T + 1 : T;
+            for (int m = 0; m < NM; ++m) av[m] = *(const bf16x8*)(st + ((Tw * NM + m) * 64 + lane) * 16);
+            // both query tiles' MFMA chains first (independent: the second hides the first's latency), then the harvests
+            f32x16 acc[QT];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            f32x16 acc;
+            for (int t = 0; t < QT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = cut[t];
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bq[t][m], acc, 0, 0, 0);
-                if (t == QT - 1) av[m] = chunk(Tn, m);
+                for (int r = 0; r < 16; ++r) acc[t][r] = cut[t];
             }
-            // harvest: bit r <-> row 16 T + r of the lane's segment may qualify (thr2 - approx < 0)
-            u32 mask = 0;
 #pragma unroll
-            for (int r = 15; r >= 0; --r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(acc[r]), 31);
-            mask &= keep;
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bq[t][m], acc[t], 0, 0, 0);
+            // harvest: bit r <-> row 16 T + r of the lane's segment may qualify (thr2 - approx < 0)
+            u32 mask[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                u32 mm = 0;
+#pragma unroll
+                for (int r = 15; r >= 0; --r) mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(acc[t][r]), 31);
+                mask[t] = mm & keep;
+            }
             // drain: the owning lane writes the row numbers of its hits, lowest row first; the score comes later
-            while (__any(mask != 0u)) {
-                if (mask != 0u) {
-                    const int r = __builtin_ctz(mask);
-                    mask &= mask - 1u;
-                    if (room[t]) {
-                        wp[t][cnt[t]] = (u64)(g.idx_base + (u32)((i64)s * g.L + T * 16 + r));
-                        ++cnt[t];
-                        --room[t];
-                    } else {
-                        ++dropped[t];
+            u32 any_mask = 0;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) any_mask |= mask[t];
+            while (__any(any_mask != 0u)) {
+                any_mask = 0;
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    if (mask[t] != 0u) {
+                        const int r = __builtin_ctz(mask[t]);
+                        mask[t] &= mask[t] - 1u;
+                        if (room[t]) {
+                            wp[t][cnt[t]] = (u64)(g.idx_base + (u32)((i64)s * g.L + T * 16 + r));
+                            ++cnt[t];
+                            --room[t];
+                        } else {
+                            ++dropped[t];
+                        }
                     }
+                    any_mask |= mask[t];
                 }
             }
         }
@@ -200,10 +231,10 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
 
 // Rescore: wavefront = (group of SG consecutive slices, query); lane = one kept row.  The query's features are
 // wave-uniform (scalar loads); consecutive wavefronts take consecutive queries of the SAME segment group, whose rows
-// (SG x real_segment_bytes) stay in the L2 while all queries pass.  The 64 rows of a round are fetched COALESCED --
-// 16 lanes per row, 4 rows per load instruction, whole cache lines -- and turned through LDS (rows padded to 272 bytes)
-// so that every lane then walks its own row in feature order: one float32 fma chain, k ascending.
-constexpr int RS_ROWB = 272;                                 // bytes per staged row: 64 floats + 16 (bank spread)
+// (SG x real_segment_bytes) stay in the L2 while all queries pass.  The 64 rows of a round are fetched COALESCED, 32
+// features at a time -- 8 lanes per row, 8 rows per load instruction, whole cache lines -- and turned through LDS (rows
+// padded to 144 bytes) so that every lane then walks its own row in feature order: one float32 fma chain, k ascending.
+constexpr int RS_ROWB = 144;                                 // bytes per staged row: 32 floats + 16 (bank spread)
 constexpr int rescore_lds_bytes() { return WPB * 64 * RS_ROWB; }
 
 template <int KP, int SG>
@@ -232,7 +263,7 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
 #pragma unroll
     for (int x = 0; x < SG; ++x) kept[x] = 0;
     const u64 below = (1ull << lane) - 1ull;
-    const int pr = lane >> 4, pp = lane & 15;                // staging role: row 4 e + pr of the round, piece pp
+    const int pr = lane >> 3, pp = lane & 7;                 // staging role: row 8 e + pr of the round, 16-byte piece pp
     for (u32 base = 0; base < total; base += 64) {
         const u32 i = base + lane;
         const bool valid = i < total;
@@ -242,26 +273,25 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
         u32 off = i;
 #pragma unroll
         for (int x = 1; x < SG; ++x) off = k == x ? i - pre[x] : off;
-        u64* p = rows + (i64)k * cap + off;
-        const u32 idx = valid ? (u32)*p : g.idx_base;        // idle lanes: any valid row
+        const u32 idx = valid ? (u32)rows[(i64)k * cap + off] : g.idx_base;     // idle lanes: any valid row
         const u32 local = idx - g.idx_base;
+        u32 ridx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ridx[e] = (u32)__shfl((int)local, 8 * e + pr);
         float acc = 0.0f;
 #pragma unroll 1
-        for (int c0 = 0; c0 < KP; c0 += 64) {                // 64 features at a time
-            constexpr int CH = KP < 64 ? KP : 64;            // (KP > 64: the last chunk may be shorter, guarded below)
+        for (int c0 = 0; c0 < KP; c0 += 32) {                // 32 features at a time (KP is a multiple of 16)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const u32 ridx = (u32)__shfl((int)local, 4 * e + pr);
+            for (int e = 0; e < 8; ++e)
                 if (c0 + 4 * pp < KP)
-                    *(float4*)(st + (4 * e + pr) * RS_ROWB + pp * 16) = *(const float4*)(dbf + (i64)ridx * KP + c0 + 4 * pp);
-            }
+                    *(float4*)(st + (8 * e + pr) * RS_ROWB + pp * 16) = *(const float4*)(dbf + (i64)ridx[e] * KP + c0 + 4 * pp);
             wave_lds_sync();
-            float4 v[CH / 4];
+            float4 v[8];
 #pragma unroll
-            for (int e = 0; e < CH / 4; ++e) v[e] = *(const float4*)(st + lane * RS_ROWB + e * 16);
+            for (int e = 0; e < 8; ++e) v[e] = *(const float4*)(st + lane * RS_ROWB + e * 16);
             wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < CH / 4; ++e) {
+            for (int e = 0; e < 8; ++e) {
                 if (c0 + 4 * e < KP) {
                     acc = __builtin_fmaf(qrow[c0 + 4 * e + 0], v[e].x, acc);
                     acc = __builtin_fmaf(qrow[c0 + 4 * e + 1], v[e].y, acc);

@@ -235,7 +235,10 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * "host_pack", "keep_floats", "pack_threads" (hg_set_*_f32, see there), "second_bet" (1, default: a one-shot bet that too many queries lost is retried once with twice the margin and record
  * budget before the exact two-pass sequence runs), "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
  * {match, dist} through per-slice LDS rings instead of 8-byte {idx, dist, match} records),
- * "real_mfma" (1, default: the real-valued select pass on the float32 matrix-core instruction; 0: vector ALU),
+ * "real_mfma" (real-valued select pass -- 2, default: bfloat16 matrix-core filter with a rigorous margin, then the exact
+ * float32 chain for the rows it keeps; 1: every pair exactly on the float32 matrix-core instruction; 0: vector ALU; same
+ * lists either way), "real_sort_lds" (1, default: after the filter a query's records are ranked by one LDS-resident
+ * kernel when they fit; 0: always the global-memory radix passes),
  * "real_queries_per_lane", "real_segment_bytes" (real-valued path), "step_graph" (1, default: hg_map captures its
  * one-shot sequence into a hipGraph the second time it sees the same problem and replays it afterwards; 0: always
  * enqueue kernel by kernel). */
@@ -245,7 +248,9 @@ int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
  * "segment_rows", "slice_capacity", "record_row"; census of the float tables loaded by hg_set_*_f32 --
  * "db_nonbinary" / "q_nonbinary" (entries outside {-1,0,+1}), "db_zeros" / "q_zeros", "db_minus_ones" /
  * "q_minus_ones" -- from which the caller tells +-1 codes, {0,1} bits and real-valued features apart;
- * "db_floats" / "q_floats" (the float tables are on the GPU), "probe_build", "graph_captures", "graph_replays". */
+ * "db_floats" / "q_floats" (the float tables are on the GPU), "probe_build", "graph_captures", "graph_replays";
+ * of the last real-valued ranking: "real_attempts" (1 = the first sampled cut held), "real_filtered" (filter + rescore
+ * ran), "real_lds_ranked" (the LDS-resident rank kernel produced the lists). */
 int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
 /* Work buffers only grow; hg_trim frees everything except the resident code/label/feature tables
  * (stat "device_bytes" reports what the context holds). */

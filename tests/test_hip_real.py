@@ -97,3 +97,57 @@ def test_maps_ranks_non_pm1_codes_like_np_dot(name):
             MAP(c["qf"], c["dbf"], c["qlab"], c["dblab"], c["R"])
         with pytest.raises(ValueError):   # spellings must agree between queries and database
             MAP((c["qf"] > 0).astype(np.float32), np.where(c["dbf"] > 0, 1.0, -1.0).astype(np.float32), c["qlab"], c["dblab"], c["R"])
+
+
+def _adversarial(kind, rng, Q, N, b):
+    if kind == "tanh":
+        return np.tanh(rng.standard_normal((N, b))), np.tanh(rng.standard_normal((Q, b)))
+    if kind == "wide":          # magnitudes over six decades, one dominant direction: many scores crowd the cut
+        d = rng.standard_normal((N, b)) * 10.0 ** rng.integers(-3, 4, (N, 1))
+        d[:, 0] += 50.0
+        q = rng.standard_normal((Q, b)) * 10.0 ** rng.integers(-3, 4, (Q, 1))
+        q[:, 0] += 50.0
+        return d, q
+    if kind == "bits":          # {0,1} features: integer scores, ties by the thousand, the cut falls inside a tie group
+        return (rng.random((N, b)) < 0.5).astype(np.float64), (rng.random((Q, b)) < 0.5).astype(np.float64)
+    if kind == "dups":          # a few distinct rows repeated all over the database
+        base = np.tanh(rng.standard_normal((37, b)))
+        return base[rng.integers(0, 37, N)], np.tanh(rng.standard_normal((Q, b)))
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,Q,N,b,R", [("tanh", 70, 80000, 64, 3000), ("wide", 40, 70000, 48, 2000), ("bits", 33, 90000, 32, 5000),
+                                          ("dups", 20, 66000, 16, 1500), ("tanh", 12, 131072, 128, 6000)])
+def test_filter_and_rescore_equals_the_exact_passes(kind, Q, N, b, R, ctx):
+    """The sampled bet at sizes where it applies (N >= 65536, R <= N / 8): the bfloat16 filter + exact rescoring
+    (hg_real_bf.hpp, real_mfma = 2), the float32 matrix-core pass (1) and the vector-ALU pass (0) must all deliver
+    the oracle's ranked lists, scores and AP bit for bit -- whatever the features look like; so must the
+    global-memory ranking passes (real_sort_lds = 0) that take over when a query's records exceed the LDS."""
+    rng = np.random.default_rng(len(kind) * 1000 + b)
+    d, q = _adversarial(kind, rng, Q, N, b)
+    dbf, qf = d.astype(np.float32), q.astype(np.float32)
+    C = 9
+    dl = (rng.random((N, C)) < 0.2).astype(np.int8)
+    ql = (rng.random((Q, C)) < 0.2).astype(np.int8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, ap_ref, idx_ref, score_ref = RM.map_from_features(qf, dbf, ql, dl, R)
+    ctx.set_database_f32(dbf, dl.astype(np.int64))
+    ctx.set_queries_f32(qf, ql.astype(np.int64))
+    try:
+        for mode, lds in ((2, 1), (2, 0), (1, 1), (0, 1)):
+            ctx.set_option("real_mfma", mode)
+            ctx.set_option("real_sort_lds", lds)
+            idx, score = ctx.topr_real(R)
+            assert np.array_equal(score.view(np.uint32), score_ref.view(np.uint32)), (kind, mode, lds)
+            assert np.array_equal(idx, idx_ref), (kind, mode, lds)
+            if kind != "bits":          # (a cut inside a tie group of thousands overflows the slices: deeper attempts, same lists)
+                assert ctx.get_stat("real_attempts") == 1, (kind, mode, lds)
+            assert ctx.get_stat("real_filtered") == (1 if mode == 2 else 0)
+            if ctx.get_stat("real_attempts") == 1 and kind != "bits":   # (tie groups can exceed the LDS: the global passes take over)
+                assert ctx.get_stat("real_lds_ranked") == (1 if mode == 2 and lds and R <= 6144 else 0)
+            ap, rel = ctx.map_real(R)
+            assert np.array_equal(ap, ap_ref, equal_nan=True), (kind, mode, lds)
+    finally:
+        ctx.set_option("real_mfma", 2)
+        ctx.set_option("real_sort_lds", 1)
