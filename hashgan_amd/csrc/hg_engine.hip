@@ -811,6 +811,7 @@ template <int KP> int real_launch_select_mx(hg_ctx* c) {
 }
 // filter + rescore (hg_real_bf.hpp): bf16 pair pass with a rigorous margin, then the exact chain for the survivors
 template <int KP> int real_launch_select_bf(hg_ctx* c) {
+    constexpr int QT = KP <= 128 ? 2 : 1;
     if (!c->dbfb_valid) {
         const i64 n16 = (c->N + 15) / 16 * 16;
         HG_TRY(c->dbfb.reserve((size_t)n16 * KP * 2));
@@ -832,7 +833,7 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     c->t_end();
     HG_TRY(c->check_launch("k_real_thr2"));
     const int nSP = (g.S + 1) / 2;
-    const int nQB = (g.Q + WPB * 64 - 1) / (WPB * 64);
+    const int nQB = (g.Q + WPB * 32 * QT - 1) / (WPB * 32 * QT);
     Geo gs = g;
     gs.nQT = nQB;
     gs.nUnits = (i64)nSP * nQB;
@@ -841,8 +842,8 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
     c->t_begin(KI_REAL_SELECT);
     if (real_bf_lds_bytes(KP) > 64 * 1024)
-        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_select_bf<KP>), hipFuncAttributeMaxDynamicSharedMemorySize, real_bf_lds_bytes(KP)));
-    hipLaunchKernelGGL((k_real_select_bf<KP>), dim3(padded_grid(gs.nBlk)), dim3(256), real_bf_lds_bytes(KP), c->stream,
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_select_bf<KP, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, real_bf_lds_bytes(KP)));
+    hipLaunchKernelGGL((k_real_select_bf<KP, QT>), dim3(padded_grid(gs.nBlk)), dim3(256), real_bf_lds_bytes(KP), c->stream,
                        c->qf.as<float>(), c->dbfb.as<u8>(), c->thr2.as<float>(), a, c->cand.as<u64>(), gs);
     c->t_end();
     HG_TRY(c->check_launch("k_real_select_bf"));
@@ -853,9 +854,9 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     c->t_begin(KI_REAL_RESCORE);
 #define HG_RESCORE(sg)                                                                                                                   \
     case sg:                                                                                                                             \
-        hipLaunchKernelGGL((k_real_rescore<KP, sg>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(), \
+        hipLaunchKernelGGL((k_real_rescore<sg>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(),  \
                            c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(),               \
-                           c->sl_cnt.as<u32>(), g);                                                                                      \
+                           c->sl_cnt.as<u32>(), KP, g);                                                                                  \
         break;
     switch (SG) { HG_RESCORE(8) HG_RESCORE(4) HG_RESCORE(3) HG_RESCORE(2) HG_RESCORE(1) }
 #undef HG_RESCORE
@@ -873,7 +874,15 @@ int real_select_bf(hg_ctx* c) {
         case 96: return real_launch_select_bf<96>(c);
         case 112: return real_launch_select_bf<112>(c);
         case 128: return real_launch_select_bf<128>(c);
-        default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 128 features (have %d)", c->b);
+        case 144: return real_launch_select_bf<144>(c);
+        case 160: return real_launch_select_bf<160>(c);
+        case 176: return real_launch_select_bf<176>(c);
+        case 192: return real_launch_select_bf<192>(c);
+        case 208: return real_launch_select_bf<208>(c);
+        case 224: return real_launch_select_bf<224>(c);
+        case 240: return real_launch_select_bf<240>(c);
+        case 256: return real_launch_select_bf<256>(c);
+        default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 256 features (have %d)", c->b);
     }
 }
 int real_select_mx(hg_ctx* c) {
@@ -902,10 +911,23 @@ int real_select_mx(hg_ctx* c) {
         case 64: return fn<64>(c, ##__VA_ARGS__);                   \
         default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 128 features (have %d)", (c)->b); \
     }
-int real_sample(hg_ctx* c, i64 M, i64 stride) { HG_DISPATCH_BP(real_launch_sample, c, M, stride) }
+int real_sample(hg_ctx* c, i64 M, i64 stride) {
+    if (c->bpad > 128) {                                 // k_real_sample keeps the query in registers: the staged form beyond
+        const Geo& g = c->geo;
+        const i64 units = (M + 63) / 64 * g.nQT;
+        const size_t lds = (size_t)WPB * (64 * 65 * 4 + 16 * 128);
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_sample_any), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->t_begin(KI_REAL_SAMPLE);
+        hipLaunchKernelGGL(k_real_sample_any, dim3(grid_for(units, WPB)), dim3(256), lds, c->stream, c->qf.as<float>(), c->dbf.as<float>(),
+                           c->samp.as<float>(), M, stride, c->bpad, g);
+        c->t_end();
+        return c->check_launch("k_real_sample_any");
+    }
+    HG_DISPATCH_BP(real_launch_sample, c, M, stride)
+}
 int real_select(hg_ctx* c) {
     c->real_filtered = false;
-    if (c->opt_real_mfma == 2 && c->geo.L % 16 == 0) return real_select_bf(c);
+    if ((c->opt_real_mfma == 2 || c->bpad > 128) && c->geo.L % 16 == 0) return real_select_bf(c);   // (the only pass for > 128 features)
     if (c->opt_real_mfma && c->geo.L % 16 == 0) return real_select_mx(c);
     HG_DISPATCH_BP(real_launch_select, c)
 }

@@ -92,12 +92,12 @@ __global__ __launch_bounds__(256) void k_real_thr2(const float* __restrict__ qf,
 constexpr int RB_WT = 4;                                     // row tiles per staged window
 constexpr int real_bf_lds_bytes(int KP) { return 2 * RB_WT * (KP / 16) * 1024; }
 
-template <int KP>
+template <int KP, int QT>          // QT query tiles (of 32) per wavefront: 2 up to 128 features, 1 beyond (B fragments live in registers)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, KP <= 64 ? 4 : 2)))
 void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, const float* __restrict__ thr2, const RealSelArgs a,
                       u64* __restrict__ cand, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 blds[];
-    constexpr int QT = 2, WQ = 32 * QT;
+    constexpr int WQ = 32 * QT;
     constexpr int NM = KP / 16;                              // MFMAs (and 16-byte A chunks per lane) per tile
 
     const int lb = logical_block(g.nBlk);
@@ -237,10 +237,10 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
 constexpr int RS_ROWB = 144;                                 // bytes per staged row: 32 floats + 16 (bank spread)
 constexpr int rescore_lds_bytes() { return WPB * 64 * RS_ROWB; }
 
-template <int KP, int SG>
+template <int SG>
 __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ qf, const float* __restrict__ dbf, const u32* sl_cnt,
                                                       u64* __restrict__ cand, u32 cap, i64 crow, const float* __restrict__ thr,
-                                                      u32* sl_cnt_out, const Geo g) {      // (sl_cnt_out may be sl_cnt)
+                                                      u32* sl_cnt_out, const int KP, const Geo g) {      // (sl_cnt_out may be sl_cnt)
     extern __shared__ __attribute__((aligned(16))) u8 rlds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -318,6 +318,68 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
 #pragma unroll
     for (int x = 0; x < SG; ++x)
         if (lane == x && s0 + x < g.S) sl_cnt_out[(i64)(s0 + x) * g.Qpad + q] = kept[x];
+}
+
+// Sample pass for any feature count (k_real_sample keeps a query's features in registers: up to 128): wavefront =
+// (64 sampled rows, 64 queries), lane = query.  16 rows at a time, 32 features at a time: the rows' pieces are staged
+// coalesced in LDS and read back as broadcasts, the lane's query piece sits in registers; each of the 16 accumulators
+// runs the float32 fma chain over k ascending, across the pieces.
+__global__ __launch_bounds__(256) void k_real_sample_any(const float* __restrict__ qf, const float* __restrict__ dbf, float* __restrict__ samp,
+                                                         i64 M, i64 stride, const int KP, const Geo g) {
+    extern __shared__ __attribute__((aligned(16))) u8 slds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const i64 unit = (i64)blockIdx.x * WPB + wave;
+    const i64 nTiles = (M + 63) / 64;
+    if (unit >= nTiles * g.nQT) return;
+    const i64 tile = unit / g.nQT;
+    const int qt = (int)(unit - tile * g.nQT);
+    const int q = qt * 64 + lane;
+    const i64 j0 = tile * 64;
+    const int nj = (int)(M - j0 < 64 ? M - j0 : 64);
+    float* tl = (float*)(slds + wave * (64 * 65 * 4 + 16 * 128));       // [64][65] score tile, then [16][32] row pieces
+    float* rowp = tl + 64 * 65;
+    const float* __restrict__ qrow = qf + (i64)(q < g.Q ? q : 0) * KP;
+    const int pr = lane >> 3, pp = lane & 7;                 // staging role: row 8 e + pr of the group, 16-byte piece pp
+    for (int rg = 0; rg < 64; rg += 16) {
+        float acc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int c0 = 0; c0 < KP; c0 += 32) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int jr = rg + 8 * e + pr;
+                float4 v = {0.f, 0.f, 0.f, 0.f};
+                if (jr < nj && c0 + 4 * pp < KP) v = *(const float4*)(dbf + (j0 + jr) * stride * KP + c0 + 4 * pp);
+                *(float4*)(rowp + (8 * e + pr) * 32 + 4 * pp) = v;
+            }
+            float4 qv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[e] = c0 + 4 * e < KP ? *(const float4*)(qrow + c0 + 4 * e) : float4{0.f, 0.f, 0.f, 0.f};
+            wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (c0 + 4 * e < KP) {
+                        const float4 x = *(const float4*)(rowp + r * 32 + 4 * e);   // same address in every lane: a broadcast
+                        acc[r] = __builtin_fmaf(qv[e].x, x.x, acc[r]);
+                        acc[r] = __builtin_fmaf(qv[e].y, x.y, acc[r]);
+                        acc[r] = __builtin_fmaf(qv[e].z, x.z, acc[r]);
+                        acc[r] = __builtin_fmaf(qv[e].w, x.w, acc[r]);
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tl[(rg + r) * 65 + lane] = acc[r] + 0.0f;
+    }
+    wave_lds_sync();
+    for (int qq = 0; qq < 64; ++qq) {                         // transposed write: lane <-> sample
+        const int qo = qt * 64 + qq;
+        if (qo < g.Q && lane < nj) samp[(i64)qo * M + j0 + lane] = tl[lane * 65 + qq];
+    }
 }
 
 // Rank + finish in one kernel, one block of 1024 threads per query (replaces 4 x k_radix_pass + k_real_finish when a

@@ -200,8 +200,8 @@ def _rank(eng, q_codes, q_labels, R, mode):
         raise ValueError("codes must be binary -- all {0,1} or all {-1,+1}, the same spelling for queries and "
                          "database (found %s queries, %s database); binarise first (np.sign), or hand real-valued "
                          "features to MAPs.get_maps_by_feature, which ranks them by inner product like metric.py:13" % (qk, dk))
-    if q_codes.shape[1] > 128:
-        raise ValueError("inner-product ranking supports up to 128 features (have %d)" % q_codes.shape[1])
+    if q_codes.shape[1] > 255:                        # (the loaders take up to 255 columns)
+        raise ValueError("inner-product ranking supports up to 255 features (have %d)" % q_codes.shape[1])
     if not eng.ctx.get_stat("db_floats"):             # a +-1 database whose floats stayed on the host: bring them over now
         _load_database(eng, eng.db_src[0], eng.db_src[1], floats=1)
         eng.ctx.set_queries_f32(q_codes, q_labels)

@@ -40,7 +40,8 @@ def test_grid_features_match_reference_golden(name, ctx):
 
 
 @pytest.mark.parametrize("Q,N,b,R,C", [(40, 3000, 20, 700, 7), (65, 70000, 64, 2500, 10), (10, 2000, 128, 2000, 3),
-                                       (3, 500, 1, 40, 2), (33, 5000, 33, 1200, 70)])
+                                       (3, 500, 1, 40, 2), (33, 5000, 33, 1200, 70), (9, 3000, 129, 500, 4),
+                                       (70, 66000, 200, 1000, 5), (5, 1000, 255, 1000, 3)])
 def test_generic_float_features_match_oracle_bit_for_bit(Q, N, b, R, C, ctx):
     """Arbitrary float32 features (tanh of Gaussians): the kernel's summation order is restated
     exactly by the oracle (fma32 chains), so scores, order and AP agree bit for bit."""
