@@ -854,7 +854,7 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     c->t_begin(KI_REAL_RESCORE);
 #define HG_RESCORE(sg)                                                                                                                   \
     case sg:                                                                                                                             \
-        hipLaunchKernelGGL((k_real_rescore<sg>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(),  \
+        hipLaunchKernelGGL((k_real_rescore<(KP <= 128 ? KP : 0), sg>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(),  \
                            c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(),               \
                            c->sl_cnt.as<u32>(), KP, g);                                                                                  \
         break;

@@ -237,10 +237,11 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
 constexpr int RS_ROWB = 144;                                 // bytes per staged row: 32 floats + 16 (bank spread)
 constexpr int rescore_lds_bytes() { return WPB * 64 * RS_ROWB; }
 
-template <int SG>
+template <int KPT, int SG>          // KPT: the (padded) feature count, 0 = taken at run time (kp_rt; beyond 128 features)
 __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ qf, const float* __restrict__ dbf, const u32* sl_cnt,
                                                       u64* __restrict__ cand, u32 cap, i64 crow, const float* __restrict__ thr,
-                                                      u32* sl_cnt_out, const int KP, const Geo g) {      // (sl_cnt_out may be sl_cnt)
+                                                      u32* sl_cnt_out, const int kp_rt, const Geo g) {      // (sl_cnt_out may be sl_cnt)
+    const int KP = KPT ? KPT : kp_rt;
     extern __shared__ __attribute__((aligned(16))) u8 rlds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -290,13 +291,23 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = *(const float4*)(st + lane * RS_ROWB + e * 16);
             wave_lds_sync();
+            // KP is a multiple of 16: a piece is whole or half -- no per-feature guards, so the query's scalar loads batch
+            const float* __restrict__ qc = qrow + c0;
+            if (c0 + 32 <= KP) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (c0 + 4 * e < KP) {
-                    acc = __builtin_fmaf(qrow[c0 + 4 * e + 0], v[e].x, acc);
-                    acc = __builtin_fmaf(qrow[c0 + 4 * e + 1], v[e].y, acc);
-                    acc = __builtin_fmaf(qrow[c0 + 4 * e + 2], v[e].z, acc);
-                    acc = __builtin_fmaf(qrow[c0 + 4 * e + 3], v[e].w, acc);
+                for (int e = 0; e < 8; ++e) {
+                    acc = __builtin_fmaf(qc[4 * e + 0], v[e].x, acc);
+                    acc = __builtin_fmaf(qc[4 * e + 1], v[e].y, acc);
+                    acc = __builtin_fmaf(qc[4 * e + 2], v[e].z, acc);
+                    acc = __builtin_fmaf(qc[4 * e + 3], v[e].w, acc);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __builtin_fmaf(qc[4 * e + 0], v[e].x, acc);
+                    acc = __builtin_fmaf(qc[4 * e + 1], v[e].y, acc);
+                    acc = __builtin_fmaf(qc[4 * e + 2], v[e].z, acc);
+                    acc = __builtin_fmaf(qc[4 * e + 3], v[e].w, acc);
                 }
             }
         }
