@@ -17,6 +17,9 @@ context's stream, ordered with its kernels):
 (the exchange BASELINE.json's north star names, hg_allgather_topr) for callers
 that want them.
 
+The real-valued (inner-product) ranking scales over GPUs by splitting the queries
+instead (`evaluate_real_queries`): its float table is small enough to replicate.
+
 The reference has no counterpart (lib/metric.py runs in one process); the
 result is bit-identical to the single-GPU path, which the tests check with
 virtual shards on one GPU (LocalComm) and, for the orchestration, with a NumPy
@@ -52,6 +55,17 @@ class RcclComm:
 
     def barrier(self):
         self.ctx.barrier()
+
+    def all_gather_host(self, arr):
+        """all_gather of one small host array (same shape on every rank) -> [world, ...]: up to the GPU, hg_allgather, back."""
+        arr = np.ascontiguousarray(arr)
+        dev = self.ctx.scratch(3, arr.nbytes)
+        self.ctx.memcpy_htod(dev, arr, arr.nbytes)
+        g = self.all_gather(DevBuf(dev, arr.nbytes))
+        out = np.empty((self.world,) + arr.shape, arr.dtype)
+        self.ctx.memcpy_dtoh(out, g.ptr, g.nbytes)
+        self.ctx.synchronize()
+        return out
 
     def allreduce_max(self, x):
         """max over the ranks of one host number (a benchmark's step time)."""
@@ -149,6 +163,13 @@ class LocalComm:
 
     def barrier(self):
         self._s.barrier.wait()
+
+    def all_gather_host(self, arr):
+        self._s.slots[self.rank] = np.ascontiguousarray(arr)
+        self._s.barrier.wait()
+        out = np.stack(self._s.slots)
+        self._s.barrier.wait()
+        return out
 
 
 # ------------------------------------------------------------------ HIP shard engine
@@ -292,6 +313,29 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
             lists = engine.ctx.get_topr()
     ap, rel = engine.finish(B, comm.world)
     return (ap, rel, lists) if gather_topr else (ap, rel)
+
+
+def evaluate_real_queries(ctx, comm, q_feats, q_labels, R):
+    """Real-valued (float32 inner-product) ranking on G GPUs.  This path splits the QUERIES, not the database: every
+    rank holds the whole float table (256 MB at N = 1M x 64 features -- hg_set_database_f32 on each context before the
+    call) and ranks its contiguous share of the queries against it, so nothing has to be merged; the only exchange is
+    the all-gather of 16 bytes per query (AP, relevant count).  -> (ap[Q] float64, rel[Q] int64), identical on every
+    rank and equal to the one-GPU hg_map_real bit for bit (a query's result does not depend on the others)."""
+    q_feats, q_labels = np.asarray(q_feats), np.asarray(q_labels)
+    Q = q_feats.shape[0]
+    bounds = shard_bounds(Q, comm.world)
+    lo, n = bounds[comm.rank]
+    width = max(b[1] for b in bounds)
+    mine = np.zeros((width, 2), np.float64)
+    if n:
+        ctx.set_queries_f32(np.ascontiguousarray(q_feats[lo:lo + n], np.float32), np.ascontiguousarray(q_labels[lo:lo + n], np.int64))
+        ap, rel = ctx.map_real(R)
+        mine[:n, 0] = ap
+        mine[:n, 1] = rel                          # a count <= R: exact in a double
+    every = comm.all_gather_host(mine)
+    ap = np.concatenate([every[r, :bounds[r][1], 0] for r in range(comm.world)])
+    rel = np.concatenate([every[r, :bounds[r][1], 1] for r in range(comm.world)]).astype(np.int64)
+    return ap, rel
 
 
 def shard_bounds(n_total, world):

@@ -108,3 +108,47 @@ def test_rccl_id_rendezvous_between_processes(tmp_path):
     ids = [open(tmp_path / ("id%d" % r), "rb").read() for r in range(3)]
     assert ids[0] == ids[1] == ids[2] and len(ids[0]) == 128 and ids[0] != b"\0" * 128
     assert not os.path.exists(stale)
+
+
+def _real_worker(rank, world, port, name, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from tests import cases
+    from oracle import real_map as RM
+    from hashgan_amd import sharded
+    from tests.torch_comm import TorchComm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = cases.build_real_case(name)
+
+    class OracleCtx:                     # stands in for a context holding the whole float table (test infrastructure)
+        def set_queries_f32(self, x, lab):
+            self.q, self.ql = x, lab
+
+        def map_real(self, R):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                _, ap, *_ = RM.map_from_features(self.q, c["dbf"], self.ql, c["dblab"], R)
+            rel = np.array([0 if np.isnan(a) else 1 for a in ap], np.int64)
+            return np.nan_to_num(ap), rel
+
+    ap, rel = sharded.evaluate_real_queries(OracleCtx(), TorchComm(), c["qf"], c["qlab"], c["R"])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ap=ap, rel=rel)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("real_multi", 2), ("real_bits01", 3)])
+def test_gloo_query_split_of_the_real_valued_ranking(name, world, tmp_path):
+    """evaluate_real_queries (queries split over the ranks, database replicated) over a gloo group: every rank ends
+    up with every query's AP, in query order, equal to the unmodified reference's."""
+    from tests import cases
+    port = 29300 + (os.getpid() % 250)
+    mp.spawn(_real_worker, args=(world, port, name, str(tmp_path)), nprocs=world, join=True)
+    g = cases.load_golden(name)
+    rs = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    for r in rs[1:]:
+        assert np.array_equal(rs[0]["ap"], r["ap"]) and np.array_equal(rs[0]["rel"], r["rel"])
+    want = np.nan_to_num(g["ap"])
+    assert np.array_equal(rs[0]["ap"], want)
+    assert np.array_equal(rs[0]["rel"] != 0, ~np.isnan(g["ap"]))

@@ -220,3 +220,55 @@ def test_bench_multi_rank_control_flow(world, workload, tmp_path):
     assert abs(d["value"] - 2100 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # raw queries per second
     assert d["optimistic_runs"] == (3 if world == 2 else 0) and d["optimistic_fallbacks"] == 0
     assert "dry_run_not_a_measurement" in d and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("G", [1, 3])
+def test_real_valued_ranking_splits_queries_over_ranks(G):
+    """evaluate_real_queries: every (virtual) rank holds the whole float table and ranks its share of the queries; the
+    gathered per-query results equal one context's hg_map_real bit for bit.  G = 1 runs over the library's own RCCL
+    communicator (all_gather_host -> hg_allgather), G = 3 over threads."""
+    rng = np.random.default_rng(5)
+    Q, N, b, R, C = 37, 70000, 48, 900, 6
+    dbf = np.tanh(rng.standard_normal((N, b))).astype(np.float32)
+    qf = np.tanh(rng.standard_normal((Q, b))).astype(np.float32)
+    dl = (rng.random((N, C)) < 0.2).astype(np.int64)
+    ql = (rng.random((Q, C)) < 0.2).astype(np.int64)
+    ql[3] = 0                                            # a query that matches nothing: skipped
+    one = _native.Context(0)
+    one.set_database_f32(dbf, dl)
+    one.set_queries_f32(qf, ql)
+    ap0, rel0 = one.map_real(R)
+    one.close()
+    if G == 1:
+        ctx = _native.Context(0)
+        try:
+            ctx.set_database_f32(dbf, dl)
+            comm = sharded.init_rccl(ctx, rank=0, world=1)
+            ap, rel = sharded.evaluate_real_queries(ctx, comm, qf, ql, R)
+            ctx.comm_destroy()
+        finally:
+            ctx.close()
+        assert np.array_equal(ap, ap0, equal_nan=True) and np.array_equal(rel, rel0)
+        return
+    comms = sharded.LocalComm.create(G)
+    results, errors = [None] * G, []
+
+    def work(r):
+        try:
+            ctx = _native.Context(0)
+            ctx.set_database_f32(dbf, dl)
+            comms[r].ctx = ctx
+            results[r] = sharded.evaluate_real_queries(ctx, comms[r], qf, ql, R)
+            ctx.close()
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+            comms[r]._s.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errors:
+        raise errors[0]
+    for ap, rel in results:
+        assert np.array_equal(ap, ap0, equal_nan=True) and np.array_equal(rel, rel0)
+    assert rel0[3] == 0

@@ -20,3 +20,8 @@ class TorchComm:
 
     def barrier(self):
         dist.barrier(group=self.group)
+
+    def all_gather_host(self, arr):
+        import numpy as np
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        return self.all_gather(t).numpy()
