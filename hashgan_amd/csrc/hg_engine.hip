@@ -2209,7 +2209,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         c->t_begin(KI_RADIX);
         hipLaunchKernelGGL(k_real_rank_lds<NA>, dim3(g.Q), dim3(1024), real_rank_lds_bytes<NA>(), c->stream, c->cand.as<u64>(), c->crow, c->cap,
                            c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->thr.as<float>(), c->out_idx.as<u32>(), c->scores.as<float>(),
-                           c->err.as<int>(), c->qbad.as<u32>(), g);
+                           c->dblab.as<u64>(), c->qlab.as<u64>(), c->mbits.as<u64>(), c->RW, c->err.as<int>(), c->qbad.as<u32>(), g);
         c->t_end();
         HG_TRY(c->check_launch("k_real_rank_lds"));
         int flag = 0;
@@ -2219,7 +2219,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
             *lost = flag & 1;
             c->stage = ST_DB | ST_Q | ST_SELECT;
             if (*lost) return HG_OK;
-            HG_TRY(do_match(c));
+            c->stage |= ST_MATCH;                          // the rank kernel left the match bits too
             if (with_ap) HG_TRY(do_ap(c));
             return c->sync();
         }

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void k_real_sample_any(const float* __restrict
 //   3  ordered compaction IN PLACE: the R chosen records, still in index order, A[0 .. R)
 //   4  four stable counting passes over 16-bit positions P[0 .. R) by the bytes of the key (per-wave digit counters,
 //      ballot matching inside a 64-record batch: k_radix_pass's scheme, but LDS to LDS)
-//   5  the ranked list: idx and score of A[P[k]].
+//   5  the ranked list: idx and score of A[P[k]], and the label-match bit of every rank (k_match's gather).
 // A query whose records exceed NA sets bit 1 of *err (the host then ranks with the global-memory passes); one whose
 // cut was too high or whose slices overflowed sets bit 0 (a lost bet).
 constexpr int RK_SMAX = 4096;                                // slices per query the offsets array takes
@@ -427,6 +427,7 @@ template <int NA>
 __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ cand, i64 crow, u32 cap, const u32* __restrict__ sl_cnt,
                                                         const u32* __restrict__ fail, const float* __restrict__ thr,
                                                         u32* __restrict__ out_idx, float* __restrict__ scores,
+                                                        const u64* __restrict__ dblab, const u64* __restrict__ qlab, u64* __restrict__ mbits, i64 RW,
                                                         int* __restrict__ err, u32* __restrict__ qbad, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     u64* A = smem;                                           // [NA] records
@@ -556,11 +557,22 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
                 __syncthreads();
                 u16* t = Pin; Pin = Pout; Pout = t;
             }
-            // ---- 5: the ranked list ----
-            for (u32 k = tid; k < R; k += 1024) {
-                const u64 rec = A[Pin[k]];
-                out_idx[(i64)q * g.R + k] = (u32)rec;
-                if (scores) scores[(i64)q * g.R + k] = mono_inv(~(u32)(rec >> 32));
+            // ---- 5: the ranked list, and its label-match bits (metric.py:17-19; k_match's gather, one launch saved) ----
+            const u64* __restrict__ ql = qlab + (i64)q * g.LW;
+            for (u32 k = tid; k < (u32)RW * 64u; k += 1024) {
+                bool m = false;
+                if (k < R) {
+                    const u64 rec = A[Pin[k]];
+                    const u32 gi = (u32)rec;
+                    out_idx[(i64)q * g.R + k] = gi;
+                    if (scores) scores[(i64)q * g.R + k] = mono_inv(~(u32)(rec >> 32));
+                    const u64* __restrict__ dl = dblab + (i64)(gi - g.idx_base) * g.LW;
+                    u64 any = 0;
+                    for (int w = 0; w < g.LW; ++w) any |= dl[w] & ql[w];
+                    m = any != 0;
+                }
+                const u64 word = __ballot(m);
+                if (lane == 0) mbits[(i64)q * RW + (k >> 6)] = word;
             }
         }
     }
