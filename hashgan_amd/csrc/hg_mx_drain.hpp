@@ -245,9 +245,21 @@ struct MxDrain {
     // and one emit.  What makes that safe is decided once, wave-uniformly: the queue takes the window's entries; no
     // slice fills up (nothing to trim); compact: every slice's ring takes its new records on top of what is pending.
     // Windows that do not fit drain in two halves, each with its own decision between the checked pushes and the
-    // word-by-word form.  (Flushing pieces lazily -- only when a ring could not take the next window -- was tried: with
+    // word-by-word form.  (Tried and dropped: a lane-private walk of the words for dense windows, R/N of several per
+    // cent -- its registers spilled in the sparse path, 0.89 -> 1.38 ms at C2, and it was no faster where it ran.
+    // Flushing pieces lazily -- only when a ring could not take the next window -- was tried: with
     // 128 slices per wavefront some ring is nearly always close to full, it saved nothing.)
     __device__ __forceinline__ void drain_window(const u32 (&m)[QT][4], const i64 win, const u8* st) {
+        if (QT > 2) {                                                 // four query tiles: a window's entries rarely fit the queue
+#pragma unroll 1
+            for (int hw = 0; hw < 2; ++hw) {
+                u32 wd[QT][2];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) { wd[t][0] = hw ? m[t][2] : m[t][0]; wd[t][1] = hw ? m[t][3] : m[t][1]; }
+                drain(wd, 2 * hw, win, st);
+            }
+            return;
+        }
         u64 bal[QT][4];
         u32 nz = 0, want[QT];
 #pragma unroll

@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from hashgan_amd import _native, synth, metric
 
-def run(Q, N, b, R, steps=5):
+def run(Q, N, b, R, steps=5, opts=()):
     dl, _ = synth.onehot_labels(1, N, 10)
     ql, _ = synth.onehot_labels(2, Q, 10)
     dw = synth.splitmix64(3, N * ((b + 63) // 64)).reshape(N, -1)
@@ -15,6 +15,7 @@ def run(Q, N, b, R, steps=5):
         m = np.uint64((1 << (b % 64)) - 1)
         dw[:, -1] &= m; qw[:, -1] &= m
     ctx = _native.Context(0)
+    for k, v in opts: ctx.set_option(k, v)
     ctx.set_database(dw, metric.pack_labels(dl), b, 10)
     ctx.set_queries(qw, metric.pack_labels(ql))
     ctx.map(R); ctx.map(R)
@@ -30,6 +31,10 @@ def run(Q, N, b, R, steps=5):
     ctx.close()
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # shape_sweep.py Q N b R [opt=val ...]
+        Q, N, b, R = map(int, sys.argv[1:5])
+        run(Q, N, b, R, opts=[(kv.split("=")[0], int(kv.split("=")[1])) for kv in sys.argv[5:]])
+        sys.exit(0)
     for (Q, N, b, R) in [(10000, 1000000, 64, 5000), (10000, 1000000, 64, 100), (10000, 1000000, 64, 50000), (10000, 1000000, 64, 500000),
                          (10000, 1000000, 32, 5000), (10000, 1000000, 48, 5000), (10000, 1000000, 128, 5000), (10000, 1000000, 255, 5000),
                          (1000, 1000000, 64, 5000), (50000, 1000000, 64, 5000), (10000, 100000, 64, 5000), (10000, 10000000, 64, 5000),
