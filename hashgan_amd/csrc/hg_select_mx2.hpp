@@ -89,7 +89,7 @@ __host__ __device__ inline Mx2Lds mx2_lds_layout(int NW, int LW, bool compact) {
 
 // Geo as set by the launcher: g.nQT = query blocks (of 256 queries) per segment pair, g.nBlk = blocks; g.L % 32 == 0.
 template <int NW, int LW, bool COMPACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW == 2 ? 3 : 4, NW == 2 ? 3 : 4)))
 void k_select_mx2(const u32* __restrict__ qc, const u64* __restrict__ qlab, const u8* __restrict__ qx,
                   const u32* __restrict__ db, const u8* __restrict__ dbx, const u64* __restrict__ dblab,
                   const SelArgs a, u64* __restrict__ cand, const Geo g) {
