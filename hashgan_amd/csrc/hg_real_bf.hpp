@@ -165,39 +165,46 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
         __syncthreads();                                     // ... and nobody still reads the other buffer
         if (win + 1 < nwin) stage_window(win + 1, buf ^ 1);
         const u8* st = blds + buf * STAGE;
+        const u32 rowbase = g.idx_base + (u32)((i64)s * g.L);      // (dead lanes: never used)
 #pragma unroll 1
-        for (int Tw = 0; Tw < RB_WT; ++Tw) {
+        for (int Tw = 0; Tw < RB_WT; Tw += 2) {              // two tiles (32 rows of the lane's segment) per drain
             const i64 T = win * RB_WT + Tw;
             if (T >= ntile) break;
-            const i64 left = mylen - T * 16;                 // valid rows of this lane in the tile
-            const u32 keep = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : (1u << (int)left) - 1u);
-            bf16x8 av[NM];
-#pragma unroll
-            for (int m = 0; m < NM; ++m) av[m] = *(const bf16x8*)(st + ((Tw * NM + m) * 64 + lane) * 16);
-            // both query tiles' MFMA chains first (independent: the second hides the first's latency), then the harvests
-            f32x16 acc[QT];
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = cut[t];
-            }
-#pragma unroll
-            for (int m = 0; m < NM; ++m)
-#pragma unroll
-                for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bq[t][m], acc[t], 0, 0, 0);
-            // harvest: bit r <-> row 16 T + r of the lane's segment may qualify (thr2 - approx < 0)
             u32 mask[QT];
 #pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                u32 mm = 0;
+            for (int t = 0; t < QT; ++t) mask[t] = 0;
 #pragma unroll
-                for (int r = 15; r >= 0; --r) mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(acc[t][r]), 31);
-                mask[t] = mm & keep;
+            for (int half = 0; half < 2; ++half) {
+                const i64 left = mylen - (T + half) * 16;    // valid rows of this lane in the tile (tiles past the end: none)
+                const u32 keep = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : (1u << (int)left) - 1u);
+                bf16x8 av[NM];
+#pragma unroll
+                for (int m = 0; m < NM; ++m) av[m] = *(const bf16x8*)(st + (((Tw + half) * NM + m) * 64 + lane) * 16);
+                // both query tiles' MFMA chains first (independent: the second hides the first's latency), then the harvests
+                f32x16 acc[QT];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = cut[t];
+                }
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bq[t][m], acc[t], 0, 0, 0);
+                // harvest: bit r <-> row 16 (T + half) + r of the lane's segment may qualify (thr2 - approx < 0)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    u32 mm = 0;
+#pragma unroll
+                    for (int r = 15; r >= 0; --r) mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(acc[t][r]), 31);
+                    mask[t] |= (mm & keep) << (16 * half);
+                }
             }
             // drain: the owning lane writes the row numbers of its hits, lowest row first; the score comes later
             u32 any_mask = 0;
 #pragma unroll
             for (int t = 0; t < QT; ++t) any_mask |= mask[t];
+            const u32 row0 = rowbase + (u32)(T * 16);
             while (__any(any_mask != 0u)) {
                 any_mask = 0;
 #pragma unroll
@@ -206,7 +213,7 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
                         const int r = __builtin_ctz(mask[t]);
                         mask[t] &= mask[t] - 1u;
                         if (room[t]) {
-                            wp[t][cnt[t]] = (u64)(g.idx_base + (u32)((i64)s * g.L + T * 16 + r));
+                            wp[t][cnt[t]] = (u64)(row0 + (u32)r);
                             ++cnt[t];
                             --room[t];
                         } else {
