@@ -10,6 +10,7 @@
 #include "hg_select_mx2.hpp"
 #include "hg_real_mx.hpp"
 #include "hg_real_bf.hpp"
+#include "hg_hist_i8.hpp"
 #include "hg_hist_mx.hpp"
 #include "hg_host_pack.hpp"
 #include "../../include/hashgan_amd.h"
@@ -240,8 +241,10 @@ struct hg_ctx {
     bool dbx_valid = false, qx_valid = false;
     DevBuf dbx2, qx2;          // the same for k_select_mx2 (two rows per accumulator, codes of <= 64 bits)
     bool dbx2_valid = false, qx2_valid = false;
+    DevBuf dbx8;               // i8 image of the database codes in A-fragment order (k_hist_i8), built on first use
+    bool dbx8_valid = false;
     bool direct_rank = false;  // R = N: k_rank_fused computes distance and match bit per row itself (no records)
-    i64 opt_hist_mfma = 1;     // "hist_mfma": histograms (sampled pass; full pass of the one-shot exact sequence) on the matrix cores
+    i64 opt_hist_mfma = 2;     // "hist_mfma": histograms (sampled pass; full pass of the one-shot exact sequence) on the matrix cores -- 2: the integer instruction delivers the counter address (k_hist_i8, codes of <= 128 bits), 1: fp4 distances (k_hist_mx), 0: vector ALU
     bool hist_pairs = false;   // the last FULL histogram pass ran per segment pair (k_hist_mx)
     bool exact_mx = false;     // the matrix-core select runs with the EXACT threshold (hg_hist + k_plan) instead of a guess
     i64 opt_exact_mfma = 1;    // "exact_mfma": the one-shot exact sequence selects on the matrix cores when R << N
@@ -701,7 +704,54 @@ template <int NW> int launch_select_nw(hg_ctx* c) {
     }
 
 int launch_hist(hg_ctx* c) { HG_DISPATCH_NW(launch_hist_t, c) }
-int launch_hist_mx(hg_ctx* c) { HG_DISPATCH_NW(launch_hist_mx_t, c) }
+// the same pass with the integer matrix instruction delivering the counter addresses (hg_hist_i8.hpp); codes of <= 128 bits
+template <int NW> int launch_hist_i8_t(hg_ctx* c) {
+    if (!c->dbx8_valid) {
+        const i64 n16 = (c->N + 15) / 16 * 16;
+        HG_TRY(c->dbx8.reserve((size_t)n16 * NW * 32));
+        c->t_begin(KI_PACK);
+        hipLaunchKernelGGL(k_expand_db_i8, dim3(grid_for(n16 * NW * 2)), dim3(256), 0, c->stream, c->db.as<u32>(), c->dbx8.as<uint4>(),
+                           (i64)c->N, n16, NW);
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_db_i8"));
+        c->dbx8_valid = true;
+    }
+    Geo g = c->geo;
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + 255) / 256;
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    const i64 tiles_per_half = ((g.L + 15) / 16 + g.hist_stride - 1) / g.hist_stride;
+    const bool pack16 = 2 * tiles_per_half * 16 < 65536;
+    const size_t lds = (size_t)WPB * hist_i8_cols(pack16) * g.NB * 32 * 4;
+    c->t_begin(KI_HIST);
+    if (pack16) {
+        if (lds > 64 * 1024)
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist_i8<NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_hist_i8<NW, true>), dim3(padded_grid(g.nBlk)), dim3(256), lds, c->stream, c->qc.as<u32>(), c->dbx8.as<u8>(),
+                           c->hist.as<u32>(), g);
+    } else {
+        if (lds > 64 * 1024)
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist_i8<NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_hist_i8<NW, false>), dim3(padded_grid(g.nBlk)), dim3(256), lds, c->stream, c->qc.as<u32>(), c->dbx8.as<u8>(),
+                           c->hist.as<u32>(), g);
+    }
+    c->t_end();
+    return c->check_launch("k_hist_i8");
+}
+int launch_hist_mx(hg_ctx* c) {
+    if (c->opt_hist_mfma == 2 && c->NW <= 4) {
+        switch (c->NW) {
+            case 1: return launch_hist_i8_t<1>(c);
+            case 2: return launch_hist_i8_t<2>(c);
+            case 3: return launch_hist_i8_t<3>(c);
+            default: return launch_hist_i8_t<4>(c);
+        }
+    }
+    HG_DISPATCH_NW(launch_hist_mx_t, c)
+}
 int launch_select(hg_ctx* c) { HG_DISPATCH_NW(launch_select_nw, c) }
 
 // rows k_hist visits with batch stride `stride` (mirrors its loop)
@@ -978,7 +1028,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -1029,6 +1079,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     c->stage = ST_DB;   // queries must be (re)set after the database: b, C may have changed
     c->dbx_valid = false;
     c->dbx2_valid = false;
+    c->dbx8_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;    // a new database: earlier lost bets say nothing about it
     c->cfg_epoch++;
     return HG_OK;
@@ -1140,6 +1191,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->stage = ST_DB;
     c->dbx_valid = false;
     c->dbx2_valid = false;
+    c->dbx8_valid = false;
     c->dbfx_valid = false;
     c->dbfb_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;
@@ -2575,7 +2627,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         if (value < 0 || value > 24 * 1024) return fail(HG_ERR_ARG, "lds_pad must be 0..24576");
         c->opt_lds_pad = value;
     } else if (!strcmp(key, "hist_mfma")) {
-        c->opt_hist_mfma = value != 0;
+        if (value < 0 || value > 2) return fail(HG_ERR_ARG, "hist_mfma must be 0, 1 or 2");
+        c->opt_hist_mfma = value;
     } else if (!strcmp(key, "exact_mfma")) {
         c->opt_exact_mfma = value != 0;
     } else if (!strcmp(key, "select_mfma")) {
@@ -2620,6 +2673,7 @@ int hg_trim(hg_ctx* c) {
     for (auto& d : c->scratch) d.release();
     c->gath_idx.release(); c->gath_dist.release();
     c->dbx_valid = c->qx_valid = c->dbx2_valid = c->qx2_valid = false;
+    c->dbx8.release(); c->dbx8_valid = false;
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     c->stage &= (ST_DB | ST_Q);
     c->lists_valid = false;

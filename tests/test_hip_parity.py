@@ -179,17 +179,43 @@ def test_matrix_core_histogram_is_exact(case_cache):
         _load(ctx, c)
         ctx.set_option("optimistic", 0)
         g = cases.load_golden("c2_q64")
-        for units, maxseg in [(16384, 2048), (3, 2048), (16384, 7)]:        # S = 2048-ish, 3 long segments (dword counters), 7
-            ctx.set_option("target_units", units)
-            ctx.set_option("max_segments", maxseg)
-            ap, rel = ctx.map(c["R"])
-            assert np.array_equal(ap, g["ap"], equal_nan=True), (units, maxseg)
-            h = ctx.get_hist().astype(np.int64)                      # [b + 1][Q] from the pass that just ran
-            if Dref is None:
-                D = O.hamming_matrix(O.pack_bits(c["qbits"]), O.pack_bits(c["dbbits"]))
-                Dref = np.stack([np.bincount(D[i], minlength=c["b"] + 1) for i in range(D.shape[0])]).T
-            assert np.array_equal(h, Dref), (units, maxseg)
-            assert ctx.get_stat("optimistic_fallbacks") == 0
+        for kernel in (2, 1):                                               # k_hist_i8 (addresses from the integer MFMA), k_hist_mx (fp4)
+            ctx.set_option("hist_mfma", kernel)
+            for units, maxseg in [(16384, 2048), (3, 2048), (16384, 7)]:    # S = 2048-ish, 3 long segments (dword counters), 7
+                ctx.set_option("target_units", units)
+                ctx.set_option("max_segments", maxseg)
+                ap, rel = ctx.map(c["R"])
+                assert np.array_equal(ap, g["ap"], equal_nan=True), (kernel, units, maxseg)
+                h = ctx.get_hist().astype(np.int64)                  # [b + 1][Q] from the pass that just ran
+                if Dref is None:
+                    D = O.hamming_matrix(O.pack_bits(c["qbits"]), O.pack_bits(c["dbbits"]))
+                    Dref = np.stack([np.bincount(D[i], minlength=c["b"] + 1) for i in range(D.shape[0])]).T
+                assert np.array_equal(h, Dref), (kernel, units, maxseg)
+                assert ctx.get_stat("optimistic_fallbacks") == 0
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("b", [1, 8, 17, 31, 32, 33, 48, 63, 65, 96, 100, 127, 128])
+def test_histogram_kernels_agree_on_odd_code_lengths(b):
+    """The matrix-core histogram kernels against the oracle for code lengths around the word boundaries (k_hist_i8 zeroes
+    the B operand beyond the code; one MFMA per 32 bits), ragged N, exact sequence."""
+    rng = np.random.default_rng(b)
+    Q, N, R = 70, 5003, 400
+    qb = (rng.random((Q, b)) < 0.5).astype(np.uint8)
+    db = (rng.random((N, b)) < 0.5).astype(np.uint8)
+    lab = (rng.random((N, 5)) < 0.3).astype(np.uint8)
+    ql = (rng.random((Q, 5)) < 0.3).astype(np.uint8)
+    D = O.hamming_matrix(O.pack_bits(qb), O.pack_bits(db))
+    Dref = np.stack([np.bincount(D[i], minlength=b + 1) for i in range(Q)]).T
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=lab, b=b))
+        ctx.set_option("optimistic", 0)
+        for kernel in (2, 1, 0):
+            ctx.set_option("hist_mfma", kernel)
+            ctx.map(R)
+            assert np.array_equal(ctx.get_hist().astype(np.int64), Dref), (b, kernel)
     finally:
         ctx.close()
 
