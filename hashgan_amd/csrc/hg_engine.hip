@@ -2002,6 +2002,9 @@ static int rerun_lost_queries(hg_ctx* c, int64_t R, bool lists, bool with_ap, bo
     s->N = c->N; s->b = c->b; s->C = c->C; s->n_total = c->n_total; s->NW = c->NW; s->NB = c->NB; s->LW = c->LW;
     s->idx_base = c->idx_base;
     s->target_units = c->target_units; s->min_segment = c->min_segment; s->opt_enable = 0;
+    // a handful of queries: the per-segment bookkeeping (k_hist_reduce, k_seg_layout walk S segments per query) costs more than
+    // the pair passes themselves -- 2048 segments: 0.8 ms of a 1 ms rerun; 256 keep every CU busy and cost 0.1
+    s->opt_max_segments = 256;
     s->timing = 0;
     s->db.borrow(c->db);
     s->dblab.borrow(c->dblab);
