@@ -444,6 +444,7 @@ void make_geometry(hg_ctx* c) {
     g.S = (int)S; g.L = L;
     g.nUnits = (i64)g.S * g.nQT;
     g.hist_stride = 1;
+    g.hcap = 0;
     g.wpb = WPB;
     g.nBlk = (int)((g.nUnits + WPB - 1) / WPB);
 }
@@ -1250,10 +1251,11 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     return HG_OK;
 }
 
-static int do_hist(hg_ctx* c, int stride, bool reduce = true, bool pairs_ok = false) {
+static int do_hist(hg_ctx* c, int stride, bool reduce = true, bool pairs_ok = false, int hcap = 0) {
     make_geometry(c);
     c->geo.hist_stride = stride;
     const bool mx = hist_mx_applies(c, stride, pairs_ok);
+    c->geo.hcap = mx && !reduce && stride > 1 ? hcap : 0;
     c->hist_pairs = mx && stride == 1;                 // full pass per segment pair: the plan's per-segment steps follow suit
     const Geo& g = c->geo;
     const size_t plane = (size_t)g.NB * g.Qpad * 4;
@@ -1937,7 +1939,10 @@ static int enqueue_exact_mx(hg_ctx* c, int64_t R) {
 
 static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     (void)need_cnt;
-    HG_TRY(do_hist(c, stride, false));
+    // the guess stops at the cut, far below b/2 when R <= N/8 on any data whose queries resemble the database: the
+    // sampled pass writes only those planes (130 -> 68 MB per launch at C2).  A cut beyond them reads as a thin
+    // sample -- everything is taken, the slices overflow, the exact sequence answers.
+    HG_TRY(do_hist(c, stride, false, false, c->NB / 2 + 2));
     HG_TRY(set_R(c, R, 1, 0));
     const Geo& g = c->geo;
     const size_t qb = (size_t)g.Qpad * 4;

@@ -146,7 +146,8 @@ void k_hist_i8(const u32* __restrict__ qc, const u8* __restrict__ dbx8, u32* __r
     const int q = q0w + lane;
     if (q < g.Qpad) {
         u32* __restrict__ out = hist + (i64)sp * NB * g.Qpad + q;
-        for (int d = 0; d < NB; ++d) {
+        const int dn = g.hcap > 0 && g.hcap < NB ? g.hcap : NB;      // (the bet's sampled pass: the guess never reads beyond)
+        for (int d = 0; d < dn; ++d) {
             const u32 v = PACK16 ? (col[d * 32 + j] >> (16 * h)) & 0xFFFFu : col[(h * NB + d) * 32 + j];
             out[(i64)d * g.Qpad] = v;
         }

@@ -50,6 +50,7 @@ struct Geo {
     int hist_stride;    // k_hist visits every hist_stride-th row batch (1 = all rows; >1 = sampling pass)
     int wpb;            // wavefronts (= units) per block of the launch this Geo goes to
     int nBlk;           // logical blocks = ceil(nUnits / wpb); the grid is padded to a multiple of 8
+    int hcap;           // sampled pass of the one-shot bet: only the distance planes [0, hcap) are written and read (0: all)
 };
 
 // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8).  Give
@@ -362,9 +363,10 @@ __global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hs
     const int per = (Sh + PARTS - 1) / PARTS;          // part p sums segments [p * per, (p + 1) * per)
     const int s0 = part * per < Sh ? part * per : Sh, s1 = s0 + per < Sh ? s0 + per : Sh;
     u64 cum = 0, below = 0;
-    int t = g.NB - 1;                                  // sample too thin: take everything
+    int t = g.NB - 1;                                  // sample too thin (or the cut beyond the planes the pass wrote): take everything
     bool found = false;
-    for (int d = 0; d < g.NB; ++d) {
+    const int dn = g.hcap > 0 && g.hcap < g.NB ? g.hcap : g.NB;
+    for (int d = 0; d < dn; ++d) {
         u32 c = 0;
         const u32* __restrict__ col = hseg + (i64)d * g.Qpad + qq;
         int sh = s0;
