@@ -530,3 +530,28 @@ def test_longest_code_and_largest_distance(ctx):
     with pytest.raises(_native.HashganNativeError) as e:
         ctx.set_database(metric.pack_codes(wide), metric.pack_labels(dl), 256, C)
     assert e.value.code == _native.HG_ERR_ARG
+
+
+def test_queries_far_from_every_row_fall_back_exactly():
+    """Queries on the other side of the code space (every distance > b/2): the cut lies beyond the distance planes the
+    bet's sampled pass writes (hg_engine.hip::enqueue_optimistic), the guess reads a thin sample, the bet is lost and the
+    exact sequence must answer -- same AP as the oracle."""
+    rng = np.random.default_rng(77)
+    Q, N, b, R, C = 70, 300000, 64, 2000, 6
+    proto = (rng.random(b) < 0.5).astype(np.uint8)
+    db = proto ^ (rng.random((N, b)) < 0.1).astype(np.uint8)
+    qb = (1 - proto) ^ (rng.random((Q, b)) < 0.1).astype(np.uint8)
+    dl = (rng.random((N, C)) < 0.3).astype(np.int8)
+    ql = (rng.random((Q, C)) < 0.3).astype(np.int8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb, db, ql, dl, R)
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        ap, rel = ctx.map(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        assert ctx.get_stat("optimistic_runs") >= 1                  # the bet was placed ...
+        assert ctx.get_stat("optimistic_fallbacks") + ctx.get_stat("optimistic_requeried") >= 1      # ... and lost
+    finally:
+        ctx.close()
