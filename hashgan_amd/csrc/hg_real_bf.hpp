@@ -93,7 +93,7 @@ constexpr int RB_WT = 4;                                     // row tiles per st
 constexpr int real_bf_lds_bytes(int KP) { return 2 * RB_WT * (KP / 16) * 1024; }
 
 template <int KP, int QT>          // QT query tiles (of 32) per wavefront: 2 up to 128 features, 1 beyond (B fragments live in registers)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, KP <= 64 ? 4 : 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KP <= 64 ? 4 : 2, KP <= 64 ? 4 : 2)))
 void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, const float* __restrict__ thr2, const RealSelArgs a,
                       u64* __restrict__ cand, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 blds[];
@@ -180,23 +180,17 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
                 bf16x8 av[NM];
 #pragma unroll
                 for (int m = 0; m < NM; ++m) av[m] = *(const bf16x8*)(st + (((Tw + half) * NM + m) * 64 + lane) * 16);
-                // both query tiles' MFMA chains first (independent: the second hides the first's latency), then the harvests
-                f32x16 acc[QT];
-#pragma unroll
-                for (int t = 0; t < QT; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] = cut[t];
-                }
-#pragma unroll
-                for (int m = 0; m < NM; ++m)
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bq[t][m], acc[t], 0, 0, 0);
                 // harvest: bit r <-> row 16 (T + half) + r of the lane's segment may qualify (thr2 - approx < 0)
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = cut[t];
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bq[t][m], acc, 0, 0, 0);
                     u32 mm = 0;
 #pragma unroll
-                    for (int r = 15; r >= 0; --r) mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(acc[t][r]), 31);
+                    for (int r = 15; r >= 0; --r) mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(acc[r]), 31);
                     mask[t] |= (mm & keep) << (16 * half);
                 }
             }
