@@ -282,33 +282,44 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
         for (int e = 0; e < 8; ++e) ridx[e] = (u32)__shfl((int)local, 8 * e + pr);
         float acc = 0.0f;
 #pragma unroll 1
-        for (int c0 = 0; c0 < KP; c0 += 32) {                // 32 features at a time (KP is a multiple of 16)
+        for (int c0 = 0; c0 < KP; c0 += 64) {                // 64 features per trip: both 32-feature pieces' loads in flight at once
+            float4 gl[2][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (c0 + 4 * pp < KP)
-                    *(float4*)(st + (8 * e + pr) * RS_ROWB + pp * 16) = *(const float4*)(dbf + (i64)ridx[e] * KP + c0 + 4 * pp);
-            wave_lds_sync();
-            float4 v[8];
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = *(const float4*)(st + lane * RS_ROWB + e * 16);
-            wave_lds_sync();
-            // KP is a multiple of 16: a piece is whole or half -- no per-feature guards, so the query's scalar loads batch
-            const float* __restrict__ qc = qrow + c0;
-            if (c0 + 32 <= KP) {
+                for (int e = 0; e < 8; ++e)
+                    gl[u][e] = c0 + 32 * u + 4 * pp < KP ? *(const float4*)(dbf + (i64)ridx[e] * KP + c0 + 32 * u + 4 * pp)
+                                                         : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    acc = __builtin_fmaf(qc[4 * e + 0], v[e].x, acc);
-                    acc = __builtin_fmaf(qc[4 * e + 1], v[e].y, acc);
-                    acc = __builtin_fmaf(qc[4 * e + 2], v[e].z, acc);
-                    acc = __builtin_fmaf(qc[4 * e + 3], v[e].w, acc);
-                }
-            } else {
+            for (int u = 0; u < 2; ++u) {
+                const int cu = c0 + 32 * u;
+                if (cu < KP) {                                // (wave-uniform)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc = __builtin_fmaf(qc[4 * e + 0], v[e].x, acc);
-                    acc = __builtin_fmaf(qc[4 * e + 1], v[e].y, acc);
-                    acc = __builtin_fmaf(qc[4 * e + 2], v[e].z, acc);
-                    acc = __builtin_fmaf(qc[4 * e + 3], v[e].w, acc);
+                    for (int e = 0; e < 8; ++e) *(float4*)(st + (8 * e + pr) * RS_ROWB + pp * 16) = gl[u][e];
+                    wave_lds_sync();
+                    float4 v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = *(const float4*)(st + lane * RS_ROWB + e * 16);
+                    wave_lds_sync();
+                    // KP is a multiple of 16: a piece is whole or half -- no per-feature guards, so the query's scalar loads batch
+                    const float* __restrict__ qc = qrow + cu;
+                    if (cu + 32 <= KP) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            acc = __builtin_fmaf(qc[4 * e + 0], v[e].x, acc);
+                            acc = __builtin_fmaf(qc[4 * e + 1], v[e].y, acc);
+                            acc = __builtin_fmaf(qc[4 * e + 2], v[e].z, acc);
+                            acc = __builtin_fmaf(qc[4 * e + 3], v[e].w, acc);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc = __builtin_fmaf(qc[4 * e + 0], v[e].x, acc);
+                            acc = __builtin_fmaf(qc[4 * e + 1], v[e].y, acc);
+                            acc = __builtin_fmaf(qc[4 * e + 2], v[e].z, acc);
+                            acc = __builtin_fmaf(qc[4 * e + 3], v[e].w, acc);
+                        }
+                    }
                 }
             }
         }
