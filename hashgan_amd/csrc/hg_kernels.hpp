@@ -1164,7 +1164,9 @@ __global__ __launch_bounds__(256) void k_match(const u32* __restrict__ out_idx, 
     bool m = false;
     if (k < g.R) {
         const u32 gi = out_idx[(i64)q * g.R + k];
-        if (gi != IDX_NONE) {
+        // (a query that lost its bet leaves its list row as it found it -- stale words of an earlier allocation; its
+        // bits are recomputed by the rerun, but the gather must not follow them out of the table)
+        if (gi != IDX_NONE && (i64)(gi - g.idx_base) < g.N) {
             const u64* __restrict__ dl = dblab + (i64)(gi - g.idx_base) * g.LW;
             const u64* __restrict__ ql = qlab + (i64)q * g.LW;
             u64 any = 0;

@@ -555,3 +555,19 @@ def test_queries_far_from_every_row_fall_back_exactly():
         assert ctx.get_stat("optimistic_fallbacks") + ctx.get_stat("optimistic_requeried") >= 1      # ... and lost
     finally:
         ctx.close()
+
+
+def test_bet_equals_exact_over_random_shapes():
+    """A slice of tools/fuzz_bet_vs_exact.py: random code lengths, sizes, hit densities (R/N 0.05 % .. 12 %), label widths
+    (up to 130 classes: match bits gathered through the ranked list) and duplicated neighbours; the one-shot bet with
+    compact and with 8-byte records and the matrix-core exact sequence must equal the vector-ALU exact sequence.
+    Seeds 54..56 once ended in a memory fault: a query that lost its bet left stale words in its list row, and k_match
+    followed them out of the label table."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_bet_vs_exact.py")
+    spec = importlib.util.spec_from_file_location("fuzz_bet_vs_exact", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for seed in range(44, 64):
+        r = fz.one(seed)
+        assert r.startswith("ok"), r
