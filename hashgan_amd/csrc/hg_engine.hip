@@ -271,6 +271,7 @@ struct hg_ctx {
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
     DevBuf dbfx;               // float features of the database in MFMA A-fragment order (k_real_select_mx), built on first use
     bool dbfx_valid = false;
+    DevBuf sampx;              // float features of the sampled rows in MFMA A-fragment order (k_real_sample_mx), rebuilt per call
     DevBuf dbfb, thr2, xmax2;  // filter + rescore path (hg_real_bf.hpp): bf16 image of the database, lowered cuts, max row norm^2
     bool dbfb_valid = false;
     i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit
@@ -841,7 +842,7 @@ template <int KP> int real_launch_select_mx(hg_ctx* c) {
         const i64 items = n16 * (KP / 4);
         c->t_begin(KI_PACK);
         hipLaunchKernelGGL(k_expand_dbf, dim3(grid_for(items)), dim3(256), 0, c->stream, c->dbf.as<float>(), c->dbfx.as<float4>(),
-                           (i64)c->N, n16, KP);
+                           (i64)c->N, n16, KP, (i64)1);
         c->t_end();
         HG_TRY(c->check_launch("k_expand_dbf"));
         c->dbfx_valid = true;
@@ -962,7 +963,44 @@ int real_select_mx(hg_ctx* c) {
         case 64: return fn<64>(c, ##__VA_ARGS__);                   \
         default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 128 features (have %d)", (c)->b); \
     }
-int real_sample(hg_ctx* c, i64 M, i64 stride) {
+// sample pass on the float32 MFMA: image of the M sampled rows (rebuilt per call: a few MB), 16 segments
+template <int KP> int real_launch_sample_mx(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
+    const i64 m16 = (M + 15) / 16 * 16;
+    HG_TRY(c->sampx.reserve((size_t)m16 * KP * 4));
+    c->t_begin(KI_REAL_SAMPLE);
+    hipLaunchKernelGGL(k_expand_dbf, dim3(grid_for(m16 * (KP / 4))), dim3(256), 0, c->stream, c->dbf.as<float>(), c->sampx.as<float4>(),
+                       M, m16, KP, stride);
+    Geo g = c->geo;
+    g.N = M;
+    i64 L = (M + 31) / 32;                               // ~32 segments (16 pairs) of a multiple of 16 rows
+    L = (L + 15) / 16 * 16;
+    g.L = L;
+    g.S = (int)((M + L - 1) / L);
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + WPB * 32 * RMX_QT - 1) / (WPB * 32 * RMX_QT);
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    hipLaunchKernelGGL((k_real_sample_mx<KP>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
+                       c->samp.as<float>(), mstride, g);
+    c->t_end();
+    return c->check_launch("k_real_sample_mx");
+}
+int real_sample_mx(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
+    switch (c->bpad) {
+        case 16: return real_launch_sample_mx<16>(c, M, stride, mstride);
+        case 32: return real_launch_sample_mx<32>(c, M, stride, mstride);
+        case 48: return real_launch_sample_mx<48>(c, M, stride, mstride);
+        case 64: return real_launch_sample_mx<64>(c, M, stride, mstride);
+        case 80: return real_launch_sample_mx<80>(c, M, stride, mstride);
+        case 96: return real_launch_sample_mx<96>(c, M, stride, mstride);
+        case 112: return real_launch_sample_mx<112>(c, M, stride, mstride);
+        default: return real_launch_sample_mx<128>(c, M, stride, mstride);
+    }
+}
+int real_sample(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
+    if (c->bpad <= 128 && c->opt_real_mfma) return real_sample_mx(c, M, stride, mstride);
     if (c->bpad > 128) {                                 // k_real_sample keeps the query in registers: the staged form beyond
         const Geo& g = c->geo;
         const i64 units = (M + 63) / 64 * g.nQT;
@@ -974,6 +1012,7 @@ int real_sample(hg_ctx* c, i64 M, i64 stride) {
         c->t_end();
         return c->check_launch("k_real_sample_any");
     }
+    (void)mstride;                                       // (the vector kernels write samp[q][M] densely: the caller passes mstride = M)
     HG_DISPATCH_BP(real_launch_sample, c, M, stride)
 }
 int real_select(hg_ctx* c) {
@@ -1029,7 +1068,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->sampx};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -2235,10 +2274,12 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         const i64 M = (c->N + stride - 1) / stride;
         const double fr = (double)R * (double)M / (double)c->N;
         const u32 rank_s = (u32)std::ceil(fr + sigma * std::sqrt(fr)) + 1u;
-        HG_TRY(c->samp.reserve((size_t)g.Q * M * 4));
-        HG_TRY(real_sample(c, M, stride));
+        // samp[q][mstride]: the matrix-core sample pass stores 16 samples at a time (rows 64-byte aligned), the vector kernels M densely
+        const i64 mstride = c->bpad <= 128 && c->opt_real_mfma ? (M + 15) / 16 * 16 : M;
+        HG_TRY(c->samp.reserve((size_t)g.Q * mstride * 4));
+        HG_TRY(real_sample(c, M, stride, mstride));
         c->t_begin(KI_REAL_GUESS);
-        hipLaunchKernelGGL(k_real_guess, dim3(g.Q), dim3(256), 0, c->stream, c->samp.as<float>(), M, rank_s, c->thr.as<float>());
+        hipLaunchKernelGGL(k_real_guess, dim3(g.Q), dim3(256), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
         c->t_end();
         HG_TRY(c->check_launch("k_real_guess"));
         const double mean = budget * (double)R / (double)g.S;
@@ -2673,7 +2714,7 @@ int hg_trim(hg_ctx* c) {
     HG_TRY(c->sync());
     DevBuf* work[] = {&c->hist, &c->seglt, &c->segtie, &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->cand, &c->out_idx,
                       &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->scores, &c->bigq, &c->mbits2,
-                      &c->dbx, &c->qx, &c->dbx2, &c->qx2, &c->dbfx, &c->dbfb};   // the images are rebuilt on demand
+                      &c->dbx, &c->qx, &c->dbx2, &c->qx2, &c->dbfx, &c->dbfb, &c->sampx};   // the images are rebuilt on demand
     for (auto* d : work) d->release();
     c->dbfx_valid = false;
     c->dbfb_valid = false;

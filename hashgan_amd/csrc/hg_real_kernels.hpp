@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256) void k_real_sample(const float* __restrict__ q
 // pass keeps ip > thr[q], thr = the next float below that value (so ip >= it qualifies).
 // rank_s > M: everything qualifies (thr = -inf).
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_real_guess(const float* __restrict__ samp, i64 M, u32 rank_s,
+__global__ __launch_bounds__(256) void k_real_guess(const float* __restrict__ samp, i64 M, i64 mstride, u32 rank_s,
                                                     float* __restrict__ thr) {
     __shared__ u32 hist[2048];
     __shared__ u32 s_prefix, s_rank, s_wsum[4];
     const int q = blockIdx.x, tid = threadIdx.x;
-    const float* __restrict__ col = samp + (i64)q * M;
+    const float* __restrict__ col = samp + (i64)q * mstride;    // M samples, rows mstride apart
     if (rank_s > (u32)M) {
         if (tid == 0) thr[q] = __uint_as_float(0xFF800000u);  // -inf
         return;

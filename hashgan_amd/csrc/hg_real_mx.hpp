@@ -24,7 +24,8 @@ constexpr int RMX_QT = 2;                // query tiles (of 32) per wavefront
 
 // Database image in A-fragment order: groups of 16 rows; chunk (group G, m4, parity h, row r) = 16 bytes at
 // (((G * (KP/8) + m4) * 2 + h) * 16 + r) * 16 holding features 8 m4 + 2 u + h, u = 0..3, of row 16 G + r.
-__global__ __launch_bounds__(256) void k_expand_dbf(const float* __restrict__ dbf, float4* __restrict__ img, i64 N, i64 n16, int KP) {
+// (rstride > 1: image row i is table row i * rstride -- the sample pass's image of every rstride-th row)
+__global__ __launch_bounds__(256) void k_expand_dbf(const float* __restrict__ dbf, float4* __restrict__ img, i64 N, i64 n16, int KP, i64 rstride) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     const int per_row = KP / 4;                              // chunks per row: (KP / 8) m4 x 2 parities
     if (i >= n16 * per_row) return;
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void k_expand_dbf(const float* __restrict__ db
     const int c = (int)(i - row * per_row), m4 = c >> 1, h = c & 1;
     float4 v = {0.f, 0.f, 0.f, 0.f};
     if (row < N) {
-        const float* f = dbf + row * KP + 8 * m4 + h;
+        const float* f = dbf + row * rstride * KP + 8 * m4 + h;
         v.x = f[0]; v.y = f[2]; v.z = f[4]; v.w = f[6];
     }
     img[(((row >> 4) * (KP / 8) + m4) * 2 + h) * 16 + (row & 15)] = v;
@@ -150,6 +151,83 @@ void k_real_select_mx(const float* __restrict__ qf, const u8* __restrict__ img, 
             const bool live = q < g.Q;
             a.sl_cnt[(i64)s * g.Qpad + q] = live ? cnt[t] : 0u;
             if (dropped[t] && live) a.fail[q] = 1u;
+        }
+    }
+}
+
+// Sample pass on the float32 MFMA (replaces k_real_sample up to 128 features): the inner products of every query with
+// the M sampled rows, the same fma chains bit for bit, so the guessed cut does not change.  The sampled rows' image is
+// cut into segments like a database (k_real_select_mx's mapping); a lane ends a tile with 16 consecutive samples of
+// its query in its accumulator and stores them as they are: samp[q][mstride], 64 contiguous bytes per lane and tile.
+template <int KP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, KP <= 64 ? 3 : 2)))
+void k_real_sample_mx(const float* __restrict__ qf, const u8* __restrict__ img, float* __restrict__ samp, i64 mstride, const Geo g) {
+    constexpr int QT = RMX_QT, WQ = 32 * QT;
+    constexpr int NM4 = KP / 8;
+    const int lb = logical_block(g.nBlk);
+    if (lb < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nQB = g.nQT;
+    const int sp = lb / nQB, qb = lb - sp * nQB;
+    const int h = lane >> 5, j = lane & 31;
+    const int s = 2 * sp + h;
+    const i64 lo0 = (i64)(2 * sp) * g.L, lo1 = lo0 + g.L;
+    const i64 len0 = lo0 >= g.N ? 0 : (lo0 + g.L < g.N ? g.L : g.N - lo0);
+    const i64 len1 = lo1 >= g.N ? 0 : (lo1 + g.L < g.N ? g.L : g.N - lo1);
+    const i64 mylen = h ? len1 : len0;
+    const i64 ntile = ((len0 > len1 ? len0 : len1) + 15) / 16;
+    const i64 NG = (g.N + 15) >> 4;
+    const int q0w = (qb * WPB + wave) * WQ;
+    float bq[QT][KP / 2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = q0w + t * 32 + j;
+#pragma unroll
+        for (int m = 0; m < KP / 2; ++m) bq[t][m] = q < g.Q ? qf[(i64)q * KP + 2 * m + h] : 0.0f;
+    }
+    const int ah = (j >> 2) & 1;
+    const int ar = (j & 3) + 4 * (j >> 3);
+    const i64 ag0 = (ah ? lo1 : lo0) >> 4;
+    auto chunk = [&](const i64 T, const int m4) -> float4 {
+        i64 G = ag0 + T;
+        G = G < NG ? G : NG - 1;
+        return *(const float4*)(img + ((((G * NM4 + m4) * 2 + h) * 16 + ar) * 16));
+    };
+    float4 av[NM4];
+    if (ntile > 0) {
+#pragma unroll
+        for (int m4 = 0; m4 < NM4; ++m4) av[m4] = chunk(0, m4);
+    }
+    for (i64 T = 0; T < ntile; ++T) {
+        const i64 left = mylen - T * 16;
+        const i64 Tn = T + 1 < ntile ? T + 1 : T;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int m4 = 0; m4 < NM4; ++m4) {
+                const float4 x = av[m4];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, bq[t][4 * m4 + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, bq[t][4 * m4 + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, bq[t][4 * m4 + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, bq[t][4 * m4 + 3], acc, 0, 0, 0);
+                if (t == QT - 1) av[m4] = chunk(Tn, m4);
+            }
+            const int q = q0w + t * 32 + j;
+            if (q < g.Q && left > 0) {
+                float* out = samp + (i64)q * mstride + (i64)s * g.L + T * 16;       // 64-byte aligned: L and mstride are multiples of 16
+                if (left >= 16) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        ((float4*)out)[r4] = float4{acc[4 * r4] + 0.0f, acc[4 * r4 + 1] + 0.0f, acc[4 * r4 + 2] + 0.0f, acc[4 * r4 + 3] + 0.0f};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) if (r < left) out[r] = acc[r] + 0.0f;
+                }
+            }
         }
     }
 }
