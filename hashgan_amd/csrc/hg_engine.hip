@@ -2279,7 +2279,8 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         HG_TRY(c->samp.reserve((size_t)g.Q * mstride * 4));
         HG_TRY(real_sample(c, M, stride, mstride));
         c->t_begin(KI_REAL_GUESS);
-        hipLaunchKernelGGL(k_real_guess, dim3(g.Q), dim3(256), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
+        if (M <= RG_MMAX) hipLaunchKernelGGL(k_real_guess_lds, dim3(g.Q), dim3(1024), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
+        else hipLaunchKernelGGL(k_real_guess, dim3(g.Q), dim3(256), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
         c->t_end();
         HG_TRY(c->check_launch("k_real_guess"));
         const double mean = budget * (double)R / (double)g.S;

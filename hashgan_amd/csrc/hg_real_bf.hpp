@@ -591,4 +591,50 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
     if (tid == 0) { qbad[q] = bad ? 1u : 0u; if (bad) atomicOr(err, over ? 2 : 1); }
 }
 
+// The guess with the sample in LDS (k_real_guess reads its M samples three times from global memory with 256 threads):
+// 1024 threads copy the query's samples (as order-preserving keys) once, then the same 11 + 11 + 10 bit radix select of
+// the rank_s-th largest runs out of LDS.  M <= RG_MMAX.
+constexpr int RG_MMAX = 16384;
+__global__ __launch_bounds__(1024) void k_real_guess_lds(const float* __restrict__ samp, i64 M, i64 mstride, u32 rank_s,
+                                                         float* __restrict__ thr) {
+    __shared__ u32 keys[RG_MMAX];
+    __shared__ u32 hist[2048];
+    __shared__ u32 s_w[16];
+    __shared__ u32 s_prefix, s_rank;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* __restrict__ col = samp + (i64)q * mstride;
+    if (rank_s > (u32)M) {
+        if (tid == 0) thr[q] = __uint_as_float(0xFF800000u);  // -inf: everything qualifies
+        return;
+    }
+    for (i64 i = tid; i < M; i += 1024) keys[i] = mono_key(col[i]);
+    if (tid == 0) { s_prefix = 0; s_rank = rank_s; }
+    u32 mask = 0;
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        hist[tid] = 0u; hist[tid + 1024] = 0u;
+        __syncthreads();
+        const u32 prefix = s_prefix, need = s_rank, bins = 1u << widths[pass];
+        for (u32 i = tid; i < (u32)M; i += 1024) {
+            const u32 k = keys[i];
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shifts[pass]) & (bins - 1u)], 1u);
+        }
+        __syncthreads();
+        // digits from the largest down: thread t speaks for digits bins - 1 - 2 t and bins - 2 - 2 t
+        const u32 d0 = bins - 1u - 2u * tid, d1 = d0 - 1u;
+        const u32 c0 = 2u * tid < bins ? hist[d0] : 0u, c1 = 2u * tid + 1u < bins ? hist[d1] : 0u;
+        u32 tot;
+        const u32 ex = block_excl_scan_1024(c0 + c1, s_w, tot);
+        if (ex < need && need <= ex + c0) { s_prefix = prefix | (d0 << shifts[pass]); s_rank = need - ex; }
+        else if (ex + c0 < need && need <= ex + c0 + c1) { s_prefix = prefix | (d1 << shifts[pass]); s_rank = need - ex - c0; }
+        __syncthreads();
+        mask |= (bins - 1u) << shifts[pass];
+    }
+    if (tid == 0) {
+        const u32 k = s_prefix;                               // the key of the rank_s-th largest sample
+        thr[q] = k ? mono_inv(k - 1u) : __uint_as_float(0xFF800000u);
+    }
+}
+
 }  // namespace hg
