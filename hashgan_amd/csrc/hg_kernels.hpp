@@ -878,6 +878,9 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
     auto fetch = [&](const Walk& w) -> u64 {
         const u32 i = w.base + lane;
         if (!(w.s < s1 && i < a.cap)) return 0ull;
+        // dense mode: the run ends at tot[q], and the buffer may end with the last query's run -- never read past it
+        // (slice mode reads up to the slice's capacity, which is allocated; the count masks the rest afterwards)
+        if (a.dense && !a.direct && (u32)w.s * a.cap + i >= dense_tot) return 0ull;
         if (a.direct) {
             const i64 n = (i64)w.s * a.cap + i;               // row of the shard
             if (n >= g.N) return 0ull;

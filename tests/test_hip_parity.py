@@ -571,3 +571,18 @@ def test_bet_equals_exact_over_random_shapes():
     for seed in range(44, 64):
         r = fz.one(seed)
         assert r.startswith("ok"), r
+
+
+def test_random_option_combinations_equal_the_exact_sequence():
+    """A slice of tools/fuzz_options.py: random kernel choices, record formats, segment geometries and safety margins thin
+    enough to lose bets, on random shapes; hg_map and hg_topr must equal the vector-ALU exact sequence.  Seed 796 once
+    ended in a memory fault: the rerun of seven lost queries ranked its dense record runs with k_rank_fused, whose
+    read-ahead went up to a chunk's capacity -- past the end of the last query's run, which is where the buffer ends."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_options.py")
+    spec = importlib.util.spec_from_file_location("fuzz_options", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for seed in list(range(790, 800)) + [3, 17, 60]:
+        r = fz.one(seed)
+        assert r.startswith("ok"), r
