@@ -60,26 +60,86 @@ int fail(int code, const char* fmt, ...) {
 // Bumped whenever a device buffer moves: captured graphs hold raw addresses and die with the epoch they were built in.
 unsigned long long g_alloc_epoch = 1;
 
+// HG_EFENCE=1 (debugging): every device buffer ends 64..127 bytes before an UNMAPPED 2 MiB page of its own virtual range
+// (hipMemAddressReserve / hipMemMap), so a kernel reading or writing past a buffer -- beyond the 64 bytes of slack the
+// kernels are allowed -- faults at once instead of only when hipMalloc happens to place the buffer at the end of a mapping;
+// and every new buffer starts out filled with 0xCB, so nothing can rely on fresh memory being zero.  HG_EFENCE=2: the
+// fill only, on plain allocations.  (tools/fuzz_*.py and the gpu tests run under both.)
+struct Fence { void* va = nullptr; size_t va_size = 0, map_size = 0; hipMemGenericAllocationHandle_t h{}; };
+inline int efence_mode() { static const int m = getenv("HG_EFENCE") ? atoi(getenv("HG_EFENCE")) : 0; return m; }
+inline bool efence_on() { return efence_mode() != 0; }
+inline hipError_t fence_alloc(Fence& f, void** out, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;
+    f.map_size = (bytes + gran - 1) / gran * gran;
+    f.va_size = f.map_size + gran;                                   // the last granule stays unmapped
+    e = hipMemAddressReserve(&f.va, f.va_size, gran, nullptr, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemCreate(&f.h, f.map_size, &prop, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemMap(f.va, f.map_size, 0, f.h, 0);
+    if (e != hipSuccess) return e;
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess(f.va, f.map_size, &acc, 1);
+    if (e != hipSuccess) return e;
+    *out = (char*)f.va + ((f.map_size - bytes) & ~(size_t)63);       // 64-byte aligned, ends < 64 bytes before the fence
+    return hipSuccess;
+}
+inline void fence_free(Fence& f) {
+    if (!f.va) return;
+    (void)hipDeviceSynchronize();                                    // hipFree waits for the device; unmapping does not
+    (void)hipMemUnmap(f.va, f.map_size);
+    (void)hipMemRelease(f.h);
+    // (the virtual range is NOT returned: a later buffer at the same address could meet stale cache lines of this one)
+    f = Fence{};
+}
+
 // A device buffer that only ever grows.
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     bool borrowed = false;      // points into another context's allocation
+    Fence fence;                // HG_EFENCE: the buffer's own virtual range
+    void drop() {
+        if (p && !borrowed) { if (fence.va) fence_free(fence); else (void)hipFree(p); }
+    }
     int reserve(size_t bytes) {
         if (bytes <= cap) return HG_OK;
-        if (p && !borrowed) { HG_HIP(hipFree(p)); }
+        drop();
         p = nullptr; cap = 0; borrowed = false;
-        HG_HIP(hipMalloc(&p, bytes + 64));      // slack: 16-byte wide copies may read past the last row of a table
+        // slack: 16-byte wide copies may read past the last row of a table
+        if (efence_mode() == 2) {                           // plain allocation, poisoned
+            HG_HIP(hipMalloc(&p, bytes + 64));
+            HG_HIP(hipMemset(p, 0xCB, bytes + 64));
+            HG_HIP(hipDeviceSynchronize());                  // (the fill runs on the null stream; the context's stream does not wait for it)
+        } else if (efence_on()) {
+            HG_HIP(fence_alloc(fence, &p, bytes + 64));
+            HG_HIP(hipMemset(p, 0xCB, bytes + 64));
+            HG_HIP(hipDeviceSynchronize());
+        } else {
+            HG_HIP(hipMalloc(&p, bytes + 64));
+        }
         cap = bytes;
         ++g_alloc_epoch;
         return HG_OK;
     }
     void borrow(const DevBuf& o) {
-        if (p && !borrowed) (void)hipFree(p);
+        drop();
         if (p != o.p) ++g_alloc_epoch;
         p = o.p; cap = o.cap; borrowed = true;
     }
-    void release() { if (p && !borrowed) (void)hipFree(p); if (p) ++g_alloc_epoch; p = nullptr; cap = 0; borrowed = false; }
+    void release() { drop(); if (p) ++g_alloc_epoch; p = nullptr; cap = 0; borrowed = false; }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -190,7 +250,6 @@ struct hg_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = true;    // false: the stream belongs to the caller (hg_set_stream) or to the parent context
     bool stage_sync = true;    // staged calls synchronise the stream before returning
-    u32 tail_host[TAIL_WORDS] = {0};   // staging for the histogram tail words (must outlive the async copy)
     unsigned stage = ST_NONE;
 
     // problem
@@ -1302,11 +1361,9 @@ static int do_hist(hg_ctx* c, int stride, bool reduce = true, bool pairs_ok = fa
     HG_TRY(c->hown.reserve(plane + TAIL_WORDS * 4));
     if (reduce) {   // tail of the exported histogram: [0] overflow flag, [1] rows this pass visited
         const u32 visited = (u32)(stride == 1 ? g.N : sampled_rows(c, stride));
-        if (c->tail_host[1] != visited) {          // the staging words must not change under a copy in flight
-            HG_HIP(hipStreamSynchronize(c->stream));
-            c->tail_host[1] = visited;
-        }
-        HG_HIP(hipMemcpyAsync(c->hown.as<char>() + plane, c->tail_host, sizeof c->tail_host, hipMemcpyHostToDevice, c->stream));
+        // written by a kernel: ordered with the kernels that read it, no pageable staging memory to keep alive
+        hipLaunchKernelGGL(k_set_tail, dim3(1), dim3(64), 0, c->stream, (u32*)(c->hown.as<char>() + plane), visited);
+        HG_TRY(c->check_launch("k_set_tail"));
     }
     HG_TRY(mx ? launch_hist_mx(c) : launch_hist(c));
     if (!reduce) { c->stage = ST_DB | ST_Q; return HG_OK; }      // the caller reads the per-segment histograms itself

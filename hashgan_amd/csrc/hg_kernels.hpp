@@ -1181,6 +1181,11 @@ __global__ __launch_bounds__(256) void k_match(const u32* __restrict__ out_idx, 
     if ((threadIdx.x & 63) == 0 && (k >> 6) < RW) mbits[(i64)q * RW + (k >> 6)] = word;
 }
 
+// tail of an exported histogram: [0] overflow flag (cleared), [1] rows the pass visited, the rest 0
+__global__ void k_set_tail(u32* __restrict__ tail, u32 visited) {
+    if (threadIdx.x < TAIL_WORDS) tail[threadIdx.x] = threadIdx.x == 1 ? visited : 0u;
+}
+
 // OR of G shards' bit rows (disjoint by construction).
 __global__ __launch_bounds__(256) void k_or_bits(const u64* __restrict__ all, u64* __restrict__ out, i64 n, int G) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
