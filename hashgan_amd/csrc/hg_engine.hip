@@ -64,8 +64,9 @@ unsigned long long g_alloc_epoch = 1;
 // (hipMemAddressReserve / hipMemMap), so a kernel reading or writing past a buffer -- beyond the 64 bytes of slack the
 // kernels are allowed -- faults at once instead of only when hipMalloc happens to place the buffer at the end of a mapping;
 // and every new buffer starts out filled with 0xCB, so nothing can rely on fresh memory being zero.  HG_EFENCE=2: the
-// fill only, on plain allocations.  (tools/fuzz_*.py and the gpu tests run under both.)
-struct Fence { void* va = nullptr; size_t va_size = 0, map_size = 0; hipMemGenericAllocationHandle_t h{}; };
+// fill only, on plain allocations; HG_EFENCE=3: the unmapped page in FRONT of every buffer.  (tools/fuzz_*.py and the gpu
+// tests run under all three.)
+struct Fence { void* va = nullptr; void* map_at = nullptr; size_t va_size = 0, map_size = 0; hipMemGenericAllocationHandle_t h{}; };
 inline int efence_mode() { static const int m = getenv("HG_EFENCE") ? atoi(getenv("HG_EFENCE")) : 0; return m; }
 inline bool efence_on() { return efence_mode() != 0; }
 inline hipError_t fence_alloc(Fence& f, void** out, size_t bytes) {
@@ -86,20 +87,23 @@ inline hipError_t fence_alloc(Fence& f, void** out, size_t bytes) {
     if (e != hipSuccess) return e;
     e = hipMemCreate(&f.h, f.map_size, &prop, 0);
     if (e != hipSuccess) return e;
-    e = hipMemMap(f.va, f.map_size, 0, f.h, 0);
+    // HG_EFENCE=3: the unmapped granule comes FIRST and the buffer starts right behind it (reads before a buffer)
+    const bool front = efence_mode() == 3;
+    f.map_at = (char*)f.va + (front ? gran : 0);
+    e = hipMemMap(f.map_at, f.map_size, 0, f.h, 0);
     if (e != hipSuccess) return e;
     hipMemAccessDesc acc{};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    e = hipMemSetAccess(f.va, f.map_size, &acc, 1);
+    e = hipMemSetAccess(f.map_at, f.map_size, &acc, 1);
     if (e != hipSuccess) return e;
-    *out = (char*)f.va + ((f.map_size - bytes) & ~(size_t)63);       // 64-byte aligned, ends < 64 bytes before the fence
+    *out = front ? f.map_at : (char*)f.va + ((f.map_size - bytes) & ~(size_t)63);       // 64-byte aligned, ends < 64 bytes before the fence
     return hipSuccess;
 }
 inline void fence_free(Fence& f) {
     if (!f.va) return;
     (void)hipDeviceSynchronize();                                    // hipFree waits for the device; unmapping does not
-    (void)hipMemUnmap(f.va, f.map_size);
+    (void)hipMemUnmap(f.map_at, f.map_size);
     (void)hipMemRelease(f.h);
     // (the virtual range is NOT returned: a later buffer at the same address could meet stale cache lines of this one)
     f = Fence{};
