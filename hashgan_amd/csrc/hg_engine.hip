@@ -1521,13 +1521,16 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
         i64 r2 = (i64)(2.5 * (double)c->R * share) + 256;         // a tile of the records: the usual list (1.3 - 2 R) in one
         if (r2 < 4096) r2 = 4096;                                  // (small R: the guess's margin is relatively larger)
         r2 = r2 / 64 * 64;
-        RankCntLds L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0);
-        while (L.total > 64 * 1024 && r2 > 64) { r2 -= 64; L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0); }
+        // a one-shot bet's guess stops below b/2 + 2 (enqueue_optimistic), so its records need no counters beyond: the
+        // block fits 32 KB and five of them a CU; a query with farther records (thin sample: everything taken) goes to k_rank_fused
+        const int nbc = (mode == 0 && !c->exact_mx && c->G == 1) ? g.NB / 2 + 2 : 0;
+        RankCntLds L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0, nbc);
+        while (L.total > 64 * 1024 && r2 > 64) { r2 -= 64; L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0, nbc); }
         if (L.total <= 64 * 1024 && r2 >= 4096) {
             HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
             RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
                            c->cap, c->crow, c->want_lists ? 1 : 0, c->rec8 ? 1 : 0, c->RW, (int)r2, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
-                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>()};
+                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc};
             c->t_begin(KI_RANK_LDS);
             hipLaunchKernelGGL(k_rank_cnt, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, c->cand.as<u64>(), la, c->out_idx.as<u32>(),
                                c->out_dist.as<u8>(), c->mbits.as<u32>(), g);
@@ -1543,7 +1546,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
             if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
             RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
                            c->cap, c->crow, c->want_lists ? 1 : 0, c->rec8 ? 1 : 0, c->RW, (int)recs, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
-                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>()};
+                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), 0};
             const size_t lb = fixed + (size_t)recs * per_rec;
             c->t_begin(KI_RANK_LDS);
             hipLaunchKernelGGL(k_rank_lds<4>, dim3(g.Q), dim3(256), lb, c->stream, c->cand.as<u64>(), la, c->out_idx.as<u32>(),

@@ -25,11 +25,12 @@ namespace hg {
 inline __host__ __device__ int rank_cnt_maxb(int NB) { return NB <= 65 ? 16 : 32; }    // distances a ranked list may span on this path
 
 struct RankCntLds { int cnt, off, tot, misc, wsum, bm, pref, rec, idx, total; };     // byte offsets
-__host__ __device__ inline RankCntLds rank_cnt_layout(int NB, i64 RW, int S, int recs, int want_lists) {
+__host__ __device__ inline RankCntLds rank_cnt_layout(int NB, i64 RW, int S, int recs, int want_lists, int nbc = 0) {
     RankCntLds l;
     const int RC_MAXB = rank_cnt_maxb(NB);
     l.cnt = 0;                                   // [NB][64] u32: byte counter of thread 4 i + j = byte j of dword i
-    l.off = l.cnt + (NB < 128 ? NB : 128) * 256; // (distances beyond 127 never reach this path)   [RC_MAXB + 1][128] u32: 16-bit offset of thread 2 i + j = half j of dword i
+    const int NBc = nbc > 0 && nbc < (NB < 128 ? NB : 128) ? nbc : (NB < 128 ? NB : 128);
+    l.off = l.cnt + NBc * 256;                   // (distances beyond the counters never reach this path)   [RC_MAXB + 1][128] u32: 16-bit offset of thread 2 i + j = half j of dword i
     l.tot = l.off + (RC_MAXB + 1) * 512;         // [NB] u32   (offsets row RC_MAXB is a dummy: records beyond the cut add there)
     l.misc = l.tot + NB * 4;                     // [8] u32
     l.wsum = l.misc + 32;                        // [8] u32, then done[32] and tilecnt[32] (several tiles: per-bucket progress)
@@ -41,7 +42,7 @@ __host__ __device__ inline RankCntLds rank_cnt_layout(int NB, i64 RW, int S, int
     return l;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rank_cnt(const u64* __restrict__ cand, const RankLdsArgs a,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_rank_cnt(const u64* __restrict__ cand, const RankLdsArgs a,
                                                   u32* __restrict__ out_idx, u8* __restrict__ out_dist,
                                                   u32* __restrict__ mbits32, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 rlds[];
@@ -50,11 +51,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NB = g.NB, S = g.S;
-    const int NBc = NB < 128 ? NB : 128;             // distances that have counters (records beyond 127 leave this path)
+    const int NBall = NB < 128 ? NB : 128;
+    const int NBc = a.nbc > 0 && a.nbc < NBall ? a.nbc : NBall;   // distances that have counters (records beyond them leave this path)
     constexpr int nthr = 256, NWAV = 4;
     const int RC_MAXB = rank_cnt_maxb(NB);
     const int bmw = (int)(2 * a.RW);
-    const RankCntLds L = rank_cnt_layout(NB, a.RW, S, a.lds_recs, a.want_lists);
+    const RankCntLds L = rank_cnt_layout(NB, a.RW, S, a.lds_recs, a.want_lists, a.nbc);
     u32* cnt32 = (u32*)(rlds + L.cnt);
     u32* off32 = (u32*)(rlds + L.off);
     u32* tot = (u32*)(rlds + L.tot);
@@ -249,7 +251,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const u32 d = (v >> (8 * j)) & 0x7Fu;
-                if (i + j < i1 && d < (u32)NBc) atomicAdd(&cnt32[d * 64 + (tid >> 2)], one);
+                if (i + j < i1) {
+                    if (d < (u32)NBc) atomicAdd(&cnt32[d * 64 + (tid >> 2)], one);
+                    else misc[7] = 1u;                                   // a distance without a counter: the general kernel
+                }
             }
         }
     };
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }        // a distance beyond 127: the general kernel
         count_tile(n);
         __syncthreads();
+        if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }
         add_totals();
         __syncthreads();
     } else {
@@ -288,6 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }
             count_tile(T1 - T0);
             __syncthreads();
+            if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }
             add_totals();
             __syncthreads();
             zero_counters();

@@ -36,6 +36,7 @@ struct RankLdsArgs {
     const u32* xquota;
     const u32* xtie_before;
     const u32* xposbase;   // [NB][Qpad]
+    int nbc;               // k_rank_cnt: distances that have counters (0: all up to 127); a record beyond them sends the query to k_rank_fused
 };
 
 template <int NWAV>
