@@ -589,6 +589,13 @@ template <int NW> int ensure_mx_images(hg_ctx* c) {
 // histogram on the matrix cores: blocks = (pair of segments) x (256 queries); stride in tiles of 16 rows
 bool hist_mx_applies(const hg_ctx* c, int stride, bool pairs_ok) {
     if (!c->opt_hist_mfma || !c->opt_select_mfma || c->NW > 8 || c->is_sub) return false;
+    {   // long segments (>= 65536 visited rows per pair) need one dword counter per query tile: with long codes the four
+        // wavefronts' columns then exceed the CU's LDS -- the vector kernel, which shrinks its block, takes those
+        const Geo& g = c->geo;
+        const i64 tiles_per_half = ((g.L + 15) / 16 + stride - 1) / stride;
+        const bool pack16 = 2 * tiles_per_half * 16 < 65536;
+        if ((size_t)WPB * (pack16 ? 1 : 2) * g.NB * 32 * 4 > 160u * 1024u) return false;
+    }
     return stride > 1 ? c->opt_sample_ratio == 2 : pairs_ok;
 }
 template <int NW> int launch_hist_mx_t(hg_ctx* c) {

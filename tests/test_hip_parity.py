@@ -586,3 +586,29 @@ def test_random_option_combinations_equal_the_exact_sequence():
     for seed in list(range(790, 800)) + [3, 17, 60]:
         r = fz.one(seed)
         assert r.startswith("ok"), r
+
+
+def test_long_codes_in_long_segments_use_the_vector_histogram():
+    """Codes of 200 bits in segments of > 32768 rows: the matrix-core histogram would need one dword counter per query tile
+    and distance for four wavefronts -- more LDS than a CU has (the launch once failed with 'invalid argument');
+    hist_mx_applies must hand such geometries to the vector kernel.  Bet and exact sequence against the oracle's AP."""
+    rng = np.random.default_rng(200)
+    Q, N, b, R, C = 40, 250000, 200, 300, 5
+    db = (rng.random((N, b)) < 0.5).astype(np.uint8)
+    qb = (rng.random((Q, b)) < 0.5).astype(np.uint8)
+    dl = (rng.random((N, C)) < 0.3).astype(np.int8)
+    ql = (rng.random((Q, C)) < 0.3).astype(np.int8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb, db, ql, dl, R)
+    ctx = _native.Context(0)
+    try:
+        ctx.set_option("max_segments", 7)
+        ctx.set_option("target_units", 64)
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        for optimistic in (1, 0):
+            ctx.set_option("optimistic", optimistic)
+            ap, rel = ctx.map(R)
+            assert np.array_equal(ap, ap_ref, equal_nan=True), optimistic
+    finally:
+        ctx.close()
