@@ -627,9 +627,9 @@ template <int NW> int launch_hist_mx_t(hg_ctx* c) {
 
 template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c);
 template <int NW, int LW> int launch_select_mx_t(hg_ctx* c) {
-    // codes of up to 128 bits: two query tiles per wavefront, 4 wavefronts per SIMD; longer codes need the registers of the
-    // 2-waves-per-SIMD variant (B fragments: 4 per query tile and 64 bits) and take four tiles
-    constexpr int QT = NW <= 4 ? 2 : 4;
+    // two query tiles per wavefront; codes of up to 128 bits run 4 wavefronts per SIMD, longer codes need the registers of
+    // the 2-waves-per-SIMD variant (B fragments: 4 per query tile and 64 bits) -- window lengths: mx_wt()
+    constexpr int QT = mx_qt(NW);
     return c->rec8 ? launch_select_mx_q<NW, LW, QT, true>(c) : launch_select_mx_q<NW, LW, QT, false>(c);
 }
 template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c) {

@@ -25,8 +25,8 @@
 // by the same expand_word() below.
 //
 // Data movement.  A block = 4 wavefronts = one segment pair x 128 QT queries (QT tiles of 32
-// per wave; QT = 2 by default, 4 for codes longer than 128 bits whose B fragments need the
-// registers).  The database streams through LDS in windows of 8 row tiles (128 rows per half): the
+// per wave; QT = 2).  The database streams through LDS in windows of 8 row tiles (128 rows per half; 4 tiles for
+// codes longer than 64 bits -- mx_wt() below): the
 // fp4 image of the rows (A fragments, lane-linear) plus their packed codes and labels (for the
 // drain's exact distance and match bit) are copied global -> LDS by direct-to-LDS loads, one
 // window ahead, shared by the four waves; one barrier per window.  Hits leave through a
@@ -43,6 +43,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MX_WT = 8;                // row tiles per window
 constexpr int MX_WROWS = 16 * MX_WT;    // rows per lane-half per window
+// Window length and query tiles by code length.  What decides is how many blocks a CU holds (160 KB of LDS): with 8-tile
+// windows a block of 65..128-bit codes (two MFMAs per tile, twice the image) needs 62 KB -- two per CU, 2 wavefronts per
+// SIMD -- and four query tiles of 129..256-bit codes 124 KB, one per CU.  Windows of 4 tiles bring the former back to
+// 40 KB (four per CU: C5 1.59 -> 1.08 ms), and two query tiles + 4-tile windows the latter to 64 KB (two per CU, the
+// 256 registers of 2 wavefronts per SIMD: b = 255 4.72 -> 1.87 ms).  A 4-tile window is one half-window drain.
+#ifndef HG_MX_WT_LONG
+#define HG_MX_WT_LONG 4
+#endif
+#ifndef HG_MX_WT_XL
+#define HG_MX_WT_XL 4
+#endif
+#ifndef HG_MX_QT_XL
+#define HG_MX_QT_XL 2
+#endif
+__host__ __device__ constexpr int mx_wt(int NW) { return NW <= 2 ? MX_WT : NW <= 4 ? HG_MX_WT_LONG : HG_MX_WT_XL; }
+__host__ __device__ constexpr int mx_qt(int NW) { return NW <= 4 ? 2 : HG_MX_QT_XL; }
 
 // 8 code bits -> 8 nibbles, bit j at bit 4 j
 __device__ __forceinline__ u32 spread8(u32 y) {
@@ -103,6 +119,7 @@ struct MxLds {                 // byte offsets inside the block's dynamic LDS
 __host__ __device__ inline MxLds mx_lds_layout(int NW, int LW, int QT, bool compact) {
     const int QBLK = WPB * 32 * QT;            // queries per block
     const int NM = (NW + 1) / 2;
+    const int MX_WT = mx_wt(NW), MX_WROWS = 16 * MX_WT;
     MxLds l;
     l.a = 0;
     l.codes = MX_WT * NM * 1024;
@@ -122,11 +139,11 @@ __host__ __device__ inline MxLds mx_lds_layout(int NW, int LW, int QT, bool comp
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
 // Geo as set by the launcher: g.nQT = query blocks (of 128 QT queries) per segment pair, g.nBlk = blocks.
-// QT: query tiles (of 32) per wavefront -- 4: 512 queries per block, ~180 VGPRs, 2 wavefronts per SIMD;
-//     2: 256 queries per block, 4 wavefronts per SIMD.
+// QT: query tiles (of 32) per wavefront -- 2: 256 queries per block (what the launcher picks, mx_qt(); codes of up to 128
+//     bits run 4 wavefronts per SIMD in 128 registers, longer ones 2 per SIMD); 4: 512 queries per block (HG_MX_QT_XL = 4).
 // COMPACT: one-byte records through per-slice LDS rings (AP only -- hg_mx_drain.hpp); else 8-byte records with the index.
 template <int NW, int LW, int QT, bool COMPACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QT == 4 ? 2 : 4, QT == 4 ? 2 : 4)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW > 4 ? 2 : 4, NW > 4 ? 2 : 4)))
 void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const u8* __restrict__ qx,
                  const u32* __restrict__ db, const u8* __restrict__ dbx, const u64* __restrict__ dblab,
                  const SelArgs a, u64* __restrict__ cand, const Geo g) {
@@ -135,6 +152,7 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
     constexpr int NM = (NW + 1) / 2;
     constexpr int CB = NW * 4, LB = LW * 8;
     constexpr int LWA = LW > 0 ? LW : 1;
+    constexpr int MX_WT = mx_wt(NW), MX_WROWS = 16 * MX_WT, NWORD = MX_WT / 2;     // (shadow the defaults: this code length's window)
     const MxLds L = mx_lds_layout(NW, LW, QT, COMPACT);
 
     const int lb = logical_block(g.nBlk);
@@ -255,9 +273,11 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         if (win + 1 < nwin) stage_window(win + 1, buf ^ 1);
         const u8* st = mxlds + buf * L.stage;
 
-        u32 m[QT][4];
+        u32 m[QT][NWORD];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) { m[t][0] = 0; m[t][1] = 0; m[t][2] = 0; m[t][3] = 0; }
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int w = 0; w < NWORD; ++w) m[t][w] = 0;
         i32x4 acur[NM], anext[NM];
         load_a(acur, st, 0);
         f32x16 accn = issue(acur, 0);
@@ -283,7 +303,7 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         const i64 left = mylen - win * MX_WROWS;                     // valid rows of this lane in the window
         if (left < MX_WROWS) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NWORD; ++c) {
                 const i64 v = left - 32 * c;                         // valid rows among the 32 of mask word c
                 const u32 keep = v >= 32 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ~(0xFFFFFFFFu >> (int)v));
 #pragma unroll
@@ -292,9 +312,10 @@ void k_select_mx(const u32* __restrict__ qc, const u64* __restrict__ qlab, const
         }
         if (kProbes && (a.probe & 2)) {                                      // measurement probe: no drain
 #pragma unroll
-            for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][3] == 0x1234567u) dr.flags |= 0x100u << t;
+            for (int t = 0; t < QT; ++t) if (m[t][0] == 0x12345678u && m[t][NWORD - 1] == 0x1234567u) dr.flags |= 0x100u << t;
         } else {
-            dr.drain_window(m, win, st);
+            if constexpr (NWORD == 4) dr.drain_window(m, win, st);
+            else dr.drain(m, 0, win, st);                            // a 64-row window is one half-window drain
         }
     }
     dr.finish();
