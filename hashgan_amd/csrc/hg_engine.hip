@@ -330,7 +330,7 @@ struct hg_ctx {
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
     DevBuf mbits2;             // hg_merge_ranked's output (swapped with mbits)
     bool ranked_local = false; // mbits holds this shard's bitmap in LOCAL rank order (hg_select_ranked)
-    DevBuf cand, out_idx, out_dist, mbits, shapes, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
+    DevBuf cand, out_idx, out_dist, mbits, shapes, ap_recip, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
     DevBuf dbfx;               // float features of the database in MFMA A-fragment order (k_real_select_mx), built on first use
     bool dbfx_valid = false;
@@ -353,6 +353,8 @@ struct hg_ctx {
     bool dbf_resident = false, qf_resident = false;   // float tables as loaded: entries outside {-1,0,+1}, zeros, minus ones
     bool real_lists = false;
     i64 shapes_for_R = -1;
+    i64 recip_for_R = -1;      // ap_recip holds RN(1 / k) for k = 1 .. this
+    i64 opt_ap_recip = 1;      // "ap_recip": k_ap divides through the table of reciprocals (bit for bit the division; 0: divide)
 
     // collectives (RCCL over xGMI), one communicator per context; gathered[] are the landing zones of hg_allgather
     ncclComm_t comm = nullptr;
@@ -1138,7 +1140,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->sampx};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->sampx, &c->ap_recip};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -1682,11 +1684,20 @@ static int do_ap(hg_ctx* c) {
         HG_HIP(hipStreamSynchronize(c->stream));   // sh goes out of scope
         c->shapes_for_R = g.R;
     }
+    // reciprocals of the ranks 1 .. R (k_ap's division in three multiply-adds); lists beyond 2^20 divide
+    const bool use_recip = c->opt_ap_recip && g.R <= (1ll << 20);
+    if (use_recip && c->recip_for_R != g.R) {
+        HG_TRY(c->ap_recip.reserve((size_t)(g.R + 1) * 8));
+        hipLaunchKernelGGL(k_recip_table, dim3(grid_for(g.R + 1)), dim3(256), 0, c->stream, c->ap_recip.as<double>(), (i64)g.R);
+        HG_TRY(c->check_launch("k_recip_table"));
+        c->recip_for_R = g.R;
+    }
     HG_TRY(c->ap.reserve((size_t)g.Q * 8));
     HG_TRY(c->rel.reserve((size_t)g.Q * 4));
     c->t_begin(KI_AP);
     hipLaunchKernelGGL(k_ap, dim3(g.Q), dim3(AP_THREADS), 0, c->stream, c->mbits.as<u64>(), c->RW, g.R,
-                       c->shapes.as<ApShape>(), c->ap.as<double>(), c->rel.as<u32>());
+                       c->shapes.as<ApShape>(), use_recip ? c->ap_recip.as<double>() : (const double*)nullptr,
+                       c->ap.as<double>(), c->rel.as<u32>());
     c->t_end();
     HG_TRY(c->check_launch("k_ap"));
     c->stage |= ST_AP;
@@ -2750,6 +2761,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "hist_mfma")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "hist_mfma must be 0, 1 or 2");
         c->opt_hist_mfma = value;
+    } else if (!strcmp(key, "ap_recip")) {
+        c->opt_ap_recip = value != 0;
     } else if (!strcmp(key, "exact_mfma")) {
         c->opt_exact_mfma = value != 0;
     } else if (!strcmp(key, "select_mfma")) {
@@ -2817,7 +2830,8 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err,
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
-                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2};
+                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2,
+                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->sampx, &c->ap_recip};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
         *value = total;

@@ -238,7 +238,9 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * "hist_mfma" (histogram passes -- the sampled pass of the bet, the full pass of the one-shot exact sequence: 2, default:
  * the integer matrix instruction delivers the counter addresses, k_hist_i8, codes of <= 128 bits; 1: fp4 distances,
  * k_hist_mx; 0: vector ALU), "exact_mfma" (1, default: the one-shot exact sequence selects on the matrix cores when
- * R << N), "lds_pad" (extra LDS per block of the matrix-core select: occupancy experiments),
+ * R << N), "ap_recip" (1, default: the AP kernel replaces its division by three multiply-adds against a table of
+ * correctly rounded reciprocals of the ranks -- the same bits; 0: divide), "lds_pad" (extra LDS per block of the
+ * matrix-core select: occupancy experiments),
  * "real_mfma" (real-valued select pass -- 2, default: bfloat16 matrix-core filter with a rigorous margin, then the exact
  * float32 chain for the rows it keeps; 1: every pair exactly on the float32 matrix-core instruction; 0: vector ALU; same
  * lists either way), "real_sort_lds" (1, default: after the filter a query's records are ranked by one LDS-resident

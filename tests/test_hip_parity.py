@@ -612,3 +612,29 @@ def test_long_codes_in_long_segments_use_the_vector_histogram():
             assert np.array_equal(ap, ap_ref, equal_nan=True), optimistic
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("R", [1, 7, 129, 5000, 8192, 8193, 20000])
+def test_ap_through_reciprocals_equals_the_division(R):
+    """k_ap's px[k] = cumsum / (k + 1) (metric.py:21) as three multiply-adds against a table of correctly rounded
+    reciprocals: the same float64 bits as the division, and as the oracle's, across chunk boundaries of np.sum (8192)."""
+    rng = np.random.default_rng(R)
+    Q, N, b, C = 64, 70000, 32, 4
+    db = (rng.random((N, b)) < 0.5).astype(np.uint8)
+    qb = (rng.random((Q, b)) < 0.5).astype(np.uint8)
+    dl = (rng.random((N, C)) < 0.3).astype(np.int8)
+    ql = (rng.random((Q, C)) < 0.3).astype(np.int8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb, db, ql, dl, R)
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        got = {}
+        for v in (0, 1):
+            ctx.set_option("ap_recip", v)
+            got[v], _ = ctx.map(R)
+        assert np.array_equal(got[0], got[1], equal_nan=True)
+        assert np.array_equal(got[1], ap_ref, equal_nan=True)
+    finally:
+        ctx.close()
