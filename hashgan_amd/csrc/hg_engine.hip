@@ -2081,6 +2081,8 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
         hipLaunchKernelGGL(k_guess_direct<P>, dim3(grid_for(g.Qpad, WPB * (64 / P))), dim3(256), 0, c->stream,          \
                            c->hist.as<u32>(), gh.S, ratio, (double)c->opt_sigma, (i64)c->n_total, srows,                \
                            c->tguess.as<int>(), c->sstar.as<int>(), c->failq.as<u32>(), c->err.as<int>(), g)
+        // (more lanes per query shorten a lane's share of a plane but scatter a wavefront's loads over more lines: with 64
+        // lanes for every query that the chip has room for, Q = 1000 went 0.068 -> 0.090 ms, C3 0.032 -> 0.061)
         if (gh.S <= 64) HG_GUESS(4);
         else if (gh.S <= 512) HG_GUESS(16);
         else HG_GUESS(64);
