@@ -196,7 +196,7 @@ def kernel_rooflines(timing, spec, rows, step_s, rec_bytes=1):
     return roof, out
 
 
-def h2d_inclusive(spec, packed, reps=3):
+def h2d_inclusive(spec, packed, reps=10):
     """The drop-in call itself, from HOST arrays as forward_all() returns them (float32 +-1 features, int64 labels):
     MAPs(R).get_maps_by_feature(database, query) packs them with a pool of host threads (hg_host_pack.hpp), uploads
     the packed tables over PCIe, then runs the step.  Never `value`."""
@@ -208,7 +208,8 @@ def h2d_inclusive(spec, packed, reps=3):
     q = types.SimpleNamespace(output=unpack_bits(qw, b).astype(np.float32) * 2 - 1, label=unpack_bits(ql, C).astype(np.int64))
     m = MAPs(R)
     try:
-        val = m.get_maps_by_feature(db, q)              # first call: allocations
+        for _ in range(3):                              # first calls: allocations, the packing threads, host clocks
+            val = m.get_maps_by_feature(db, q)
         t0 = time.perf_counter()
         for _ in range(reps):
             val = m.get_maps_by_feature(db, q)
@@ -223,7 +224,7 @@ def h2d_inclusive(spec, packed, reps=3):
     Q = qw.shape[0]
     host_bytes = db.output.nbytes + db.label.nbytes + q.output.nbytes + q.label.nbytes
     return {"call": "MAPs(R).get_maps_by_feature(database, query) from host float32 features + int64 labels",
-            "ms_per_call": full * 1e3, "queries_per_sec": Q / full, "host_array_bytes": host_bytes,
+            "calls_timed": reps, "ms_per_call": full * 1e3, "queries_per_sec": Q / full, "host_array_bytes": host_bytes,
             "bytes_over_pcie": int(dw.nbytes + dl.nbytes + qw.nbytes + ql.nbytes),
             "with_resident_database": {"call": "MAPs.set_database(database) once, then get_maps_by_feature(None, query)",
                                        "ms_per_call": resident * 1e3, "queries_per_sec": Q / resident},

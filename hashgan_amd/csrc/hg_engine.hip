@@ -347,7 +347,7 @@ struct hg_ctx {
     // hand-over of float32 / int64 arrays: packed on the host by a thread pool before the upload (hg_host_pack.hpp)
     i64 opt_host_pack = 1;     // "host_pack": 0 = upload the raw arrays and pack on the GPU (k_pack_*)
     i64 opt_keep_floats = 2;   // "keep_floats": database float table on the GPU -- 0 never, 1 always, 2 only if it is not a +-1 code
-    i64 opt_pack_threads = 0;  // "pack_threads": 0 = up to 32
+    i64 opt_pack_threads = 0;  // "pack_threads": 0 = from the hardware (up to 96)
     void* hpk = nullptr;       // pinned staging for the packed tables
     size_t hpk_cap = 0;
     bool dbf_resident = false, qf_resident = false;   // float tables as loaded: entries outside {-1,0,+1}, zeros, minus ones
