@@ -24,7 +24,7 @@ void host_pack(const float* x, const int64_t* lab, long long n, int b, int C, ui
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
-#include <unistd.h>
+#include <pthread.h>
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -126,17 +126,15 @@ namespace hostpack {
 
 // Workers that outlive a call: starting and joining 31 threads cost 0.5 ms of a 4 ms call at C2 (17 us each on the GPU
 // box's EPYC).  One job at a time (a second caller in another thread finds the pool busy and starts threads of its own,
-// as every call did before).  The pool is never torn down (its workers sleep until the process ends); the workers of
-// a process that forked do not exist in the child, which starts new ones.
+// as every call did before).
 class Pool {
 public:
     template <class F> bool run(int parts, const F& f) {                  // f(0) .. f(parts - 1), the caller takes part; false: busy
         std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
         if (!job.owns_lock()) return false;
-        if (pid_ != getpid()) { th_ = new std::vector<std::thread>(); pid_ = getpid(); }      // forked child (the old vector is abandoned)
-        while ((int)th_->size() < parts - 1) {
+        while ((int)th_.size() < parts - 1) {
             const unsigned long long seen = gen_;                         // (gen_ only changes under job_mu_)
-            th_->emplace_back([this, seen] { worker(seen); });
+            th_.emplace_back([this, seen] { worker(seen); });
         }
         struct Ctx { const F* f; } ctx{&f};
         {
@@ -148,7 +146,10 @@ public:
             ++gen_;
             next_.store((gen_ << 32) | 1ull);                             // {generation, next part}: a late worker cannot claim a part of a newer job
         }
-        cv_work_.notify_all();
+        // wake as many workers as there are parts for them (a small job -- the queries of a resident database: 3 parts --
+        // must not stampede a hundred sleepers through the mutex; those left asleep join a later job with a stale `seen`)
+        if (2 * (parts - 1) >= (int)th_.size()) cv_work_.notify_all();
+        else for (int i = 1; i < parts; ++i) cv_work_.notify_one();
         f(0);
         const unsigned long long mine = gen_ & 0xFFFFFFFFull;
         int done = 0;                                                     // the caller takes what the workers have not claimed yet
@@ -187,15 +188,28 @@ private:
     }
     std::mutex job_mu_, mu_;
     std::condition_variable cv_work_, cv_done_;
-    std::vector<std::thread>* th_ = new std::vector<std::thread>();
+    std::vector<std::thread> th_;
     void (*call_)(void*, int) = nullptr;
     void* arg_ = nullptr;
     int parts_ = 0, left_ = 0;
     std::atomic<unsigned long long> next_{0};
     unsigned long long gen_ = 0;
-    pid_t pid_ = getpid();
 };
-inline Pool& pool() { static Pool* p = new Pool; return *p; }
+// The pool is never torn down (its workers sleep until the process ends).  A forked child has none of the workers and must
+// not touch the parent's mutexes and condition variables (a broadcast on the copy of one with sleepers never returns):
+// the fork handler drops the pointer, the child's first call builds a pool of its own.
+inline std::atomic<Pool*>& pool_slot() { static std::atomic<Pool*> slot{nullptr}; return slot; }
+inline Pool& pool() {
+    static const int at_fork = pthread_atfork(nullptr, nullptr, +[] { pool_slot().store(nullptr); });
+    (void)at_fork;
+    Pool* p = pool_slot().load(std::memory_order_acquire);
+    if (!p) {
+        Pool* fresh = new Pool;                                           // (no threads yet: they start with the first job)
+        if (pool_slot().compare_exchange_strong(p, fresh)) p = fresh;
+        else delete fresh;
+    }
+    return *p;
+}
 
 }  // namespace hostpack
 
