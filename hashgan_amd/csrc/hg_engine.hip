@@ -8,6 +8,7 @@
 #include "hg_rank_lds.hpp"
 #include "hg_rank_cnt.hpp"
 #include "hg_select_mx2.hpp"
+#include "hg_select_mx3.hpp"
 #include "hg_real_mx.hpp"
 #include "hg_real_bf.hpp"
 #include "hg_hist_i8.hpp"
@@ -279,7 +280,8 @@ struct hg_ctx {
     i64 opt_rank_waves = 0;    // k_rank_fused wavefronts per query: 0 = by list length, else 4 or 16
     i64 opt_select_mfma = 1;   // optimistic select: 1 = matrix-core kernel (k_select_mx), 0 = vector-ALU k_select
     i64 opt_probe = 0;         // measurement probes of the matrix-core select kernels (SelArgs::probe)
-    i64 opt_select_packed = 1; // codes of <= 64 bits: k_select_mx2 (two distances per MFMA accumulator)
+    i64 opt_select_packed = 3; // codes of <= 64 bits, several distances per MFMA accumulator: 1 = k_select_mx2 (two) for <= 32 bits,
+                               // 2 = k_select_mx2 up to 64 bits, 3 = 1 + k_select_mx3 (three, batched drain) for 33..64 bits with compact records
     i64 opt_sample_ratio = 2;  // the sampled pass works on segments this many times longer than the select pass's
     i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
@@ -306,6 +308,8 @@ struct hg_ctx {
     bool dbx2_valid = false, qx2_valid = false;
     DevBuf dbx8;               // i8 image of the database codes in A-fragment order (k_hist_i8), built on first use
     bool dbx8_valid = false;
+    DevBuf dbx3;               // fp4 image for k_select_mx3 (48-row supertiles, three rows per accumulator), built on first use
+    bool dbx3_valid = false;
     bool direct_rank = false;  // R = N: k_rank_fused computes distance and match bit per row itself (no records)
     i64 opt_hist_mfma = 2;     // "hist_mfma": histograms (sampled pass; full pass of the one-shot exact sequence) on the matrix cores -- 2: the integer instruction delivers the counter address (k_hist_i8, codes of <= 128 bits), 1: fp4 distances (k_hist_mx), 0: vector ALU
     bool hist_pairs = false;   // the last FULL histogram pass ran per segment pair (k_hist_mx)
@@ -484,8 +488,9 @@ void make_geometry(hg_ctx* c) {
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     i64 L = (c->N + S - 1) / S;
-    L = (L + 31) / 32 * 32;                            // k_select_mx2 walks segments in 32-row tiles
-    if (L < 32) L = 32;
+    const i64 lq = (c->opt_select_packed == 3 && c->NW == 2) ? 96 : 32;   // k_select_mx2 walks segments in 32-row tiles, k_select_mx3 in 48-row supertiles
+    L = (L + lq - 1) / lq * lq;
+    if (L < lq) L = lq;
     S = (c->N + L - 1) / L;
     if (S < 1) S = 1;
     if (c->opt_enable && c->opt_select_mfma && S >= 4) {
@@ -501,7 +506,7 @@ void make_geometry(hg_ctx* c) {
         if (S2 > maxS) S2 = maxS / 2 * 2;
         for (; S2 >= 4; S2 -= 2) {                 // rounding L up to 16 rows can drop segments: land on an even count
             i64 L2 = (c->N + S2 - 1) / S2;
-            L2 = (L2 + 31) / 32 * 32;
+            L2 = (L2 + lq - 1) / lq * lq;
             const i64 Sr = (c->N + L2 - 1) / L2;
             if (Sr * 4 < S * 3) break;             // too far from the target: keep the plain choice
             if (Sr % 2 == 0 && Sr * 4 <= S * 5 && (Sr / 2) * nQB <= slots * k) { S = Sr; L = L2; break; }
@@ -710,6 +715,41 @@ template <int NW, int LW, bool COMPACT> int launch_select_mx2_c(hg_ctx* c) {
     return c->check_launch("k_select_mx2");
 }
 
+// codes of 33..64 bits, compact records: three rows per accumulator and the batched drain (k_select_mx3);
+// blocks = (pair of segments) x (256 queries); the query image is k_select_mx's
+template <int NW, int LW> int launch_select_mx3_t(hg_ctx* c) {
+    HG_TRY(ensure_mx_images<NW>(c));
+    if (!c->dbx3_valid) {
+        const i64 n48 = (c->N + M3_ROWS - 1) / M3_ROWS * M3_ROWS;
+        HG_TRY(c->dbx3.reserve((size_t)(n48 > 0 ? n48 : M3_ROWS) * 32));
+        const i64 items = n48 * 2;
+        c->t_begin(KI_PACK);
+        if (items) hipLaunchKernelGGL(k_expand_db3, dim3(grid_for(items)), dim3(256), 0, c->stream, c->db.as<u32>(),
+                                      c->dbx3.as<uint4>(), (i64)c->N, n48, NW);
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_db3"));
+        c->dbx3_valid = true;
+    }
+    Geo g = c->geo;
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + 255) / 256;
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    const Mx3Lds L = mx3_lds_layout(NW, LW);
+    if (L.total > 64 * 1024)
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx3<NW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
+              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
+    c->t_begin(KI_SELECT_MX);
+    hipLaunchKernelGGL((k_select_mx3<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total + (size_t)c->opt_lds_pad, c->stream, c->qc.as<u32>(),
+                       c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx3.as<u8>(), c->dblab.as<u64>(), a,
+                       c->cand.as<u8>(), g);
+    c->t_end();
+    return c->check_launch("k_select_mx3");
+}
+
 template <int NW, int LW> int launch_select_dense_t(hg_ctx* c) {
     const Geo& g = c->geo;
     SelArgs a{c->t.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(),
@@ -733,10 +773,15 @@ template <int NW> int launch_select_nw(hg_ctx* c) {
             default: return launch_select_dense_t<NW, 0>(c);
         }
     }
+    // three rows per accumulator + batched drain: codes of 33..64 bits, one-byte records (<= 128 classes)
+    if (NW == 2 && c->rec8 && c->opt_select_packed == 3 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) {
+        if (lw == 1) return launch_select_mx3_t<(NW == 2 ? 2 : 1), 1>(c);
+        return launch_select_mx3_t<(NW == 2 ? 2 : 1), 2>(c);
+    }
     // two rows per accumulator: wins for one-word codes (half the MFMAs: 0.92 vs 1.02 ms at b = 32); for 33-64 bits
     // its cheaper harvest (0.36 vs 0.44 ms) is eaten by the wider queue entries (select_packed = 2 forces it)
     if (c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS) && c->geo.L % 32 == 0 &&
-        ((c->opt_select_packed == 1 && NW == 1) || (c->opt_select_packed == 2 && NW <= 2))) {
+        (((c->opt_select_packed == 1 || c->opt_select_packed == 3) && NW == 1) || (c->opt_select_packed == 2 && NW <= 2))) {
         switch (lw) {
             case 1: return launch_select_mx2_t<(NW <= 2 ? NW : 1), 1>(c);
             case 2: return launch_select_mx2_t<(NW <= 2 ? NW : 1), 2>(c);
@@ -1140,7 +1185,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->sampx, &c->ap_recip};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -1191,6 +1236,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     c->stage = ST_DB;   // queries must be (re)set after the database: b, C may have changed
     c->dbx_valid = false;
     c->dbx2_valid = false;
+    c->dbx3_valid = false;
     c->dbx8_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;    // a new database: earlier lost bets say nothing about it
     c->cfg_epoch++;
@@ -1303,6 +1349,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->stage = ST_DB;
     c->dbx_valid = false;
     c->dbx2_valid = false;
+    c->dbx3_valid = false;
     c->dbx8_valid = false;
     c->dbfx_valid = false;
     c->dbfb_valid = false;
@@ -2810,6 +2857,7 @@ int hg_trim(hg_ctx* c) {
     c->gath_idx.release(); c->gath_dist.release();
     c->dbx_valid = c->qx_valid = c->dbx2_valid = c->qx2_valid = false;
     c->dbx8.release(); c->dbx8_valid = false;
+    c->dbx3.release(); c->dbx3_valid = false;
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     c->stage &= (ST_DB | ST_Q);
     c->lists_valid = false;
@@ -2833,7 +2881,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
                          &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2,
-                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->sampx, &c->ap_recip};
+                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
         *value = total;
