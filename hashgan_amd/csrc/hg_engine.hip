@@ -720,7 +720,7 @@ template <int NW, int LW, bool COMPACT> int launch_select_mx2_c(hg_ctx* c) {
 template <int NW, int LW> int launch_select_mx3_t(hg_ctx* c) {
     HG_TRY(ensure_mx_images<NW>(c));
     if (!c->dbx3_valid) {
-        const i64 n48 = (c->N + M3_ROWS - 1) / M3_ROWS * M3_ROWS;
+        const i64 n48 = (c->N + M3_ROWS - 1) / M3_ROWS * M3_ROWS + M3_WROWS;     // + one window of zero rows: the last segment's last window may run past the end
         HG_TRY(c->dbx3.reserve((size_t)(n48 > 0 ? n48 : M3_ROWS) * 32));
         const i64 items = n48 * 2;
         c->t_begin(KI_PACK);

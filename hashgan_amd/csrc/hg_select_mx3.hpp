@@ -66,6 +66,14 @@ __global__ __launch_bounds__(256) void k_expand_db3(const u32* __restrict__ db, 
     dbx[((G * 3 + f) * 2 + kb) * 16 + r] = e;
 }
 
+// (x << sh) | y in ONE op: the compiler prefers two shifts + v_or3 for a three-way merge
+template <int SH> __device__ __forceinline__ u32 m3_lshl_or_t(const u32 x, const u32 y) {
+    u32 d;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "n"(SH), "v"(y));
+    return d;
+}
+#define m3_lshl_or(x, sh, y) m3_lshl_or_t<sh>(x, y)
+
 struct Mx3Lds {                // byte offsets inside the block's dynamic LDS
     int a, abuf;               // A fragments: 2 buffers of abuf bytes
     int cl, clbuf, labels;     // packed codes + labels of a window's rows (both halves): 3 buffers of clbuf bytes; labels inside a buffer
@@ -124,20 +132,24 @@ struct Mx3Drain {
     __device__ __forceinline__ u8* slice(const int t) const { return tb0 + (i64)t * 32 * crow + lane_off; }
 
     // ---- owner side: completed 8-record pieces below limit[t] leave the ring with one aligned 8-byte store each ----
+    // (a slice that is already full keeps advancing: its surplus pieces land on its last piece -- the query is flagged
+    // as lost at the end of the kernel, what its slice holds no longer matters, only that the stores stay inside it)
     __device__ __forceinline__ void flush_to(const u32 (&limit)[QT]) {
         bool need = false;
 #pragma unroll
         for (int t = 0; t < QT; ++t) need |= limit[t] - flushed[t] >= 8u;
-        if (!__any(need)) return;
+        while (__any(need)) {                                         // a second pass only if some slice had 16 pending
+            need = false;
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const u32 f = flushed[t], have = limit[t] - f;           // <= M3_RING: at most two pieces
-            const u8* ring = rings + (t * 64 + lane) * M3_RING;
-            u8* tb = tb0 + (i64)t * 32 * crow;
-            if (have >= 8u) {
-                if (f < cap) *(u64*)(tb + (lane_off + f)) = *(const u64*)(ring + (f & 8u));
-                if (have >= 16u && f + 8u < cap) *(u64*)(tb + (lane_off + f + 8u)) = *(const u64*)(ring + ((f + 8u) & 8u));
-                flushed[t] = f + (have & ~7u);
+            for (int t = 0; t < QT; ++t) {
+                const u32 f = flushed[t];
+                if (limit[t] - f >= 8u) {
+                    const u8* ring = rings + (t * 64 + lane) * M3_RING;
+                    u8* tb = tb0 + (i64)t * 32 * crow;                // wave-uniform base; the lane's part fits 32 bits
+                    *(u64*)(tb + (lane_off + min(f, cap - 8u))) = *(const u64*)(ring + (f & 8u));
+                    flushed[t] = f + 8u;
+                    need |= limit[t] - f >= 16u;
+                }
             }
         }
         wave_lds_sync();                                              // ring reads done before an emit reuses the slots
@@ -299,11 +311,11 @@ struct Mx3Drain {
 
     // End of a window: entries pushed before it must be emitted now (their codes/labels buffer is recycled next); of
     // this window's, whole batches only.  Then the owners flush what was pushed before this window.
-    __device__ __forceinline__ void end_window() {
+    __device__ __forceinline__ void end_window(const bool do_flush) {
         while (qfill >= 64u) emit_batch(64u);
         if (old) emit_batch(qfill);
         old = qfill;
-        flush_to(prev);
+        if (do_flush) flush_to(prev);
 #pragma unroll
         for (int t = 0; t < QT; ++t) prev[t] = cnt[t];
     }
@@ -316,9 +328,9 @@ struct Mx3Drain {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const u32 f = flushed[t];
-            if (cnt[t] > f && f < cap) {
+            if (cnt[t] > f) {
                 const u8* ring = rings + (t * 64 + lane) * M3_RING;
-                *(u64*)(slice(t) + f) = *(const u64*)(ring + (f & 8u));
+                *(u64*)(slice(t) + min(f, cap - 8u)) = *(const u64*)(ring + (f & 8u));
             }
         }
     }
@@ -326,7 +338,10 @@ struct Mx3Drain {
 
 // Geo as set by the launcher: g.nQT = query blocks (of 256 queries) per segment pair, g.nBlk = blocks; g.L % 48 == 0.
 template <int NW, int LW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef HG_M3_WAVES
+#define HG_M3_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HG_M3_WAVES, HG_M3_WAVES)))
 void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, const u8* __restrict__ qx,
                   const u32* __restrict__ db, const u8* __restrict__ dbx, const u64* __restrict__ dblab,
                   const SelArgs a, u8* __restrict__ cand8, const Geo g) {
@@ -405,28 +420,38 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
     const int sa_sh = m3_shift(ar);
     const int scale_a = (127 + sa_sh) | ((134 + sa_sh) << 8) | ((141 + sa_sh) << 16);      // E8M0: tile f rides at 2^(7 f + s)
     const int scale_b = 0x7F7F7F7F;
+    // The image is one linear array of 512-byte half-chunks: chunk c of window win sits (win * WS * 3 + c) * 512 bytes past the
+    // lane's first one.  (A segment's windows may run up to WS supertiles past the end of the database: the image has that
+    // slack, zero-filled; an absent second segment reads the first supertile, its rows are masked.)
+    const u8* a_lane = dbx + ((((ag0 < NG ? ag0 : 0) * 3 * 2 + h) * 16 + ar) * 16);
+    const u32 lane16 = (u32)lane * 16u;
     auto stage_window = [&](const i64 win, const int abuf, const int clsel) {
         u8* sa = mxlds + L.a + abuf * L.abuf;
         u8* scl = mxlds + L.cl + clsel * L.clbuf;
-        for (int c = wave; c < M3_WS * 3; c += WPB) {
-            const int st = c / 3, f = c - st * 3;
-            i64 G = ag0 + win * M3_WS + st;
-            G = G < NG ? G : NG - 1;                                 // past the end: any valid supertile (masked later)
-            const u8* src = dbx + ((((G * 3 + f) * 2 + h) * 16 + ar) * 16);
-            HG_GLDS16(src, sa + c * 1024);
+#pragma unroll
+        for (int k = 0; k < (M3_WS * 3 + WPB - 1) / WPB; ++k) {
+            const int c = wave + k * WPB;
+            if (c < M3_WS * 3) HG_GLDS16(a_lane + (win * (M3_WS * 3) + c) * 512, sa + c * 1024);
         }
         constexpr int CPH = (M3_WROWS * CB + 1023) / 1024, LPH = (M3_WROWS * LB + 1023) / 1024;
-        for (int c = wave; c < 2 * (CPH + LPH); c += WPB) {
-            const int hh = c & 1, k = c >> 1;
-            const bool is_lab = k >= CPH;
-            const int piece = is_lab ? k - CPH : k;
-            const int rowb = is_lab ? LB : CB;
-            const i64 seg_lo = hh ? lo1 : lo0;
-            const i64 off = (seg_lo + win * M3_WROWS) * rowb + piece * 1024 + lane * 16;
-            const u8* tab = is_lab ? (const u8*)dblab : (const u8*)db;
-            const u8* src = tab + (off < g.N * rowb ? off : 0);      // rows past the table: anything (masked); see k_select_mx
-            u8* dst = scl + (is_lab ? L.labels : 0) + hh * M3_WROWS * rowb + piece * 1024;
-            if (piece * 1024 + lane * 16 < M3_WROWS * rowb) HG_GLDS16(src, dst);
+#pragma unroll
+        for (int k = 0; k < (2 * (CPH + LPH) + WPB - 1) / WPB; ++k) {
+            const int c = wave + k * WPB;                            // wave-uniform: which table, half and piece
+            if (c < 2 * (CPH + LPH)) {
+                const int hh = c & 1, kk = c >> 1;
+                const bool is_lab = kk >= CPH;
+                const int piece = is_lab ? kk - CPH : kk;
+                const int rowb = is_lab ? LB : CB;
+                const i64 off = ((hh ? lo1 : lo0) + win * M3_WROWS) * rowb + piece * 1024;     // wave-uniform
+                const i64 lim = g.N * rowb;
+                const u8* tab = is_lab ? (const u8*)dblab : (const u8*)db;
+                // rows past the table: anything (masked); the last chunk may overhang the table by < 16 B (allocation slack, see k_select_mx)
+                u8* dst = scl + (is_lab ? L.labels : 0) + hh * M3_WROWS * rowb + piece * 1024;
+                if (piece * 1024 + (int)lane16 < M3_WROWS * rowb) {
+                    if (off + 1024 <= lim) HG_GLDS16(tab + off + lane16, dst);
+                    else HG_GLDS16(tab + (off + lane16 < lim ? off + lane16 : 0), dst);
+                }
+            }
         }
     };
 
@@ -435,11 +460,11 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
         const u32 a0 = (HG_U(2) & K[t][2]) | ((HG_U(1) & K[t][1]) | (HG_U(0) & K[t][0]));
         const u32 a1 = (HG_U(5) & K[t][2]) | ((HG_U(4) & K[t][1]) | (HG_U(3) & K[t][0]));
         const u32 a2 = HG_U(6) & K[t][0];
-        w[0] = (a2 << 6) | ((a1 << 3) | a0);
+        w[0] = m3_lshl_or(a2, 6, m3_lshl_or(a1, 3, a0));
         const u32 b0 = (HG_U(9) & K[t][2]) | ((HG_U(8) & K[t][1]) | (HG_U(7) & K[t][0]));
         const u32 b1 = (HG_U(12) & K[t][2]) | ((HG_U(11) & K[t][1]) | (HG_U(10) & K[t][0]));
         const u32 b2 = HG_U(13) & K[t][0];
-        w[1] = (b2 << 6) | ((b1 << 3) | b0);
+        w[1] = m3_lshl_or(b2, 6, m3_lshl_or(b1, 3, b0));
         w[2] = (HG_U(15) & K[t][1]) | (HG_U(14) & K[t][0]);
 #undef HG_U
         asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]));      // pin here (pure ops would sink into the drain)
@@ -491,7 +516,10 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
             if (!(kProbes && (a.probe & 2))) dr.push(w, st, (u32)clsel);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(kProbes && (a.probe & 2))) dr.end_window();
+#ifndef HG_M3_FLUSH_EVERY
+#define HG_M3_FLUSH_EVERY 2
+#endif
+        if (!(kProbes && (a.probe & 2))) dr.end_window(HG_M3_FLUSH_EVERY == 1 || (win % HG_M3_FLUSH_EVERY) == HG_M3_FLUSH_EVERY - 1);
         clsel = clnext;
     }
     dr.finish();
