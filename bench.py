@@ -11,9 +11,11 @@ the host -> mean.  `value` = Q / step time: queries per second, whole job.
                        the metric is quoted on.
   --gpus G > 1         C4 = configs[3]: the FIXED N=10M database sharded over the G GPUs of one node (contiguous
                        index ranges, shard_bounds(10M, G)), Q=10k queries replicated; strong scaling.  One process per
-                       GPU, launched as `python -m torch.distributed.run --nproc-per-node G ... bench.py --gpus G`
-                       (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT from the environment); the exchanges are native
-                       RCCL all-gathers through the library's C ABI (hashgan_amd/sharded.py) -- no torch in the process.
+                       GPU: either launched as `python -m torch.distributed.run --nproc-per-node G ... bench.py --gpus G`
+                       (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment), or -- with no
+                       WORLD_SIZE in the environment -- `python bench.py --gpus G` spawns the G rank processes itself and
+                       prints rank 0's line.  The exchanges are native RCCL all-gathers through the library's C ABI
+                       (hashgan_amd/sharded.py) -- no torch in the process.
                        HG_BENCH_FORCE_SHARDED=1 runs this leg with one rank (`--workload c2` keeps its database small).
   --workload c4 --gpus 1   C4 on a single GPU: the reference point for the scaling curve.
 
@@ -231,6 +233,70 @@ def h2d_inclusive(spec, packed, reps=10):
             "map_equal_to_resident_path": bool(val == val2)}, float(val)
 
 
+def error_line(msg, n_gpus, steps=0, warmup=0):
+    """The one JSON line of a run that could not measure anything."""
+    return json.dumps({"metric": METRIC, "value": None, "unit": "queries/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
+                       "ms_per_step": None, "higher_is_better": True, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+                       "error": msg})
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus G` with no launcher around it: start the G rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT in their environment, the RCCL id file inside a private fresh directory), pass rank 0's
+    stdout through, and if a rank dies or the launch times out print a JSON line with an `error` key instead of hanging."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+    n = args.gpus
+    d = tempfile.mkdtemp(prefix="hashgan_amd_bench_")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    limit = float(os.environ.get("HG_BENCH_LAUNCH_TIMEOUT", "1800"))
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HG_COMM_ID_FILE=os.path.join(d, "rccl.id"))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        t0 = time.time()
+        failed = None
+        while failed is None and any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = "rank %d exited with code %d" % (r, p.returncode)
+            if failed is None and time.time() - t0 > limit:
+                failed = "launch of %d ranks not finished after %.0f s" % (n, limit)
+        for r, p in enumerate(procs):
+            if failed is None and p.returncode not in (None, 0):
+                failed = "rank %d exited with code %d" % (r, p.returncode)
+        if failed:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                # the processes this function started, by their own handles
+        out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if lines and not failed:
+            print(lines[-1])
+            return 0
+        if lines and '"error"' in lines[-1]:
+            print(lines[-1])
+        else:
+            print(error_line(failed or "rank 0 printed no result line", n, args.steps, args.warmup))
+        return 1
+    finally:
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:      # noqa: BLE001
+                pass
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,13 +311,15 @@ def main():
                          "kernel (events keep kernels from being dispatched back to back), or none")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))           # no launcher: be one
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    if args.gpus != world:
+        if rank == 0:
+            print(error_line("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world), args.gpus, args.steps, args.warmup))
+        sys.exit(2)
     force = os.environ.get("HG_BENCH_FORCE_SHARDED") == "1"
     sharded_leg = world > 1 or force
     wl = args.workload or ("c4" if world > 1 else "c2")
@@ -279,7 +347,12 @@ def main():
             comm = FileComm(dry_dir, rank, world, ctx)
             eng = sharded.HipShardEngine(ctx, want_lists=False)
         else:
-            comm = sharded.init_rccl(ctx, rank, world)
+            try:
+                comm = sharded.init_rccl(ctx, rank, world, timeout=float(os.environ.get("HG_COMM_TIMEOUT", "120")))
+            except (TimeoutError, RuntimeError) as e:
+                if rank == 0:
+                    print(error_line("RCCL rendezvous failed: %s" % e, world, args.steps, args.warmup))
+                sys.exit(3)
             eng = sharded.HipShardEngine(ctx, want_lists=False, async_stages=True)   # one stream, no host waits between stages
 
         def step():
@@ -327,7 +400,7 @@ def main():
     out = {
         "metric": METRIC, "value": Q / per_step, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True,
-        "scaling": "strong" if sharded_leg or wl == "c4" else "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "%s: Q=%d N=%d b=%d R=%d C=%d, %s codes" % (wl.upper(), Q, N, b, R, C, spec["kind"]),
                    "parallelism": ("database sharded over %d GPU%s (%d rows on rank 0); native RCCL all-gather of shard "
                                    "histograms / record counts and match bitmaps" % (world, "s" if world > 1 else "", rows))
@@ -336,6 +409,8 @@ def main():
         "optimistic_runs": ctx.get_stat("optimistic_runs"), "optimistic_fallbacks": ctx.get_stat("optimistic_fallbacks"),
         "pairs_per_sec": Q * N / per_step,
     }
+    if sharded_leg or wl == "c4":
+        out["scaling"] = "strong"                            # the fixed N = 10M database over the GPUs (a one-GPU C2 line scales nothing)
     if sharded_leg:
         out["value_definition"] = "Q queries ranked against the WHOLE %d-row database per step / step time (max over ranks)" % N
         out["weak_scaling_equivalent"] = {"definition": "query x per-GPU-shard evaluations per second = value * n_gpus",

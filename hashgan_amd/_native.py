@@ -127,6 +127,17 @@ def _carray(a, dtype):
     return a
 
 
+def _labels_i64(labels):
+    """Labels as the int64 matrix the C ABI takes.  The {0,1} census runs on the GPU AFTER this conversion, so a
+    conversion that changes a value (0.5 -> 0, 1.7 -> 1) would let a matrix through that lib/metric.py:19's
+    `database.label == label` never matches: such labels are refused here."""
+    a = np.asarray(labels)
+    out = _carray(a, np.int64)
+    if a.dtype.kind not in "iub" and not np.array_equal(out, a):
+        raise ValueError("labels must be {0,1} indicator matrices")
+    return out
+
+
 class Context:
     """One GPU context (hg_ctx).  Thin, 1:1 with the C ABI."""
 
@@ -168,7 +179,7 @@ class Context:
         """float32 [N, b] features + int64 [N, C] labels; binarise + pack on the GPU.
         -> (entries outside {-1,0,+1}, label entries outside {0,1})"""
         x = _carray(features, np.float32)
-        lab = _carray(labels, np.int64)
+        lab = _labels_i64(labels)
         N, b = x.shape
         n_total = N if n_total is None else int(n_total)
         bc, bl = _i64(), _i64()
@@ -179,7 +190,7 @@ class Context:
 
     def set_queries_f32(self, features, labels):
         x = _carray(features, np.float32)
-        lab = _carray(labels, np.int64)
+        lab = _labels_i64(labels)
         bc, bl = _i64(), _i64()
         check(self._lib.hg_set_queries_f32(self._h, _ptr(x), _ptr(lab), x.shape[0], C.byref(bc), C.byref(bl)))
         self.Q = x.shape[0]

@@ -17,6 +17,8 @@
 #include "../../include/hashgan_amd.h"
 
 #include <rccl/rccl.h>     // types and enums only: the library itself is dlopen'ed by hg_comm_init (573 MB, not every process needs it)
+#include <atomic>
+#include <mutex>
 #include <dlfcn.h>
 #include <unistd.h>
 
@@ -59,7 +61,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 // Bumped whenever a device buffer moves: captured graphs hold raw addresses and die with the epoch they were built in.
-unsigned long long g_alloc_epoch = 1;
+std::atomic<unsigned long long> g_alloc_epoch{1};   // bumped by every context's buffers (one MAPs object per thread is supported): atomic
 
 // HG_EFENCE=1 (debugging): every device buffer ends 64..127 bytes before an UNMAPPED 2 MiB page of its own virtual range
 // (hipMemAddressReserve / hipMemMap), so a kernel reading or writing past a buffer -- beyond the 64 bytes of slack the
@@ -210,7 +212,10 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 
+std::mutex g_rccl_mu;                              // contexts of several threads may initialise communicators at once
+
 int rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.handle) return HG_OK;
     const char* cands[] = {getenv("HG_RCCL_LIBRARY"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     void* h = nullptr;
@@ -2234,7 +2239,7 @@ static int enqueue_bet_with_ap(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
 // Second sighting of the same step (same tables, options, R, timing level; no buffer moved since): capture it.
 static int capture_step(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     c->drop_graph();
-    const unsigned long long epoch0 = g_alloc_epoch;
+    const unsigned long long epoch0 = g_alloc_epoch.load();
     HG_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
     c->capturing = true;
     const int rc = enqueue_bet_with_ap(c, R, stride, need_cnt);

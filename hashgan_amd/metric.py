@@ -52,19 +52,13 @@ def pack_labels(lab):
     return np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(n, LW)
 
 
-def is_binary(x):
-    """True when every entry is in {-1, +1} or every entry is in {0, 1}."""
-    x = np.asarray(x)
-    return bool(np.isin(x, (-1, 1)).all() or np.isin(x, (0, 1)).all())
-
-
 # ------------------------------------------------------------------ engine
 class RetrievalEngine:
     """A database shard resident on one GPU, evaluated against query batches."""
 
     def __init__(self, device=0):
         self.ctx = _native.Context(device)
-        self.b = self.C = None
+        self.b = self.C = self.N = self.db_kind = self.db_src = None
 
     def close(self):
         self.ctx.close()
@@ -170,6 +164,7 @@ def _load_database(eng, db_codes, db_labels, mode="reference", floats=None):
     """Pack on the host, upload (hg_set_database_f32).  The float table itself goes to the GPU only when it may be ranked
     by inner product: never for the spellings that binarise or insist on binary codes, and in 'reference' mode only if
     the database is not a +-1 code (a +-1 database meeting real-valued queries is uploaded again with it, below)."""
+    eng.b = eng.C = eng.N = eng.db_kind = eng.db_src = None      # nothing is resident until this load has succeeded
     eng.ctx.set_option("keep_floats", floats if floats is not None else (2 if mode == "reference" else 0))
     bad_c, bad_l = eng.ctx.set_database_f32(db_codes, db_labels)
     if bad_l:
@@ -203,7 +198,8 @@ def _rank(eng, q_codes, q_labels, R, mode):
     if q_codes.shape[1] > 255:                        # (the loaders take up to 255 columns)
         raise ValueError("inner-product ranking supports up to 255 features (have %d)" % q_codes.shape[1])
     if not eng.ctx.get_stat("db_floats"):             # a +-1 database whose floats stayed on the host: bring them over now
-        _load_database(eng, eng.db_src[0], eng.db_src[1], floats=1)
+        src = eng.db_src
+        _load_database(eng, src[0], src[1], floats=1)
         eng.ctx.set_queries_f32(q_codes, q_labels)
     return eng.ctx.map_real(R)
 
@@ -214,8 +210,20 @@ def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, mode):
     _check_shapes(q_codes, db_codes, q_labels, db_labels, R)
     eng = _Shared.get(device)
     with eng.lock:
-        _load_database(eng, db_codes, db_labels, mode)
-        ap, rel = _rank(eng, q_codes, q_labels, R, mode)
+        # the same read-only arrays as the last call (an evaluation loop over one database): the packed copy on the GPU
+        # is still theirs -- skip pack + upload, like MAPs does (a writable array may have changed in place: reload)
+        res = getattr(eng, "resident", None)
+        same = (res is not None and res[0] is db_codes and res[1] is db_labels and res[2] == mode
+                and not db_codes.flags.writeable and not db_labels.flags.writeable)
+        if not same:
+            eng.resident = None
+            _load_database(eng, db_codes, db_labels, mode)
+            eng.resident = (db_codes, db_labels, mode)
+        try:
+            ap, rel = _rank(eng, q_codes, q_labels, R, mode)
+        except Exception:
+            eng.resident = None
+            raise
     return mean_over_hits(ap, rel), ap, rel
 
 
@@ -267,6 +275,7 @@ class MAPs:
         if out.ndim != 2 or lab.ndim != 2 or out.shape[0] != lab.shape[0]:
             raise ValueError("database.output must be [N, b] and database.label [N, C]")
         with self._lock:
+            self._resident = None                      # a failed load leaves NO database (never the previous one half replaced)
             _load_database(self._engine(), out, lab, "sign" if self.binarize else "reference")
             self._resident = ("explicit", database)
 
@@ -283,6 +292,7 @@ class MAPs:
             return                                     # the very same immutable arrays as last time
         if out.ndim != 2 or lab.ndim != 2 or out.shape[0] != lab.shape[0]:
             raise ValueError("database.output must be [N, b] and database.label [N, C]")
+        self._resident = None                          # a failed load leaves NO database
         _load_database(self._engine(), out, lab, "sign" if self.binarize else "reference")
         self._resident = ("auto", out, lab)
 
@@ -292,6 +302,9 @@ class MAPs:
         with self._lock:
             self._ensure_database(database)
             eng = self._engine()
+            if eng.b is None:
+                self._resident = None
+                raise ValueError("no resident database: the last load failed")
             if q_codes.ndim != 2 or q_codes.shape[1] != eng.b:
                 raise ValueError("query and database codes must be [n, b] with the same b")
             if q_labels.ndim != 2 or q_labels.shape[1] != eng.C or q_labels.shape[0] != q_codes.shape[0]:

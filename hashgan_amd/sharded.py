@@ -72,46 +72,67 @@ class RcclComm:
         return self.ctx.allreduce_max(x)
 
 
-def _id_file(world, port):
+def _id_file(world):
+    """Where rank 0 publishes the RCCL id of this launch.  HG_COMM_ID_FILE names it outright (a launcher that spawns the
+    ranks itself -- bench.py --gpus N -- passes a path inside a fresh private directory).  Otherwise the name comes from
+    what EVERY rank of one launch shares whatever started it (torchrun, mpirun, shell wrappers -- never a parent pid):
+    the rendezvous address and port, the world size, the launcher's run id if it set one, and the user."""
     explicit = os.environ.get("HG_COMM_ID_FILE")
     if explicit:
         return explicit
-    # ranks of one launch are children of one launcher process: its pid (and the rendezvous port) name the launch
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "hashgan_amd_rccl_%d_%s_%d.id" % (os.getppid(), port, world))
+    tag = "%s_%s_%d_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"), world,
+                           os.environ.get("HG_COMM_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or "0")
+    tag = "".join(ch if ch.isalnum() or ch in "._-" else "-" for ch in tag)
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "hashgan_amd_rccl_%d_%s.id" % (os.getuid(), tag))
+
+
+def exchange_id(rank, world, make_id, nbytes, timeout=300.0, path=None):
+    """Rank 0 draws an id (make_id() -> `nbytes` bytes) and publishes it; every rank returns the same bytes.
+    The file is created exclusively with mode 0600 after removing any leftover of the same name, and carries rank 0's
+    start time; a reader ignores files older than its own start (minus the launch skew it tolerates), so the id of a
+    crashed earlier launch is never taken.  TimeoutError after `timeout` seconds -- no rank waits forever."""
+    path = path or _id_file(world)
+    if rank == 0:
+        uid = bytes(make_id())
+        if len(uid) != nbytes:
+            raise RuntimeError("id of %d bytes, expected %d" % (len(uid), nbytes))
+        try:
+            os.unlink(path)                        # a leftover (crashed launch, or planted): never reused, never followed
+        except OSError:
+            pass
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        try:
+            os.write(fd, uid + np.float64(_PROCESS_START).tobytes())
+        finally:
+            os.close(fd)
+        os.replace(tmp, path)                      # atomic: a reader sees no file or all of it
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            if os.path.getmtime(path) >= _PROCESS_START - _LAUNCH_SKEW:
+                with open(path, "rb") as f:
+                    data = f.read()
+                if len(data) == nbytes + 8 and float(np.frombuffer(data[nbytes:], np.float64)[0]) >= _PROCESS_START - _LAUNCH_SKEW:
+                    return data[:nbytes]
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise TimeoutError("rank %d of %d: no RCCL id from rank 0 in %s after %.0f s (is rank 0 running? do all ranks "
+                               "share MASTER_ADDR / MASTER_PORT, or HG_COMM_ID_FILE?)" % (rank, world, path, timeout))
+        time.sleep(0.02)
 
 
 def init_rccl(ctx, rank=None, world=None, timeout=300.0):
-    """Create the context's RCCL communicator from the launcher's environment (RANK, WORLD_SIZE, MASTER_PORT as
-    `python -m torch.distributed.run` or any torchrun-like launcher sets them; one node).  Rank 0 draws the unique
-    id (hg_comm_unique_id) and publishes its 128 bytes in a file named after the launch (HG_COMM_ID_FILE
-    overrides the name); the other ranks pick it up.  -> RcclComm"""
+    """Create the context's RCCL communicator from the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT
+    as `python -m torch.distributed.run` or any torchrun-like launcher sets them; one node).  Rank 0 draws the unique
+    id (hg_comm_unique_id) and publishes its 128 bytes through exchange_id().  -> RcclComm"""
     from . import _native
     rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
-    path = _id_file(world, os.environ.get("MASTER_PORT", "0"))
-    if rank == 0:
-        uid = _native.comm_unique_id()
-        tmp = "%s.%d.tmp" % (path, os.getpid())
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)                      # atomic: a reader sees no file or all 128 bytes
-    else:
-        t0 = time.time()
-        uid = None
-        while uid is None:
-            try:
-                # a file of an earlier launch with the same name (pid reuse) would be older than this process
-                if os.path.getmtime(path) >= _PROCESS_START - 120.0:
-                    with open(path, "rb") as f:
-                        data = f.read()
-                    if len(data) == _native.COMM_ID_BYTES:
-                        uid = data
-            except OSError:
-                pass
-            if uid is None:
-                if time.time() - t0 > timeout:
-                    raise RuntimeError("rank %d: no RCCL id from rank 0 in %s after %.0f s" % (rank, path, timeout))
-                time.sleep(0.02)
+    path = _id_file(world)
+    uid = exchange_id(rank, world, _native.comm_unique_id, _native.COMM_ID_BYTES, timeout, path)
     ctx.comm_init(uid, rank, world)
     comm = RcclComm(ctx)
     comm.barrier()                                 # everybody has read the id: rank 0 may remove the file
@@ -123,6 +144,7 @@ def init_rccl(ctx, rank=None, world=None, timeout=300.0):
     return comm
 
 
+_LAUNCH_SKEW = 120.0           # seconds one rank of a launch may start before another
 _PROCESS_START = time.time()
 
 

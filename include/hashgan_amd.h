@@ -163,7 +163,8 @@ int hg_map(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel);
 
 /* ---- real-valued features (what main.py feeds when nothing is binarised) ----
  * Ranking by float32 inner product, lib/metric.py:13-14 as written, on the float tables kept by
- * hg_set_database_f32 / hg_set_queries_f32 (b <= 128, one shard).  Order: inner product descending,
+ * hg_set_database_f32 / hg_set_queries_f32 (up to 255 features; one context holds the whole table -- several GPUs split
+ * the QUERIES, hashgan_amd/sharded.py::evaluate_real_queries).  Order: inner product descending,
  * database index ascending.  The product's summation order is fixed (one float32 fma chain in feature
  * order: what the chained v_mfma_f32_32x32x2_f32 computes) and restated exactly by oracle/real_map.py; it equals the reference's
  * np.dot wherever float32 rounding does not reorder near-equal products, exactly so on inputs
@@ -229,8 +230,9 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * k_select_mx; 0: vector-ALU xor+popcount k_select; same records either way), "probe_select" (probe build only --
  * python -m hashgan_amd.build --probes: bits 2/4/8 switch parts of the matrix-core kernels' drain off; the bet
  * then fails and the exact sequence runs, so results stay right; the production library refuses the key),
- * "select_packed" (k_select_mx2, two rows per
- * MFMA accumulator: 1 = for codes of <= 32 bits, 2 = also for 33..64 bits, 0 = never), "rank_lds" (0/1), "rank_cnt" (0/1:
+ * "select_packed" (several rows per MFMA accumulator: 3, default = k_select_mx2 (two rows) for codes of <= 32 bits and
+ * k_select_mx3 (three rows through per-row MX scales, batched drain) for 33..64 bits with one-byte records; 1 = k_select_mx2
+ * for <= 32 bits only, 2 = k_select_mx2 up to 64 bits, 0 = never), "rank_lds" (0/1), "rank_cnt" (0/1:
  * the bet's rank stage as a per-thread counting sort, k_rank_cnt),
  * "host_pack", "keep_floats", "pack_threads" (hg_set_*_f32, see there), "second_bet" (1, default: a one-shot bet that too many queries lost is retried once with twice the margin and record
  * budget before the exact two-pass sequence runs), "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
@@ -245,9 +247,9 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * float32 chain for the rows it keeps; 1: every pair exactly on the float32 matrix-core instruction; 0: vector ALU; same
  * lists either way), "real_sort_lds" (1, default: after the filter a query's records are ranked by one LDS-resident
  * kernel when they fit; 0: always the global-memory radix passes),
- * "real_queries_per_lane", "real_segment_bytes" (real-valued path), "step_graph" (1, default: hg_map captures its
- * one-shot sequence into a hipGraph the second time it sees the same problem and replays it afterwards; 0: always
- * enqueue kernel by kernel). */
+ * "real_queries_per_lane", "real_segment_bytes" (real-valued path), "step_graph" (0, default: always enqueue kernel
+ * by kernel; 1: hg_map captures its one-shot sequence into a hipGraph the second time it sees the same problem and
+ * replays it afterwards). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
 /* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
  * (single queries rerun exactly after losing their bet), "optimistic_rebets" (second bets), "last_optimistic", "device_bytes", "segments",

@@ -14,7 +14,7 @@ folds -0.0 into +0.0 so that equal values compare equal as bit patterns).  Ranki
 index ascending.  AP/mAP: the expressions of metric.py:17-24, via oracle.hamming_map.
 
 Parity pin: on features whose products and partial sums are exactly representable in float32
-(multiples of 1/64 in [-1, 1], b <= 128) EVERY summation order gives the same value, so the
+(multiples of 1/64 in [-1, 1], up to the 255 features the loaders take) EVERY summation order gives the same value, so the
 unmodified reference -- fed float64 copies plus the tie-breaking coordinate of
 hamming_map.tie_free_features -- must agree with this oracle bit for bit: tests/golden/real_*.npz.
 """

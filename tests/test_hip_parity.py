@@ -638,3 +638,59 @@ def test_ap_through_reciprocals_equals_the_division(R):
         assert np.array_equal(got[1], ap_ref, equal_nan=True)
     finally:
         ctx.close()
+
+
+def test_failed_database_load_leaves_nothing_resident():
+    """a load that fails on its labels must not leave MAPs ranking against a half-replaced database (or, with
+    a wider code, reading past the query buffer).  Float labels that an int64 cast would turn into {0,1} are refused too."""
+    import types
+    rng = np.random.default_rng(3)
+    N, Q, b, C = 5000, 20, 32, 4
+    mk = lambda n, bb: types.SimpleNamespace(output=(rng.integers(0, 2, (n, bb)) * 2 - 1).astype(np.float32),
+                                             label=np.eye(C, dtype=np.int64)[rng.integers(0, C, n)])
+    good, q = mk(N, b), mk(Q, b)
+    bad = mk(N, 2 * b)
+    bad.label = bad.label.copy()
+    bad.label[7, 1] = 3                                   # not an indicator matrix
+    m = metric.MAPs(100)
+    try:
+        want = m.get_maps_by_feature(good, q)
+        m.set_database(good)
+        with pytest.raises(ValueError):
+            m.get_maps_by_feature(bad, q)
+        with pytest.raises(ValueError):                   # nothing is resident now: not the old database, not the bad one
+            m.get_maps_by_feature(None, q)
+        with pytest.raises(ValueError):
+            m.set_database(bad)
+        with pytest.raises(ValueError):
+            m.get_maps_by_feature(None, q)
+        assert m.get_maps_by_feature(good, q) == want     # and the object still works
+        half = types.SimpleNamespace(output=good.output, label=good.label.astype(np.float64) * 0.5 + 0.25)   # 0.25 / 0.75
+        with pytest.raises(ValueError):
+            m.get_maps_by_feature(half, q)
+    finally:
+        m.close()
+
+
+def test_function_spelling_reuses_a_read_only_database():
+    """MAP / calc_map keep the packed database of the last call when handed the very same read-only arrays again (an
+    evaluation loop over one database); writable arrays are uploaded again because they may have changed in place."""
+    rng = np.random.default_rng(4)
+    N, Q, b, C = 20000, 30, 48, 5
+    db = rng.integers(0, 2, (N, b)).astype(np.float32)
+    dl = np.eye(C, dtype=np.int64)[rng.integers(0, C, N)]
+    qs = [rng.integers(0, 2, (Q, b)).astype(np.float32) for _ in range(2)]
+    ql = np.eye(C, dtype=np.int64)[rng.integers(0, C, Q)]
+    want = [metric.MAP(x, db, ql, dl, 500) for x in qs]   # writable: every call uploads
+    db.flags.writeable = False
+    dl.flags.writeable = False
+    eng = metric._Shared.get(0)
+    got = [metric.MAP(x, db, ql, dl, 500) for x in qs] + [metric.calc_map(qs[0], db, ql, dl, 500)]
+    assert got[:2] == want and got[2] == want[0]
+    assert eng.resident is not None and eng.resident[0] is db
+    db2 = db.copy()
+    db2[:, 0] = 1 - db2[:, 0]
+    db2.flags.writeable = False
+    metric.MAP(qs[0], db2, ql, dl, 500)                   # another database: reloaded
+    assert eng.resident[0] is db2
+    assert metric.MAP(qs[1], db, ql, dl, 500) == want[1]  # and back

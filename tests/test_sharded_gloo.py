@@ -100,7 +100,8 @@ def test_rccl_id_rendezvous_between_processes(tmp_path):
     rendezvous file is gone afterwards, and a stale file of an earlier launch is not mistaken for the id."""
     from hashgan_amd import sharded
     port = 31000 + (os.getpid() % 500)
-    stale = sharded._id_file(3, str(port)).replace("_%d_" % os.getppid(), "_%d_" % os.getpid())   # the name the children will use
+    os.environ["MASTER_PORT"] = str(port)
+    stale = sharded._id_file(3)                          # the name the children will use (address, port, world size)
     with open(stale, "wb") as f:
         f.write(b"\0" * 128)
     os.utime(stale, (1, 1))                              # ancient
@@ -152,3 +153,77 @@ def test_gloo_query_split_of_the_real_valued_ranking(name, world, tmp_path):
     want = np.nan_to_num(g["ap"])
     assert np.array_equal(rs[0]["ap"], want)
     assert np.array_equal(rs[0]["rel"] != 0, ~np.isnan(g["ap"]))
+
+
+# ---------------------------------------------------------------- the launch itself (no GPU needed)
+_RENDEZVOUS = """import os, sys
+sys.path.insert(0, %r)
+from hashgan_amd import sharded
+uid = sharded.exchange_id(int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), lambda: os.urandom(128), 128, timeout=60)
+sys.stdout.write(uid.hex())
+"""
+
+
+def test_rccl_id_rendezvous_does_not_depend_on_the_launcher(tmp_path):
+    """The id file is named from what all ranks of a launch share (MASTER_ADDR, MASTER_PORT, world size), not from a
+    parent pid: ranks started through separate nested `bash -c` wrappers (every rank another parent) still meet, and every
+    rank gets rank 0's 128 bytes."""
+    import subprocess
+    world = 3
+    script = tmp_path / "rank.py"
+    script.write_text(_RENDEZVOUS % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29877", TMPDIR=str(tmp_path))
+        env.pop("HG_COMM_ID_FILE", None)
+        procs.append(subprocess.Popen(["bash", "-c", "bash -c '%s %s'; exit $?" % (sys.executable, script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    assert len(outs[0][0]) == 256 and all(o[0] == outs[0][0] for o in outs)
+    files = [f for f in os.listdir(tmp_path) if f.startswith("hashgan_amd_rccl_")]
+    assert files and all((os.stat(tmp_path / f).st_mode & 0o077) == 0 for f in files)     # private to the user
+
+
+def test_rccl_id_rendezvous_ignores_a_stale_file_and_times_out(tmp_path):
+    """A leftover id file of an earlier (crashed) launch is older than this process: a rank > 0 never takes it, and
+    without a rank 0 it gives up with TimeoutError instead of hanging."""
+    import time
+    from hashgan_amd import sharded
+    path = str(tmp_path / "stale.id")
+    with open(path, "wb") as f:
+        f.write(b"\x01" * 128 + np.float64(time.time() - 1000.0).tobytes())
+    os.utime(path, (time.time() - 1000.0, time.time() - 1000.0))
+    t0 = time.time()
+    with pytest.raises(TimeoutError):
+        sharded.exchange_id(1, 2, None, 128, timeout=0.5, path=path)
+    assert time.time() - t0 < 5.0
+    # rank 0 replaces the leftover (never follows or reuses it)
+    uid = sharded.exchange_id(0, 2, lambda: b"\x02" * 128, 128, path=path)
+    assert uid == b"\x02" * 128 and sharded.exchange_id(1, 2, None, 128, timeout=5.0, path=path) == uid
+
+
+def test_bench_without_a_launcher_reports_instead_of_hanging():
+    """`python bench.py --gpus 2` with no WORLD_SIZE spawns its own ranks; on a box where they cannot run (no GPU here)
+    the parent prints ONE JSON line with an `error` key and exits non-zero.  A --gpus / WORLD_SIZE mismatch likewise."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HG_BENCH_LAUNCH_TIMEOUT"] = "120"
+    try:
+        import ctypes
+        gpu = ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(ctypes.c_int())) == 0
+    except OSError:
+        gpu = False
+    if not gpu:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert r.returncode != 0 and len(lines) == 1, (r.stdout[-500:], r.stderr[-500:])
+        d = json.loads(lines[0])
+        assert "error" in d and d["value"] is None and d["n_gpus"] == 2
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode != 0 and "WORLD_SIZE" in d["error"]

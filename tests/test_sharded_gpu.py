@@ -222,6 +222,27 @@ def test_bench_multi_rank_control_flow(world, workload, tmp_path):
     assert "dry_run_not_a_measurement" in d and "cpu_baseline" not in d
 
 
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment (how a driver may call it): the
+    parent spawns the two rank processes itself and prints rank 0's single JSON line.  Dry run on one GPU, the file
+    communicator standing in for RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["HG_BENCH_FILECOMM"] = str(tmp_path / "comm")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c3", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "error" not in d
+    assert d["parity_vs_reference_golden"] is True and d["optimistic_fallbacks"] == 0
+
+
 @pytest.mark.parametrize("G", [1, 3])
 def test_real_valued_ranking_splits_queries_over_ranks(G):
     """evaluate_real_queries: every (virtual) rank holds the whole float table and ranks its share of the queries; the
