@@ -233,6 +233,74 @@ def h2d_inclusive(spec, packed, reps=10):
             "map_equal_to_resident_path": bool(val == val2)}, float(val)
 
 
+def real_valued(spec, reps=5):
+    """The caller's REAL input: main.py:157,164 hands tanh outputs (lib/architecture.py:147,192,384-389), not codes, to the
+    metric, which ranks them by float32 inner product (metric.py:13-14 as written).  The same call on such features at
+    this workload's shape: from host arrays, and with the database kept resident.  Never `value`."""
+    import types
+    from hashgan_amd import MAPs
+    Q, N, b, C, R = spec["Q"], spec["N"], spec["b"], spec["C"], spec["R"]
+    rng = np.random.default_rng(spec["seed"])
+    eye = np.eye(C, dtype=np.int64)
+    db = types.SimpleNamespace(output=np.tanh(rng.standard_normal((N, b), dtype=np.float32)), label=eye[rng.integers(0, C, N)])
+    q = types.SimpleNamespace(output=np.tanh(rng.standard_normal((Q, b), dtype=np.float32)), label=eye[rng.integers(0, C, Q)])
+    m = MAPs(R)
+    try:
+        for _ in range(2):
+            val = m.get_maps_by_feature(db, q)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            val = m.get_maps_by_feature(db, q)
+        full = (time.perf_counter() - t0) / reps
+        m.set_database(db)
+        m.get_maps_by_feature(None, q)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            val2 = m.get_maps_by_feature(None, q)
+        resident = (time.perf_counter() - t0) / reps
+    finally:
+        m.close()
+    return {"call": "MAPs(R).get_maps_by_feature(database, query) on tanh(N(0,1)) float32 features, one-hot labels, Q=%d N=%d b=%d R=%d" % (Q, N, b, R),
+            "ranking": "float32 inner product (bf16 MFMA filter with a rigorous margin + exact float32 fma-chain rescoring), ties by index",
+            "from_host": {"ms_per_call": full * 1e3, "queries_per_sec": Q / full,
+                          "host_array_bytes": int(db.output.nbytes + db.label.nbytes + q.output.nbytes + q.label.nbytes)},
+            "with_resident_database": {"ms_per_call": resident * 1e3, "queries_per_sec": Q / resident},
+            "map": float(val), "map_equal_to_resident_path": bool(val == val2), "calls_timed": reps}
+
+
+def c4_reference(opts, steps=5, warmup=2):
+    """The one-GPU point of the scaling curve: C4 (the fixed N = 10M database, configs[3]) unsharded on this GPU -- what
+    `bench.py --gpus G` (G > 1) strong-scales from.  Reported beside the C2 line so that a 1/2/4/8 series has its origin."""
+    from hashgan_amd import _native, metric
+    spec = WORKLOADS["c4"]
+    qw, ql, dw, dl = build_packed(spec, 0, spec["N"])
+    ctx = _native.Context(0)
+    try:
+        for k_, v_ in opts:
+            ctx.set_option(k_, v_)
+        ctx.set_database(dw, dl, spec["b"], spec["C"])
+        ctx.set_queries(qw, ql)
+        for _ in range(warmup):
+            a, r = ctx.map(spec["R"])
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a, r = ctx.map(spec["R"])
+            m = metric.mean_over_hits(a, r)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        from tests import cases
+        g = cases.load_golden(spec["golden"])
+        k = g["ap"].shape[0]
+        return {"workload": "C4: Q=%d N=%d b=%d R=%d, one GPU, unsharded" % (spec["Q"], spec["N"], spec["b"], spec["R"]),
+                "n_gpus": 1, "steps": steps, "ms_per_step": dt * 1e3, "value": spec["Q"] / dt, "unit": "queries/s",
+                "pairs_per_sec": spec["Q"] * spec["N"] / dt, "map": float(m),
+                "parity_vs_reference_golden": bool(np.array_equal(a[:k], g["ap"], equal_nan=True)),
+                "optimistic_fallbacks": ctx.get_stat("optimistic_fallbacks")}
+    finally:
+        ctx.close()
+
+
 def error_line(msg, n_gpus, steps=0, warmup=0):
     """The one JSON line of a run that could not measure anything."""
     return json.dumps({"metric": METRIC, "value": None, "unit": "queries/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
@@ -305,6 +373,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive MAPs(...) timing")
+    ap.add_argument("--no-real", action="store_true", help="skip the real-valued (tanh features) call timing")
+    ap.add_argument("--no-c4-ref", action="store_true", help="skip the one-GPU C4 point of the scaling curve")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (hg_set_option), repeatable")
     ap.add_argument("--kernel-timing", default="pair-passes", choices=["pair-passes", "all", "none"],
                     help="HIP events around the passes over the pairs only (the roofline kernel; default), around every "
@@ -437,6 +507,10 @@ def main():
         if not args.no_h2d:
             out["h2d_inclusive"], m2 = h2d_inclusive(spec, packed)
             out["h2d_inclusive"]["map_equal_to_timed_path"] = bool(m2 == out["map"])
+        if not args.no_real:
+            out["real_valued"] = real_valued(spec)
+        if not args.no_c4_ref and wl == "c2":
+            out["scaling_reference_c4_one_gpu"] = c4_reference([(kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt])
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, packed)
     print(json.dumps(out))

@@ -152,3 +152,25 @@ def test_filter_and_rescore_equals_the_exact_passes(kind, Q, N, b, R, ctx):
     finally:
         ctx.set_option("real_mfma", 2)
         ctx.set_option("real_sort_lds", 1)
+
+
+def test_real_valued_ranking_vs_np_dot_envelope(ctx):
+    """What main.py:164 really hands over (tanh outputs) against lib/metric.py:13-14 as written -- float32 np.dot (OpenBLAS)
+    -> np.argsort: the ranked lists differ only where float32 rounding reorders near-equal products.  The bounds are the
+    ones tests/test_oracle_real.py holds the oracle to (measured: 1e-4 of the positions, 2e-8 in mAP)."""
+    from tests.test_oracle_real import _tanh_case, REAL_ORDER_MISMATCH_MAX, REAL_MAP_DELTA_MAX
+    from oracle import hamming_map as H
+    from hashgan_amd import MAPs
+    qf, dbf, ql, dl = _tanh_case()
+    R = 1000
+    ctx.set_database_f32(dbf, dl)
+    ctx.set_queries_f32(qf, ql)
+    idx, score = ctx.topr_real(R)
+    ref_idx = np.argsort(-np.dot(qf, dbf.T), 1)[:, :R]
+    frac = float(np.mean(idx.astype(np.int64) != ref_idx))
+    assert frac <= REAL_ORDER_MISMATCH_MAX, frac
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m_ref = H.reference_as_written(dbf, dl, qf, ql, R)
+    m = MAPs(R).get_maps_by_feature(types.SimpleNamespace(output=dbf, label=dl), types.SimpleNamespace(output=qf, label=ql))
+    assert abs(m - m_ref) <= REAL_MAP_DELTA_MAX, (m, m_ref)
