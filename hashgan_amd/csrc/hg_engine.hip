@@ -502,9 +502,10 @@ void make_geometry(hg_ctx* c) {
         // k_select_mx runs (S / 2) x ceil(Q / 256 or 512) equal blocks, 4 or 2 resident per CU: pick the S near the
         // target that fills a whole number of such rounds, so the last round is not a nearly empty one
         const bool qt2 = c->NW <= 4;                                // mirrors launch_select_mx_t
-        const i64 qblk = qt2 ? 256 : 512;
+        const bool mx3 = c->opt_select_packed == 3 && c->NW == 2;   // k_select_mx3: blocks of M3_WPB wavefronts x 64 queries
+        const i64 qblk = mx3 ? 64 * M3_WPB : qt2 ? 256 : 512;
         const i64 nQB = (c->Q + qblk - 1) / qblk;
-        const i64 slots = (i64)c->n_cu * (qt2 ? 4 : 2);
+        const i64 slots = (i64)c->n_cu * (mx3 ? 16 / M3_WPB : qt2 ? 4 : 2);
         i64 k = (S / 2 * nQB + slots / 2) / slots;
         if (k < 1) k = 1;
         i64 S2 = 2 * (slots * k / nQB);
@@ -725,7 +726,7 @@ template <int NW, int LW, bool COMPACT> int launch_select_mx2_c(hg_ctx* c) {
 template <int NW, int LW> int launch_select_mx3_t(hg_ctx* c) {
     HG_TRY(ensure_mx_images<NW>(c));
     if (!c->dbx3_valid) {
-        const i64 n48 = (c->N + M3_ROWS - 1) / M3_ROWS * M3_ROWS + M3_WROWS;     // + one window of zero rows: the last segment's last window may run past the end
+        const i64 n48 = (c->N + M3_ROWS - 1) / M3_ROWS * M3_ROWS + M3_WS_MAX * M3_ROWS;     // + one window of zero rows: the last segment's last window may run past the end
         HG_TRY(c->dbx3.reserve((size_t)(n48 > 0 ? n48 : M3_ROWS) * 32));
         const i64 items = n48 * 2;
         c->t_begin(KI_PACK);
@@ -737,10 +738,10 @@ template <int NW, int LW> int launch_select_mx3_t(hg_ctx* c) {
     }
     Geo g = c->geo;
     const int nSP = (g.S + 1) / 2;
-    const int nQB = (g.Q + 255) / 256;
+    const int nQB = (g.Q + 64 * M3_WPB - 1) / (64 * M3_WPB);
     g.nQT = nQB;
     g.nUnits = (i64)nSP * nQB;
-    g.wpb = WPB;
+    g.wpb = M3_WPB;
     g.nBlk = (int)g.nUnits;
     const Mx3Lds L = mx3_lds_layout(NW, LW);
     if (L.total > 64 * 1024)
@@ -748,7 +749,7 @@ template <int NW, int LW> int launch_select_mx3_t(hg_ctx* c) {
     SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
               c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
     c->t_begin(KI_SELECT_MX);
-    hipLaunchKernelGGL((k_select_mx3<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total + (size_t)c->opt_lds_pad, c->stream, c->qc.as<u32>(),
+    hipLaunchKernelGGL((k_select_mx3<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(64 * M3_WPB), (size_t)L.total + (size_t)c->opt_lds_pad, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx3.as<u8>(), c->dblab.as<u64>(), a,
                        c->cand.as<u8>(), g);
     c->t_end();

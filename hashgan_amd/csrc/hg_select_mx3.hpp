@@ -35,11 +35,23 @@
 namespace hg {
 
 constexpr int M3_QT = 2;                   // query tiles (of 32) per wavefront
-constexpr int M3_WS = 2;                   // supertiles per window
 constexpr int M3_ROWS = 48;                // rows per supertile and lane-half
-constexpr int M3_WROWS = M3_WS * M3_ROWS;  // rows per window and lane-half
+// Supertiles per window (<= 4: two bits of a queue entry).  A window costs LDS -- 3 KiB of A fragments per supertile, twice,
+// and the packed codes + labels of its rows three times -- and buys fewer barriers, flushes and window ends per row.
+// Eight wavefronts share it: 79 KB per block with 4 supertiles and one label word (two blocks per CU, four wavefronts per
+// SIMD); two label words (65..128 classes) get 2 supertiles (67 KB).  Measured at C2, 8 wavefronts per block: 2 supertiles
+// 0.678 ms, 3: 0.672, 4: 0.662 (4 wavefronts per block, 2 supertiles: 0.688).
+#ifndef HG_M3_WS
+#define HG_M3_WS 4
+#endif
+__host__ __device__ constexpr int m3_ws(int LW) { return LW <= 1 ? HG_M3_WS : 2; }
+constexpr int M3_WS_MAX = HG_M3_WS > 2 ? HG_M3_WS : 2;
 constexpr int M3_QCAP = 128;               // queue entries per wavefront (ring buffer; a power of two)
 constexpr int M3_RING = 16;                // records per slice ring
+#ifndef HG_M3_WPB
+#define HG_M3_WPB 8
+#endif
+constexpr int M3_WPB = HG_M3_WPB;          // wavefronts per block: they share the staged window (4: 40 KB of LDS, four blocks per CU; 8: two)
 
 // register r (0..15) of tile f (0..2) -> row of the 48-row supertile; the register's scale shift
 __host__ __device__ constexpr int m3_row(int f, int r) { return r < 7 ? 7 * f + r : r < 14 ? 21 + 7 * f + (r - 7) : 42 + 2 * f + (r - 14); }
@@ -84,23 +96,25 @@ struct Mx3Lds {                // byte offsets inside the block's dynamic LDS
 };
 __host__ __device__ inline Mx3Lds mx3_lds_layout(int NW, int LW) {
     Mx3Lds l;
+    const int M3_WS = m3_ws(LW), M3_WROWS = M3_WS * M3_ROWS;
     l.a = 0;
     l.abuf = M3_WS * 3 * 1024;
     l.cl = 2 * l.abuf;
     l.labels = 2 * M3_WROWS * NW * 4;
     l.clbuf = (l.labels + 2 * M3_WROWS * LW * 8 + 15) & ~15;
     l.qcodes = l.cl + 3 * l.clbuf;
-    l.qlabels = l.qcodes + WPB * 64 * NW * 4;
-    l.qab = l.qlabels + WPB * 64 * LW * 8;
-    l.qc = l.qab + WPB * M3_QCAP * 8;
-    l.rings = l.qc + WPB * M3_QCAP * 4;
-    l.total = l.rings + WPB * 64 * M3_QT * M3_RING;
+    l.qlabels = l.qcodes + M3_WPB * 64 * NW * 4;
+    l.qab = l.qlabels + M3_WPB * 64 * LW * 8;
+    l.qc = l.qab + M3_WPB * M3_QCAP * 8;
+    l.rings = l.qc + M3_WPB * M3_QCAP * 4;
+    l.total = l.rings + M3_WPB * 64 * M3_QT * M3_RING;
     return l;
 }
 
 template <int NW, int LW>
 struct Mx3Drain {
     static constexpr int QT = M3_QT, CB = NW * 4, LB = LW * 8;
+    static constexpr int M3_WS = m3_ws(LW), M3_WROWS = M3_WS * M3_ROWS;
     u8* lds;
     Mx3Lds L;
     u64* qab;                            // this wavefront's queue
@@ -124,7 +138,7 @@ struct Mx3Drain {
         rings = lds + L.rings + wave * (64 * QT * M3_RING);
         const int h = lane >> 5, j = lane & 31;
         lane_off = (u32)j * (u32)crow + (u32)h * cap;
-        tb0 = cand8 + (i64)(qb * WPB + wave) * 64 * crow + (i64)(2 * sp) * cap;
+        tb0 = cand8 + (i64)(qb * M3_WPB + wave) * 64 * crow + (i64)(2 * sp) * cap;
         qhead = qfill = old = 0;
 #pragma unroll
         for (int t = 0; t < QT; ++t) cnt[t] = prev[t] = flushed[t] = 0;
@@ -163,7 +177,7 @@ struct Mx3Drain {
             const u64 ab = qab[i];
             const u32 c = qc[i];
             const u32 a = (u32)ab, b = (u32)(ab >> 32);
-            const u32 src = a & 63u, t = (a >> 27) & 1u, st = (a >> 28) & 1u, sel = (a >> 29) & 3u;
+            const u32 src = a & 63u, t = (a >> 27) & 1u, st = (a >> 28) & 3u, sel = a >> 30;
             u32 pos = b >> 27;                                        // slice position & 15 of the entry's first hit
             // flat hit mask of the supertile: bit P <-> row P
             const u32 a21 = (a >> 6) & 0x1FFFFFu, b21 = (b >> 6) & 0x1FFFFFu, c6 = ((c * 0x421u) >> 16) & 0x3Fu;
@@ -293,7 +307,7 @@ struct Mx3Drain {
                 want[t] = cnt[t] + (u32)__builtin_popcount(w[t][0]) + (u32)__builtin_popcount(w[t][1]) + (u32)__builtin_popcount(w[t][2]);
             }
         }
-        const u32 desc = ((u32)st << 28) | (sel << 29);
+        const u32 desc = ((u32)st << 28) | (sel << 30);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const u64 b = bal[t];
@@ -341,7 +355,7 @@ template <int NW, int LW>
 #ifndef HG_M3_WAVES
 #define HG_M3_WAVES 4
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HG_M3_WAVES, HG_M3_WAVES)))
+__global__ __launch_bounds__(64 * M3_WPB) __attribute__((amdgpu_waves_per_eu(HG_M3_WAVES, HG_M3_WAVES)))
 void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, const u8* __restrict__ qx,
                   const u32* __restrict__ db, const u8* __restrict__ dbx, const u64* __restrict__ dblab,
                   const SelArgs a, u8* __restrict__ cand8, const Geo g) {
@@ -349,6 +363,7 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
     extern __shared__ __attribute__((aligned(1024))) u8 mxlds[];
     constexpr int QT = M3_QT, WQ = 32 * QT;
     constexpr int CB = NW * 4, LB = LW * 8;
+    constexpr int M3_WS = m3_ws(LW), M3_WROWS = M3_WS * M3_ROWS;      // this label width's window
     const Mx3Lds L = mx3_lds_layout(NW, LW);
 
     const int lb = logical_block(g.nBlk);
@@ -371,7 +386,7 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
     const i64 NG = (g.N + M3_ROWS - 1) / M3_ROWS;        // supertiles in the image
 
     // ---- query side: LDS tables for the emit, B fragments, C = the bias, harvest masks ----
-    const int q0w = (qb * WPB + wave) * WQ;               // first query of this wavefront
+    const int q0w = (qb * M3_WPB + wave) * WQ;               // first query of this wavefront
     {
         u32* qcl = (u32*)(mxlds + L.qcodes + wave * WQ * CB);
         for (int e = lane; e < WQ * NW; e += 64) {
@@ -429,14 +444,14 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
         u8* sa = mxlds + L.a + abuf * L.abuf;
         u8* scl = mxlds + L.cl + clsel * L.clbuf;
 #pragma unroll
-        for (int k = 0; k < (M3_WS * 3 + WPB - 1) / WPB; ++k) {
-            const int c = wave + k * WPB;
+        for (int k = 0; k < (M3_WS * 3 + M3_WPB - 1) / M3_WPB; ++k) {
+            const int c = wave + k * M3_WPB;
             if (c < M3_WS * 3) HG_GLDS16(a_lane + (win * (M3_WS * 3) + c) * 512, sa + c * 1024);
         }
         constexpr int CPH = (M3_WROWS * CB + 1023) / 1024, LPH = (M3_WROWS * LB + 1023) / 1024;
 #pragma unroll
-        for (int k = 0; k < (2 * (CPH + LPH) + WPB - 1) / WPB; ++k) {
-            const int c = wave + k * WPB;                            // wave-uniform: which table, half and piece
+        for (int k = 0; k < (2 * (CPH + LPH) + M3_WPB - 1) / M3_WPB; ++k) {
+            const int c = wave + k * M3_WPB;                            // wave-uniform: which table, half and piece
             if (c < 2 * (CPH + LPH)) {
                 const int hh = c & 1, kk = c >> 1;
                 const bool is_lab = kk >= CPH;
@@ -516,10 +531,8 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
             if (!(kProbes && (a.probe & 2))) dr.push(w, st, (u32)clsel);
             __builtin_amdgcn_sched_barrier(0);
         }
-#ifndef HG_M3_FLUSH_EVERY
-#define HG_M3_FLUSH_EVERY 2
-#endif
-        if (!(kProbes && (a.probe & 2))) dr.end_window(HG_M3_FLUSH_EVERY == 1 || (win % HG_M3_FLUSH_EVERY) == HG_M3_FLUSH_EVERY - 1);
+        // the owners flush every fourth supertile (192 rows: ~1.2 records per slice at C2; every second one cost 4 % more)
+        if (!(kProbes && (a.probe & 2))) dr.end_window(((win + 1) * M3_WS) % 4 == 0);
         clsel = clnext;
     }
     dr.finish();
