@@ -47,6 +47,8 @@ _SIGNATURES = {
     "hg_bet_verdict": [_p, C.POINTER(C.c_int)],
     "hg_select_ranked": [_p],
     "hg_merge_ranked": [_p, _p, _p, C.c_int, C.POINTER(C.c_int)],
+    "hg_merge_ap_part": [_p, _p, _p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.POINTER(_p), C.POINTER(C.c_int64)],
+    "hg_unpack_parts": [_p, _p, C.c_int, C.c_int64, _p, _p, C.POINTER(C.c_int)],
     "hg_match": [_p],
     "hg_match_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
     "hg_merge_match": [_p, _p, C.c_int],
@@ -247,6 +249,21 @@ class Context:
         check(self._lib.hg_merge_ranked(self._h, _p(dev_hist_all) if dev_hist_all else None,
                                         _p(dev_bits_all) if dev_bits_all else None, int(G), C.byref(lost)))
         return None if lost.value < 0 else bool(lost.value)
+
+    def merge_ap_part(self, dev_hist_all, dev_bits_all, G, q0, nq, width):
+        """-> (device address, bytes) of this rank's part: hg_merge_ap_part."""
+        p, n = _p(), _i64()
+        check(self._lib.hg_merge_ap_part(self._h, _p(dev_hist_all) if dev_hist_all else None, _p(dev_bits_all) if dev_bits_all else None,
+                                         int(G), int(q0), int(nq), int(width), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def unpack_parts(self, dev_parts_all, G, width):
+        """-> (ap [Q] float64, rel [Q] int64, bet lost?) from the gathered parts: hg_unpack_parts."""
+        ap = np.empty(self.Q, dtype=np.float64)
+        rel = np.empty(self.Q, dtype=np.int64)
+        lost = C.c_int()
+        check(self._lib.hg_unpack_parts(self._h, _p(dev_parts_all), int(G), int(width), _ptr(ap), _ptr(rel), C.byref(lost)))
+        return ap, rel, bool(lost.value)
 
     def bet_verdict(self):
         lost = C.c_int()

@@ -338,6 +338,7 @@ struct hg_ctx {
     DevBuf t, tguess, sstar, cnt_lt, quota, tie_before, n_lt, err;
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
     DevBuf mbits2;             // hg_merge_ranked's output (swapped with mbits)
+    DevBuf part;               // hg_merge_ap_part's output: {AP, hits} of this rank's queries + its verdict
     bool ranked_local = false; // mbits holds this shard's bitmap in LOCAL rank order (hg_select_ranked)
     DevBuf cand, out_idx, out_dist, mbits, shapes, ap_recip, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
@@ -1191,7 +1192,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip};
+                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip, &c->part};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -1725,7 +1726,7 @@ int hg_merge_match(hg_ctx* c, const uint64_t* dev_bits_all, int G) {
     return c->stage_end();
 }
 
-static int do_ap(hg_ctx* c) {
+static int do_ap_range(hg_ctx* c, i64 q0, i64 nq) {      // k_ap's block index is the query: a range is a pointer offset
     c->ap_staged = false;
     const Geo& g = c->geo;
     if (c->shapes_for_R != g.R) {
@@ -1748,14 +1749,16 @@ static int do_ap(hg_ctx* c) {
     HG_TRY(c->ap.reserve((size_t)g.Q * 8));
     HG_TRY(c->rel.reserve((size_t)g.Q * 4));
     c->t_begin(KI_AP);
-    hipLaunchKernelGGL(k_ap, dim3(g.Q), dim3(AP_THREADS), 0, c->stream, c->mbits.as<u64>(), c->RW, g.R,
-                       c->shapes.as<ApShape>(), use_recip ? c->ap_recip.as<double>() : (const double*)nullptr,
-                       c->ap.as<double>(), c->rel.as<u32>());
+    if (nq > 0)
+        hipLaunchKernelGGL(k_ap, dim3((unsigned)nq), dim3(AP_THREADS), 0, c->stream, c->mbits.as<u64>() + (size_t)q0 * c->RW, c->RW, g.R,
+                           c->shapes.as<ApShape>(), use_recip ? c->ap_recip.as<double>() : (const double*)nullptr,
+                           c->ap.as<double>() + q0, c->rel.as<u32>() + q0);
     c->t_end();
     HG_TRY(c->check_launch("k_ap"));
     c->stage |= ST_AP;
     return HG_OK;
 }
+static int do_ap(hg_ctx* c) { return do_ap_range(c, 0, c->geo.Q); }
 
 int hg_ap(hg_ctx* c) {
     HG_TRY(need(c, ST_MATCH, "hg_ap", "hg_match"));
@@ -1896,12 +1899,13 @@ int hg_select_ranked(hg_ctx* c) {
     return c->stage_end();
 }
 
-int hg_merge_ranked(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, int* bet_lost) {
-    HG_TRY(need(c, ST_MATCH, "hg_merge_ranked", "hg_select_ranked"));
-    if (!c->ranked_local) return fail(HG_ERR_STATE, "hg_merge_ranked: hg_select_ranked has not run");
-    if (!bet_lost || G < 1 || G > 64 || (G > 1 && (!dev_hist_all || !dev_bits_all)))
-        return fail(HG_ERR_ARG, "hg_merge_ranked: bad argument (1 <= G <= 64, gathered buffers for G > 1)");
+static int merge_ranked_range(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, i64 q0, i64 nq, const char* who) {
+    HG_TRY(need(c, ST_MATCH, who, "hg_select_ranked"));
+    if (!c->ranked_local) return fail(HG_ERR_STATE, "%s: hg_select_ranked has not run", who);
+    if (G < 1 || G > 64 || (G > 1 && (!dev_hist_all || !dev_bits_all)))
+        return fail(HG_ERR_ARG, "%s: bad argument (1 <= G <= 64, gathered buffers for G > 1)", who);
     const Geo& g = c->geo;
+    if (q0 < 0 || nq < 0 || q0 + nq > g.Q) return fail(HG_ERR_ARG, "%s: queries [%lld, %lld) of %d", who, (long long)q0, (long long)(q0 + nq), g.Q);
     HG_TRY(c->mbits2.reserve((size_t)g.Q * c->RW * 8));
     HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
     const u32* hall = G > 1 ? (const u32*)dev_hist_all : c->hown.as<u32>();
@@ -1916,13 +1920,20 @@ int hg_merge_ranked(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev
     if (merge_lds > 64 * 1024)
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_ranked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds));
     c->t_begin(KI_MERGE);
-    hipLaunchKernelGGL(k_merge_ranked, dim3(grid_for(g.Q, WPB)), dim3(256), merge_lds, c->stream, hall, ball, G,
-                       c->RW, c->mbits2.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(), use_lds, g);
+    if (nq > 0)
+        hipLaunchKernelGGL(k_merge_ranked, dim3(grid_for(nq, WPB)), dim3(256), merge_lds, c->stream, hall, ball, G,
+                           c->RW, c->mbits2.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(), use_lds, g, (int)q0, (int)(q0 + nq));
     c->t_end();
     HG_TRY(c->check_launch("k_merge_ranked"));
     std::swap(c->mbits, c->mbits2);                    // the global bitmap is what hg_ap and hg_get_match see
     c->ranked_local = false;
     c->G = G;
+    return HG_OK;
+}
+
+int hg_merge_ranked(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, int* bet_lost) {
+    if (!bet_lost) return fail(HG_ERR_ARG, "hg_merge_ranked: null argument");
+    HG_TRY(merge_ranked_range(c, dev_hist_all, dev_bits_all, G, 0, c ? c->geo.Q : 0, "hg_merge_ranked"));
     if (c->defer_verdict) {
         *bet_lost = -1;
         c->verdict_pending = true;
@@ -2024,6 +2035,68 @@ int hg_bet_verdict(hg_ctx* c, int* bet_lost) {
     c->shard_bet_fail++;
     c->lists_valid = false;
     c->stage = ST_DB | ST_Q;
+    return HG_OK;
+}
+
+// The sharded bet with the per-query stages SPLIT over the ranks: after the all-gather of record counts and local bitmaps
+// every rank merges and evaluates only its own queries [q0, q0 + nq) (instead of all Q on every rank), packs {AP, hits}
+// and its verdict into `part`; one small all-gather later hg_unpack_parts gives every rank all of it.
+int hg_merge_ap_part(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, int64_t q0, int64_t nq,
+                     int64_t width, void** dev_part, int64_t* nbytes) {
+    if (!c || !dev_part || !nbytes || width < nq || width < 1) return fail(HG_ERR_ARG, "hg_merge_ap_part: bad argument");
+    HG_TRY(merge_ranked_range(c, dev_hist_all, dev_bits_all, G, q0, nq, "hg_merge_ap_part"));
+    const Geo& g = c->geo;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
+    // AP of the merged rows only: k_ap's block index is the query
+    {
+        const i64 Qsave = c->geo.Q;
+        HG_TRY(c->ap.reserve((size_t)Qsave * 8));
+        HG_TRY(c->rel.reserve((size_t)Qsave * 4));
+        HG_TRY(do_ap_range(c, q0, nq));
+    }
+    const size_t pb = (size_t)(width + 1) * 16;
+    HG_TRY(c->part.reserve(pb));
+    hipLaunchKernelGGL(k_pack_part, dim3(grid_for(width + 1)), dim3(256), 0, c->stream, c->ap.as<double>(), c->rel.as<u32>(),
+                       c->err.as<int>(), (i64)q0, (i64)nq, (i64)width, c->part.as<double>());
+    HG_TRY(c->check_launch("k_pack_part"));
+    (void)g;
+    *dev_part = c->part.p;
+    *nbytes = (int64_t)pb;
+    return c->stage_end();
+}
+
+int hg_unpack_parts(hg_ctx* c, const void* dev_parts_all, int G, int64_t width, double* host_ap, int64_t* host_rel, int* bet_lost) {
+    if (!c || !dev_parts_all || G < 1 || width < 1 || !host_ap || !host_rel || !bet_lost) return fail(HG_ERR_ARG, "hg_unpack_parts: bad argument");
+    HG_TRY(c->use());
+    const i64 Q = c->geo.Q;
+    const size_t pb = (size_t)(width + 1) * 16, total = pb * (size_t)G;
+    HG_TRY(ensure_pin(c, total));
+    HG_HIP(hipMemcpyAsync(c->pin, dev_parts_all, total, hipMemcpyDeviceToHost, c->stream));
+    HG_TRY(c->sync());
+    int flag = 0;
+    i64 done = 0;
+    for (int r = 0; r < G; ++r) {
+        const double* p = (const double*)((const char*)c->pin + (size_t)r * pb);
+        const i64 n = (i64)p[2 * width + 1];
+        if (n < 0 || n > width || done + n > Q) return fail(HG_ERR_ARG, "hg_unpack_parts: rank %d reports %lld queries (width %lld, %lld of %lld placed)",
+                                                            r, (long long)n, (long long)width, (long long)done, (long long)Q);
+        flag |= p[2 * width] != 0.0;
+        for (i64 i = 0; i < n; ++i) { host_ap[done + i] = p[2 * i]; host_rel[done + i] = (int64_t)p[2 * i + 1]; }
+        done += n;
+    }
+    if (done != Q) return fail(HG_ERR_ARG, "hg_unpack_parts: the parts cover %lld of %lld queries", (long long)done, (long long)Q);
+    *bet_lost = flag;
+    c->verdict_pending = false;
+    c->verdict_known = false;
+    c->opt_runs++;                                     // the verdict comes from gathered data: the same on every rank
+    if (flag) {
+        c->opt_fallbacks++;
+        c->shard_bet_fail++;
+        c->lists_valid = false;
+        c->stage = ST_DB | ST_Q;
+    } else {
+        c->shard_bet_fail = 0;
+    }
     return HG_OK;
 }
 
@@ -2887,7 +2960,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
                          &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2,
-                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip};
+                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip, &c->part};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
         *value = total;

@@ -1092,13 +1092,14 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
 // ----------------------------------------------------------------------------
 // use_lds: the G local bitmap rows of the query are first copied into LDS with all loads in flight (the
 // stitching reads them bit range by bit range, one dependent load per 64 bits otherwise).
+// q0, q1: the queries this launch merges (a rank of the sharded bet takes its own share of them: hg_merge_ap_part).
 __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restrict__ hall, const u64* __restrict__ ball, int G,
                                                       i64 RW, u64* __restrict__ out, int* __restrict__ err,
-                                                      u32* __restrict__ qbad, int use_lds, const Geo g) {
+                                                      u32* __restrict__ qbad, int use_lds, const Geo g, const int q0, const int q1) {
     extern __shared__ __attribute__((aligned(16))) u64 mrows[];       // [WPB][G][RW] when use_lds
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (q >= g.Q) return;
+    const int q = q0 + blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (q >= q1) return;
     const int wv = threadIdx.x >> 6;
     u64* lrows = mrows + (i64)wv * G * RW;
     // the query's record counts of all shards, [G][NB], fetched with every load in flight
@@ -1116,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restrict__ ha
     wave_lds_sync();
     const i64 plane = (i64)g.NB * g.Qpad + TAIL_WORDS;
     const bool mine = lane < G;                                       // lane r speaks for shard r (G <= 64)
-    if (q == 0 && mine && hall[(i64)lane * plane + plane - TAIL_WORDS]) atomicExch(err, 1);   // a slice overflowed somewhere
+    if (q == q0 && mine && hall[(i64)lane * plane + plane - TAIL_WORDS]) atomicExch(err, 1);   // a slice overflowed somewhere
     u64* __restrict__ orow = out + (i64)q * RW;
     u64 acc = 0;                // output bits not yet written (wave-uniform), `fill` of them
     int fill = 0;
@@ -1436,6 +1437,19 @@ __global__ __launch_bounds__(256) void k_move_rows(const u8* __restrict__ src, u
 __global__ __launch_bounds__(256) void k_fill_u32(u32* __restrict__ p, u32 v, i64 n) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
+}
+
+// What a rank of the sharded bet hands to the all-gather after merging + evaluating ITS queries [q0, q0 + nq): pairs of
+// doubles, pair i < nq = {AP, hit count} of query q0 + i, pairs nq .. width - 1 zero, pair `width` = {lost-bet flag, nq}.
+__global__ __launch_bounds__(256) void k_pack_part(const double* __restrict__ ap, const u32* __restrict__ rel, const int* __restrict__ err,
+                                                   const i64 q0, const i64 nq, const i64 width, double* __restrict__ out) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i > width) return;
+    double a = 0.0, b = 0.0;
+    if (i < nq) { a = ap[q0 + i]; b = (double)rel[q0 + i]; }
+    else if (i == width) { a = *err ? 1.0 : 0.0; b = (double)nq; }
+    out[2 * i] = a;
+    out[2 * i + 1] = b;
 }
 
 }  // namespace hg

@@ -12,6 +12,8 @@ context's stream, ordered with its kernels):
         merge is ever needed, shards interleave by (distance, shard, index).
   2. per-shard label-match bit rows, uint64 [Q][ceil(R/64)] (6.3 MB at C2)
      -> OR (global position space) or stitching (local rank order) -> AP.
+  3. (the bet with locally ranked records) 16 bytes per query: every rank stitches and evaluates only its own
+     share of the queries, the per-query APs and the verdict are gathered.
 
 `gather_topr` additionally all-gathers the ranked (idx, dist) lists themselves
 (the exchange BASELINE.json's north star names, hg_allgather_topr) for callers
@@ -257,6 +259,19 @@ class HipShardEngine:
     def merge_ranked(self, gathered_hist, gathered_bits, world):
         return self.ctx.merge_ranked(self._ptr(gathered_hist), self._ptr(gathered_bits), world)
 
+    def merge_ap_part(self, gathered_hist, gathered_bits, world, rank):
+        """The merge and the AP of THIS rank's share of the queries only (shard_bounds(Q, world)[rank]) -> its part
+        (a device buffer of the same size on every rank) for the all-gather: hg_merge_ap_part."""
+        bounds = shard_bounds(self.ctx.Q, world)
+        width = max(n for _, n in bounds)
+        q0, nq = bounds[rank]
+        return DevBuf(*self.ctx.merge_ap_part(self._ptr(gathered_hist), self._ptr(gathered_bits), world, q0, nq, width))
+
+    def unpack_parts(self, gathered_parts, world):
+        """-> (ap, rel, lost) of ALL queries from the gathered parts; synchronises (the step's one download)."""
+        width = max(n for _, n in shard_bounds(self.ctx.Q, world))
+        return self.ctx.unpack_parts(gathered_parts.ptr, world, width)
+
     def verdict(self):
         """True if a deferred bet (rank_candidates returned None) turned out lost."""
         return self.ctx.bet_verdict()
@@ -294,7 +309,17 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
         # global bitmap is stitched from the gathered local ones (hg_merge_ranked)
         engine.guess(R, gather(engine.sample_hist(R)), comm.world, comm.rank)
         h, b = engine.select_ranked()
-        lost = engine.merge_ranked(gather(h), gather(b), comm.world)
+        if multi and hasattr(engine, "merge_ap_part"):
+            # the per-query stages split over the ranks: each merges and evaluates its own share of the queries, a third,
+            # tiny all-gather (16 bytes per query) brings every rank all APs and the verdict (the same on every rank)
+            part = engine.merge_ap_part(gather(h), gather(b), comm.world, comm.rank)
+            ap, rel, lost = engine.unpack_parts(comm.all_gather(part), comm.world)
+            if not lost:
+                return ap, rel
+            bet = False
+            lost = True
+        else:
+            lost = engine.merge_ranked(gather(h), gather(b), comm.world)
         if not lost:                                  # held, or verdict deferred
             ap, rel = engine.finish(None, comm.world)
             if lost is not None or not engine.verdict():

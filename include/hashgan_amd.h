@@ -144,6 +144,17 @@ int hg_bet_verdict(hg_ctx* ctx, int* bet_lost);
  *                    *bet_lost as in hg_rank (-1 with "defer_verdict"); G <= 64. */
 int hg_select_ranked(hg_ctx* ctx);
 int hg_merge_ranked(hg_ctx* ctx, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, int* bet_lost);
+/* The same with the per-query stages split over the ranks (hashgan_amd/sharded.py::evaluate_shard): after the all-gather
+ * of record counts and local bitmaps, rank r merges and evaluates (k_merge_ranked + k_ap) only its own contiguous share
+ * [q0, q0 + nq) of the queries instead of all Q on every rank.  Its results leave in one device buffer *dev_part of
+ * (width + 1) pairs of doubles -- pair i < nq = {AP, hit count} of query q0 + i, pairs nq .. width - 1 zero, pair `width` =
+ * {this rank's lost-bet flag, nq}; width >= nq is the same on every rank so that the parts can be all-gathered.
+ * hg_unpack_parts takes the gathered G parts (rank order = query order), fills AP / hit counts of all Q queries on the host
+ * and returns the bet's verdict (the OR of the ranks' flags: computed from gathered data, identical on every rank), doing
+ * hg_bet_verdict's bookkeeping.  The reference has no counterpart (lib/metric.py:16-24 loops over all queries in one process). */
+int hg_merge_ap_part(hg_ctx* ctx, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, int64_t q0, int64_t nq,
+                     int64_t width, void** dev_part, int64_t* nbytes);
+int hg_unpack_parts(hg_ctx* ctx, const void* dev_parts_all, int G, int64_t width, double* host_ap, int64_t* host_rel, int* bet_lost);
 
 /* Ranked lists in global-position space: uint32 idx [Q][R] (HG_IDX_NONE where a
  * slot belongs to another shard), uint8 dist [Q][R] (0xFF there). */

@@ -124,3 +124,24 @@ class NumpyRankedEngine(NumpyShardEngine):
             packed = np.packbits(self.bits, axis=1, bitorder="little")[None]
             return NumpyShardEngine.finish(self, torch.from_numpy(packed), 1)
         return NumpyShardEngine.finish(self, gathered_bits, world)
+
+    # the per-query stages split over the ranks (HipShardEngine.merge_ap_part / unpack_parts, hg_merge_ap_part)
+    def merge_ap_part(self, gathered_hist, gathered_bits, world, rank):
+        from hashgan_amd.sharded import shard_bounds
+        lost = self.merge_ranked(gathered_hist, gathered_bits, world)            # (all queries: the stand-in is not about speed)
+        ap, rel = NumpyShardEngine.finish(self, torch.from_numpy(np.packbits(self.bits, axis=1, bitorder="little")[None]), 1)
+        bounds = shard_bounds(self.D.shape[0], world)
+        width = max(n for _, n in bounds)
+        q0, nq = bounds[rank]
+        part = np.zeros((width + 1, 2), dtype=np.float64)
+        part[:nq, 0], part[:nq, 1] = ap[q0:q0 + nq], rel[q0:q0 + nq]
+        part[width] = (1.0 if lost else 0.0, nq)
+        return torch.from_numpy(part)
+
+    def unpack_parts(self, gathered_parts, world):
+        P = gathered_parts.numpy()
+        width = P.shape[1] - 1
+        ns = [int(P[r, width, 1]) for r in range(world)]
+        ap = np.concatenate([P[r, :ns[r], 0] for r in range(world)])
+        rel = np.concatenate([P[r, :ns[r], 1] for r in range(world)]).astype(np.int64)
+        return ap, rel, bool(P[:, width, 0].any())

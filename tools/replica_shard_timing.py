@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""What ONE rank of a G-GPU run executes, alone on the GPU: the sharded sequence on a 10M / G-row shard of C4 with a
+communicator whose all_gather hands back G copies of this rank's own buffer (device-to-device copies on the context's
+stream stand in for the wire).  i.i.d. shards are statistically alike, so G copies of one shard's histograms / counts /
+bitmaps cost the merge stages what the true gathered tables would -- the mAP is NOT the database's, the stage times are.
+Prints wall time per step (one stream, no host waits between stages) and the per-kernel times.
+
+    python tools/replica_shard_timing.py [G ...]
+"""
+import sys, time
+import numpy as np
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from hashgan_amd import _native, sharded, synth
+
+N, Q, b, C, R, seed = 10_000_000, 10000, 64, 10, 5000, 0xC4
+
+
+class ReplicaComm:
+    def __init__(self, ctx, world):
+        self.ctx, self.world, self.rank, self._slot = ctx, world, 0, 0
+
+    def all_gather(self, buf):
+        slot = self._slot
+        self._slot = (slot + 1) % 4
+        base = self.ctx.scratch(slot, buf.nbytes * self.world)
+        for r in range(self.world):
+            self.ctx.memcpy_dtod(base + r * buf.nbytes, buf.ptr, buf.nbytes)
+        return sharded.DevBuf(base, buf.nbytes * self.world)
+
+    def barrier(self):
+        self.ctx.synchronize()
+
+
+def one(G, steps=10):
+    rows = N // G
+    ctx = _native.Context(0)
+    try:
+        ctx.set_database(synth.random_code_words(seed, rows, b), synth.onehot_label_words(seed * 3 + 1, rows, C), b, C, idx_base=0, n_total=N)
+        ctx.set_queries(synth.random_code_words(seed + 7, Q, b), synth.onehot_label_words(seed * 3 + 2, Q, C))
+        comm = ReplicaComm(ctx, G)
+        eng = sharded.HipShardEngine(ctx, want_lists=False, async_stages=True)
+        for _ in range(3):
+            sharded.evaluate_shard(eng, comm, R, always_gather=True)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ap, rel = sharded.evaluate_shard(eng, comm, R, always_gather=True)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ctx.timing_enable(2); ctx.timing_reset()
+        for _ in range(3):
+            sharded.evaluate_shard(eng, comm, R, always_gather=True)
+        ctx.synchronize()
+        k = {n: round(v[0] / max(v[1], 1), 4) for n, v in ctx.timing_read().items()}
+        ctx.timing_enable(False)
+        print("G=%d  shard rows %d  step %.3f ms   kernels (ms per launch, timed separately): %s   [bets %d, lost %d]"
+              % (G, rows, dt * 1e3, k, ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks")), flush=True)
+    finally:
+        ctx.close()
+
+
+if __name__ == "__main__":
+    for G in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]):
+        one(G)
