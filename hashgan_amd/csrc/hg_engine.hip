@@ -286,7 +286,7 @@ struct hg_ctx {
     i64 opt_select_mfma = 1;   // optimistic select: 1 = matrix-core kernel (k_select_mx), 0 = vector-ALU k_select
     i64 opt_probe = 0;         // measurement probes of the matrix-core select kernels (SelArgs::probe)
     i64 opt_select_packed = 3; // codes of <= 64 bits, several distances per MFMA accumulator: 1 = k_select_mx2 (two) for <= 32 bits,
-                               // 2 = k_select_mx2 up to 64 bits, 3 = 1 + k_select_mx3 (three, batched drain) for 33..64 bits with compact records
+                               // 2 = k_select_mx2 up to 64 bits, 3 = k_select_mx3 (three, batched drain) for compact records, else like 1
     i64 opt_sample_ratio = 2;  // the sampled pass works on segments this many times longer than the select pass's
     i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
@@ -494,7 +494,7 @@ void make_geometry(hg_ctx* c) {
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     i64 L = (c->N + S - 1) / S;
-    const i64 lq = (c->opt_select_packed == 3 && c->NW == 2) ? 96 : 32;   // k_select_mx2 walks segments in 32-row tiles, k_select_mx3 in 48-row supertiles
+    const i64 lq = (c->opt_select_packed >= 3 && c->NW <= 2) ? 96 : 32;   // k_select_mx2 walks segments in 32-row tiles, k_select_mx3 in 48-row supertiles
     L = (L + lq - 1) / lq * lq;
     if (L < lq) L = lq;
     S = (c->N + L - 1) / L;
@@ -503,7 +503,7 @@ void make_geometry(hg_ctx* c) {
         // k_select_mx runs (S / 2) x ceil(Q / 256 or 512) equal blocks, 4 or 2 resident per CU: pick the S near the
         // target that fills a whole number of such rounds, so the last round is not a nearly empty one
         const bool qt2 = c->NW <= 4;                                // mirrors launch_select_mx_t
-        const bool mx3 = c->opt_select_packed == 3 && c->NW == 2;   // k_select_mx3: blocks of M3_WPB wavefronts x 64 queries
+        const bool mx3 = c->opt_select_packed == 3 && c->NW <= 2;   // k_select_mx3: blocks of M3_WPB wavefronts x 64 queries
         const i64 qblk = mx3 ? 64 * M3_WPB : qt2 ? 256 : 512;
         const i64 nQB = (c->Q + qblk - 1) / qblk;
         const i64 slots = (i64)c->n_cu * (mx3 ? 16 / M3_WPB : qt2 ? 4 : 2);
@@ -780,15 +780,16 @@ template <int NW> int launch_select_nw(hg_ctx* c) {
             default: return launch_select_dense_t<NW, 0>(c);
         }
     }
-    // three rows per accumulator + batched drain: codes of 33..64 bits, one-byte records (<= 128 classes)
-    if (NW == 2 && c->rec8 && c->opt_select_packed == 3 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) {
+    // three rows per accumulator + batched drain: codes of <= 64 bits, one-byte records (<= 128 classes).  (For <= 32 bits the
+    // second k-half of every MFMA is empty, and it still beats k_select_mx2's two rows per accumulator: 0.69 vs 0.85 ms at b = 32.)
+    if (NW <= 2 && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) {
         if (lw == 1) return launch_select_mx3_t<(NW == 2 ? 2 : 1), 1>(c);
         return launch_select_mx3_t<(NW == 2 ? 2 : 1), 2>(c);
     }
     // two rows per accumulator: wins for one-word codes (half the MFMAs: 0.92 vs 1.02 ms at b = 32); for 33-64 bits
     // its cheaper harvest (0.36 vs 0.44 ms) is eaten by the wider queue entries (select_packed = 2 forces it)
     if (c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS) && c->geo.L % 32 == 0 &&
-        (((c->opt_select_packed == 1 || c->opt_select_packed == 3) && NW == 1) || (c->opt_select_packed == 2 && NW <= 2))) {
+        (((c->opt_select_packed == 1 || c->opt_select_packed >= 3) && NW == 1) || (c->opt_select_packed == 2 && NW <= 2))) {
         switch (lw) {
             case 1: return launch_select_mx2_t<(NW <= 2 ? NW : 1), 1>(c);
             case 2: return launch_select_mx2_t<(NW <= 2 ? NW : 1), 2>(c);

@@ -241,9 +241,9 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * k_select_mx; 0: vector-ALU xor+popcount k_select; same records either way), "probe_select" (probe build only --
  * python -m hashgan_amd.build --probes: bits 2/4/8 switch parts of the matrix-core kernels' drain off; the bet
  * then fails and the exact sequence runs, so results stay right; the production library refuses the key),
- * "select_packed" (several rows per MFMA accumulator: 3, default = k_select_mx2 (two rows) for codes of <= 32 bits and
- * k_select_mx3 (three rows through per-row MX scales, batched drain) for 33..64 bits with one-byte records; 1 = k_select_mx2
- * for <= 32 bits only, 2 = k_select_mx2 up to 64 bits, 0 = never), "rank_lds" (0/1), "rank_cnt" (0/1:
+ * "select_packed" (several rows per MFMA accumulator: 3, default = k_select_mx3 (three rows through per-row MX scales,
+ * batched drain) for codes of <= 64 bits with one-byte records, k_select_mx2 (two rows) for <= 32 bits otherwise; 1 =
+ * k_select_mx2 for <= 32 bits only, 2 = k_select_mx2 up to 64 bits, 0 = never), "rank_lds" (0/1), "rank_cnt" (0/1:
  * the bet's rank stage as a per-thread counting sort, k_rank_cnt),
  * "host_pack", "keep_floats", "pack_threads" (hg_set_*_f32, see there), "second_bet" (1, default: a one-shot bet that too many queries lost is retried once with twice the margin and record
  * budget before the exact two-pass sequence runs), "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
