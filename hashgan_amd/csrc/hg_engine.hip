@@ -573,9 +573,9 @@ template <int NW, int LW, bool OPT> int launch_select_t(hg_ctx* c) {
 // matrix-core optimistic select: units = (pair of segments) x (group of 32 QT queries)
 // matrix-core optimistic select: blocks = (pair of segments) x (block of 512 queries)
 // the fp4 images of the codes in MFMA fragment order (k_select_mx, k_hist_mx), built on first use
-template <int NW> int ensure_mx_images(hg_ctx* c) {
+template <int NW> int ensure_mx_images(hg_ctx* c, const bool need_db = true) {     // need_db = false: the query image only (k_select_mx3 has its own database image)
     constexpr int NM = (NW + 1) / 2;
-    if (!c->dbx_valid) {
+    if (need_db && !c->dbx_valid) {
         const i64 n16 = (c->N + 15) / 16 * 16;
         HG_TRY(c->dbx.reserve((size_t)(n16 > 0 ? n16 : 16) * NM * 32));
         const i64 items = n16 * 2 * NM;
@@ -725,7 +725,7 @@ template <int NW, int LW, bool COMPACT> int launch_select_mx2_c(hg_ctx* c) {
 // codes of 33..64 bits, compact records: three rows per accumulator and the batched drain (k_select_mx3);
 // blocks = (pair of segments) x (256 queries); the query image is k_select_mx's
 template <int NW, int LW> int launch_select_mx3_t(hg_ctx* c) {
-    HG_TRY(ensure_mx_images<NW>(c));
+    HG_TRY(ensure_mx_images<NW>(c, false));
     if (!c->dbx3_valid) {
         const i64 n48 = (c->N + M3_ROWS - 1) / M3_ROWS * M3_ROWS + M3_WS_MAX * M3_ROWS;     // + one window of zero rows: the last segment's last window may run past the end
         HG_TRY(c->dbx3.reserve((size_t)(n48 > 0 ? n48 : M3_ROWS) * 32));
@@ -1306,15 +1306,31 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
     u32* hc = (u32*)c->hpk;
     u64* hl = (u64*)((char*)c->hpk + ((cb + 63) & ~(size_t)63));
     HostPackCensus cs;
+    HG_TRY(codes.reserve(cb + 64 * 4));
+    HG_TRY(labels.reserve(lbytes));
+    // the packed rows cross PCIe while the host threads still pack the rest: the calling thread ships every finished
+    // prefix (a quarter of a big table at a time), the workers claim row ranges in ascending order
+    i64 shipped = 0;
+    hipError_t ship_err = hipSuccess;
+    const i64 piece = n >= (1 << 18) ? (n + 3) / 4 : n;
+    auto ship = [&](long long rows_done) {
+        if (rows_done < n && rows_done - shipped < piece) return;
+        if (rows_done <= shipped || ship_err != hipSuccess) return;
+        hipError_t e = hipMemcpyAsync((char*)codes.p + (size_t)shipped * NW * 4, (const char*)hc + (size_t)shipped * NW * 4,
+                                      (size_t)(rows_done - shipped) * NW * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((char*)labels.p + (size_t)shipped * LW * 8, (const char*)hl + (size_t)shipped * LW * 8,
+                               (size_t)(rows_done - shipped) * LW * 8, hipMemcpyHostToDevice, c->stream);
+        ship_err = e;
+        shipped = rows_done;
+    };
     try {
-        host_pack(x, lab, n, b, C, hc, hl, &cs, (int)c->opt_pack_threads);
+        host_pack_ship(x, lab, n, b, C, hc, hl, &cs, (int)c->opt_pack_threads,
+                       +[](void* f, long long rows) { (*static_cast<decltype(ship)*>(f))(rows); }, &ship);
     } catch (const std::exception& e) {               // no exception crosses the C ABI (thread creation can fail)
         return fail(HG_ERR_NOMEM, "host-side packing failed: %s", e.what());
     }
-    HG_TRY(codes.reserve(cb + 64 * 4));
-    HG_TRY(labels.reserve(lbytes));
-    HG_HIP(hipMemcpyAsync(codes.p, hc, cb, hipMemcpyHostToDevice, c->stream));
-    HG_HIP(hipMemcpyAsync(labels.p, hl, lbytes, hipMemcpyHostToDevice, c->stream));
+    if (ship_err != hipSuccess) return fail(HG_ERR_HIP, "upload of the packed tables failed: %s", hipGetErrorString(ship_err));
     const bool pm1 = cs.nonbinary == 0 && cs.zeros == 0;
     const bool up = floats == 1 || (floats == 2 && !pm1);
     if (up) {

@@ -19,12 +19,18 @@ struct HostPackCensus {
 // x may be null (labels only) and lab may be null (codes only).  threads <= 0: pick from the hardware.
 void host_pack(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,
                HostPackCensus* census, int threads);
+// the same with the calling thread SHIPPING finished row prefixes instead of packing: (*on_rows)(rows_done), rows_done growing
+void host_pack_ship(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,
+                    HostPackCensus* census, int threads, void (*on_rows)(void*, long long), void* on_rows_arg);
 
 }  // namespace hg
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
+#include <linux/futex.h>
 #include <pthread.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -124,76 +130,95 @@ inline void rows_avx512(const float* x, const int64_t* lab, long long r0, long l
 
 namespace hostpack {
 
+inline long futex(std::atomic<uint32_t>* addr, int op, uint32_t val) {
+    return syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), op | FUTEX_PRIVATE_FLAG, val, nullptr, nullptr, 0);
+}
+
 // Workers that outlive a call: starting and joining 31 threads cost 0.5 ms of a 4 ms call at C2 (17 us each on the GPU
 // box's EPYC).  One job at a time (a second caller in another thread finds the pool busy and starts threads of its own,
 // as every call did before).
+// Sleepers wait on a futex word (the job generation) and are woken by ONE system call; nobody takes a mutex on the way in
+// or out: with a condition variable a hundred woken workers queue for its mutex one after the other, and the call
+// started 0.3 - 0.5 ms late (round 3: hg_set_database_f32 at C2 2.0 -> 1.6 ms with 96 threads).  A job lives in one of two
+// slots (generation parity); parts are claimed from {generation, next part} with compare-and-swap, so a worker that wakes
+// up late can never run a part of a newer job with an older job's arguments.
 class Pool {
 public:
-    template <class F> bool run(int parts, const F& f) {                  // f(0) .. f(parts - 1), the caller takes part; false: busy
+    // f(0) .. f(parts - 1); the caller takes parts too unless `caller_waits` hands it another duty: then it runs
+    // on_progress(done_parts) in a loop (done_parts: how many of the LOWEST-numbered parts are complete, monotone) until all
+    // are -- parts are claimed in ascending order, so a caller can ship finished prefixes while the rest is in the works.
+    template <class F> bool run(int parts, const F& f) { return run_impl(parts, f, (void (*)(void*, int))nullptr, nullptr); }
+    template <class F, class P> bool run_progress(int parts, const F& f, const P& on_progress) {
+        struct PC { const P* p; } pc{&on_progress};
+        return run_impl(parts, f, +[](void* c, int done) { (*static_cast<PC*>(c)->p)(done); }, &pc);
+    }
+private:
+    struct Job { void (*call)(void*, int) = nullptr; void* arg = nullptr; int parts = 0; };
+    template <class F> bool run_impl(int parts, const F& f, void (*progress)(void*, int), void* parg) {
         std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
         if (!job.owns_lock()) return false;
-        while ((int)th_.size() < parts - 1) {
-            const unsigned long long seen = gen_;                         // (gen_ only changes under job_mu_)
+        const int helpers = progress ? parts : parts - 1;                // (a caller that ships prefixes packs nothing itself)
+        while ((int)th_.size() < helpers) {
+            const uint32_t seen = gen_.load();
             th_.emplace_back([this, seen] { worker(seen); });
         }
         struct Ctx { const F* f; } ctx{&f};
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            call_ = [](void* c, int i) { (*static_cast<Ctx*>(c)->f)(i); };
-            arg_ = &ctx;
-            parts_ = parts;
-            left_ = parts - 1;
-            ++gen_;
-            next_.store((gen_ << 32) | 1ull);                             // {generation, next part}: a late worker cannot claim a part of a newer job
+        if ((int)flags_.size() < parts) flags_ = std::vector<std::atomic<unsigned char>>((size_t)parts);
+        for (int i = 0; i < parts; ++i) flags_[(size_t)i].store(0, std::memory_order_relaxed);
+        const uint32_t g = gen_.load(std::memory_order_relaxed) + 1;
+        Job& j = jobs_[g & 1];
+        j.call = [](void* c, int i) { (*static_cast<Ctx*>(c)->f)(i); };
+        j.arg = &ctx;
+        j.parts = parts;
+        left_.store(parts, std::memory_order_relaxed);
+        next_.store(((unsigned long long)g << 32), std::memory_order_release);
+        gen_.store(g, std::memory_order_release);
+        futex(&gen_, FUTEX_WAKE, helpers < (int)th_.size() ? (uint32_t)helpers : 0x7FFFFFFFu);     // one system call wakes them
+        if (!progress) {
+            work_on(g, j);
+        } else {
+            int done = 0;
+            while (done < parts) {
+                int d = done;
+                while (d < parts && flags_[(size_t)d].load(std::memory_order_acquire)) ++d;
+                if (d != done) { done = d; progress(parg, done); }
+                else __builtin_ia32_pause();
+            }
         }
-        // wake as many workers as there are parts for them (a small job -- the queries of a resident database: 3 parts --
-        // must not stampede a hundred sleepers through the mutex; those left asleep join a later job with a stale `seen`)
-        if (2 * (parts - 1) >= (int)th_.size()) cv_work_.notify_all();
-        else for (int i = 1; i < parts; ++i) cv_work_.notify_one();
-        f(0);
-        const unsigned long long mine = gen_ & 0xFFFFFFFFull;
-        int done = 0;                                                     // the caller takes what the workers have not claimed yet
-        for (;;) {
-            unsigned long long v = next_.load();
-            if ((v >> 32) != mine || (int)(v & 0xFFFFFFFFull) >= parts) break;
-            if (next_.compare_exchange_weak(v, v + 1)) { f((int)(v & 0xFFFFFFFFull)); ++done; }
+        // wait for the parts others still run (short: spin, then sleep on the counter)
+        for (int spin = 0; left_.load(std::memory_order_acquire) != 0; ++spin) {
+            if (spin < 4000) { __builtin_ia32_pause(); continue; }
+            const uint32_t v = left_.load(std::memory_order_acquire);
+            if (v) futex(&left_, FUTEX_WAIT, v);
         }
-        std::unique_lock<std::mutex> lk(mu_);
-        left_ -= done;
-        cv_done_.wait(lk, [this] { return left_ == 0; });
         return true;
     }
-private:
-    void worker(unsigned long long seen) {
+    void work_on(const uint32_t g, const Job& j) {
         for (;;) {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_work_.wait(lk, [&] { return gen_ != seen; });
-            seen = gen_;
-            void (*call)(void*, int) = call_;
-            void* arg = arg_;
-            const int parts = parts_;
-            lk.unlock();
-            int done = 0;
-            for (;;) {
-                unsigned long long v = next_.load();
-                if ((v >> 32) != (seen & 0xFFFFFFFFull) || (int)(v & 0xFFFFFFFFull) >= parts) break;
-                if (next_.compare_exchange_weak(v, v + 1)) { call(arg, (int)(v & 0xFFFFFFFFull)); ++done; }
-            }
-            if (done) {                                                   // (then the job is still this one: its caller waits for these parts)
-                lk.lock();
-                left_ -= done;
-                if (left_ == 0) cv_done_.notify_one();
-            }
+            unsigned long long v = next_.load(std::memory_order_acquire);
+            if ((uint32_t)(v >> 32) != g || (int)(v & 0xFFFFFFFFull) >= j.parts) break;
+            if (!next_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) continue;
+            const int i = (int)(v & 0xFFFFFFFFull);
+            j.call(j.arg, i);                                             // (the job is still g: its caller waits for this part)
+            flags_[(size_t)i].store(1, std::memory_order_release);
+            if (left_.fetch_sub(1, std::memory_order_acq_rel) == 1) futex(&left_, FUTEX_WAKE, 1);
         }
     }
-    std::mutex job_mu_, mu_;
-    std::condition_variable cv_work_, cv_done_;
+    void worker(uint32_t seen) {
+        for (;;) {
+            uint32_t g;
+            while ((g = gen_.load(std::memory_order_acquire)) == seen) futex(&gen_, FUTEX_WAIT, seen);
+            seen = g;
+            const Job j = jobs_[g & 1];                                   // (a copy that may be torn if the job is over already: then no claim succeeds)
+            work_on(g, j);
+        }
+    }
+    std::mutex job_mu_;
     std::vector<std::thread> th_;
-    void (*call_)(void*, int) = nullptr;
-    void* arg_ = nullptr;
-    int parts_ = 0, left_ = 0;
-    std::atomic<unsigned long long> next_{0};
-    unsigned long long gen_ = 0;
+    Job jobs_[2];
+    std::vector<std::atomic<unsigned char>> flags_;                       // part i done (only resized under job_mu_, between jobs)
+    std::atomic<unsigned long long> next_{0};                             // {generation, next part}
+    std::atomic<uint32_t> gen_{0}, left_{0};
 };
 // The pool is never torn down (its workers sleep until the process ends).  A forked child has none of the workers and must
 // not touch the parent's mutexes and condition variables (a broadcast on the copy of one with sleepers never returns):
@@ -213,36 +238,58 @@ inline Pool& pool() {
 
 }  // namespace hostpack
 
-inline void host_pack(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,
-                      HostPackCensus* census, int threads) {
+// on_rows(rows_done): optional; called from the CALLING thread, with a growing count, whenever another prefix of the rows
+// is packed (the caller then packs nothing itself: it ships those rows -- hipMemcpyAsync -- while the workers go on).
+inline void host_pack_ship(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,
+                           HostPackCensus* census, int threads, void (*on_rows)(void*, long long), void* on_rows_arg) {
     const bool wide = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
     if (threads <= 0) {
         const unsigned hw = std::thread::hardware_concurrency();
-        // the pass is memory bound: on the GPU box (2 x 64 cores, 256 hardware threads) the C2 call takes 4.3 ms with 32
-        // threads, 3.3 with 64, 3.15 with 96 or 128 (tools/h2d_threads.py) -- now that the workers are not started per call
-        threads = hw <= 64 ? (int)std::min<unsigned>(hw ? hw : 1u, 32u) : (int)std::min<unsigned>(hw / 2, 96u);
+        // the pass is memory bound: on the GPU box (2 x 64 cores, 256 hardware threads) hg_set_database_f32 at C2 takes
+        // 1.67 ms with 32 threads, 1.38 with 64, 1.39 with 96, 1.59 with 128, 1.86 with 192 (tools/h2d_split.py, round 3:
+        // futex wake-up, four parts per thread claimed in order, prefixes shipped while the rest packs; with the
+        // condition-variable pool and one part per thread it was 2.8 / 2.2 / 2.0 / 1.65 / 1.66)
+        threads = hw <= 64 ? (int)std::min<unsigned>(hw ? hw : 1u, 32u) : (int)std::min<unsigned>(hw / 4, 64u);
     }
     const long long bytes = n * ((long long)(x ? b * 4 : 0) + (lab ? C * 8 : 0));
     threads = (int)std::max<long long>(1, std::min<long long>(threads, bytes >> 20));    // at least ~1 MB of input per thread
-    std::vector<HostPackCensus> part((size_t)threads);
+    // with a shipping caller: four parts per thread, claimed in ascending order, so prefixes complete early
+    const int parts = on_rows && threads > 1 ? threads * 4 : threads;
+    std::vector<HostPackCensus> part((size_t)parts);
     auto work = [&](int t) {
-        const long long r0 = n * t / threads, r1 = n * (t + 1) / threads;
+        const long long r0 = n * t / parts, r1 = n * (t + 1) / parts;
         if (wide) hostpack::rows_avx512(x, lab, r0, r1, b, C, codes, labels, part[(size_t)t]);
         else hostpack::rows_scalar(x, lab, r0, r1, b, C, codes, labels, part[(size_t)t]);
     };
-    if (threads == 1) {
+    bool ran = false;
+    if (parts == 1) {
         work(0);
-    } else if (!hostpack::pool().run(threads, work)) {
+        ran = true;
+    } else if (on_rows) {
+        ran = hostpack::pool().run_progress(parts, work, [&](int done) { on_rows(on_rows_arg, n * done / parts); });
+    } else {
+        ran = hostpack::pool().run(parts, work);
+    }
+    if (!ran) {                                                           // the pool is busy with another caller's job
         std::vector<std::thread> own;
-        for (int t = 1; t < threads; ++t) own.emplace_back(work, t);
-        work(0);
+        const int nt = std::min(threads, parts);
+        std::atomic<int> next{0};
+        auto loop = [&] { for (int i; (i = next.fetch_add(1)) < parts;) work(i); };
+        for (int t = 1; t < nt; ++t) own.emplace_back(loop);
+        loop();
         for (auto& th : own) th.join();
     }
+    if (on_rows) on_rows(on_rows_arg, n);
     HostPackCensus tot;
     for (const auto& p : part) {
         tot.nonbinary += p.nonbinary; tot.zeros += p.zeros; tot.minus_ones += p.minus_ones; tot.bad_labels += p.bad_labels;
     }
     if (census) *census = tot;
+}
+
+inline void host_pack(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,
+                      HostPackCensus* census, int threads) {
+    host_pack_ship(x, lab, n, b, C, codes, labels, census, threads, nullptr, nullptr);
 }
 
 }  // namespace hg
