@@ -145,7 +145,12 @@ def traffic_from_profiles(kernel):
     sha = d.get("_kernel_sources_sha")
     if sha != kernel_sources_sha():
         return None, "profiles/latest_traffic.json was measured on other kernel sources (%s); rerun tools/pmc_traffic.py" % sha
-    return d.get(kernel, {}).get("hbm_bytes_per_launch"), "rocprofv3 PMC pass of these sources (%s)" % d.get("_collected", "?")
+    # the timing slot "k_select_mx" covers the kernel variants k_select_mx / k_select_mx2 / k_select_mx3: take the one the pass saw most
+    cands = [k for k in d if k.startswith(kernel) and isinstance(d[k], dict)]
+    if not cands:
+        return None, "the PMC pass holds no %s* kernel" % kernel
+    best = max(cands, key=lambda k: d[k].get("launches_sampled", 0))
+    return d[best].get("hbm_bytes_per_launch"), "rocprofv3 PMC pass of these sources (%s), kernel %s" % (d.get("_collected", "?"), best)
 
 
 def kernel_rooflines(timing, spec, rows, step_s, rec_bytes=1):
