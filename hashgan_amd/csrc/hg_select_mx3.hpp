@@ -435,10 +435,13 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
     const int sa_sh = m3_shift(ar);
     const int scale_a = (127 + sa_sh) | ((134 + sa_sh) << 8) | ((141 + sa_sh) << 16);      // E8M0: tile f rides at 2^(7 f + s)
     const int scale_b = 0x7F7F7F7F;
-    // The image is one linear array of 512-byte half-chunks: chunk c of window win sits (win * WS * 3 + c) * 512 bytes past the
-    // lane's first one.  (A segment's windows may run up to WS supertiles past the end of the database: the image has that
-    // slack, zero-filled; an absent second segment reads the first supertile, its rows are masked.)
-    const u8* a_lane = dbx + ((((ag0 < NG ? ag0 : 0) * 3 * 2 + h) * 16 + ar) * 16);
+    // The image is one linear array of 512-byte half-chunks: chunk c of window win is chunk number ch0 + win * WS * 3 + c of
+    // the lane's segment.  The two segments of a pair walk the SAME number of windows, so the shorter one (the database's
+    // ragged last segment, or none at all) runs past its rows -- into the next segment's, or past the image: the chunk
+    // number is clamped to the image's last one (those rows are masked anyway; the image ends with a window of zero rows).
+    const u32 ch_last = (u32)((NG + M3_WS_MAX) * 3 - 1);
+    const u32 ch0 = (u32)(ag0 < NG ? ag0 : 0) * 3u;
+    const u8* a_row = dbx + (h * 16 + ar) * 16;                      // the lane's 16 bytes inside a half-chunk pair
     const u32 lane16 = (u32)lane * 16u;
     auto stage_window = [&](const i64 win, const int abuf, const int clsel) {
         u8* sa = mxlds + L.a + abuf * L.abuf;
@@ -446,7 +449,10 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
 #pragma unroll
         for (int k = 0; k < (M3_WS * 3 + M3_WPB - 1) / M3_WPB; ++k) {
             const int c = wave + k * M3_WPB;
-            if (c < M3_WS * 3) HG_GLDS16(a_lane + (win * (M3_WS * 3) + c) * 512, sa + c * 1024);
+            if (c < M3_WS * 3) {
+                const u32 ch = min(ch0 + (u32)win * (u32)(M3_WS * 3) + (u32)c, ch_last);
+                HG_GLDS16(a_row + (i64)ch * 512, sa + c * 1024);
+            }
         }
         constexpr int CPH = (M3_WROWS * CB + 1023) / 1024, LPH = (M3_WROWS * LB + 1023) / 1024;
 #pragma unroll
