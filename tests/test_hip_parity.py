@@ -694,3 +694,30 @@ def test_function_spelling_reuses_a_read_only_database():
     metric.MAP(qs[0], db2, ql, dl, 500)                   # another database: reloaded
     assert eng.resident[0] is db2
     assert metric.MAP(qs[1], db, ql, dl, 500) == want[1]  # and back
+
+
+@pytest.mark.parametrize("b,sigma", [(64, 12), (64, 40), (64, 64), (40, 40), (24, 64)])
+def test_wild_guesses_never_change_the_result(b, sigma):
+    """The bet's guess pushed far too high (guess_sigma): the three-distances-per-accumulator select then sees dense
+    hits -- full queues, rings that overflow (the lanes' direct route), slices beyond their capacity -- and, at b = 64
+    a thin sample, cuts beyond the 63 its 7-bit fields can hold (test_queries_far_from_every_row_fall_back_exactly).  Whatever it does, a lost bet
+    must be noticed and the answer must be the oracle's."""
+    rng = np.random.default_rng(500 + b + sigma)
+    Q, N, R, C = 200, 150000, 700, 7
+    db = (rng.random((N, b)) < 0.5).astype(np.uint8)
+    qb = db[rng.integers(0, N, Q)] ^ (rng.random((Q, b)) < 0.2).astype(np.uint8)
+    db[1000:1400] = db[1000]                                    # a run of identical rows: bursts of hits in one slice
+    dl = (rng.random((N, C)) < 0.25).astype(np.int8)
+    ql = (rng.random((Q, C)) < 0.25).astype(np.int8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb, db, ql, dl, R)
+    ctx = _native.Context(0)
+    try:
+        ctx.set_option("guess_sigma", sigma)
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        for _ in range(2):
+            ap, rel = ctx.map(R)
+            assert np.array_equal(ap, ap_ref, equal_nan=True)
+    finally:
+        ctx.close()
