@@ -306,6 +306,42 @@ def c4_reference(opts, steps=5, warmup=2):
         ctx.close()
 
 
+def query_split_leg(args, spec, rank, world, local_rank, dry_dir, comm, qw, ql):
+    """The same workload decomposed the other way (hashgan_amd.sharded.evaluate_query_split): the WHOLE database on every
+    GPU, the queries split, no data-path collective -- timed like the main leg (barrier, K steps, barrier, max over ranks)
+    on a second context per rank.  Reported beside `value`, which stays the database-sharded form the north star names."""
+    from hashgan_amd import _native, metric, sharded
+    N, R, b, C = spec["N"], spec["R"], spec["b"], spec["C"]
+    _, _, dw, dl = build_packed(spec, 0, N)
+    ctx2 = _native.Context(0 if dry_dir else local_rank)
+    try:
+        for kv in args.opt:
+            k_, v_ = kv.split("=")
+            ctx2.set_option(k_, int(v_))
+        ctx2.set_database(dw, dl, b, C)
+        del dw, dl
+        steps, warm = max(1, args.steps), max(1, min(args.warmup, 3))
+        for _ in range(warm):
+            a, r = sharded.evaluate_query_split(ctx2, comm, qw, ql, R)
+        comm.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a, r = sharded.evaluate_query_split(ctx2, comm, qw, ql, R)
+            m = sharded.mean_ap(a, r)
+        comm.barrier()
+        dt = comm.allreduce_max(time.perf_counter() - t0) / steps
+        from tests import cases
+        g = cases.load_golden(spec["golden"])
+        k = g["ap"].shape[0]
+        return {"decomposition": "whole database (%d rows, %d MB packed) on each of %d GPUs; queries split %s; the only exchange "
+                                 "is the all-gather of 16 bytes per query" % (N, N * 16 // 1000000, world,
+                                                                            [n for _, n in sharded.shard_bounds(spec["Q"], world)]),
+                "steps": steps, "ms_per_step": dt * 1e3, "value": spec["Q"] / dt, "unit": "queries/s", "map": float(m),
+                "parity_vs_reference_golden": bool(np.array_equal(a[:k], g["ap"], equal_nan=True))}
+    finally:
+        ctx2.close()
+
+
 def error_line(msg, n_gpus, steps=0, warmup=0):
     """The one JSON line of a run that could not measure anything."""
     return json.dumps({"metric": METRIC, "value": None, "unit": "queries/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
@@ -380,6 +416,7 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive MAPs(...) timing")
     ap.add_argument("--no-real", action="store_true", help="skip the real-valued (tanh features) call timing")
     ap.add_argument("--no-c4-ref", action="store_true", help="skip the one-GPU C4 point of the scaling curve")
+    ap.add_argument("--no-query-split", action="store_true", help="sharded runs: skip the replicated-database / split-queries leg")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (hg_set_option), repeatable")
     ap.add_argument("--kernel-timing", default="pair-passes", choices=["pair-passes", "all", "none"],
                     help="HIP events around the passes over the pairs only (the roofline kernel; default), around every "
@@ -458,6 +495,9 @@ def main():
         dt = comm.allreduce_max(dt)                     # the slowest rank's clock
     timing = ctx.timing_read()
     ctx.timing_enable(False)
+    qsplit = None
+    if sharded_leg and not args.no_query_split:
+        qsplit = query_split_leg(args, spec, rank, world, local_rank, dry_dir, comm, qw, ql)
     if rank != 0:
         if sharded_leg:
             comm.barrier()
@@ -486,6 +526,8 @@ def main():
     }
     if sharded_leg or wl == "c4":
         out["scaling"] = "strong"                            # the fixed N = 10M database over the GPUs (a one-GPU C2 line scales nothing)
+    if qsplit is not None:
+        out["query_split"] = qsplit
     if sharded_leg:
         out["value_definition"] = "Q queries ranked against the WHOLE %d-row database per step / step time (max over ranks)" % N
         out["weak_scaling_equivalent"] = {"definition": "query x per-GPU-shard evaluations per second = value * n_gpus",

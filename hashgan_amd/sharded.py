@@ -385,6 +385,31 @@ def evaluate_real_queries(ctx, comm, q_feats, q_labels, R):
     return ap, rel
 
 
+def evaluate_query_split(ctx, comm, q_code_words, q_label_words, R):
+    """The OTHER decomposition of the path over G GPUs: queries are independent (lib/metric.py:16 loops over them), so every
+    rank holds the WHOLE packed database (16 bytes per row: 160 MB at N = 10M, nothing for a 288 GB part -- hg_set_database on
+    each context before the call) and evaluates its contiguous share of the queries with the one-GPU sequence (hg_map).  No
+    data-path collective at all: the only exchange is the all-gather of 16 bytes per query (AP, hit count).
+    -> (ap [Q] float64, rel [Q] int64), identical on every rank and equal to one GPU's hg_map bit for bit (a query's result
+    does not depend on the other queries).  Database sharding (evaluate_shard) is what BASELINE.json's north star
+    prescribes and what `bench.py --gpus G` reports as `value`; this form is reported beside it (`query_split`)."""
+    q_code_words, q_label_words = np.asarray(q_code_words), np.asarray(q_label_words)
+    Q = q_code_words.shape[0]
+    bounds = shard_bounds(Q, comm.world)
+    lo, n = bounds[comm.rank]
+    width = max(b[1] for b in bounds)
+    mine = np.zeros((width, 2), np.float64)
+    if n:
+        ctx.set_queries(np.ascontiguousarray(q_code_words[lo:lo + n]), np.ascontiguousarray(q_label_words[lo:lo + n]))
+        ap, rel = ctx.map(R)
+        mine[:n, 0] = ap
+        mine[:n, 1] = rel                          # a count <= R: exact in a double
+    every = comm.all_gather_host(mine)
+    ap = np.concatenate([every[r, :bounds[r][1], 0] for r in range(comm.world)])
+    rel = np.concatenate([every[r, :bounds[r][1], 1] for r in range(comm.world)]).astype(np.int64)
+    return ap, rel
+
+
 def shard_bounds(n_total, world):
     """Contiguous, near-equal index ranges: [(base, rows)] * world."""
     per, extra = divmod(int(n_total), int(world))

@@ -66,3 +66,10 @@ class FileComm:
         vals = [np.frombuffer(p, np.float64)[0] for p in self._collect("max")]
         self._n += 1
         return float(max(vals))
+
+    def all_gather_host(self, arr):
+        arr = np.ascontiguousarray(arr)
+        self._publish("agh", arr.tobytes())
+        parts = self._collect("agh")
+        self._n += 1
+        return np.stack([np.frombuffer(p, arr.dtype).reshape(arr.shape) for p in parts])

@@ -155,6 +155,50 @@ def test_gloo_query_split_of_the_real_valued_ranking(name, world, tmp_path):
     assert np.array_equal(rs[0]["rel"] != 0, ~np.isnan(g["ap"]))
 
 
+def _qsplit_worker(rank, world, port, name, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from tests import cases
+    from oracle import hamming_map as O
+    from hashgan_amd import sharded, metric
+    from tests.torch_comm import TorchComm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = cases.build_case(name)
+
+    class OracleCtx:                     # stands in for a context holding the whole packed database (test infrastructure)
+        def set_queries(self, codes, labels):
+            self.qw, self.qlw = codes, labels
+
+        def map(self, R):
+            b, C = c["b"], c["dblab"].shape[1]
+            unpack = lambda w, n: np.unpackbits(np.ascontiguousarray(w).view(np.uint8).reshape(w.shape[0], -1), axis=1, bitorder="little")[:, :n]
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                _, ap, *_ = O.map_from_codes(unpack(self.qw, b), c["dbbits"], unpack(self.qlw, C).astype(np.int8), c["dblab"], R)
+            rel = np.array([0 if np.isnan(a) else 1 for a in ap], np.int64)
+            return ap, rel
+
+    ap, rel = sharded.evaluate_query_split(OracleCtx(), TorchComm(), metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"]), c["R"])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ap=ap, rel=rel)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("e_some_skipped", 2), ("e_ragged", 3)])
+def test_gloo_query_split_of_the_hamming_ranking(name, world, tmp_path):
+    """evaluate_query_split (database replicated, queries split, no data-path collective) over a gloo group: every rank
+    ends up with every query's AP, in query order, equal to the unmodified reference's golden."""
+    from tests import cases
+    port = 29600 + (os.getpid() % 250)
+    mp.spawn(_qsplit_worker, args=(world, port, name, str(tmp_path)), nprocs=world, join=True)
+    g = cases.load_golden(name)
+    rs = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    for r in rs[1:]:
+        assert np.array_equal(rs[0]["ap"], r["ap"], equal_nan=True) and np.array_equal(rs[0]["rel"], r["rel"])
+    assert np.array_equal(rs[0]["ap"], g["ap"], equal_nan=True)
+
+
 # ---------------------------------------------------------------- the launch itself (no GPU needed)
 _RENDEZVOUS = """import os, sys
 sys.path.insert(0, %r)

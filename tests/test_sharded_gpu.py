@@ -222,6 +222,53 @@ def test_bench_multi_rank_control_flow(world, workload, tmp_path):
     assert "dry_run_not_a_measurement" in d and "cpu_baseline" not in d
 
 
+@pytest.mark.parametrize("G", [1, 3])
+def test_query_split_equals_one_gpu(G):
+    """evaluate_query_split: the whole database on every (virtual) rank, the queries split, 16 bytes per query gathered --
+    equal to one context's hg_map bit for bit.  G = 1 over the library's RCCL communicator, G = 3 over threads."""
+    c = cases.build_case("e_ragged")
+    dw, dl = metric.pack_codes(c["dbbits"]), metric.pack_labels(c["dblab"])
+    qw, ql = metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"])
+    C = c["dblab"].shape[1]
+    one = _native.Context(0)
+    one.set_database(dw, dl, c["b"], C)
+    one.set_queries(qw, ql)
+    ap0, rel0 = one.map(c["R"])
+    one.close()
+    if G == 1:
+        ctx = _native.Context(0)
+        try:
+            ctx.set_database(dw, dl, c["b"], C)
+            comm = sharded.init_rccl(ctx, rank=0, world=1)
+            ap, rel = sharded.evaluate_query_split(ctx, comm, qw, ql, c["R"])
+            ctx.comm_destroy()
+        finally:
+            ctx.close()
+        assert np.array_equal(ap, ap0, equal_nan=True) and np.array_equal(rel, rel0)
+        return
+    comms = sharded.LocalComm.create(G)
+    results, errors = [None] * G, []
+
+    def work(r):
+        try:
+            ctx = _native.Context(0)
+            ctx.set_database(dw, dl, c["b"], C)
+            comms[r].ctx = ctx
+            results[r] = sharded.evaluate_query_split(ctx, comms[r], qw, ql, c["R"])
+            ctx.close()
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+            comms[r]._s.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errors:
+        raise errors[0]
+    for ap, rel in results:
+        assert np.array_equal(ap, ap0, equal_nan=True) and np.array_equal(rel, rel0)
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment (how a driver may call it): the
     parent spawns the two rank processes itself and prints rank 0's single JSON line.  Dry run on one GPU, the file
@@ -241,6 +288,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "error" not in d
     assert d["parity_vs_reference_golden"] is True and d["optimistic_fallbacks"] == 0
+    assert d["query_split"]["parity_vs_reference_golden"] is True and d["query_split"]["map"] == d["map"]
 
 
 @pytest.mark.parametrize("G", [1, 3])
