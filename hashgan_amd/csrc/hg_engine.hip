@@ -7,6 +7,7 @@
 #include "hg_select_mx.hpp"
 #include "hg_rank_lds.hpp"
 #include "hg_rank_cnt.hpp"
+#include "hg_rank_wave.hpp"
 #include "hg_select_mx2.hpp"
 #include "hg_select_mx3.hpp"
 #include "hg_real_mx.hpp"
@@ -291,6 +292,10 @@ struct hg_ctx {
     i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
     i64 opt_rank_cnt = 1;      // ... and ranks them with the per-thread counting sort (k_rank_cnt) where it applies
+    i64 opt_rank_wave = 40;    // "rank_wave": one wavefront per query (k_rank_wave) for SHORT lists of one-byte records; the value is the
+                               // record capacity of a query's LDS share in tenths of the shard's share of R (+ 256; lists beyond it
+                               // go to k_rank_fused); 0 = off
+    i64 opt_rank_wave_max = 4608;   // "rank_wave_max": ... used when that capacity is at most this many records (<= 16128)
     i64 opt_select_qt = 2;     // k_select_mx query tiles per wavefront (2: 4 wavefronts per SIMD, 4: 2)
 
     // run state
@@ -347,6 +352,7 @@ struct hg_ctx {
     DevBuf sampx;              // float features of the sampled rows in MFMA A-fragment order (k_real_sample_mx), rebuilt per call
     DevBuf dbfb, thr2, xmax2;  // filter + rescore path (hg_real_bf.hpp): bf16 image of the database, lowered cuts, max row norm^2
     bool dbfb_valid = false;
+    i64 opt_real_sample_hits = 64;   // "real_sample_hits": the real-valued bet samples so that this many of a query's top R rows are in the sample
     i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit
     bool real_filtered = false;   // the last real_select left unscored candidates that k_real_rescore completed
     i64 real_attempts = 0;        // statistics of the last real-valued ranking: attempts made (1 = the first bet held) ...
@@ -1594,7 +1600,39 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
     }
     const u32* only = nullptr;
     bool counted = false;
-    if (c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
+    if (c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_wave > 0 && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
+        g.S <= RW_SMAX) {
+        // one wavefront per query (k_rank_wave): no block barriers, 5 KB + the records of LDS per query in flight
+        // ... which pays for SHORT lists only (a sharded rank's share of R, a small R): a wavefront walks its query's records
+        // with 64 lanes where k_rank_cnt has 256, and at C2's 6500 records (16 KB of LDS per query, 10 in flight per CU) it
+        // is slower, 0.23 vs 0.19 ms; at 800 records (7 KB, 22 in flight) it wins, 0.105 vs 0.134 ms.
+        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
+        i64 r2 = (i64)(0.1 * (double)c->opt_rank_wave * (double)c->R * share) + 256;
+        if (r2 < 1024) r2 = 1024;
+        r2 = (r2 + 63) / 64 * 64;
+        if (r2 > (i64)c->opt_rank_wave_max) r2 = 0;                 // long lists: k_rank_cnt below
+        const int nbc = (mode == 0 && !c->exact_mx && c->G == 1) ? g.NB / 2 + 2 : 0;
+        const RankWaveLds L = rank_wave_layout(g.NB, c->RW, g.S, (int)r2, nbc);
+        // wavefronts per block: the split that wastes the least of a CU's 160 KB
+        const int fit1 = (int)(160 * 1024 / L.per_wave), fit2 = 2 * (int)(160 * 1024 / (2 * L.per_wave));
+        const int wpb = fit2 >= fit1 ? 2 : 1;
+        if (r2 > 0 && fit1 >= 4) {
+            HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
+            RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
+                           c->cap, c->crow, 0, 1, c->RW, (int)r2, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
+                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc};
+            const size_t lds = (size_t)wpb * L.per_wave;
+            if (lds > 64 * 1024)
+                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            c->t_begin(KI_RANK_LDS);
+            hipLaunchKernelGGL(k_rank_wave, dim3(grid_for(g.Q, wpb)), dim3(64 * wpb), lds, c->stream, c->cand.as<u8>(), la, c->mbits.as<u32>(), g);
+            c->t_end();
+            HG_TRY(c->check_launch("k_rank_wave"));
+            only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
+            counted = true;
+        }
+    }
+    if (!counted && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
         // per-thread counting sort (k_rank_cnt): byte counters for every distance + a tile of the records, <= 64 KiB per
         // block; lists longer than a tile are ranked tile by tile
         const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
@@ -2496,7 +2534,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     if (bet) {
         // sample so that about 64 of a query's top R rows are in it; guess the cut `sigma` deviations deep
-        i64 stride = (i64)((double)R / 64.0);
+        i64 stride = (i64)((double)R / (double)c->opt_real_sample_hits);
         if (stride < 1) stride = 1;
         const i64 M = (c->N + stride - 1) / stride;
         const double fr = (double)R * (double)M / (double)c->N;
@@ -2882,6 +2920,12 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_sample_ratio = value;
     } else if (!strcmp(key, "defer_verdict")) {
         c->defer_verdict = value != 0;
+    } else if (!strcmp(key, "rank_wave")) {
+        if (value < 0 || value > 400) return fail(HG_ERR_ARG, "rank_wave must be 0 (off) or the LDS record capacity in tenths of R, <= 400");
+        c->opt_rank_wave = value;
+    } else if (!strcmp(key, "rank_wave_max")) {
+        if (value < 0 || value > 16128) return fail(HG_ERR_ARG, "rank_wave_max must be 0..16128 (a lane's chunk must fit its byte counters)");
+        c->opt_rank_wave_max = value;
     } else if (!strcmp(key, "select_packed")) {
         c->opt_select_packed = value;
     } else if (!strcmp(key, "rank_lds")) {
@@ -2924,6 +2968,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_real_mfma = value;
     } else if (!strcmp(key, "real_sort_lds")) {
         c->opt_real_sort_lds = value != 0;
+    } else if (!strcmp(key, "real_sample_hits")) {
+        if (value < 16 || value > 4096) return fail(HG_ERR_ARG, "real_sample_hits must be 16..4096");
+        c->opt_real_sample_hits = value;
     } else if (!strcmp(key, "real_segment_bytes")) {
         if (value < 4096) return fail(HG_ERR_ARG, "real_segment_bytes must be >= 4096");
         c->opt_real_seg_bytes = value;

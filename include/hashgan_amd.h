@@ -241,6 +241,9 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * k_select_mx; 0: vector-ALU xor+popcount k_select; same records either way), "probe_select" (probe build only --
  * python -m hashgan_amd.build --probes: bits 2/4/8 switch parts of the matrix-core kernels' drain off; the bet
  * then fails and the exact sequence runs, so results stay right; the production library refuses the key),
+ * "rank_wave" (40, default: the bet's rank stage runs one wavefront per query, k_rank_wave, when a query's list of one-byte
+ * records is short -- capacity value/10 x the shard's share of R + 256 records of LDS per query, used when that is at most
+ * "rank_wave_max" = 4608 records: a sharded rank, a small R; 0 = always the block-per-query k_rank_cnt),
  * "select_packed" (several rows per MFMA accumulator: 3, default = k_select_mx3 (three rows through per-row MX scales,
  * batched drain) for codes of <= 64 bits with one-byte records, k_select_mx2 (two rows) for <= 32 bits otherwise; 1 =
  * k_select_mx2 for <= 32 bits only, 2 = k_select_mx2 up to 64 bits, 0 = never), "rank_lds" (0/1), "rank_cnt" (0/1:
