@@ -1593,6 +1593,9 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
     HG_TRY(c->err.reserve(4));
     HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
     if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
+#ifdef HG_RANK_PROFILE
+    HG_TRY(c->hwq.reserve((size_t)4096 * 16 * 4 + (size_t)g.Q * nwav * g.NB * 4));
+#endif
     if (mode == 0) {
         if (c->optimistic) { if (!c->err_zeroed) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream)); }
         else HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
@@ -3029,6 +3032,9 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
         *value = total;
     }
+#ifdef HG_RANK_PROFILE
+    else if (!strcmp(key, "dbg_hwq_ptr")) *value = (int64_t)(uintptr_t)c->hwq.p;
+#endif
     else if (!strcmp(key, "db_nonbinary")) *value = c->census_db[0];
     else if (!strcmp(key, "db_zeros")) *value = c->census_db[1];
     else if (!strcmp(key, "db_minus_ones")) *value = c->census_db[2];

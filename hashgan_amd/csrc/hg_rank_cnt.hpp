@@ -70,6 +70,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     u32* idx32 = (u32*)(rlds + L.idx);
     u32* __restrict__ grow = mbits32 + (i64)q * 2 * a.RW;
 
+#ifdef HG_RANK_PROFILE
+    const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+    int tkn = 0;
+#define HG_TK() do { if (tid == 0 && q < 4096) a.hwq[(i64)q * 16 + tkn] = (u32)(__builtin_amdgcn_s_memtime() - tk0); ++tkn; } while (0)
+#else
+#define HG_TK() do {} while (0)
+#endif
     if (tid == 0) a.big[q] = 0u;
     if (a.fail[q]) {                                  // a slice of this query overflowed
         if (tid == 0) {
@@ -81,11 +88,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     }
     for (int i = tid; i < (L.pref - L.cnt) / 4; i += nthr) ((u32*)rlds)[i] = 0u;       // counters, offsets, totals, misc, bitmap
 
+    // One-byte records: the first 96 bytes of the first 128 slices are fetched NOW, before anybody knows how many records
+    // a slice holds (thread = half a slice, three 16-byte loads): they fly while the slice counts make their own round trip
+    // through memory and the prefix is scanned -- one global latency instead of three in a row (profile of round 3: the
+    // dependent copy was 37 % of a block's life).  Bytes past a slice's count are simply not used.
+    constexpr int SPEC_SL = nthr / 2, SPEC_B = 48;                 // slices covered, bytes per thread
+    const int sp_s = tid >> 1, sp_h = tid & 1;
+    uint4 spec[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if (a.rec8 && sp_s < S) {
+        const u8* r = (const u8*)cand + (i64)q * a.crow + (i64)sp_s * a.cap + sp_h * SPEC_B;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if ((u32)(sp_h * SPEC_B + 16 * j + 16) <= a.cap) spec[j] = *(const uint4*)(r + 16 * j);
+    }
+
     // ---- slice counts -> exclusive prefix (thread t owns a run of consecutive slices) ----
     const int per = (S + nthr - 1) / nthr;
     const int sb = tid * per, se = sb + per < S ? sb + per : S;
     u32 mine = 0;
-    for (int s = sb; s < se; ++s) mine += a.sl_cnt[(i64)s * g.Qpad + q];
+    u32 first = 0;                                    // (one slice per thread is the usual case: its count is not read twice)
+    for (int s = sb; s < se; ++s) {
+        const u32 v = a.sl_cnt[(i64)s * g.Qpad + q];
+        if (s == sb) first = v;
+        mine += v;
+    }
     u32 incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -100,10 +126,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     u32 run = wbase + incl - mine;
     for (int s = sb; s < se; ++s) {
         pref[s] = run;
-        run += a.sl_cnt[(i64)s * g.Qpad + q];
+        run += s == sb ? first : a.sl_cnt[(i64)s * g.Qpad + q];
     }
     if (tid == nthr - 1) pref[S] = run;
     __syncthreads();
+    HG_TK();                                          // 0: slice counts + prefix
     const u32 n = pref[S];
     // The records are ranked in tiles of up to TC (they need not all fit the LDS): pass A counts every tile into the
     // totals, the plan follows, pass B re-reads the tiles in order and places them, carrying per-bucket progress.
@@ -116,6 +143,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 
     // ---- copy records [T0, T0 + TC) of the query's list into LDS, compacted in slice (= index) order ----
     auto copy_all = [&]() {                           // single tile: many slices' loads in flight per wavefront
+        if (a.rec8) {
+            // the prefetched bytes: thread (slice sp_s, half sp_h) owns records [48 sp_h, 48 sp_h + 48) of its slice
+            if (sp_s < S) {
+                const u32 p0 = pref[sp_s], c0 = pref[sp_s + 1] - p0;
+                const u32 b0 = (u32)(sp_h * SPEC_B);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const u32 w[4] = {spec[j].x, spec[j].y, spec[j].z, spec[j].w};
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const u32 i = b0 + 16 * j + e;
+                        if (i < c0) rec8[p0 + i] = (u8)(w[e >> 2] >> (8 * (e & 3)));
+                    }
+                }
+            }
+            // what they do not cover: records beyond the 96th of a slice (or beyond its capacity's last whole 16 bytes), slices beyond the 128th
+            const u32 cov = (a.cap & ~15u) < 2u * SPEC_B ? (a.cap & ~15u) : 2u * SPEC_B;     // piece k (16 bytes) was loaded iff 16 k + 16 <= cap
+            // (lane l looks at slice wave + 4 l, all at once; the few slices that need more are then copied by the whole wavefront)
+            for (int sbase = wave; sbase < S; sbase += NWAV * 64) {
+                const int s2 = sbase + NWAV * lane;
+                const u32 p2 = s2 < S ? pref[s2] : 0u, c2 = s2 < S ? pref[s2 + 1] - p2 : 0u;
+                const u32 lo2 = s2 < SPEC_SL ? cov : 0u;
+                u64 m = __ballot(c2 > lo2);
+                while (m) {
+                    const int l = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const u32 pp = (u32)__builtin_amdgcn_readlane((int)p2, l), cc = (u32)__builtin_amdgcn_readlane((int)c2, l);
+                    const u32 ll = (u32)__builtin_amdgcn_readlane((int)lo2, l);
+                    const u8* r = row8 + (i64)(sbase + NWAV * l) * a.cap;
+                    for (u32 i = ll + lane; i < cc; i += 64) rec8[pp + i] = r[i];
+                }
+            }
+            return;
+        }
         if (a.rec8) {
             constexpr int NSL = 16;
             for (int s = wave; s < S; s += NSL * NWAV) {
@@ -245,6 +306,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         i0 = (u32)tid * chunk < m ? (u32)tid * chunk : m;
         i1 = i0 + chunk < m ? i0 + chunk : m;
         const u32 one = 1u << (8 * (tid & 3));
+        if (i1 - i0 <= 32u) {                         // the usual chunk (~26 records): all its words in flight, then the adds
+            u32 wv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wv[k] = i0 + 4u * k < i1 ? rec32[(i0 >> 2) + k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32 d = (wv[k] >> (8 * j)) & 0x7Fu;
+                    if (i0 + 4u * k + j < i1) {
+                        if (d < (u32)NBc) atomicAdd(&cnt32[d * 64 + (tid >> 2)], one);
+                        else misc[7] = 1u;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll 2
         for (u32 i = i0; i < i1; i += 4) {
             const u32 v = rec32[i >> 2];
@@ -280,12 +358,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     if (ntile == 1) {
         copy_all();
         __syncthreads();
+        HG_TK();                                      // 1: copy
         if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }        // a distance beyond 127: the general kernel
         count_tile(n);
         __syncthreads();
+        HG_TK();                                      // 2: count
         if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }
         add_totals();
         __syncthreads();
+        HG_TK();                                      // 3: totals
     } else {
         for (u32 tl = 0; tl < ntile; ++tl) {
             const u32 T0 = tl * TC, T1 = T0 + TC < n ? T0 + TC : n;
@@ -354,6 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         }
     }
     __syncthreads();
+    HG_TK();                                          // 4: plan
     const int t = (int)misc[0];
     if (t < 0) {
         if (a.mode == 3) for (int w = tid; w < bmw; w += nthr) grow[w] = 0u;   // nothing to rank: an empty bitmap
@@ -393,21 +475,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             if (lane == 63) tilecnt[k] = inc;                            // the tile's records of this distance
         }
         __syncthreads();
+        HG_TK();                                      // 5: offsets
         // place: four records per round -- their returning LDS adds are issued back to back (same-thread adds to one
         // offset stay in order), so a round pays one LDS round trip, not four; records beyond the cut add to a dummy row
         {
             const int sh = 16 * (tid & 1);
             const u32 one = 1u << sh;
-            for (u32 i = i0; i < i1; i += 4) {
-                u32 meta[4], r[4], st[4];
-                const u32 v = rec32[i >> 2];
+            constexpr int PG = 4;                                         // records per round (8 = two words per round was slower: 14.5 k vs 13.1 k cycles for the phase)
+            for (u32 i = i0; i < i1; i += PG) {
+                u32 meta[PG], r[PG], st[PG];
+                const u32 v0 = rec32[i >> 2], v1 = PG > 4 && i + 4 < i1 ? rec32[(i >> 2) + 1] : 0u;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {                             // -> {dist:8 | match at bit 8}; 0xFFFF: past the chunk
-                    const u32 m = (v >> (8 * j)) & 0xFFu;
+                for (int j = 0; j < PG; ++j) {                            // -> {dist:8 | match at bit 8}; 0xFFFF: past the chunk
+                    const u32 m = ((j < 4 ? v0 : v1) >> (8 * (j & 3))) & 0xFFu;
                     meta[j] = i + j < i1 ? (m & 0x7Fu) | ((m >> 7) << 8) : 0xFFFFu;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < PG; ++j) {
                     const int d = (int)(meta[j] & 0xFFu);
                     const bool in = d <= t && meta[j] != 0xFFFFu;
                     const int k = in ? d - dmin : RC_MAXB;
@@ -415,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                     st[j] = (in ? tot[d] : 0u) + done[in ? k : 0];           // bucket start + what earlier tiles placed there
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < PG; ++j) {
                     const int d = (int)(meta[j] & 0xFFu);
                     const bool in = d <= t && meta[j] != 0xFFFFu;
                     const u32 rk = (r[j] >> sh) & 0xFFFFu;
@@ -432,6 +516,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             }
         }
         __syncthreads();
+        HG_TK();                                      // 6: place
         if (ntile > 1) {
             if (tid < nbk) done[tid] += tilecnt[tid];
             zero_counters();
@@ -439,6 +524,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         }
     }
     for (int w = tid; w < bmw; w += nthr) grow[w] = bm[w];
+    HG_TK();                                          // 7: bitmap out
 }
 
 }  // namespace hg
