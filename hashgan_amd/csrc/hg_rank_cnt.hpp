@@ -92,8 +92,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     // a slice holds (thread = half a slice, three 16-byte loads): they fly while the slice counts make their own round trip
     // through memory and the prefix is scanned -- one global latency instead of three in a row (profile of round 3: the
     // dependent copy was 37 % of a block's life).  Bytes past a slice's count are simply not used.
-    constexpr int SPEC_SL = nthr / 2, SPEC_B = 48;                 // slices covered, bytes per thread
-    const int sp_s = tid >> 1, sp_h = tid & 1;
+    // (slices of up to 48 bytes -- many short segments -- take one thread each: twice as many slices covered)
+    constexpr int SPEC_B = 48;                                     // bytes per thread
+    const int sp_tps = (a.cap & ~15u) > (u32)SPEC_B ? 2 : 1;       // threads per slice
+    const int SPEC_SL = nthr / sp_tps;                             // slices covered
+    const int sp_s = sp_tps == 2 ? tid >> 1 : tid, sp_h = sp_tps == 2 ? tid & 1 : 0;
     uint4 spec[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     if (a.rec8 && sp_s < S) {
         const u8* r = (const u8*)cand + (i64)q * a.crow + (i64)sp_s * a.cap + sp_h * SPEC_B;
@@ -158,13 +161,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                     }
                 }
             }
-            // what they do not cover: records beyond the 96th of a slice (or beyond its capacity's last whole 16 bytes), slices beyond the 128th
-            const u32 cov = (a.cap & ~15u) < 2u * SPEC_B ? (a.cap & ~15u) : 2u * SPEC_B;     // piece k (16 bytes) was loaded iff 16 k + 16 <= cap
+            // what they do not cover: records beyond the 96th of a slice (or beyond its capacity's last whole 16 bytes)
+            const u32 cov = (a.cap & ~15u) < (u32)(sp_tps * SPEC_B) ? (a.cap & ~15u) : (u32)(sp_tps * SPEC_B);     // piece k (16 bytes) was loaded iff 16 k + 16 <= cap
             // (lane l looks at slice wave + 4 l, all at once; the few slices that need more are then copied by the whole wavefront)
-            for (int sbase = wave; sbase < S; sbase += NWAV * 64) {
+            const int Sp = S < SPEC_SL ? S : SPEC_SL;                     // the prefetched slices
+            for (int sbase = wave; sbase < Sp; sbase += NWAV * 64) {
                 const int s2 = sbase + NWAV * lane;
-                const u32 p2 = s2 < S ? pref[s2] : 0u, c2 = s2 < S ? pref[s2 + 1] - p2 : 0u;
-                const u32 lo2 = s2 < SPEC_SL ? cov : 0u;
+                const u32 p2 = s2 < Sp ? pref[s2] : 0u, c2 = s2 < Sp ? pref[s2 + 1] - p2 : 0u;
+                const u32 lo2 = cov;
                 u64 m = __ballot(c2 > lo2);
                 while (m) {
                     const int l = (int)__builtin_ctzll(m);
@@ -175,11 +179,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                     for (u32 i = ll + lane; i < cc; i += 64) rec8[pp + i] = r[i];
                 }
             }
-            return;
         }
-        if (a.rec8) {
+        if (a.rec8) {                                 // slices beyond the prefetched 128: sixteen slices' loads in flight per wavefront
             constexpr int NSL = 16;
-            for (int s = wave; s < S; s += NSL * NWAV) {
+            for (int s = SPEC_SL + wave; s < S; s += NSL * NWAV) {
                 u32 p[NSL], c[NSL], v[NSL];
 #pragma unroll
                 for (int k = 0; k < NSL; ++k) {
