@@ -499,7 +499,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                     const bool in = d <= t && meta[j] != 0xFFFFu;
                     const int k = in ? d - dmin : RC_MAXB;
                     r[j] = atomicAdd(&off32[k * 128 + (tid >> 1)], one);
-                    st[j] = (in ? tot[d] : 0u) + done[in ? k : 0];           // bucket start + what earlier tiles placed there
+                }
+#pragma unroll
+                for (int j = 0; j < PG; ++j) {
+                    const int d = (int)(meta[j] & 0xFFu);
+                    const bool in = d <= t && meta[j] != 0xFFFFu;
+                    st[j] = (in ? tot[d] : 0u) + (ntile > 1 ? done[in ? d - dmin : 0] : 0u);      // bucket start + what earlier tiles placed there
                 }
 #pragma unroll
                 for (int j = 0; j < PG; ++j) {
