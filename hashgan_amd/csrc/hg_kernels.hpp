@@ -369,37 +369,36 @@ __global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hs
     // The walk over the distances is a chain of L2 round trips (a plane's counts must be in before the next is worth
     // reading): two planes per step, eight segments of each in flight -- 16 loads per trip instead of 4 (0.038 -> 0.025 ms
     // at C2, where a lane sums 13 segments per plane and stops at the 19th; C5 0.083 -> 0.049).
-    for (int d = 0; d < dn; d += 2) {
-        const bool two = d + 1 < dn;
-        u32 c0 = 0, c1 = 0;
-        const u32* __restrict__ col0 = hseg + (i64)d * g.Qpad + qq;
-        const u32* __restrict__ col1 = col0 + (two ? g.Qpad : 0);
+    constexpr int PL = 4;                              // planes per trip (round 3: 2 -> 4, 32 loads in flight: 0.0255 -> 0.0205 ms at C2, C5 0.047 -> 0.034)
+    for (int d = 0; d < dn && !found; d += PL) {
+        u32 cs[PL];
+        const u32* __restrict__ col[PL];
+#pragma unroll
+        for (int p = 0; p < PL; ++p) { cs[p] = 0; col[p] = hseg + (i64)(d + p < dn ? d + p : d) * g.Qpad + qq; }
         for (int sh = s0; sh < s1; sh += 8) {
-            u32 v0[8], v1[8];
+            u32 v[PL][8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const i64 o = (i64)(sh + k < s1 ? sh + k : 0) * plane;     // past the part: any valid segment, not counted
-                v0[k] = col0[o];
-                v1[k] = col1[o];
+#pragma unroll
+                for (int p = 0; p < PL; ++p) v[p][k] = col[p][o];
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                c0 += sh + k < s1 ? v0[k] : 0u;
-                c1 += sh + k < s1 ? v1[k] : 0u;
-            }
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int p = 0; p < PL; ++p) cs[p] += sh + k < s1 ? v[p][k] : 0u;
         }
 #pragma unroll
-        for (int off = QPW; off < 64; off <<= 1) {                        // sums over the query's parts
-            c0 += (u32)__shfl_xor((int)c0, off);
-            c1 += (u32)__shfl_xor((int)c1, off);
-        }
-        below = cum;
-        cum += c0;
-        if (cum >= need) { t = d; found = true; break; }
-        if (two) {
-            below = cum;
-            cum += c1;
-            if (cum >= need) { t = d + 1; found = true; break; }
+        for (int off = QPW; off < 64; off <<= 1)                          // sums over the query's parts
+#pragma unroll
+            for (int p = 0; p < PL; ++p) cs[p] += (u32)__shfl_xor((int)cs[p], off);
+#pragma unroll
+        for (int p = 0; p < PL; ++p) {
+            if (!found && d + p < dn) {
+                below = cum;
+                cum += cs[p];
+                if (cum >= need) { t = d + p; found = true; }
+            }
         }
     }
     // all parts of a query agree on t; a wave's queries may stop at different d: the shuffles below only pair
