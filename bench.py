@@ -497,7 +497,10 @@ def main():
     ctx.timing_enable(False)
     qsplit = None
     if sharded_leg and not args.no_query_split:
-        qsplit = query_split_leg(args, spec, rank, world, local_rank, dry_dir, comm, qw, ql)
+        try:
+            qsplit = query_split_leg(args, spec, rank, world, local_rank, dry_dir, comm, qw, ql)
+        except Exception as e:      # noqa: BLE001 -- a side measurement must never cost the main line
+            qsplit = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank != 0:
         if sharded_leg:
             comm.barrier()
