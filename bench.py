@@ -419,7 +419,7 @@ def main():
     ap.add_argument("--no-query-split", action="store_true", help="sharded runs: skip the replicated-database / split-queries leg")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (hg_set_option), repeatable")
     ap.add_argument("--kernel-timing", default="pair-passes", choices=["pair-passes", "all", "none"],
-                    help="HIP events around the passes over the pairs only (the roofline kernel; default), around every "
+                    help="HIP events around the select pass over the pairs only (the roofline kernel; default), around every "
                          "kernel (events keep kernels from being dispatched back to back), or none")
     args = ap.parse_args()
 

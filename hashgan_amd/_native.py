@@ -408,7 +408,7 @@ class Context:
         return v.value
 
     def timing_enable(self, on=True):
-        """on: False/0 off, True/2 every kernel, 1 only the pair passes (k_hist, k_select, k_select_mx)."""
+        """on: False/0 off, True/2 every kernel, 1 only the select pass over the pairs (k_select, k_select_mx*) and the step's span."""
         level = 2 if on is True else (0 if on is False else int(on))
         check(self._lib.hg_timing_enable(self._h, level))
 

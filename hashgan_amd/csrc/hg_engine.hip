@@ -411,7 +411,8 @@ struct hg_ctx {
         return e;
     }
     bool t_wanted(int id) const {
-        return timing >= 2 || (timing == 1 && (id == KI_HIST || id == KI_SELECT || id == KI_SELECT_MX || id == KI_STEP));
+        // 1: the select pass (the roofline kernel) and the step's span only -- every event pair costs the stream ~2-4 us
+        return timing >= 2 || (timing == 1 && (id == KI_SELECT || id == KI_SELECT_MX || id == KI_STEP));
     }
     // while a step is being captured the events become event-record nodes of the graph and stay with it
     std::vector<Pending>& t_list() { return capturing ? sg.evs : pending; }

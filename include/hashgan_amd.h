@@ -278,7 +278,7 @@ int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
  * (stat "device_bytes" reports what the context holds). */
 int hg_trim(hg_ctx* ctx);
 /* HIP-event timing of the kernels launched on the context's stream.  on = 2: every kernel; 1: only the
- * passes over the query x database pairs (k_hist, k_select, k_select_mx) -- two events per launch keep
+ * select pass over the query x database pairs (k_select, k_select_mx*: the roofline kernel) -- two events per launch keep
  * consecutive kernels from being dispatched back to back, ~4 us each; 0: off.  Levels 1 and 2 also time the
  * whole one-shot step on the GPU ("step_gpu_span": first enqueue to the last byte of the result download), so
  * wall time per step - step_gpu_span = what the host adds.  Inside a captured step the events are event-record
