@@ -721,3 +721,33 @@ def test_wild_guesses_never_change_the_result(b, sigma):
             assert np.array_equal(ap, ap_ref, equal_nan=True)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("b", [64, 40])
+def test_one_lane_bursts_while_its_neighbours_stay_sparse(b):
+    """Inside ONE wavefront of the matrix-core select: a few queries meet long runs of rows at distance 0 (their slices'
+    rings overflow: the lane walks its hits to global memory itself, then returns to the rings), runs that straddle
+    window and segment boundaries, every third row of a stretch -- while the other lanes' queries see ordinary sparse
+    hits through the queue.  Same APs as the oracle, twice (the second call reuses every buffer)."""
+    rng = np.random.default_rng(900 + b)
+    Q, N, R, C = 130, 160000, 900, 5
+    db = (rng.random((N, b)) < 0.5).astype(np.uint8)
+    qb = (rng.random((Q, b)) < 0.5).astype(np.uint8)
+    db[5000:5600] = qb[3]                                  # 600 consecutive duplicates of query 3
+    db[20000:21200:3] = qb[70]                             # every third row over 1200 rows
+    db[47990:48110] = qb[64]                               # across a 48-row supertile / window boundary, first lane of the second tile
+    db[N - 70:] = qb[129]                                  # the database's ragged end
+    dl = (rng.random((N, C)) < 0.3).astype(np.int8)
+    ql = (rng.random((Q, C)) < 0.3).astype(np.int8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb, db, ql, dl, R)
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        for _ in range(2):
+            ap, rel = ctx.map(R)
+            assert np.array_equal(ap, ap_ref, equal_nan=True)
+        assert ctx.get_stat("optimistic_runs") >= 1
+    finally:
+        ctx.close()
