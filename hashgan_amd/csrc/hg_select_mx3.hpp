@@ -10,7 +10,7 @@
 // MX block scale is per lane = per A row, so s(r) in {0, 1, 2} differs between registers, and
 //     word = (acc[r] & K_s(r)) | word,      K_s = bits {6, 13, 20} << s
 // gathers nine hit bits of three registers; two shift-merges per word fill seven sub-positions per field.  20 vector
-// ops harvest 48 rows per lane (0.42 per pair) and 16 of them are plain v_and_b32 v, v, v -- the fast VOP2 form -- with
+// ops (24 as compiled) harvest 48 rows per lane (0.5 per pair) and 16 of them are plain v_and_b32 v, v, v -- the fast VOP2 form -- with
 // the masks in registers (dead lanes simply hold K = 0).  Measured (tools/ubench_mx3.hip): 0.22 ms per 10^10 pairs
 // against 0.34 for 16 v_alignbit per tile, 0 mismatches against xor + popcount on 1.2e7 pairs.
 //
@@ -24,9 +24,10 @@
 // lane with a hit appends ONE 12-byte entry {A | lane | tile | supertile | buffer, B | slice position & 15, C} to the
 // wavefront's queue (ring buffer in LDS, slot = rank among the pushing lanes).  The emit works the queue off in batches
 // of exactly 64 entries -- every lane busy -- and entries that do not fill a batch WAIT for the next window: the packed
-// codes and labels the emit needs are triple-buffered (3 KiB each), so an entry may be emitted one window late, and the
+// codes and labels the emit needs are triple-buffered, so an entry may be emitted one window late, and the
 // owner-side flush of the 16-record rings lags one window accordingly (it flushes what was pushed before the window
-// that just ended).  A window is two supertiles (96 rows per lane-half); ~70 entries per window and wavefront at C2.
+// that just ended).  A block is eight wavefronts = one segment pair x 512 queries sharing windows of four supertiles (192
+// rows per lane-half; two for 65..128 classes); ~140 entries per window and wavefront at C2.
 // Bursts (a ring that could overflow: > 16 records of one slice pending) drain everything and, if one supertile alone
 // still brings too many, the lane walks its own hits straight to global memory -- rare, slow, exact.
 #pragma once
@@ -350,7 +351,7 @@ struct Mx3Drain {
     }
 };
 
-// Geo as set by the launcher: g.nQT = query blocks (of 256 queries) per segment pair, g.nBlk = blocks; g.L % 48 == 0.
+// Geo as set by the launcher: g.nQT = query blocks (of 64 M3_WPB queries) per segment pair, g.nBlk = blocks; g.L % 48 == 0.
 template <int NW, int LW>
 #ifndef HG_M3_WAVES
 #define HG_M3_WAVES 4
