@@ -8,6 +8,7 @@
 #include "hg_rank_lds.hpp"
 #include "hg_rank_cnt.hpp"
 #include "hg_rank_wave.hpp"
+#include "hg_rank_direct.hpp"
 #include "hg_select_mx2.hpp"
 #include "hg_select_mx3.hpp"
 #include "hg_real_mx.hpp"
@@ -292,6 +293,8 @@ struct hg_ctx {
     i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
     i64 opt_rank_cnt = 1;      // ... and ranks them with the per-thread counting sort (k_rank_cnt) where it applies
+    i64 opt_rank_direct_lds = 80;    // "rank_direct_lds": KB of LDS a k_rank_direct block may take (80: two blocks per CU -- C1 0.25 ms vs 0.31 with 160 and one)
+    i64 opt_rank_direct = 1;   // "rank_direct": R = N on one shard in one counting-sort kernel, k_rank_direct, when its LDS fits (2: also N/8 < R < N)
     i64 opt_rank_wave = 40;    // "rank_wave": one wavefront per query (k_rank_wave) for SHORT lists of one-byte records; the value is the
                                // record capacity of a query's LDS share in tenths of the shard's share of R (+ 256; lists beyond it
                                // go to k_rank_fused); 0 = off
@@ -1569,8 +1572,37 @@ int hg_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank)
 
 // k_rank_fused in one of its modes: 0 = histogram + plan + placement in one launch (single shard),
 // 1 = histogram phase (several shards, before the exchange), 2 = placement phase (after k_plan).
+// the dense regime in one kernel (k_rank_direct): fits when a block's LDS holds the counters, the R-bit bitmap and a tile of rows
+static i64 rank_direct_tile(const hg_ctx* c, int64_t R) {
+    if (!c->opt_rank_direct || c->LW > 2 || c->NW > 8 || c->b > 127) return 0;
+    const i64 RW = (R + 63) / 64;
+    const i64 fixed = rank_direct_layout(c->b + 1, RW, 0).total;
+    i64 tile = (c->opt_rank_direct_lds * 1024 - fixed) & ~(i64)15;
+    if (tile > 252 * 256) tile = 252 * 256;             // a thread's chunk must fit its byte counters
+    const i64 n8 = (c->N + 7) / 8 * 8;
+    if (tile > n8) tile = n8;
+    return tile >= 8192 || tile >= n8 ? tile : 0;
+}
+
 static int launch_rank(hg_ctx* c, int mode, int nbits) {
     const Geo& g = c->geo;
+    if (c->direct_rank && mode == 0) {
+        const i64 tile = rank_direct_tile(c, g.R);
+        if (tile > 0) {
+            HG_TRY(c->err.reserve(4));
+            HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
+            const RankDirectLds L = rank_direct_layout(g.NB, c->RW, (int)tile);
+            if (L.total > 64 * 1024)
+                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_direct), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+            RankDirectArgs da{c->qc.as<u32>(), c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(),
+                              c->RW, (int)tile, c->want_lists ? 1 : 0};
+            c->t_begin(KI_RANK_FUSED);
+            hipLaunchKernelGGL(k_rank_direct, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, da, c->out_idx.as<u32>(), c->out_dist.as<u8>(),
+                               c->mbits.as<u32>(), g);
+            c->t_end();
+            return c->check_launch("k_rank_direct");
+        }
+    }
     int nwav = c->opt_rank_waves ? (int)c->opt_rank_waves
                                  : ((c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4);   // records per query ~ 3R / R
     // k_rank_lds: the query's records resident in LDS -- room for ~2.5 R per query (the bet keeps 1.3-2 R),
@@ -2212,6 +2244,11 @@ static int enqueue_all_rows(hg_ctx* c, int64_t R) {
 static int enqueue_exact(hg_ctx* c, int64_t R) {
     if (c->N == c->n_total && R == c->N && c->opt_all_rows && c->LW <= 2 && c->NW <= 8)
         return enqueue_all_rows(c, R);                 // one-shot calls are single-shard
+    // (k_rank_direct ranks ANY R from the rows themselves, but with one block per query it re-reads the whole database per
+    // query and runs one wavefront per SIMD: measured against k_hist + k_select + k_rank_fused it loses for N/8 < R < N --
+    // 15.7 vs 12.3 ms at N = 200k, R = 100k; 82 vs 70 ms at N = 1M, R = 500k -- so only "rank_direct" = 2 routes that regime to it)
+    if (c->opt_rank_direct == 2 && c->N == c->n_total && R * 8 > c->N && c->opt_all_rows && !c->is_sub && rank_direct_tile(c, R) > 0)
+        return enqueue_all_rows(c, R);
     HG_TRY(do_hist(c, 1));
     HG_TRY(do_plan(c, R, nullptr, 1, 0));
     return do_select(c);
@@ -2927,6 +2964,12 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_wave")) {
         if (value < 0 || value > 400) return fail(HG_ERR_ARG, "rank_wave must be 0 (off) or the LDS record capacity in tenths of R, <= 400");
         c->opt_rank_wave = value;
+    } else if (!strcmp(key, "rank_direct_lds")) {
+        if (value < 32 || value > 160) return fail(HG_ERR_ARG, "rank_direct_lds must be 32..160 (KB)");
+        c->opt_rank_direct_lds = value;
+    } else if (!strcmp(key, "rank_direct")) {
+        if (value < 0 || value > 2) return fail(HG_ERR_ARG, "rank_direct must be 0, 1 (R = N) or 2 (also N/8 < R < N)");
+        c->opt_rank_direct = value;
     } else if (!strcmp(key, "rank_wave_max")) {
         if (value < 0 || value > 16128) return fail(HG_ERR_ARG, "rank_wave_max must be 0..16128 (a lane's chunk must fit its byte counters)");
         c->opt_rank_wave_max = value;

@@ -241,6 +241,8 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * k_select_mx; 0: vector-ALU xor+popcount k_select; same records either way), "probe_select" (probe build only --
  * python -m hashgan_amd.build --probes: bits 2/4/8 switch parts of the matrix-core kernels' drain off; the bet
  * then fails and the exact sequence runs, so results stay right; the production library refuses the key),
+ * "rank_direct" (1, default: R = N on one shard is ranked straight from the packed tables by one counting-sort kernel,
+ * k_rank_direct, when its LDS fits; 2: also N/8 < R < N; 0: k_rank_fused's direct mode), "rank_direct_lds" (80: KB of LDS per block),
  * "rank_wave" (40, default: the bet's rank stage runs one wavefront per query, k_rank_wave, when a query's list of one-byte
  * records is short -- capacity value/10 x the shard's share of R + 256 records of LDS per query, used when that is at most
  * "rank_wave_max" = 4608 records: a sharded rank, a small R; 0 = always the block-per-query k_rank_cnt),

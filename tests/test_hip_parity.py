@@ -751,3 +751,36 @@ def test_one_lane_bursts_while_its_neighbours_stay_sparse(b):
         assert ctx.get_stat("optimistic_runs") >= 1
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("Q,N,b,R,C", [(40, 200000, 64, 100000, 10), (25, 70001, 33, 70001, 70), (60, 30000, 100, 9000, 3),
+                                       (33, 150000, 16, 30001, 128), (70, 9000, 64, 8999, 5)])
+def test_dense_regime_ranks_the_rows_directly(Q, N, b, R, C):
+    """R > N / 8 on one shard (up to the reference's own R = N, lib/metric.py:14,19 with MAP_R = DB_SIZE): k_rank_direct
+    ranks a query's rows straight from the packed tables -- several tiles of rows, a bitmap of R bits in LDS, ties by
+    index.  AP, ranked indices and distances equal the oracle; no bet is placed, no histogram pass runs."""
+    rng = np.random.default_rng(N + R)
+    proto = (rng.random((C, b)) < 0.5).astype(np.uint8)
+    lab_db, lab_q = rng.integers(0, C, N), rng.integers(0, C, Q)
+    db = proto[lab_db] ^ (rng.random((N, b)) < 0.3).astype(np.uint8)
+    qb = proto[lab_q] ^ (rng.random((Q, b)) < 0.3).astype(np.uint8)
+    dl = np.eye(C, dtype=np.int8)[lab_db]
+    ql = np.eye(C, dtype=np.int8)[lab_q]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, imatch_ref, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
+    ctx = _native.Context(0)
+    try:
+        ctx.set_option("rank_direct", 2)                  # R = N takes the kernel by default; N/8 < R < N on request
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        ap, rel = ctx.map(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        assert ctx.get_stat("optimistic_runs") == 0
+        ctx.topr(R)
+        idx, dist = ctx.get_topr()
+        assert np.array_equal(idx.astype(np.int64), idx_ref) and np.array_equal(dist.astype(np.int64), dist_ref)
+        ctx.set_option("rank_direct", 0)                  # the older sequences give the same
+        ap2, _ = ctx.map(R)
+        assert np.array_equal(ap2, ap_ref, equal_nan=True)
+    finally:
+        ctx.close()
