@@ -1306,6 +1306,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
         if (tid >= 64) wpre[tid + 1] += s_w0;
         __syncthreads();
         const u32 before = s_before;
+        const bool sparse = wpre[AP_CHUNK / 64] * 4u < (u32)n;   // block-uniform: fewer than one slot in four matches
         // value of element e of the chunk: (matches up to and including e) / (its 1-based rank), 0 without a match
         auto val = [&](const int e) -> double {
             const u64 word = cw[e >> 6];
@@ -1332,8 +1333,30 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
             const int ls = act ? sh->leaf_start[leaf] : 0, ll = act ? sh->leaf_len[leaf] : 0;
             const int body = ll - (ll % 8);
             double r = 0.0;
-            if (ll >= 8)
+            if (ll >= 8 && !sparse) {
                 for (int e = ls + j; e < ls + body; e += 8) r += val(e);      // 0.0 + v == v: the first add is exact
+            } else if (ll >= 8) {
+                // r_j adds elements ls + j, ls + j + 8, ... in order; only MATCHING slots contribute (r + 0.0 == r exactly,
+                // r >= 0), and they are few -- one in ten with ten classes -- so the lane walks the set bits of its stride-8
+                // sub-mask instead of all 16 slots when the chunk is sparse (same additions in the same order; dense chunks --
+                // trained codes put matches first -- keep the plain loop, which does not diverge)
+#pragma unroll
+                for (int sp = 0; sp < AP_LEAF / 64; ++sp) {
+                    const int e0 = ls + 64 * sp;                              // first element of this 64-element span of the leaf
+                    if (64 * sp >= body) break;
+                    const int wi = e0 >> 6, bs = e0 & 63;
+                    u64 win = cw[wi] >> bs;                                   // the span's 64 match bits (it may straddle two words)
+                    if (bs) win |= cw[wi + 1 < AP_CHUNK / 64 ? wi + 1 : wi] << (64 - bs);
+                    const int nv = body - 64 * sp;                            // valid elements of the span (a multiple of 8)
+                    if (nv < 64) win &= (1ull << nv) - 1ull;
+                    u64 m = (win >> j) & 0x0101010101010101ull;               // elements j, j + 8, ... of the span
+                    while (m) {
+                        const int p = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        r += val(e0 + j + p);
+                    }
+                }
+            }
             r += __shfl_xor(r, 1);
             r += __shfl_xor(r, 2);
             r += __shfl_xor(r, 4);
