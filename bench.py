@@ -421,6 +421,9 @@ def main():
     ap.add_argument("--no-c4-ref", action="store_true", help="skip the one-GPU C4 point of the scaling curve")
     ap.add_argument("--no-query-split", action="store_true", help="sharded runs: skip the replicated-database / split-queries leg")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (hg_set_option), repeatable")
+    ap.add_argument("--timing-every", type=int, default=4,
+                    help="pair-passes timing brackets the select pass on every n-th step of the timed region (its events cost a "
+                         "step ~0.025 ms: tools/gpu_event_cost.sh); the average is over those launches")
     ap.add_argument("--kernel-timing", default="pair-passes", choices=["pair-passes", "all", "none"],
                     help="HIP events around the select pass over the pairs only (the roofline kernel; default), around every "
                          "kernel (events keep kernels from being dispatched back to back), or none")
@@ -486,6 +489,8 @@ def main():
 
     for _ in range(args.warmup):
         m, a = step()
+    every = max(1, min(args.timing_every, args.steps)) if args.kernel_timing == "pair-passes" else 1
+    ctx.set_option("timing_every", every)
     ctx.timing_enable({"pair-passes": 1, "all": 2, "none": 0}[args.kernel_timing])
     ctx.timing_reset()
     fence()
@@ -542,12 +547,14 @@ def main():
         span = timing.pop("step_gpu_span", None)
         rec_bytes = 8 if any(kv.replace(" ", "") == "compact_records=0" for kv in args.opt) else 1
         roof, per_kernel = kernel_rooflines(timing, spec, rows, per_step, rec_bytes)
+        roof["launches_timed"] = per_kernel[roof["kernel"]]["launches"]
+        roof["timed"] = "HIP events around the kernel on every %s step of the timed region" % ("" if every == 1 else "%d-th" % every)
         out["roofline"] = roof
         out["kernels"] = {k_: {"avg_ms": round(v["avg_ms"], 5), "launches": v["launches"]} for k_, v in per_kernel.items()}
         if span:            # HIP events around the whole step on the GPU: what is left of the wall time is the host's
             busy = span[0] / max(span[1], 1)
             out["step_accounting"] = {"gpu_span_ms": round(busy, 5), "host_and_launch_ms": round(per_step * 1e3 - busy, 5),
-                                      "kernels_timed_ms": round(sum(v["avg_ms"] * v["launches"] for v in per_kernel.values()) / args.steps, 5),
+                                      "kernels_timed_ms": round(sum(v["avg_ms"] * v["launches"] for v in per_kernel.values()) / max(span[1], 1), 5),
                                       "graph_replays": ctx.get_stat("graph_replays"), "graph_captures": ctx.get_stat("graph_captures")}
     if dry_dir:
         out["dry_run_not_a_measurement"] = "ranks share GPU 0 and exchange through files (HG_BENCH_FILECOMM)"

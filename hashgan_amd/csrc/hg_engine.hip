@@ -415,8 +415,12 @@ struct hg_ctx {
     }
     bool t_wanted(int id) const {
         // 1: the select pass (the roofline kernel) and the step's span only -- every event pair costs the stream ~2-4 us
-        return timing >= 2 || (timing == 1 && (id == KI_SELECT || id == KI_SELECT_MX || id == KI_STEP));
+        // and only on one step in "timing_every" (the averages are over the sampled launches)
+        return timing >= 2 || (timing == 1 && (id == KI_SELECT || id == KI_SELECT_MX || id == KI_STEP) &&
+                               (capturing || opt_timing_every <= 1 || t_seq % opt_timing_every == 0));
     }
+    i64 opt_timing_every = 1;  // "timing_every": level-1 timing records its events on every n-th one-shot step only
+    i64 t_seq = 0;             // one-shot steps since timing was enabled
     // while a step is being captured the events become event-record nodes of the graph and stay with it
     std::vector<Pending>& t_list() { return capturing ? sg.evs : pending; }
     bool t_open = false;
@@ -436,6 +440,7 @@ struct hg_ctx {
     int step_slot = -1;
     void t_step_begin() {
         step_slot = -1;
+        ++t_seq;
         if (!t_wanted(KI_STEP)) return;
         Pending p{KI_STEP, get_event(), get_event()};
         (void)hipEventRecord(p.a, stream);
@@ -2964,6 +2969,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_wave")) {
         if (value < 0 || value > 400) return fail(HG_ERR_ARG, "rank_wave must be 0 (off) or the LDS record capacity in tenths of R, <= 400");
         c->opt_rank_wave = value;
+    } else if (!strcmp(key, "timing_every")) {
+        if (value < 1 || value > 1024) return fail(HG_ERR_ARG, "timing_every must be 1..1024");
+        c->opt_timing_every = value;
     } else if (!strcmp(key, "rank_direct_lds")) {
         if (value < 32 || value > 160) return fail(HG_ERR_ARG, "rank_direct_lds must be 32..160 (KB)");
         c->opt_rank_direct_lds = value;
@@ -3101,6 +3109,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
 int hg_timing_enable(hg_ctx* c, int on) {
     if (!c) return fail(HG_ERR_ARG, "hg_timing_enable: null context");
     c->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
+    c->t_seq = 0;
     return HG_OK;
 }
 

@@ -284,7 +284,9 @@ int hg_trim(hg_ctx* ctx);
  * consecutive kernels from being dispatched back to back, ~4 us each; 0: off.  Levels 1 and 2 also time the
  * whole one-shot step on the GPU ("step_gpu_span": first enqueue to the last byte of the result download), so
  * wall time per step - step_gpu_span = what the host adds.  Inside a captured step the events are event-record
- * nodes of the graph. */
+ * nodes of the graph.  Option "timing_every" = n (default 1) makes level 1 record on every n-th one-shot step only:
+ * the events of a step cost it ~0.025 ms (1.04 -> 1.07 ms at 10k x 1M), sampling one step in four keeps the average
+ * kernel duration live at a quarter of that. */
 int hg_timing_enable(hg_ctx* ctx, int on);
 int hg_timing_reset(hg_ctx* ctx);
 /* Fills up to cap entries; name[i] points to static strings. Returns count via *n. */
