@@ -293,6 +293,7 @@ struct hg_ctx {
     i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
     i64 opt_rank_cnt = 1;      // ... and ranks them with the per-thread counting sort (k_rank_cnt) where it applies
+    i64 cap_boost = 1;         // slice capacity multiplier a lost bet escalated to on this database (run_oneshot); 1 after every load
     i64 opt_rank_direct_lds = 80;    // "rank_direct_lds": KB of LDS a k_rank_direct block may take (80: two blocks per CU -- C1 0.25 ms vs 0.31 with 160 and one)
     i64 opt_rank_direct = 1;   // "rank_direct": R = N on one shard in one counting-sort kernel, k_rank_direct, when its LDS fits (2: also N/8 < R < N)
     i64 opt_rank_wave = 40;    // "rank_wave": one wavefront per query (k_rank_wave) for SHORT lists of one-byte records; the value is the
@@ -1262,6 +1263,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     c->dbx3_valid = false;
     c->dbx8_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;    // a new database: earlier lost bets say nothing about it
+    c->cap_boost = 1;
     c->cfg_epoch++;
     return HG_OK;
 }
@@ -1393,6 +1395,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->dbfx_valid = false;
     c->dbfb_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;
+    c->cap_boost = 1;
     c->cfg_epoch++;
     return HG_OK;
 }
@@ -2322,9 +2325,11 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     // distance bucket, and cumulative counts grow ~2x per bucket in the tail where the cut lies; clustered
     // codes grow faster) -- budget 4 R per query over the S segments plus 6 sigma per slice.  HBM is
     // plentiful (2.5 GB at C2); an overflow only costs the exact rerun.
-    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)R / (double)g.S;
+    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)c->cap_boost * (double)R / (double)g.S;
     u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
     cap = (cap + 15u) & ~15u;                      // a multiple of the compact records' ring (16) and flush piece (8)
+    const u32 whole = (u32)((g.L + 15) & ~15ll);   // (a slice never needs more than its segment's rows)
+    if (cap > whole) cap = whole;
     c->optimistic = true;
     c->cap = cap;
     c->crow = (i64)g.S * cap;
@@ -2495,30 +2500,41 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
         HG_TRY(rerun_lost_queries(c, R, lists, with_ap, &handled));
         if (handled) { c->opt_consecutive_fail = 0; return HG_OK; }
         // many queries lost.  Before paying for the exact two-pass sequence (3x the bet at C2), bet once more with
-        // twice the safety margin and twice the record budget -- the verification is what makes either bet exact
+        // twice the safety margin and twice the record budget -- the verification is what makes either bet exact.
+        // Still lost: the hits crowd into few segments (a database stored class by class: ten classes put ten times the
+        // mean into a query's slices), which no margin on the CUT cures -- escalate the slices' capacity (x8, x64, until a
+        // slice would hold its whole segment) and remember what worked for the next calls on this database.
         if (c->opt_second_bet) {
-            const i64 sigma0 = c->opt_sigma, budget0 = c->cand_budget_x10;
-            c->opt_sigma = 2 * sigma0 + 2;
-            c->cand_budget_x10 = 2 * budget0;
-            c->opt_rebets++;
-            c->want_lists = lists;
-            int rc;
-            if (with_ap) {
-                rc = enqueue_bet_with_ap(c, R, stride, need_cnt);
-                if (rc == HG_OK) rc = c->sync();
-                flag = *(const int*)c->pin;
-                c->ap_staged = rc == HG_OK && flag == 0;
-            } else {
-                rc = enqueue_optimistic(c, R, stride, need_cnt);
-                if (rc == HG_OK) rc = read_plan_flag(c, &flag);
+            const i64 sigma0 = c->opt_sigma, budget0 = c->cand_budget_x10, boost0 = c->cap_boost;
+            for (int attempt = 0; attempt < 3; ++attempt) {
+                if (attempt > 0) {
+                    if (c->cap >= (u32)((c->geo.L + 15) & ~15ll)) break;               // a slice already holds a segment
+                    if ((double)c->geo.Q * (double)c->crow * 8.0 * 8.0 > 64e9) break;  // the record rows would not fit comfortably
+                    c->cap_boost *= 8;
+                }
+                c->opt_sigma = 2 * sigma0 + 2;
+                c->cand_budget_x10 = 2 * budget0;
+                c->opt_rebets++;
+                c->want_lists = lists;
+                int rc;
+                if (with_ap) {
+                    rc = enqueue_bet_with_ap(c, R, stride, need_cnt);
+                    if (rc == HG_OK) rc = c->sync();
+                    flag = *(const int*)c->pin;
+                    c->ap_staged = rc == HG_OK && flag == 0;
+                } else {
+                    rc = enqueue_optimistic(c, R, stride, need_cnt);
+                    if (rc == HG_OK) rc = read_plan_flag(c, &flag);
+                }
+                c->opt_sigma = sigma0;
+                c->cand_budget_x10 = budget0;
+                if (rc != HG_OK) { c->cap_boost = boost0; return rc; }
+                if (!flag) { c->opt_consecutive_fail = 0; c->cfg_epoch++; return HG_OK; }
+                handled = false;
+                HG_TRY(rerun_lost_queries(c, R, lists, with_ap, &handled));
+                if (handled) { c->opt_consecutive_fail = 0; c->cfg_epoch++; return HG_OK; }
             }
-            c->opt_sigma = sigma0;
-            c->cand_budget_x10 = budget0;
-            HG_TRY(rc);
-            if (!flag) { c->opt_consecutive_fail = 0; return HG_OK; }
-            handled = false;
-            HG_TRY(rerun_lost_queries(c, R, lists, with_ap, &handled));
-            if (handled) { c->opt_consecutive_fail = 0; return HG_OK; }
+            c->cap_boost = boost0;                 // nothing helped: do not keep paying for big slices
         }
         c->opt_fallbacks++;                        // still too many: exact path for all
         c->opt_consecutive_fail++;
@@ -3069,6 +3085,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "optimistic_fallbacks")) *value = c->opt_fallbacks;
     else if (!strcmp(key, "optimistic_requeried")) *value = c->opt_requeried;
     else if (!strcmp(key, "optimistic_rebets")) *value = c->opt_rebets;
+    else if (!strcmp(key, "cap_boost")) *value = c->cap_boost;
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
     else if (!strcmp(key, "real_attempts")) *value = c->real_attempts;
     else if (!strcmp(key, "real_filtered")) *value = c->real_filtered ? 1 : 0;

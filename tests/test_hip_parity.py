@@ -723,6 +723,47 @@ def test_wild_guesses_never_change_the_result(b, sigma):
         ctx.close()
 
 
+def test_a_database_stored_class_by_class_keeps_the_bet():
+    """Rows sorted by label, codes that follow the labels: a query's near rows all sit in its class's tenth of the
+    segments, ten times what slices sized for an even spread hold.  The first call loses the bet twice, widens the slices
+    (cap_boost) and wins; later calls on the same database bet with the wide slices at once; a new database starts over.
+    Every answer is the oracle's."""
+    rng = np.random.default_rng(4242)
+    Q, N, R, C, b = 64, 200000, 3000, 10, 64
+    cls = np.sort(rng.integers(0, C, N))
+    proto = (rng.random((C, b)) < 0.5).astype(np.uint8)
+    db = proto[cls] ^ (rng.random((N, b)) < 0.25).astype(np.uint8)
+    qcls = rng.integers(0, C, Q)
+    qb = proto[qcls] ^ (rng.random((Q, b)) < 0.25).astype(np.uint8)
+    dl = np.eye(C, dtype=np.int8)[cls]
+    ql = np.eye(C, dtype=np.int8)[qcls]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb, db, ql, dl, R)
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        ap, rel = ctx.map(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        assert ctx.get_stat("last_optimistic") == 1 and ctx.get_stat("optimistic_fallbacks") == 0
+        boost, rebets = ctx.get_stat("cap_boost"), ctx.get_stat("optimistic_rebets")
+        assert boost > 1 and rebets >= 2
+        ap, rel = ctx.map(R)                                   # the widened slices are remembered: no further lost bet
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        assert ctx.get_stat("optimistic_rebets") == rebets and ctx.get_stat("last_optimistic") == 1
+        perm = rng.permutation(N)                              # the same rows shuffled: a new database, ordinary slices again
+        _load(ctx, dict(qbits=qb, dbbits=db[perm], qlab=ql, dblab=dl[perm], b=b))
+        assert ctx.get_stat("cap_boost") == 1
+        ap2, _ = ctx.map(R)
+        assert ctx.get_stat("cap_boost") == 1 and ctx.get_stat("optimistic_rebets") == rebets
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, ap_ref2, *_ = O.map_from_codes(qb, db[perm], ql, dl[perm], R)
+        assert np.array_equal(ap2, ap_ref2, equal_nan=True)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("b", [64, 40])
 def test_one_lane_bursts_while_its_neighbours_stay_sparse(b):
     """Inside ONE wavefront of the matrix-core select: a few queries meet long runs of rows at distance 0 (their slices'

@@ -16,8 +16,9 @@ def run(tag, qw, ql, dw, dl, b, C, R, steps=10):
     t = time.perf_counter()
     for _ in range(steps): ctx.map(R)
     dt = (time.perf_counter() - t) / steps
-    print("%-8s %8.3f ms/step  bet=%d fallbacks=%d requeried=%d  mAP=%.6f" % (tag, dt * 1e3, ctx.get_stat("last_optimistic"),
-          ctx.get_stat("optimistic_fallbacks") - f0, ctx.get_stat("optimistic_requeried"), metric.mean_over_hits(a0, r0)), flush=True)
+    print("%-8s %8.3f ms/step  bet=%d fallbacks=%d requeried=%d rebets=%d cap_boost=%d  mAP=%.6f" % (tag, dt * 1e3, ctx.get_stat("last_optimistic"),
+          ctx.get_stat("optimistic_fallbacks") - f0, ctx.get_stat("optimistic_requeried"), ctx.get_stat("optimistic_rebets"), ctx.get_stat("cap_boost"),
+          metric.mean_over_hits(a0, r0)), flush=True)
     ctx.close()
     return a0
 
