@@ -1894,6 +1894,18 @@ int hg_merge_topr(hg_ctx* c, const uint32_t* dev_idx_all, const uint8_t* dev_dis
 // ~3 % more surplus records).  The
 // guess's safety margin is relative to sqrt(sampled hits), so a small R only means relatively more
 // surplus records (R = 100: ~3.5 R of them) -- still far cheaper than a full histogram pass.
+// Capacity of a (segment, query) slice of the bet: the budgeted mean + 6 sigma, never more than the segment's rows, and
+// the record rows of all queries together stay below 64 GB ("cap_boost" may ask for more than is sensible).
+static u32 slice_capacity(const hg_ctx* c, double mean) {
+    const Geo& g = c->geo;
+    u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
+    cap = (cap + 15u) & ~15u;                      // a multiple of the compact records' ring (16) and flush piece (8)
+    const u32 whole = (u32)((g.L + 15) & ~15ll);
+    if (cap > whole) cap = whole;
+    while (cap > 64u && (double)g.Q * (double)g.S * (double)cap * 8.0 > 64e9) cap = (cap / 2u + 15u) & ~15u;
+    return cap;
+}
+
 static int auto_stride(hg_ctx* c, int64_t R) {
     (void)R;
     return c->opt_stride > 0 ? (int)c->opt_stride : 24;
@@ -1939,9 +1951,8 @@ int hg_guess(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank
     // a guessed cut keeps at most ~2.6 R rows over ALL shards; a shard's share is proportional to its size,
     // with the same 6-sigma headroom per slice as the one-shot bet
     const double share = (double)c->N / (double)c->n_total;
-    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)R * share / (double)g.S;
-    u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
-    cap = (cap + 15u) & ~15u;                      // a multiple of the compact records' ring (16) and flush piece (8)
+    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)c->cap_boost * (double)R * share / (double)g.S;
+    u32 cap = slice_capacity(c, mean);
     c->optimistic = true;
     c->cap = cap;
     c->crow = (i64)g.S * cap;
@@ -2326,10 +2337,7 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     // codes grow faster) -- budget 4 R per query over the S segments plus 6 sigma per slice.  HBM is
     // plentiful (2.5 GB at C2); an overflow only costs the exact rerun.
     const double mean = 0.1 * (double)c->cand_budget_x10 * (double)c->cap_boost * (double)R / (double)g.S;
-    u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
-    cap = (cap + 15u) & ~15u;                      // a multiple of the compact records' ring (16) and flush piece (8)
-    const u32 whole = (u32)((g.L + 15) & ~15ll);   // (a slice never needs more than its segment's rows)
-    if (cap > whole) cap = whole;
+    u32 cap = slice_capacity(c, mean);
     c->optimistic = true;
     c->cap = cap;
     c->crow = (i64)g.S * cap;
@@ -2988,6 +2996,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "timing_every")) {
         if (value < 1 || value > 1024) return fail(HG_ERR_ARG, "timing_every must be 1..1024");
         c->opt_timing_every = value;
+    } else if (!strcmp(key, "cap_boost")) {
+        if (value < 1 || value > 4096) return fail(HG_ERR_ARG, "cap_boost must be 1..4096");
+        c->cap_boost = value;
     } else if (!strcmp(key, "rank_direct_lds")) {
         if (value < 32 || value > 160) return fail(HG_ERR_ARG, "rank_direct_lds must be 32..160 (KB)");
         c->opt_rank_direct_lds = value;

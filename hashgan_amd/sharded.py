@@ -232,6 +232,16 @@ class HipShardEngine:
     def bet_eligible(self, R, world):
         return self.ctx.bet_eligible(R, world)
 
+    def widen_slices(self):
+        """After a lost bet: eight times the slice capacity (hg_set_option "cap_boost"), twice at most; False -- and the
+        ordinary capacity back -- when that has been tried.  The losses are the same on every rank, so is this."""
+        boost = self.ctx.get_stat("cap_boost")
+        if boost >= 64:
+            self.ctx.set_option("cap_boost", 1)
+            return False
+        self.ctx.set_option("cap_boost", boost * 8)
+        return True
+
     def ranked_merge_ok(self, world):
         """hg_merge_ranked's limits (shard-independent): lane r <-> shard r, and the four queries of a block keep
         their [G][b+1] record counts in LDS."""
@@ -307,24 +317,27 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
             and engine.bet_eligible(R, comm.world)):
         # the bet with one record pass and one exchange after the guess: every shard ranks its own records, the
         # global bitmap is stitched from the gathered local ones (hg_merge_ranked)
-        engine.guess(R, gather(engine.sample_hist(R)), comm.world, comm.rank)
-        h, b = engine.select_ranked()
-        if multi and hasattr(engine, "merge_ap_part"):
-            # the per-query stages split over the ranks: each merges and evaluates its own share of the queries, a third,
-            # tiny all-gather (16 bytes per query) brings every rank all APs and the verdict (the same on every rank)
-            part = engine.merge_ap_part(gather(h), gather(b), comm.world, comm.rank)
-            ap, rel, lost = engine.unpack_parts(comm.all_gather(part), comm.world)
-            if not lost:
-                return ap, rel
-            bet = False
-            lost = True
-        else:
-            lost = engine.merge_ranked(gather(h), gather(b), comm.world)
-        if not lost:                                  # held, or verdict deferred
-            ap, rel = engine.finish(None, comm.world)
-            if lost is not None or not engine.verdict():
-                return ap, rel
-        bet = False                                   # lost (the same on every rank): exact sequence below
+        while True:
+            engine.guess(R, gather(engine.sample_hist(R)), comm.world, comm.rank)
+            h, b = engine.select_ranked()
+            if multi and hasattr(engine, "merge_ap_part"):
+                # the per-query stages split over the ranks: each merges and evaluates its own share of the queries, a third,
+                # tiny all-gather (16 bytes per query) brings every rank all APs and the verdict (the same on every rank)
+                part = engine.merge_ap_part(gather(h), gather(b), comm.world, comm.rank)
+                ap, rel, lost = engine.unpack_parts(comm.all_gather(part), comm.world)
+                if not lost:
+                    return ap, rel
+            else:
+                lost = engine.merge_ranked(gather(h), gather(b), comm.world)
+                if not lost:                              # held, or verdict deferred
+                    ap, rel = engine.finish(None, comm.world)
+                    if lost is not None or not engine.verdict():
+                        return ap, rel
+            # lost, on every rank alike.  A database stored class by class piles a query's near rows into a few slices of
+            # one shard, however good the cut: widen the slices (x8, x64; remembered for the next call) before giving up
+            if not (hasattr(engine, "widen_slices") and engine.widen_slices()):
+                break
+        bet = False                                   # exact sequence below
     if bet and hasattr(engine, "bet_eligible") and engine.bet_eligible(R, comm.world):
         # one pass over the pairs: sampled histograms -> shared guess -> candidate records ->
         # exact record histograms -> shared exact plan.  `lost` is the same on every rank.

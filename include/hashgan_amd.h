@@ -251,7 +251,10 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * k_select_mx2 for <= 32 bits only, 2 = k_select_mx2 up to 64 bits, 0 = never), "rank_lds" (0/1), "rank_cnt" (0/1:
  * the bet's rank stage as a per-thread counting sort, k_rank_cnt),
  * "host_pack", "keep_floats", "pack_threads" (hg_set_*_f32, see there), "second_bet" (1, default: a one-shot bet that too many queries lost is retried once with twice the margin and record
- * budget before the exact two-pass sequence runs), "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
+ * budget before the exact two-pass sequence runs; if that loses too the slices are widened -- "cap_boost" x8, then x64, kept for
+ * the next calls on this database: hits crowded into few segments, e.g. rows stored class by class),
+ * "cap_boost" (1..4096: multiplier on the slices' record budget; every database load sets it back to 1; the sharded
+ * sequence raises it on all ranks alike after a lost bet, sharded.HipShardEngine.widen_slices), "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
  * {match, dist} through per-slice LDS rings instead of 8-byte {idx, dist, match} records),
  * "hist_mfma" (histogram passes -- the sampled pass of the bet, the full pass of the one-shot exact sequence: 2, default:
  * the integer matrix instruction delivers the counter addresses, k_hist_i8, codes of <= 128 bits; 1: fp4 distances,
@@ -268,7 +271,7 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * replays it afterwards). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
 /* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
- * (single queries rerun exactly after losing their bet), "optimistic_rebets" (second bets), "last_optimistic", "device_bytes", "segments",
+ * (single queries rerun exactly after losing their bet), "optimistic_rebets" (second and widened bets), "cap_boost", "last_optimistic", "device_bytes", "segments",
  * "segment_rows", "slice_capacity", "record_row"; census of the float tables loaded by hg_set_*_f32 --
  * "db_nonbinary" / "q_nonbinary" (entries outside {-1,0,+1}), "db_zeros" / "q_zeros", "db_minus_ones" /
  * "q_minus_ones" -- from which the caller tells +-1 codes, {0,1} bits and real-valued features apart;

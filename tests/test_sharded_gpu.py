@@ -18,6 +18,7 @@ def _run_virtual(c, G, gather_topr, defer=False):
     comms = sharded.LocalComm.create(G)
     results = [None] * G
     stats = [None] * G
+    boosts = [None] * G
     errors = []
 
     def work(r):
@@ -33,6 +34,7 @@ def _run_virtual(c, G, gather_topr, defer=False):
                 ctx.set_option("defer_verdict", 1)      # hg_rank does not wait; the verdict comes with the AP download
             results[r] = sharded.evaluate_shard(eng, comms[r], c["R"], gather_topr=gather_topr)
             stats[r] = (ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks"))
+            boosts[r] = ctx.get_stat("cap_boost")
             ctx.close()
         except Exception as e:       # noqa: BLE001
             errors.append(e)
@@ -47,6 +49,7 @@ def _run_virtual(c, G, gather_topr, defer=False):
     if errors:
         raise errors[0]
     _run_virtual.last_stats = stats
+    _run_virtual.last_boosts = boosts
     return results
 
 
@@ -90,7 +93,7 @@ def test_virtual_shards_optimistic_sequence(name, G, case_cache):
 
 def test_virtual_shards_lost_bet_is_consistent():
     """Database sorted by class: near rows pile up in a few segments of one shard, slices overflow
-    there, every rank must see the bet as lost and rerun the exact sequence -- same result."""
+    there, every rank must see the bet as lost, widen its slices alike (cap_boost) and bet again -- same result."""
     from hashgan_amd import synth
     from oracle import hamming_map as O
     Q, N, b, R, C = 128, 262144, 32, 4000, 10
@@ -108,7 +111,9 @@ def test_virtual_shards_lost_bet_is_consistent():
         for r in range(2):
             assert np.array_equal(res[r][0][:24], ap_ref, equal_nan=True)
         st = _run_virtual.last_stats
-        assert st[0] == st[1] and st[0][0] == 1, st          # both ranks took the bet, and agree on its outcome
+        assert st[0] == st[1] == (2, 1), st                  # both ranks bet twice and lost the first, alike
+        bo = _run_virtual.last_boosts
+        assert bo == [8, 8], bo                              # the escalation ran in lockstep and its second bet held
 
 
 def test_virtual_shards_wide_labels_take_the_bet():

@@ -19,6 +19,10 @@ def run(tag, qw, ql, dw, dl, b, C, R, steps=10):
     print("%-8s %8.3f ms/step  bet=%d fallbacks=%d requeried=%d rebets=%d cap_boost=%d  mAP=%.6f" % (tag, dt * 1e3, ctx.get_stat("last_optimistic"),
           ctx.get_stat("optimistic_fallbacks") - f0, ctx.get_stat("optimistic_requeried"), ctx.get_stat("optimistic_rebets"), ctx.get_stat("cap_boost"),
           metric.mean_over_hits(a0, r0)), flush=True)
+    ctx.timing_enable(2); ctx.timing_reset()
+    for _ in range(3): ctx.map(R)
+    tm = ctx.timing_read(); ctx.timing_enable(0)
+    print("         " + " ".join("%s=%.3f" % (k.replace("k_", ""), v[0] / 3) for k, v in sorted(tm.items(), key=lambda kv: -kv[1][0]) if k != "step_gpu_span" and v[0] / 3 >= 0.005), flush=True)
     ctx.close()
     return a0
 
