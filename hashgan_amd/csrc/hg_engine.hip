@@ -2537,10 +2537,13 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
                 c->opt_sigma = sigma0;
                 c->cand_budget_x10 = budget0;
                 if (rc != HG_OK) { c->cap_boost = boost0; return rc; }
-                if (!flag) { c->opt_consecutive_fail = 0; c->cfg_epoch++; return HG_OK; }
+                // held with twice the budget of a first bet at this boost: the next call's first bet gets that budget
+                // (a class-sorted database of tight clusters lost every first bet at x8 and won every second one)
+                auto keep = [&] { if (c->cap_boost < 4096) c->cap_boost *= 2; c->opt_consecutive_fail = 0; c->cfg_epoch++; };
+                if (!flag) { keep(); return HG_OK; }
                 handled = false;
                 HG_TRY(rerun_lost_queries(c, R, lists, with_ap, &handled));
-                if (handled) { c->opt_consecutive_fail = 0; c->cfg_epoch++; return HG_OK; }
+                if (handled) { keep(); return HG_OK; }
             }
             c->cap_boost = boost0;                 // nothing helped: do not keep paying for big slices
         }
