@@ -293,6 +293,7 @@ struct hg_ctx {
     i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
     i64 opt_rank_cnt = 1;      // ... and ranks them with the per-thread counting sort (k_rank_cnt) where it applies
+    i64 real_cap_boost = 1;    // the same for the real-valued ranking's slices (run_real)
     i64 cap_boost = 1;         // slice capacity multiplier a lost bet escalated to on this database (run_oneshot); 1 after every load
     i64 opt_rank_direct_lds = 80;    // "rank_direct_lds": KB of LDS a k_rank_direct block may take (80: two blocks per CU -- C1 0.25 ms vs 0.31 with 160 and one)
     i64 opt_rank_direct = 1;   // "rank_direct": R = N on one shard in one counting-sort kernel, k_rank_direct, when its LDS fits (2: also N/8 < R < N)
@@ -1263,7 +1264,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     c->dbx3_valid = false;
     c->dbx8_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;    // a new database: earlier lost bets say nothing about it
-    c->cap_boost = 1;
+    c->cap_boost = c->real_cap_boost = 1;
     c->cfg_epoch++;
     return HG_OK;
 }
@@ -1395,7 +1396,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->dbfx_valid = false;
     c->dbfb_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;
-    c->cap_boost = 1;
+    c->cap_boost = c->real_cap_boost = 1;
     c->cfg_epoch++;
     return HG_OK;
 }
@@ -2623,7 +2624,9 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         HG_TRY(c->check_launch("k_real_guess"));
         const double mean = budget * (double)R / (double)g.S;
         u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
-        c->cap = (cap + 15u) & ~15u;                      // a multiple of the compact records' ring (16) and flush piece (8)
+        cap = (cap + 15u) & ~15u;                         // a multiple of the compact records' ring (16) and flush piece (8)
+        const u32 whole = (u32)((g.L + 15) & ~15ll);      // (a slice never needs more than its segment's rows)
+        c->cap = cap < whole ? cap : whole;
     } else {
         // no bet: every row becomes a record (thr = -inf), slices are whole segments
         std::vector<float> ninf((size_t)g.Q, -INFINITY);
@@ -2633,9 +2636,12 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     }
     c->crow = (i64)g.S * c->cap;
     const size_t rows = (size_t)g.Q * c->crow * 8;
-    if (rows * 3 > (size_t)200 << 30)
+    // the record rows; the global-memory ranking passes (a query whose records exceed the LDS, the exhaustive mode) need two
+    // more buffers of that size -- a widened bet (run_real) only goes as far as the rows alone stay moderate
+    if (bet && rows > (size_t)64 << 30) { *lost = 1; return HG_OK; }
+    if (!bet && rows * 3 > (size_t)200 << 30)
         return fail(HG_ERR_NOMEM, "real-valued ranking: %zu GB of records needed (Q=%d, %lld per query)", rows * 3 >> 30, g.Q, (long long)c->crow);
-    HG_TRY(c->cand.reserve(rows)); HG_TRY(c->sortA.reserve(rows)); HG_TRY(c->sortB.reserve(rows));
+    HG_TRY(c->cand.reserve(rows));
     HG_TRY(real_select(c));
     const size_t slots = (size_t)g.Q * g.R;
     HG_TRY(c->out_idx.reserve(slots * 4));
@@ -2665,6 +2671,11 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         }
         HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));    // some query's records exceed the LDS: the global-memory passes rank them all
     }
+    if (rows * 3 > (size_t)200 << 30) {
+        if (bet) { *lost = 1; return HG_OK; }
+        return fail(HG_ERR_NOMEM, "real-valued ranking: %zu GB of records needed (Q=%d, %lld per query)", rows * 3 >> 30, g.Q, (long long)c->crow);
+    }
+    HG_TRY(c->sortA.reserve(rows)); HG_TRY(c->sortB.reserve(rows));
     const int nwav = c->crow >= 16384 ? 16 : 4;
     const size_t lds = (size_t)(nwav + 1) * 256 * 4;
     u64* bufs[2] = {c->sortA.as<u64>(), c->sortB.as<u64>()};
@@ -2703,10 +2714,25 @@ static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
     int lost = 0;
     c->real_attempts = 0;
     if (R * 8 <= c->N && c->N >= 65536) {              // bet on a sampled cut; retry once deeper, then give up betting
-        HG_TRY(real_attempt(c, R, true, 6.0, 3.0, with_ap, &lost));
+        const double boost0 = (double)c->real_cap_boost;
+        HG_TRY(real_attempt(c, R, true, 6.0, 3.0 * boost0, with_ap, &lost));
         if (!lost) { c->real_lists = true; return HG_OK; }
-        HG_TRY(real_attempt(c, R, true, 16.0, 6.0, with_ap, &lost));
-        if (!lost) { c->real_lists = true; return HG_OK; }
+        // a deeper cut with twice the budget; then -- features that follow the labels in a database stored class by class
+        // put a query's top rows into a tenth of its slices -- eight and sixty-four times the slices' capacity, kept for
+        // the next calls on this database (the exhaustive mode below writes EVERY pair down: 80 GB at 10k x 1M)
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            if (attempt > 0) {
+                if (c->cap >= (u32)((c->geo.L + 15) & ~15ll)) break;      // a slice already holds its segment
+                c->real_cap_boost *= 8;
+            }
+            HG_TRY(real_attempt(c, R, true, 16.0, 6.0 * (double)c->real_cap_boost, with_ap, &lost));
+            if (!lost) {
+                if (c->real_cap_boost < 4096) c->real_cap_boost *= 2;     // (the budget that held: 6 = 2 x 3)
+                c->real_lists = true;
+                return HG_OK;
+            }
+        }
+        c->real_cap_boost = (i64)boost0;
     }
     HG_TRY(real_attempt(c, R, false, 0.0, 0.0, with_ap, &lost));
     if (lost) return fail(HG_ERR_HIP, "real-valued ranking: internal error, exhaustive pass came up short");
@@ -3100,6 +3126,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "optimistic_requeried")) *value = c->opt_requeried;
     else if (!strcmp(key, "optimistic_rebets")) *value = c->opt_rebets;
     else if (!strcmp(key, "cap_boost")) *value = c->cap_boost;
+    else if (!strcmp(key, "real_cap_boost")) *value = c->real_cap_boost;
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
     else if (!strcmp(key, "real_attempts")) *value = c->real_attempts;
     else if (!strcmp(key, "real_filtered")) *value = c->real_filtered ? 1 : 0;

@@ -271,7 +271,7 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * replays it afterwards). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
 /* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
- * (single queries rerun exactly after losing their bet), "optimistic_rebets" (second and widened bets), "cap_boost", "last_optimistic", "device_bytes", "segments",
+ * (single queries rerun exactly after losing their bet), "optimistic_rebets" (second and widened bets), "cap_boost", "real_cap_boost" (the same for hg_map_real), "last_optimistic", "device_bytes", "segments",
  * "segment_rows", "slice_capacity", "record_row"; census of the float tables loaded by hg_set_*_f32 --
  * "db_nonbinary" / "q_nonbinary" (entries outside {-1,0,+1}), "db_zeros" / "q_zeros", "db_minus_ones" /
  * "q_minus_ones" -- from which the caller tells +-1 codes, {0,1} bits and real-valued features apart;

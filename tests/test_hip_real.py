@@ -63,6 +63,42 @@ def test_generic_float_features_match_oracle_bit_for_bit(Q, N, b, R, C, ctx):
     assert np.array_equal(ap, ap_ref, equal_nan=True)
 
 
+def test_features_that_follow_the_labels_in_a_class_sorted_database():
+    """What a trained network hands over when the database is stored class by class: a query's top rows all sit in its
+    class's tenth of the segments.  Both sampled cuts lose on slice capacity, the slices are widened (real_cap_boost) and
+    the third bet holds -- never the exhaustive mode, which writes every pair down (80 GB of records at 10k x 1M; a hard
+    error before round 3).  The next call bets with the wide slices at once.  Bit for bit the oracle's lists and APs."""
+    rng = np.random.default_rng(11)
+    Q, N, b, R, C = 5, 200000, 64, 4000, 10
+    proto = rng.standard_normal((C, b)).astype(np.float32)
+    cls, qcls = np.sort(rng.integers(0, C, N)), rng.integers(0, C, Q)
+    dbf = np.tanh(0.7 * proto[cls] + rng.standard_normal((N, b), dtype=np.float32)).astype(np.float32)
+    qf = np.tanh(0.7 * proto[qcls] + rng.standard_normal((Q, b), dtype=np.float32)).astype(np.float32)
+    eye = np.eye(C, dtype=np.int64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, ap_ref, idx_ref, score_ref = RM.map_from_features(qf, dbf, eye[qcls], eye[cls], R)
+    c = _native.Context(0)
+    try:
+        c.set_database_f32(dbf, eye[cls])
+        c.set_queries_f32(qf, eye[qcls])
+        ap, rel = c.map_real(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        assert c.get_stat("real_attempts") >= 3 and c.get_stat("real_cap_boost") > 1 and c.get_stat("real_filtered") == 1
+        idx, score = c.topr_real(R)
+        assert c.get_stat("real_attempts") == 1                      # the widened slices are remembered
+        assert np.array_equal(idx, idx_ref) and np.array_equal(score.view(np.uint32), score_ref.view(np.uint32))
+        perm = rng.permutation(N)                                    # the same rows shuffled: a new database, ordinary slices
+        c.set_database_f32(dbf[perm], eye[cls][perm])
+        c.set_queries_f32(qf, eye[qcls])
+        assert c.get_stat("real_cap_boost") == 1
+        ap2, _ = c.map_real(R)
+        assert c.get_stat("real_attempts") == 1 and c.get_stat("real_cap_boost") == 1
+        assert np.array_equal(ap2, ap_ref, equal_nan=True)           # no ties among these scores: the same lists, the same APs
+    finally:
+        c.close()
+
+
 def test_python_surface_ranks_real_features_like_the_reference():
     """MAPs(R).get_maps_by_feature on tanh-like features = the reference's own semantics."""
     from hashgan_amd import MAPs, MAP
