@@ -309,6 +309,42 @@ def c4_reference(opts, steps=5, warmup=2):
         ctx.close()
 
 
+def class_sorted(spec, packed, steps=10):
+    """The same workload with the database STORED CLASS BY CLASS (rows stably sorted by label): a query's near rows then
+    crowd into its class's share of the segments, the first bet's slices overflow, the engine widens them (cap_boost) and
+    keeps the width -- the timed steps are the steady state after that.  Ties break by index, so the APs differ from the
+    unsorted order's; parity here is the bet against the engine's own exact sequence on a sample of the queries."""
+    from hashgan_amd import _native, metric
+    qw, ql, dw, dl = packed
+    key = unpack_bits(dl, spec["C"]).astype(np.int64) @ (1 << np.arange(spec["C"], dtype=np.int64))
+    order = np.argsort(key, kind="stable")
+    dws, dls = np.ascontiguousarray(dw[order]), np.ascontiguousarray(dl[order])
+    R = spec["R"]
+    ctx = _native.Context(0)
+    try:
+        ctx.set_database(dws, dls, spec["b"], spec["C"])
+        ctx.set_queries(qw, ql)
+        t0 = time.perf_counter()
+        a, r = ctx.map(R)
+        first = time.perf_counter() - t0
+        ctx.map(R)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a, r = ctx.map(R)
+        dt = (time.perf_counter() - t0) / steps
+        out = {"workload": "the timed workload, database rows stably sorted by label", "ms_per_step": dt * 1e3, "first_call_ms": first * 1e3,
+               "queries_per_sec": spec["Q"] / dt, "bet_held": bool(ctx.get_stat("last_optimistic")), "cap_boost": ctx.get_stat("cap_boost"),
+               "lost_bets": ctx.get_stat("optimistic_rebets"), "exact_fallbacks": ctx.get_stat("optimistic_fallbacks"), "map": float(metric.mean_over_hits(a, r))}
+        k = min(256, qw.shape[0])
+        ctx.set_option("optimistic", 0)
+        ctx.set_queries(qw[:k], ql[:k])
+        a2, _ = ctx.map(R)
+        out["equal_to_exact_sequence"] = {"queries": k, "equal": bool(np.array_equal(a[:k], a2, equal_nan=True))}
+        return out
+    finally:
+        ctx.close()
+
+
 def query_split_leg(args, spec, rank, world, local_rank, dry_dir, comm, qw, ql):
     """The same workload decomposed the other way (hashgan_amd.sharded.evaluate_query_split): the WHOLE database on every
     GPU, the queries split, no data-path collective -- timed like the main leg (barrier, K steps, barrier, max over ranks)
@@ -417,6 +453,7 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive MAPs(...) timing")
+    ap.add_argument("--no-sorted", action="store_true", help="skip the class-sorted database timing")
     ap.add_argument("--no-real", action="store_true", help="skip the real-valued (tanh features) call timing")
     ap.add_argument("--no-c4-ref", action="store_true", help="skip the one-GPU C4 point of the scaling curve")
     ap.add_argument("--no-query-split", action="store_true", help="sharded runs: skip the replicated-database / split-queries leg")
@@ -576,6 +613,8 @@ def main():
             return d
         if not args.no_h2d:
             side("h2d_inclusive", h2d)
+        if not args.no_sorted and spec["kind"] == "planted":
+            side("class_sorted_database", lambda: class_sorted(spec, packed))
         if not args.no_real:
             side("real_valued", lambda: real_valued(spec))
         if not args.no_c4_ref and wl == "c2":

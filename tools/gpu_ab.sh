@@ -2,7 +2,7 @@
 # usage: tools/gpu_ab.sh <tag> [bench args] : every hashgan_amd/_lib/ab_*.so on the same box, alternating, 3 rounds
 TAG=${1:-ab}; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT
 for r in 1 2 3; do for so in hashgan_amd/_lib/ab_*.so; do n=$(basename $so .so)
-  HG_LIBRARY=$PWD/$so python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-h2d --no-real --no-c4-ref --kernel-timing all "$@" > $OUT/${n}_$r.json 2> $OUT/${n}_$r.err
+  HG_LIBRARY=$PWD/$so python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-c4-ref --kernel-timing all "$@" > $OUT/${n}_$r.json 2> $OUT/${n}_$r.err
   python -c "
 import json
 try:

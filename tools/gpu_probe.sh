@@ -2,7 +2,7 @@
 # usage: tools/gpu_probe.sh <tag> : probe-build timing breakdown of the select kernel
 TAG=${1:-p}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export HG_LIBRARY=$PWD/hashgan_amd/_lib/libhashgan_amd_probe.so
-run() { name=$1; shift; python bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --no-real --no-c4-ref "$@" > $OUT/$name.json 2> $OUT/$name.err; python -c "
+run() { name=$1; shift; python bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-c4-ref "$@" > $OUT/$name.json 2> $OUT/$name.err; python -c "
 import json
 try:
     d=json.loads(open('$OUT/$name.json').read().strip().splitlines()[-1]); print('%-28s step %.4f  '%('$name', d['ms_per_step']), {k:v['avg_ms'] for k,v in d.get('kernels',{}).items()}, 'fallbacks', d['optimistic_fallbacks'])

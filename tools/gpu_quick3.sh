@@ -2,7 +2,7 @@
 # usage: tools/gpu_quick3.sh <tag> : parity tests of the select paths + two bench lines (production build)
 TAG=${1:-q}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_random_shapes.py -m gpu -x -q > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
-for i in 1 2; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-h2d --no-real --no-c4-ref --kernel-timing all > $OUT/all_$i.json 2> $OUT/all_$i.err; done
+for i in 1 2; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-c4-ref --kernel-timing all > $OUT/all_$i.json 2> $OUT/all_$i.err; done
 for f in $OUT/all_*.json; do python -c "
 import json
 try:
