@@ -452,6 +452,14 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 R = (u32)g.R;
+#ifdef HG_REAL_RANK_PROFILE          // phase timestamps overwrite the head of the query's ranked list (tools/real_rank_phase_profile.py)
+    const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+    u32 tks[8];
+    int tkn = 0;
+#define HG_RTK() do { tks[tkn++] = (u32)(__builtin_amdgcn_s_memtime() - tk0); } while (0)
+#else
+#define HG_RTK() do {} while (0)
+#endif
 
     // ---- 1: offsets, copy ----
     u32 n = 0;
@@ -469,14 +477,40 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
     bool bad = fail[q] != 0u || over || n < R;
     if (!bad) {
         const u64* __restrict__ row = cand + (i64)q * crow;
-        for (int sb = 0; sb < g.S; sb += 64) {
-            const int s = sb + (tid >> 4);
-            if (s < g.S) {
-                const u32 o = off[s], c = off[s + 1] - o;
-                for (u32 i = tid & 15; i < c; i += 16) A[o + i] = row[(i64)s * cap + i];
+        // 16 threads per slice, 64 slices per sweep -- and the loads of eight sweeps issued before the first record is
+        // stored: one trip to memory per 512 slices instead of two per 64 (the usual slice holds ~20 records; the copy
+        // was a chain of 16 dependent round trips, a quarter of the block's life at 10k x 1M)
+        constexpr int CG = 8;
+        for (int sb0 = 0; sb0 < g.S; sb0 += 64 * CG) {
+            u64 v[CG][2];
+            u32 o_[CG], c_[CG];
+#pragma unroll
+            for (int k = 0; k < CG; ++k) {
+                const int s = sb0 + 64 * k + (tid >> 4);
+                o_[k] = s < g.S ? off[s] : 0u;
+                c_[k] = s < g.S ? off[s + 1] - o_[k] : 0u;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32 i = (u32)(tid & 15) + 16u * j;
+                    v[k][j] = i < c_[k] ? row[(i64)s * cap + i] : 0ull;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CG; ++k) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32 i = (u32)(tid & 15) + 16u * j;
+                    if (i < c_[k]) A[o_[k] + i] = v[k][j];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CG; ++k) {                                  // slices of more than 32 records
+                const int s = sb0 + 64 * k + (tid >> 4);
+                for (u32 i = 32u + (u32)(tid & 15); i < c_[k]; i += 16) A[o_[k] + i] = row[(i64)s * cap + i];
             }
         }
         __syncthreads();
+        HG_RTK();                                             // 0: offsets + copy
         // ---- 2: K = the R-th smallest key ----
         if (tid == 0) { s_prefix = 0u; s_need = R; }
         u32 mask = 0;
@@ -500,6 +534,7 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
             mask |= (bins - 1u) << shifts[pass];
         }
         const u32 K = s_prefix, need_eq = s_need;
+        HG_RTK();                                             // 1: select
         bad = !(K < ~mono_key(thr[q]));                      // the R-th record must score above thr
         if (!bad) {
             // ---- 3: the chosen R records, in index order, compacted in place (all reads, barrier, all writes) ----
@@ -528,6 +563,7 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
             }
             for (u32 i = tid; i < R; i += 1024) P0[i] = (u16)i;
             __syncthreads();
+            HG_RTK();                                         // 2: compaction
             // ---- 4: stable counting passes by key byte ----
             u16* Pin = P0;
             u16* Pout = P1;
@@ -542,6 +578,9 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
                 __syncthreads();
                 u32 dsum = 0;
                 if (tid < 256) for (int w = 0; w < 16; ++w) dsum += hw[w * 256 + tid];
+                // all R keys share this byte (the top R scores of a query usually share sign and exponent, often more): the
+                // pass would move nothing
+                if (__syncthreads_or(tid < 256 && dsum == R)) continue;
                 u32 tot;
                 u32 run = block_excl_scan_1024(tid < 256 ? dsum : 0u, s_w, tot);
                 if (tid < 256) for (int w = 0; w < 16; ++w) { const u32 x = hw[w * 256 + tid]; hw[w * 256 + tid] = run; run += x; }
@@ -569,6 +608,7 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
                 __syncthreads();
                 u16* t = Pin; Pin = Pout; Pout = t;
             }
+            HG_RTK();                                         // 3: counting passes
             // ---- 5: the ranked list, and its label-match bits (metric.py:17-19; k_match's gather, one launch saved) ----
             const u64* __restrict__ ql = qlab + (i64)q * g.LW;
             for (u32 k = tid; k < (u32)RW * 64u; k += 1024) {
@@ -589,6 +629,11 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
         }
     }
     if (tid == 0) { qbad[q] = bad ? 1u : 0u; if (bad) atomicOr(err, over ? 2 : 1); }
+#ifdef HG_REAL_RANK_PROFILE
+    HG_RTK();                                                 // 4: lists + match bits
+    __syncthreads();
+    if (tid == 0 && !bad) for (int k = 0; k < tkn; ++k) out_idx[(i64)q * g.R + k] = tks[k];
+#endif
 }
 
 // The guess with the sample in LDS (k_real_guess reads its M samples three times from global memory with 256 threads):
