@@ -369,6 +369,8 @@ struct hg_ctx {
     i64 opt_host_pack = 1;     // "host_pack": 0 = upload the raw arrays and pack on the GPU (k_pack_*)
     i64 opt_keep_floats = 2;   // "keep_floats": database float table on the GPU -- 0 never, 1 always, 2 only if it is not a +-1 code
     i64 opt_pack_threads = 0;  // "pack_threads": 0 = from the hardware (up to 96)
+    void* fstage = nullptr;    // 4 x 16 MB of pinned staging for float tables on their way to the GPU (pack_on_host)
+    hipEvent_t fstage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void* hpk = nullptr;       // pinned staging for the packed tables
     size_t hpk_cap = 0;
     bool dbf_resident = false, qf_resident = false;   // float tables as loaded: entries outside {-1,0,+1}, zeros, minus ones
@@ -1219,6 +1221,8 @@ int hg_destroy(hg_ctx* c) {
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->hpk) (void)hipHostFree(c->hpk);
+    if (c->fstage) (void)hipHostFree(c->fstage);
+    for (auto& e : c->fstage_ev) if (e) (void)hipEventDestroy(e);
     if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
     delete c;
     return HG_OK;
@@ -1356,8 +1360,35 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
         c->bpad = bpad;
         const size_t fb = (size_t)n * bpad * 4;
         HG_TRY(feats.reserve(fb + 256));
-        if (bpad != b) HG_HIP(hipMemsetAsync(feats.p, 0, fb, c->stream));
-        HG_HIP(hipMemcpy2DAsync(feats.p, (size_t)bpad * 4, x, (size_t)b * 4, (size_t)b * 4, (size_t)n, hipMemcpyHostToDevice, c->stream));
+        if (fb < ((size_t)8 << 20)) {
+            if (bpad != b) HG_HIP(hipMemsetAsync(feats.p, 0, fb, c->stream));
+            HG_HIP(hipMemcpy2DAsync(feats.p, (size_t)bpad * 4, x, (size_t)b * 4, (size_t)b * 4, (size_t)n, hipMemcpyHostToDevice, c->stream));
+        } else {
+            // a big float table (256 MB at 1M x 64): the runtime stages a pageable source at ~25 GB/s.  The pool's threads copy
+            // 16 MB chunks (rows padded on the way) into four pinned buffers instead, each chunk's DMA runs while the next is copied
+            constexpr int NSL = 4;
+            const size_t CH = (size_t)16 << 20;
+            if (!c->fstage) {
+                HG_HIP(hipHostMalloc(&c->fstage, CH * NSL, hipHostMallocDefault));
+                for (int k = 0; k < NSL; ++k) HG_HIP(hipEventCreateWithFlags(&c->fstage_ev[k], hipEventDisableTiming));
+            }
+            const i64 rows_per = (i64)(CH / ((size_t)bpad * 4));
+            int slot = 0;
+            bool used[NSL] = {false, false, false, false};
+            try {
+                for (i64 r0 = 0; r0 < n; r0 += rows_per, slot = (slot + 1) % NSL) {
+                    const i64 r1 = r0 + rows_per < n ? r0 + rows_per : n;
+                    if (used[slot]) HG_HIP(hipEventSynchronize(c->fstage_ev[slot]));
+                    float* st = (float*)((char*)c->fstage + (size_t)slot * CH);
+                    host_copy_rows(x, r0, r1, b, bpad, st, (int)c->opt_pack_threads);
+                    HG_HIP(hipMemcpyAsync((char*)feats.p + (size_t)r0 * bpad * 4, st, (size_t)(r1 - r0) * bpad * 4, hipMemcpyHostToDevice, c->stream));
+                    HG_HIP(hipEventRecord(c->fstage_ev[slot], c->stream));
+                    used[slot] = true;
+                }
+            } catch (const std::exception& e) {
+                return fail(HG_ERR_NOMEM, "host-side staging of the float table failed: %s", e.what());
+            }
+        }
     }
     *has_floats = up;
     HG_TRY(c->sync());                                 // the pinned staging is reused by the next call

@@ -22,6 +22,9 @@ void host_pack(const float* x, const int64_t* lab, long long n, int b, int C, ui
 // the same with the calling thread SHIPPING finished row prefixes instead of packing: (*on_rows)(rows_done), rows_done growing
 void host_pack_ship(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,
                     HostPackCensus* census, int threads, void (*on_rows)(void*, long long), void* on_rows_arg);
+// rows [r0, r1) of x [n][b] copied to dst [r1 - r0][bpad] (pad columns zeroed) by the pool's threads: how the float table
+// reaches pinned staging memory at memory speed before it crosses PCIe (a pageable source is staged by the runtime at ~25 GB/s)
+void host_copy_rows(const float* x, long long r0, long long r1, int b, int bpad, float* dst, int threads);
 
 }  // namespace hg
 
@@ -32,6 +35,7 @@ void host_pack_ship(const float* x, const int64_t* lab, long long n, int b, int 
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <algorithm>
+#include <cstring>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -285,6 +289,32 @@ inline void host_pack_ship(const float* x, const int64_t* lab, long long n, int 
         tot.nonbinary += p.nonbinary; tot.zeros += p.zeros; tot.minus_ones += p.minus_ones; tot.bad_labels += p.bad_labels;
     }
     if (census) *census = tot;
+}
+
+inline void host_copy_rows(const float* x, long long r0, long long r1, int b, int bpad, float* dst, int threads) {
+    const long long rows = r1 - r0;
+    if (rows <= 0) return;
+    if (threads <= 0) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        threads = hw <= 64 ? (int)std::min<unsigned>(hw ? hw : 1u, 32u) : (int)std::min<unsigned>(hw / 4, 64u);
+    }
+    // a 16 MB chunk per call: sixteen threads copy it faster than PCIe takes it (the next chunk's copy runs under this one's
+    // DMA); waking 64 for 256 KB each was slower -- 1M x 64 floats: 8.8 ms per hg_set_database_f32 against 7.0
+    const long long bytes = rows * (long long)bpad * 4;
+    threads = (int)std::max<long long>(1, std::min<long long>(std::min(threads, 16), bytes >> 20));
+    auto work = [&](int t) {
+        const long long a = rows * t / threads, e = rows * (t + 1) / threads;
+        if (bpad == b) {
+            memcpy(dst + a * bpad, x + (r0 + a) * b, (size_t)(e - a) * b * 4);
+        } else {
+            for (long long r = a; r < e; ++r) {
+                memcpy(dst + r * bpad, x + (r0 + r) * b, (size_t)b * 4);
+                memset(dst + r * bpad + b, 0, (size_t)(bpad - b) * 4);
+            }
+        }
+    };
+    if (threads == 1 || !hostpack::pool().run(threads, work))            // (a busy pool: this thread alone)
+        for (int t = 0; t < threads; ++t) work(t);
 }
 
 inline void host_pack(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,
