@@ -30,6 +30,7 @@
 #include <cstring>
 #include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace hg;
@@ -369,6 +370,8 @@ struct hg_ctx {
     i64 opt_host_pack = 1;     // "host_pack": 0 = upload the raw arrays and pack on the GPU (k_pack_*)
     i64 opt_keep_floats = 2;   // "keep_floats": database float table on the GPU -- 0 never, 1 always, 2 only if it is not a +-1 code
     i64 opt_pack_threads = 0;  // "pack_threads": 0 = from the hardware (up to 96)
+    hipStream_t stream2 = nullptr;   // the float table's uploads while the packing pool works (pack_on_host)
+    hipEvent_t stream2_ev = nullptr;
     void* fstage = nullptr;    // 4 x 16 MB of pinned staging for float tables on their way to the GPU (pack_on_host)
     hipEvent_t fstage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void* hpk = nullptr;       // pinned staging for the packed tables
@@ -1222,6 +1225,8 @@ int hg_destroy(hg_ctx* c) {
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->hpk) (void)hipHostFree(c->hpk);
     if (c->fstage) (void)hipHostFree(c->fstage);
+    if (c->stream2_ev) (void)hipEventDestroy(c->stream2_ev);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     for (auto& e : c->fstage_ev) if (e) (void)hipEventDestroy(e);
     if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1313,6 +1318,35 @@ static int pack_on_device(hg_ctx* c, const float* x, const int64_t* lab, i64 n, 
 // The same hand-over with the packing done by host threads BEFORE the upload (hg_host_pack.hpp): 16 MB instead of 339 MB
 // cross PCIe at C2.  The float table follows only when somebody will rank by inner product (`floats`: 0 no, 1 yes,
 // 2 = iff the table is not a +-1 code).  *has_floats tells what happened.
+// A big float table (256 MB at 1M x 64) on its way to the GPU: the runtime stages a pageable source at ~25 GB/s.  Host
+// threads copy 16 MB chunks (rows padded on the way) into four pinned buffers instead, each chunk's DMA runs while the next
+// is copied.  Enqueues on `stream`; which_pool: the host pool that copies (1 while pool 0 packs).
+static int stage_floats(hg_ctx* c, const float* x, i64 n, int b, int bpad, DevBuf& feats, hipStream_t stream, int which_pool) {
+    constexpr int NSL = 4;
+    const size_t CH = (size_t)16 << 20;
+    if (!c->fstage) {
+        HG_HIP(hipHostMalloc(&c->fstage, CH * NSL, hipHostMallocDefault));
+        for (int k = 0; k < NSL; ++k) HG_HIP(hipEventCreateWithFlags(&c->fstage_ev[k], hipEventDisableTiming));
+    }
+    const i64 rows_per = (i64)(CH / ((size_t)bpad * 4));
+    int slot = 0;
+    bool used[NSL] = {false, false, false, false};
+    try {
+        for (i64 r0 = 0; r0 < n; r0 += rows_per, slot = (slot + 1) % NSL) {
+            const i64 r1 = r0 + rows_per < n ? r0 + rows_per : n;
+            if (used[slot]) HG_HIP(hipEventSynchronize(c->fstage_ev[slot]));
+            float* st = (float*)((char*)c->fstage + (size_t)slot * CH);
+            host_copy_rows(x, r0, r1, b, bpad, st, (int)c->opt_pack_threads, which_pool);
+            HG_HIP(hipMemcpyAsync((char*)feats.p + (size_t)r0 * bpad * 4, st, (size_t)(r1 - r0) * bpad * 4, hipMemcpyHostToDevice, stream));
+            HG_HIP(hipEventRecord(c->fstage_ev[slot], stream));
+            used[slot] = true;
+        }
+    } catch (const std::exception& e) {
+        return fail(HG_ERR_NOMEM, "host-side staging of the float table failed: %s", e.what());
+    }
+    return HG_OK;
+}
+
 static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, DevBuf& codes, DevBuf& labels,
                         DevBuf& feats, int floats, bool* has_floats, int64_t* bad_codes, int64_t* bad_labels, i64 (&census)[3]) {
     const int b = c->b, C = c->C, NW = c->NW, LW = c->LW;
@@ -1346,6 +1380,35 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
         ship_err = e;
         shipped = rows_done;
     };
+    // Will the float table follow?  keep_floats = 1: yes; = 2: only if the features are no +-1 code -- and a single entry
+    // that is neither -1 nor +1 among the first rows settles that before the census is in (tanh outputs: the first entry).
+    // Then a second thread stages and ships the floats (its own small pool, its own stream) WHILE the packing pool works.
+    const int bpad_f = (b + 15) / 16 * 16;
+    const size_t fb_f = (size_t)n * bpad_f * 4;
+    bool early = false;
+    if (x && floats >= 1 && fb_f >= ((size_t)8 << 20)) {
+        early = floats == 1;
+        const i64 probe = (i64)std::min<i64>(n, 64) * b;
+        for (i64 k = 0; k < probe && !early; ++k) early = !(x[k] == 1.0f || x[k] == -1.0f);
+    }
+    int stage_rc = HG_OK;
+    std::string stage_msg;                               // (the error text is thread-local: carried over by hand)
+    std::thread stager;
+    if (early) {
+        if (!c->stream2) HG_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        if (!c->stream2_ev) HG_HIP(hipEventCreateWithFlags(&c->stream2_ev, hipEventDisableTiming));
+        HG_TRY(feats.reserve(fb_f + 256));
+        try {
+            stager = std::thread([&] {
+                if (hipSetDevice(c->device) != hipSuccess) { stage_rc = HG_ERR_HIP; stage_msg = "hipSetDevice failed in the staging thread"; return; }
+                stage_rc = stage_floats(c, x, n, b, bpad_f, feats, c->stream2, 1);
+                if (stage_rc != HG_OK) stage_msg = g_err;
+            });
+        } catch (const std::exception&) {
+            early = false;                               // no second thread to be had: the floats follow the packing
+        }
+    }
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{stager};
     try {
         host_pack_ship(x, lab, n, b, C, hc, hl, &cs, (int)c->opt_pack_threads,
                        +[](void* f, long long rows) { (*static_cast<decltype(ship)*>(f))(rows); }, &ship);
@@ -1355,38 +1418,23 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
     if (ship_err != hipSuccess) return fail(HG_ERR_HIP, "upload of the packed tables failed: %s", hipGetErrorString(ship_err));
     const bool pm1 = cs.nonbinary == 0 && cs.zeros == 0;
     const bool up = floats == 1 || (floats == 2 && !pm1);
+    if (stager.joinable()) stager.join();
+    if (early) {
+        if (stage_rc != HG_OK) return fail(stage_rc, "%s", stage_msg.c_str());
+        HG_HIP(hipEventRecord(c->stream2_ev, c->stream2));
+        HG_HIP(hipStreamWaitEvent(c->stream, c->stream2_ev, 0));
+    }
     if (up) {
         const int bpad = (b + 15) / 16 * 16;
         c->bpad = bpad;
         const size_t fb = (size_t)n * bpad * 4;
         HG_TRY(feats.reserve(fb + 256));
-        if (fb < ((size_t)8 << 20)) {
-            if (bpad != b) HG_HIP(hipMemsetAsync(feats.p, 0, fb, c->stream));
-            HG_HIP(hipMemcpy2DAsync(feats.p, (size_t)bpad * 4, x, (size_t)b * 4, (size_t)b * 4, (size_t)n, hipMemcpyHostToDevice, c->stream));
-        } else {
-            // a big float table (256 MB at 1M x 64): the runtime stages a pageable source at ~25 GB/s.  The pool's threads copy
-            // 16 MB chunks (rows padded on the way) into four pinned buffers instead, each chunk's DMA runs while the next is copied
-            constexpr int NSL = 4;
-            const size_t CH = (size_t)16 << 20;
-            if (!c->fstage) {
-                HG_HIP(hipHostMalloc(&c->fstage, CH * NSL, hipHostMallocDefault));
-                for (int k = 0; k < NSL; ++k) HG_HIP(hipEventCreateWithFlags(&c->fstage_ev[k], hipEventDisableTiming));
-            }
-            const i64 rows_per = (i64)(CH / ((size_t)bpad * 4));
-            int slot = 0;
-            bool used[NSL] = {false, false, false, false};
-            try {
-                for (i64 r0 = 0; r0 < n; r0 += rows_per, slot = (slot + 1) % NSL) {
-                    const i64 r1 = r0 + rows_per < n ? r0 + rows_per : n;
-                    if (used[slot]) HG_HIP(hipEventSynchronize(c->fstage_ev[slot]));
-                    float* st = (float*)((char*)c->fstage + (size_t)slot * CH);
-                    host_copy_rows(x, r0, r1, b, bpad, st, (int)c->opt_pack_threads);
-                    HG_HIP(hipMemcpyAsync((char*)feats.p + (size_t)r0 * bpad * 4, st, (size_t)(r1 - r0) * bpad * 4, hipMemcpyHostToDevice, c->stream));
-                    HG_HIP(hipEventRecord(c->fstage_ev[slot], c->stream));
-                    used[slot] = true;
-                }
-            } catch (const std::exception& e) {
-                return fail(HG_ERR_NOMEM, "host-side staging of the float table failed: %s", e.what());
+        if (!early) {
+            if (fb < ((size_t)8 << 20)) {
+                if (bpad != b) HG_HIP(hipMemsetAsync(feats.p, 0, fb, c->stream));
+                HG_HIP(hipMemcpy2DAsync(feats.p, (size_t)bpad * 4, x, (size_t)b * 4, (size_t)b * 4, (size_t)n, hipMemcpyHostToDevice, c->stream));
+            } else {
+                HG_TRY(stage_floats(c, x, n, b, bpad, feats, c->stream, 0));
             }
         }
     }

@@ -24,7 +24,7 @@ void host_pack_ship(const float* x, const int64_t* lab, long long n, int b, int 
                     HostPackCensus* census, int threads, void (*on_rows)(void*, long long), void* on_rows_arg);
 // rows [r0, r1) of x [n][b] copied to dst [r1 - r0][bpad] (pad columns zeroed) by the pool's threads: how the float table
 // reaches pinned staging memory at memory speed before it crosses PCIe (a pageable source is staged by the runtime at ~25 GB/s)
-void host_copy_rows(const float* x, long long r0, long long r1, int b, int bpad, float* dst, int threads);
+void host_copy_rows(const float* x, long long r0, long long r1, int b, int bpad, float* dst, int threads, int which_pool = 0);
 
 }  // namespace hg
 
@@ -227,14 +227,15 @@ private:
 // The pool is never torn down (its workers sleep until the process ends).  A forked child has none of the workers and must
 // not touch the parent's mutexes and condition variables (a broadcast on the copy of one with sleepers never returns):
 // the fork handler drops the pointer, the child's first call builds a pool of its own.
-inline std::atomic<Pool*>& pool_slot() { static std::atomic<Pool*> slot{nullptr}; return slot; }
-inline Pool& pool() {
-    static const int at_fork = pthread_atfork(nullptr, nullptr, +[] { pool_slot().store(nullptr); });
+// which = 0: the packing pool; 1: a second, small one that copies float chunks into pinned staging WHILE the first packs
+inline std::atomic<Pool*>& pool_slot(int which) { static std::atomic<Pool*> slot[2]{{nullptr}, {nullptr}}; return slot[which]; }
+inline Pool& pool(int which = 0) {
+    static const int at_fork = pthread_atfork(nullptr, nullptr, +[] { pool_slot(0).store(nullptr); pool_slot(1).store(nullptr); });
     (void)at_fork;
-    Pool* p = pool_slot().load(std::memory_order_acquire);
+    Pool* p = pool_slot(which).load(std::memory_order_acquire);
     if (!p) {
         Pool* fresh = new Pool;                                           // (no threads yet: they start with the first job)
-        if (pool_slot().compare_exchange_strong(p, fresh)) p = fresh;
+        if (pool_slot(which).compare_exchange_strong(p, fresh)) p = fresh;
         else delete fresh;
     }
     return *p;
@@ -291,7 +292,7 @@ inline void host_pack_ship(const float* x, const int64_t* lab, long long n, int 
     if (census) *census = tot;
 }
 
-inline void host_copy_rows(const float* x, long long r0, long long r1, int b, int bpad, float* dst, int threads) {
+inline void host_copy_rows(const float* x, long long r0, long long r1, int b, int bpad, float* dst, int threads, int which_pool) {
     const long long rows = r1 - r0;
     if (rows <= 0) return;
     if (threads <= 0) {
@@ -313,7 +314,7 @@ inline void host_copy_rows(const float* x, long long r0, long long r1, int b, in
             }
         }
     };
-    if (threads == 1 || !hostpack::pool().run(threads, work))            // (a busy pool: this thread alone)
+    if (threads == 1 || !hostpack::pool(which_pool).run(threads, work))  // (a busy pool: this thread alone)
         for (int t = 0; t < threads; ++t) work(t);
 }
 
