@@ -24,13 +24,16 @@ def one(seed):
         db = (rng.random((N, b)) < 0.5).astype(np.uint8); qb = (rng.random((Q, b)) < 0.5).astype(np.uint8)
     if rng.random() < 0.3:                       # bursts: duplicated neighbours
         db = np.repeat(db[: N // 8 + 1], 8, axis=0)[:N]; dl = np.repeat(dl[: N // 8 + 1], 8, axis=0)[:N]
+    if rng.random() < 0.35:                      # stored class by class: a query's near rows crowd into few slices (cap_boost)
+        order = np.argsort(dl.argmax(1), kind="stable")
+        db, dl = np.ascontiguousarray(db[order]), np.ascontiguousarray(dl[order])
     ctx = _native.Context(0)
     try:
         ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
         ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
         out = {}
         if "-v" in sys.argv: print("  b=%d N=%d Q=%d R=%d C=%d planted=%s" % (b, N, Q, R, C, planted), flush=True)
-        for name, opts in (("bet", {}), ("bet8", {"compact_records": 0}), ("exact", {"optimistic": 0}), ("exact_valu", {"optimistic": 0, "hist_mfma": 0, "exact_mfma": 0})):
+        for name, opts in (("bet", {}), ("bet_again", {}), ("bet8", {"compact_records": 0}), ("exact", {"optimistic": 0}), ("exact_valu", {"optimistic": 0, "hist_mfma": 0, "exact_mfma": 0})):
             for k in ("compact_records", "optimistic", "hist_mfma", "exact_mfma"):
                 ctx.set_option(k, {"compact_records": 1, "optimistic": 1, "hist_mfma": 2, "exact_mfma": 1}[k])
             for k, v in opts.items(): ctx.set_option(k, v)

@@ -22,6 +22,10 @@ def one(seed):
     else: d, q = (rng.random((N, b)) < 0.5).astype(float), (rng.random((Q, b)) < 0.5).astype(float)
     dbf, qf = d.astype(np.float32), q.astype(np.float32)
     dl = (rng.random((N, C)) < 0.15).astype(np.int64); ql = (rng.random((Q, C)) < 0.15).astype(np.int64)
+    if rng.random() < 0.35:                      # features that follow a class, rows stored class by class: the top rows crowd into few slices
+        cls, qcls = np.sort(rng.integers(0, 8, N)), rng.integers(0, 8, Q)
+        proto = rng.standard_normal((8, b)).astype(np.float32) * np.float32(np.abs(dbf).mean() + 0.1)
+        dbf, qf = (dbf + proto[cls]).astype(np.float32), (qf + proto[qcls]).astype(np.float32)
     ctx = _native.Context(0)
     try:
         ctx.set_database_f32(dbf, dl); ctx.set_queries_f32(qf, ql)
