@@ -564,12 +564,68 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
             for (u32 i = tid; i < R; i += 1024) P0[i] = (u16)i;
             __syncthreads();
             HG_RTK();                                         // 2: compaction
-            // ---- 4: stable counting passes by key byte ----
+            // ---- 4a: one bucket pass.  The R keys spread over a range whose size is known (K is the largest, a block
+            // reduction finds the smallest): 4096 buckets of equal key width hold one or two records each on continuous scores
+            // -- count, scan, scatter (any order inside a bucket), then every record counts the records of its bucket that precede
+            // it by (key, position).  Position order is index order, so this is the stable order of the counting
+            // passes below; they remain for keys that pile up (scores on a grid: thousands of equal keys in one bucket).
             u16* Pin = P0;
             u16* Pout = P1;
+            bool bucketed = false;
+            {
+                u32 kmin = 0xFFFFFFFFu;
+                for (u32 i = tid; i < R; i += 1024) { const u32 k = (u32)(A[i] >> 32); kmin = k < kmin ? k : kmin; }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) { const u32 v = (u32)__shfl_xor((int)kmin, o); kmin = v < kmin ? v : kmin; }
+                if (lane == 0) s_w[wave] = kmin;
+                for (int i = tid; i < 4096; i += 1024) hw[i] = 0u;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < 16; ++w) { const u32 v = s_w[w]; kmin = v < kmin ? v : kmin; }
+                const u32 range = K - kmin;
+                const int bsh = range < 4096u ? 0 : 32 - __builtin_clz(range) - 12;      // (key - kmin) >> bsh <= 4095
+                for (u32 i = tid; i < R; i += 1024) atomicAdd(&hw[((u32)(A[i] >> 32) - kmin) >> bsh], 1u);
+                __syncthreads();
+                u32 c4[4], sum = 0, big = 0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { c4[x] = hw[4 * tid + x]; sum += c4[x]; big |= c4[x] > 24u ? 1u : 0u; }
+                const bool piled = __syncthreads_or((int)big) != 0;
+                if (!piled) {
+                    u32 tot;
+                    u32 run = block_excl_scan_1024(sum, s_w, tot);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) { hw[4 * tid + x] = run; run += c4[x]; }
+                    __syncthreads();
+                    for (u32 i = tid; i < R; i += 1024) {
+                        const u32 pos = atomicAdd(&hw[((u32)(A[i] >> 32) - kmin) >> bsh], 1u);
+                        P1[pos] = (u16)i;
+                    }
+                    __syncthreads();
+                    // a record's place inside its bucket: how many of the bucket's records come before it by (key, position)
+                    // -- every record counts for itself (the buckets hold a handful each; R / 1024 records per thread)
+                    for (u32 a = tid; a < R; a += 1024) {
+                        const u16 p = P1[a];
+                        const u32 key = (u32)(A[p] >> 32);
+                        const u32 bk = (key - kmin) >> bsh;
+                        const u32 lo = bk ? hw[bk - 1] : 0u, hi = hw[bk];       // (after the scatter hw[b] is the END of bucket b)
+                        const u64 kp = ((u64)key << 16) | p;
+                        u32 before = 0;
+                        for (u32 e = lo; e < hi; ++e) {
+                            const u16 pq = P1[e];
+                            const u64 kq = ((u64)(u32)(A[pq] >> 32) << 16) | pq;
+                            before += kq < kp ? 1u : 0u;
+                        }
+                        P0[lo + before] = p;
+                    }
+                    __syncthreads();
+                    Pin = P0; Pout = P1;
+                    bucketed = true;
+                }
+            }
+            // ---- 4b: stable counting passes by key byte ----
             const u32 wlo = (u32)((u64)R * wave / 16), whi = (u32)((u64)R * (wave + 1) / 16);
             const u64 below = (1ull << lane) - 1ull;
-            for (int pass = 0; pass < 4; ++pass) {
+            for (int pass = 0; pass < 4 && !bucketed; ++pass) {
                 const int sh = 8 * pass;
                 for (int i = tid; i < 16 * 256; i += 1024) hw[i] = 0u;
                 __syncthreads();
