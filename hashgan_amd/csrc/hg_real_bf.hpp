@@ -511,6 +511,85 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
         }
         __syncthreads();
         HG_RTK();                                             // 0: offsets + copy
+        // ---- 2'-4': the usual case in one bucket pass over ALL n records.  4096 buckets of equal key width between the
+        // smallest and the largest key; the bucket in which the cumulative count passes R is the boundary: every record of
+        // the buckets up to it is scattered to its bucket's span (any order), then counts the records of its bucket that
+        // precede it by (key, position) -- position order is index order, the tie order -- and takes that final rank if it is
+        // below R.  One histogram instead of the select's three, the compaction and the ordering pass; keys that pile up
+        // (scores on a grid) or a boundary bucket beyond the position arrays leave it to the steps below.
+        const u16* Pfin = nullptr;
+        bool ordered = false;
+        {
+            u32 kmin = 0xFFFFFFFFu, kmax = 0u;
+            for (u32 i = tid; i < n; i += 1024) { const u32 k = (u32)(A[i] >> 32); kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const u32 v = (u32)__shfl_xor((int)kmin, o), w = (u32)__shfl_xor((int)kmax, o);
+                kmin = v < kmin ? v : kmin; kmax = w > kmax ? w : kmax;
+            }
+            __syncthreads();                                  // (off[] in hw is no longer read)
+            u32* wmax = (u32*)P1;                             // (the position arrays are idle until the scatter)
+            if (lane == 0) { s_w[wave] = kmin; wmax[wave] = kmax; }
+            for (int i = tid; i < 4096; i += 1024) hw[i] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { const u32 v = s_w[w], x = wmax[w]; kmin = v < kmin ? v : kmin; kmax = x > kmax ? x : kmax; }
+            const u32 range = kmax - kmin;
+            const int bsh = range < 4096u ? 0 : 32 - __builtin_clz(range) - 12;         // (key - kmin) >> bsh <= 4095
+            for (u32 i = tid; i < n; i += 1024) atomicAdd(&hw[((u32)(A[i] >> 32) - kmin) >> bsh], 1u);
+            __syncthreads();
+            u32 c4[4], sum = 0;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { c4[x] = hw[4 * tid + x]; sum += c4[x]; }
+            u32 tot;
+            const u32 ex = block_excl_scan_1024(sum, s_w, tot);
+            if (ex < R && R <= ex + sum) {                    // this thread's bins hold the boundary
+                u32 run = ex;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    if (run < R && R <= run + c4[x]) { s_prefix = 4u * tid + x; s_need = run + c4[x]; }
+                    run += c4[x];
+                }
+            }
+            __syncthreads();
+            const u32 bstar = s_prefix, cend = s_need;        // boundary bucket, records in the buckets up to it
+            u32 big = cend > (u32)RK_RMAX ? 1u : 0u;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) big |= (4u * tid + x <= bstar && c4[x] > 24u) ? 1u : 0u;
+            if (!__syncthreads_or((int)big)) {
+                u32 run = ex;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { hw[4 * tid + x] = run; run += c4[x]; }
+                __syncthreads();
+                HG_RTK();                                     // 1: histogram + boundary
+                for (u32 i = tid; i < n; i += 1024) {
+                    const u32 bk = ((u32)(A[i] >> 32) - kmin) >> bsh;
+                    if (bk <= bstar) P1[atomicAdd(&hw[bk], 1u)] = (u16)i;
+                }
+                __syncthreads();
+                HG_RTK();                                     // 2: scatter
+                for (u32 a = tid; a < cend; a += 1024) {
+                    const u16 p = P1[a];
+                    const u32 key = (u32)(A[p] >> 32);
+                    const u32 bk = (key - kmin) >> bsh;
+                    const u32 lo = bk ? hw[bk - 1] : 0u, hi = hw[bk];              // (after the scatter hw[b] is the END of bucket b)
+                    const u64 kp = ((u64)key << 16) | p;
+                    u32 before = 0;
+                    for (u32 e = lo; e < hi; ++e) {
+                        const u16 pq = P1[e];
+                        const u64 kq = ((u64)(u32)(A[pq] >> 32) << 16) | pq;
+                        before += kq < kp ? 1u : 0u;
+                    }
+                    if (lo + before < R) P0[lo + before] = p;
+                }
+                __syncthreads();
+                HG_RTK();                                     // 3: order
+                bad = !((u32)(A[P0[R - 1]] >> 32) < ~mono_key(thr[q]));             // the R-th record must score above thr
+                Pfin = P0;
+                ordered = true;
+            }
+        }
+        if (!ordered) {
         // ---- 2: K = the R-th smallest key ----
         if (tid == 0) { s_prefix = 0u; s_need = R; }
         u32 mask = 0;
@@ -665,12 +744,16 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
                 u16* t = Pin; Pin = Pout; Pout = t;
             }
             HG_RTK();                                         // 3: counting passes
+            Pfin = Pin;
+        }
+        }   // !ordered
+        if (!bad) {
             // ---- 5: the ranked list, and its label-match bits (metric.py:17-19; k_match's gather, one launch saved) ----
             const u64* __restrict__ ql = qlab + (i64)q * g.LW;
             for (u32 k = tid; k < (u32)RW * 64u; k += 1024) {
                 bool m = false;
                 if (k < R) {
-                    const u64 rec = A[Pin[k]];
+                    const u64 rec = A[Pfin[k]];
                     const u32 gi = (u32)rec;
                     out_idx[(i64)q * g.R + k] = gi;
                     if (scores) scores[(i64)q * g.R + k] = mono_inv(~(u32)(rec >> 32));
