@@ -360,6 +360,7 @@ struct hg_ctx {
     bool dbfb_valid = false;
     i64 opt_real_sample_hits = 64;   // "real_sample_hits": the real-valued bet samples so that this many of a query's top R rows are in the sample
     i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit
+    bool real_no_cut = false;     // the current real_attempt takes every row (thr = -inf)
     bool real_filtered = false;   // the last real_select left unscored candidates that k_real_rescore completed
     i64 real_attempts = 0;        // statistics of the last real-valued ranking: attempts made (1 = the first bet held) ...
     i64 real_lds_ranked = 0;      // ... and whether the LDS-resident rank kernel produced its lists
@@ -1164,7 +1165,10 @@ int real_sample(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
 }
 int real_select(hg_ctx* c) {
     c->real_filtered = false;
-    if ((c->opt_real_mfma == 2 || c->bpad > 128) && c->geo.L % 16 == 0) return real_select_bf(c);   // (the only pass for > 128 features)
+    // without a cut (every row a record: R = N, or after lost bets) a filter filters nothing and every pair would be rescored:
+    // the exact float32 MFMA pass gives the scores at once (C1: 4.6 -> 4.0 ms per call)
+    const bool filter = c->opt_real_mfma == 2 && !(c->real_no_cut && c->bpad <= 128);
+    if ((filter || c->bpad > 128) && c->geo.L % 16 == 0) return real_select_bf(c);   // (the only pass for > 128 features)
     if (c->opt_real_mfma && c->geo.L % 16 == 0) return real_select_mx(c);
     HG_DISPATCH_BP(real_launch_select, c)
 }
@@ -2664,6 +2668,7 @@ int hg_map(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
 static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double budget, bool with_ap, int* lost) {
     ++c->real_attempts;
     c->real_lds_ranked = 0;
+    c->real_no_cut = !bet;
     make_geometry(c);
     {   // Float rows are 4*bpad bytes (32x a 64-bit code): keep a segment's rows within ~512 KB so the few
         // segments an XCD works on at a time stay in its 4 MiB L2 while all query tiles pass over them.
