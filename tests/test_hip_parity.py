@@ -723,6 +723,36 @@ def test_wild_guesses_never_change_the_result(b, sigma):
         ctx.close()
 
 
+def test_sampled_kernel_timing_counts_every_nth_step(case_cache):
+    """hg_timing level 1 with "timing_every" = 4: the select pass is bracketed by HIP events on every fourth one-shot step
+    only (what bench.py's roofline averages over) -- and the answers do not depend on it."""
+    c = case_cache("c2_q64")
+    g = cases.load_golden("c2_q64")
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, c)
+        ctx.map(c["R"])
+        ctx.set_option("timing_every", 4)
+        ctx.timing_enable(1)
+        ctx.timing_reset()
+        for _ in range(8):
+            ap, rel = ctx.map(c["R"])
+            assert np.array_equal(ap, g["ap"], equal_nan=True)
+        t = ctx.timing_read()
+        sel = [v for k, v in t.items() if k.startswith("k_select")]
+        assert len(sel) == 1 and sel[0][1] == 2 and sel[0][0] > 0.0, t
+        assert t["step_gpu_span"][1] == 2
+        ctx.set_option("timing_every", 1)
+        ctx.timing_enable(1)
+        ctx.timing_reset()
+        for _ in range(3):
+            ctx.map(c["R"])
+        assert [v[1] for k, v in ctx.timing_read().items() if k.startswith("k_select")] == [3]
+    finally:
+        ctx.timing_enable(False)
+        ctx.close()
+
+
 def test_a_database_stored_class_by_class_keeps_the_bet():
     """Rows sorted by label, codes that follow the labels: a query's near rows all sit in its class's tenth of the
     segments, ten times what slices sized for an even spread hold.  The first call loses the bet twice, widens the slices

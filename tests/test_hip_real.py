@@ -111,6 +111,34 @@ def test_python_surface_ranks_real_features_like_the_reference():
         MAP(c["qf"], c["dbf"], c["qlab"], c["dblab"], c["R"])          # MAP() is the binary-code spelling
 
 
+@pytest.mark.parametrize("head", ["tanh", "pm1"])
+def test_float_table_upload_paths_of_the_python_surface(head):
+    """A float table big enough for the pinned staging (>= 8 MB), 50 features (rows padded to 64 on the way).  Its first
+    rows decide how it travels: real-valued from row 0 -- a second thread ships it while the codes are still packed; the
+    first hundred rows exactly +-1 -- nobody knows before the census that the rest is real-valued, the floats follow the
+    packing.  Either way MAPs must rank what np.dot ranks: the oracle's APs, bit for bit."""
+    from hashgan_amd import MAPs
+    rng = np.random.default_rng(77)
+    Q, N, b, R, C = 6, 45000, 50, 900, 6
+    dbf = np.tanh(rng.standard_normal((N, b))).astype(np.float32)
+    if head == "pm1":
+        dbf[:100] = np.where(rng.random((100, b)) < 0.5, -1.0, 1.0).astype(np.float32)
+    qf = np.tanh(rng.standard_normal((Q, b))).astype(np.float32)
+    dl = (rng.random((N, C)) < 0.3).astype(np.int64)
+    ql = (rng.random((Q, C)) < 0.3).astype(np.int64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, ap_ref, idx_ref, score_ref = RM.map_from_features(qf, dbf, ql.astype(np.int8), dl.astype(np.int8), R)
+    mp = MAPs(R)
+    try:
+        database = types.SimpleNamespace(output=dbf, label=dl)
+        query = types.SimpleNamespace(output=qf, label=ql)
+        for _ in range(2):                                            # the second call reuses the pinned buffers and the second stream
+            assert mp.get_maps_by_feature(database, query) == m
+    finally:
+        mp.close()
+
+
 @pytest.mark.parametrize("name", ["real_bits01", "real_ternary"])
 def test_maps_ranks_non_pm1_codes_like_np_dot(name):
     """{0,1} bits and +-1 codes with zeros: np.dot (metric.py:13) does NOT rank them by Hamming distance, so the
