@@ -294,6 +294,8 @@ struct hg_ctx {
     i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
     i64 opt_rank_cnt = 1;      // ... and ranks them with the per-thread counting sort (k_rank_cnt) where it applies
+    i64 real_grouped = 0;      // stat: the last real-valued ranking ordered its record lists group by group (k_real_group_*)
+    i64 opt_real_groups = 1;   // "real_groups": record lists beyond the LDS are split by score range and ordered group by group in LDS (0: the four radix passes)
     i64 real_cap_boost = 1;    // the same for the real-valued ranking's slices (run_real)
     i64 cap_boost = 1;         // slice capacity multiplier a lost bet escalated to on this database (run_oneshot); 1 after every load
     i64 opt_rank_direct_lds = 80;    // "rank_direct_lds": KB of LDS a k_rank_direct block may take (80: two blocks per CU -- C1 0.25 ms vs 0.31 with 160 and one)
@@ -352,7 +354,7 @@ struct hg_ctx {
     DevBuf part;               // hg_merge_ap_part's output: {AP, hits} of this rank's queries + its verdict
     bool ranked_local = false; // mbits holds this shard's bitmap in LOCAL rank order (hg_select_ranked)
     DevBuf cand, out_idx, out_dist, mbits, shapes, ap_recip, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
-    DevBuf dbf, qf, samp, thr, sortA, sortB, scores;   // real-valued path
+    DevBuf dbf, qf, samp, thr, sortA, sortB, scores, gtab;   // real-valued path
     DevBuf dbfx;               // float features of the database in MFMA A-fragment order (k_real_select_mx), built on first use
     bool dbfx_valid = false;
     DevBuf sampx;              // float features of the sampled rows in MFMA A-fragment order (k_real_sample_mx), rebuilt per call
@@ -1219,7 +1221,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip, &c->part};
+                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip, &c->part};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -2764,7 +2766,38 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     const size_t lds = (size_t)(nwav + 1) * 256 * 4;
     u64* bufs[2] = {c->sortA.as<u64>(), c->sortB.as<u64>()};
     const u64* in = c->cand.as<u64>();
-    for (int pass = 0; pass < 4; ++pass) {
+    bool grouped = false;
+    if (c->opt_real_groups && g.S <= 8192 && !bet && c->crow <= (i64)RG_MAXG * RG_CAP) {
+        // every row a record (R = N on a CIFAR-sized database): split by score range into LDS-sized groups, order each group
+        // in LDS (k_real_group_split / k_real_group_sort) -- two trips of the records through memory instead of the radix
+        // passes' four, 3.1 -> 0.85 ms at C1; piled-up scores come back as bit 2 of the flag.  (A bet's list beyond the LDS --
+        // 19 000 records in 489 short slices at R = 10 000 -- stays with the radix passes: 3.9 ms against 5.7 this way.)
+        HG_TRY(c->gtab.reserve((size_t)g.Q * (RG_MAXG + 1) * 4));
+        // (two consecutive groups of the greedy packing hold more than RG_CAP records together: at most 2 n / RG_CAP + 1 groups)
+        const int maxg = (int)std::min<i64>(RG_MAXG, 2 * c->crow / RG_CAP + 2);
+        static bool lds_set = false;
+        if (!lds_set) {
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_group_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)real_group_sort_lds()));
+            lds_set = true;
+        }
+        c->t_begin(KI_RADIX);
+        hipLaunchKernelGGL(k_real_group_split, dim3(g.Q), dim3(1024), real_group_split_lds(g.S), c->stream, c->cand.as<u64>(), c->crow, c->cap,
+                           c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->tot.as<u32>(), c->sortA.as<u64>(), c->gtab.as<u32>(), c->crow, c->err.as<int>(), maxg, g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_real_group_split"));
+        c->t_begin(KI_RADIX);
+        hipLaunchKernelGGL(k_real_group_sort, dim3(g.Q, maxg), dim3(1024), real_group_sort_lds(), c->stream, c->sortA.as<u64>(), c->gtab.as<u32>(),
+                           c->sortB.as<u64>(), c->crow, c->err.as<int>());
+        c->t_end();
+        HG_TRY(c->check_launch("k_real_group_sort"));
+        int flag = 0;
+        HG_TRY(read_plan_flag(c, &flag));
+        if (flag & 4) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+        else { grouped = true; in = c->sortB.as<u64>(); }
+    }
+    c->real_grouped = grouped ? 1 : 0;
+    for (int pass = 0; pass < 4 && !grouped; ++pass) {
         RadixArgs ra{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, c->crow, pass == 0, 32 + 8 * pass};
         u64* out = bufs[pass & 1];
         c->t_begin(KI_RADIX);
@@ -3161,6 +3194,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "real_mfma")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "real_mfma must be 0, 1 or 2");
         c->opt_real_mfma = value;
+    } else if (!strcmp(key, "real_groups")) {
+        c->opt_real_groups = value != 0;
     } else if (!strcmp(key, "real_sort_lds")) {
         c->opt_real_sort_lds = value != 0;
     } else if (!strcmp(key, "real_sample_hits")) {
@@ -3185,7 +3220,7 @@ int hg_trim(hg_ctx* c) {
     HG_TRY(c->use());
     HG_TRY(c->sync());
     DevBuf* work[] = {&c->hist, &c->seglt, &c->segtie, &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->cand, &c->out_idx,
-                      &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->scores, &c->bigq, &c->mbits2,
+                      &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->bigq, &c->mbits2,
                       &c->dbx, &c->qx, &c->dbx2, &c->qx2, &c->dbfx, &c->dbfb, &c->sampx};   // the images are rebuilt on demand
     for (auto* d : work) d->release();
     c->dbfx_valid = false;
@@ -3211,6 +3246,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "optimistic_rebets")) *value = c->opt_rebets;
     else if (!strcmp(key, "cap_boost")) *value = c->cap_boost;
     else if (!strcmp(key, "real_cap_boost")) *value = c->real_cap_boost;
+    else if (!strcmp(key, "real_grouped")) *value = c->real_grouped;
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
     else if (!strcmp(key, "real_attempts")) *value = c->real_attempts;
     else if (!strcmp(key, "real_filtered")) *value = c->real_filtered ? 1 : 0;
@@ -3220,7 +3256,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err,
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
-                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2,
+                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2,
                          &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip, &c->part};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;

@@ -775,6 +775,173 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
 #endif
 }
 
+// ---- record lists beyond the LDS (R = N on a CIFAR-sized database: every row a record), two kernels instead of four radix
+// passes.  k_real_group_split: a query's records are split by SCORE RANGE into groups of at most RG_CAP records (1024 coarse
+// buckets of equal score width, consecutive buckets packed greedily) and written group by group; k_real_group_sort: one
+// block per (query, group) orders its group in LDS -- the bucket pass of k_real_rank_lds on 4096 fine score buckets,
+// ranks by counting the bucket's predecessors, the record's own 64 bits (key, idx) being the order -- and writes it to its
+// place in the sorted row.  Scores that pile up (a coarse bucket beyond RG_CAP, a fine one beyond RG_PILE, more than RG_MAXG
+// groups) set bit 2 of *err: the host then runs the radix passes.
+constexpr int RG_CAP = 6144;                                 // records per group: 48 KB + positions + counters, two blocks per CU
+constexpr int RG_MAXG = 32;
+constexpr int RG_COARSE = 1024;
+constexpr u32 RG_PILE = 24;
+// score of a record key (= mono_inv(~key), spelt without a select: with the select form this compiler's instruction selection
+// died in a float -> bucket computation)
+__device__ __forceinline__ float rg_score(const u32 key) {
+    const u32 k = ~key, m = (u32)((int)k >> 31);
+    return __uint_as_float((k & m & 0x7FFFFFFFu) | (~k & ~m));
+}
+__device__ __forceinline__ u32 rg_bucket(const u32 key, const float smax, const float scale, const int nb) {
+    const int bk = (int)((smax - rg_score(key)) * scale);                       // (>= 0: smax is the largest score)
+    return (u32)(bk < nb ? bk : nb - 1);
+}
+inline size_t real_group_split_lds(int S) { return ((size_t)S + 1 + RG_COARSE + RG_COARSE / 4 + 2 * (RG_MAXG + 1)) * 4; }
+
+__global__ __launch_bounds__(1024) void k_real_group_split(const u64* __restrict__ cand, i64 crow_in, u32 cap, const u32* __restrict__ sl_cnt,
+                                                           const u32* __restrict__ fail, u32* __restrict__ tot, u64* __restrict__ grouped,
+                                                           u32* __restrict__ gtab, i64 crow_out, int* __restrict__ err, const int maxg, const Geo g) {
+    extern __shared__ __attribute__((aligned(16))) u32 gsl[];
+    u32* off = gsl;                                          // [S + 1]
+    u32* ch = off + g.S + 1;                                 // [RG_COARSE] counts
+    u8* gmap = (u8*)(ch + RG_COARSE);                        // [RG_COARSE] bucket -> group
+    u32* gstart = ch + RG_COARSE + RG_COARSE / 4;            // [RG_MAXG + 1]
+    u32* gcur = gstart + RG_MAXG + 1;                        // [RG_MAXG + 1] scatter cursors
+    __shared__ u32 s_w[16], s_x[16];
+    __shared__ int s_ng;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    u32* __restrict__ gt = gtab + (i64)q * (RG_MAXG + 1);
+    if (fail[q]) { if (tid == 0) tot[q] = 0xFFFFFFFFu; if (tid <= RG_MAXG) gt[tid] = 0u; return; }
+    u32 n = 0;
+    for (int sb = 0; sb < g.S; sb += 1024) {
+        const int s = sb + tid;
+        const u32 c = s < g.S ? sl_cnt[(i64)s * g.Qpad + q] : 0u;
+        u32 t;
+        const u32 ex = block_excl_scan_1024(c, s_w, t);
+        if (s < g.S) off[s] = n + ex;
+        n += t;
+    }
+    if (tid == 0) off[g.S] = n;
+    if (tid < RG_COARSE) ch[tid] = 0u;
+    __syncthreads();
+    const u64* __restrict__ row = cand + (i64)q * crow_in;
+    // Every row a record: the slices are whole segments, each full but the last -- the query's records are ONE dense run
+    // and the block walks it 1024 records a step.  (Any other layout: slice by slice.)
+    bool dense_ok = true;
+    for (int s = tid; s < g.S; s += 1024) dense_ok &= off[s] == (u32)s * cap;
+    const bool dense = __syncthreads_and((int)dense_ok) != 0;
+    auto for_records = [&](auto&& body) {
+        if (dense) {
+            for (u32 a = tid; a < n; a += 1024) body(row[a]);
+        } else {
+            for (int s = 0; s < g.S; ++s) {
+                const u32 c = off[s + 1] - off[s];
+                const u64* __restrict__ sl = row + (i64)s * cap;
+                for (u32 i = tid; i < c; i += 1024) body(sl[i]);
+            }
+        }
+    };
+    u32 kmin = 0xFFFFFFFFu, kmax = 0u;
+    for_records([&](const u64 rec) { const u32 k = (u32)(rec >> 32); kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; });
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const u32 v = (u32)__shfl_xor((int)kmin, o), w = (u32)__shfl_xor((int)kmax, o);
+        kmin = v < kmin ? v : kmin; kmax = w > kmax ? w : kmax;
+    }
+    if (lane == 0) { s_w[wave] = kmin; s_x[wave] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const u32 v = s_w[w], x = s_x[w]; kmin = v < kmin ? v : kmin; kmax = x > kmax ? x : kmax; }
+    const float smax = rg_score(kmin), width = smax - rg_score(kmax);
+    const bool flat = !(width > 0.0f) || !(width < 3.0e38f);                    // one score for all rows, or not finite
+    const float scale = (float)RG_COARSE / width;
+    for_records([&](const u64 rec) { atomicAdd(&ch[rg_bucket((u32)(rec >> 32), smax, scale, RG_COARSE)], 1u); });
+    __syncthreads();
+    if (tid == 0) {                                          // consecutive coarse buckets -> groups of at most RG_CAP records
+        int ng = 0;
+        u32 in_group = 0, start = 0;
+        bool bad = flat || n == 0;
+        gstart[0] = 0;
+        for (int b = 0; b < RG_COARSE && !bad; ++b) {
+            const u32 c = ch[b];
+            if (c > (u32)RG_CAP) { bad = true; break; }
+            if (in_group + c > (u32)RG_CAP) { ++ng; start += in_group; in_group = 0; if (ng >= maxg) { bad = true; break; } gstart[ng] = start; }
+            gmap[b] = (u8)ng;
+            in_group += c;
+        }
+        if (!bad) { ++ng; gstart[ng] = start + in_group; }
+        s_ng = bad ? -1 : ng;
+    }
+    __syncthreads();
+    const int ng = s_ng;
+    if (ng < 0) { if (tid == 0) atomicOr(err, 4); if (tid <= RG_MAXG) gt[tid] = 0u; return; }
+    if (tid <= RG_MAXG) { const u32 v = gstart[tid < ng ? tid : ng]; gcur[tid] = v; gt[tid] = v; }
+    __syncthreads();
+    u64* __restrict__ grp = grouped + (i64)q * crow_out;
+    for_records([&](const u64 rec) { grp[atomicAdd(&gcur[gmap[rg_bucket((u32)(rec >> 32), smax, scale, RG_COARSE)]], 1u)] = rec; });
+    if (tid == 0) tot[q] = n;
+}
+
+constexpr size_t real_group_sort_lds() { return (size_t)RG_CAP * 8 + (size_t)RG_CAP * 2 + 4096 * 4; }
+
+__global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __restrict__ grouped, const u32* __restrict__ gtab, u64* __restrict__ sorted,
+                                                          i64 crow, int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) u64 gso[];
+    u64* A = gso;                                            // [RG_CAP] the group's records
+    u16* P = (u16*)(A + RG_CAP);                             // [RG_CAP] positions, grouped by fine bucket
+    u32* hw = (u32*)(P + RG_CAP);                            // [4096] fine bucket counts -> starts -> ends
+    __shared__ u32 s_w[16], s_x[16];
+    const int q = blockIdx.x, gi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 lo = gtab[(i64)q * (RG_MAXG + 1) + gi], hi = gtab[(i64)q * (RG_MAXG + 1) + gi + 1];
+    const u32 m = hi - lo;
+    if (m == 0) return;
+    const u64* __restrict__ src = grouped + (i64)q * crow + lo;
+    u32 kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (u32 i = tid; i < m; i += 1024) {
+        const u64 rec = src[i];
+        A[i] = rec;
+        const u32 k = (u32)(rec >> 32);
+        kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const u32 v = (u32)__shfl_xor((int)kmin, o), w = (u32)__shfl_xor((int)kmax, o);
+        kmin = v < kmin ? v : kmin; kmax = w > kmax ? w : kmax;
+    }
+    if (lane == 0) { s_w[wave] = kmin; s_x[wave] = kmax; }
+    for (int i = tid; i < 4096; i += 1024) hw[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const u32 v = s_w[w], x = s_x[w]; kmin = v < kmin ? v : kmin; kmax = x > kmax ? x : kmax; }
+    const float smax = rg_score(kmin), width = smax - rg_score(kmax);
+    // (one score for the whole group: every record lands in bucket 0 and the pile check below decides)
+    const float scale = width > 0.0f ? 4096.0f / width : 0.0f;
+    for (u32 i = tid; i < m; i += 1024) atomicAdd(&hw[rg_bucket((u32)(A[i] >> 32), smax, scale, 4096)], 1u);
+    __syncthreads();
+    u32 c4[4], sum = 0, big = 0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { c4[x] = hw[4 * tid + x]; sum += c4[x]; big |= c4[x] > RG_PILE ? 1u : 0u; }
+    if (__syncthreads_or((int)big)) { if (tid == 0) atomicOr(err, 4); return; }
+    u32 t;
+    u32 run = block_excl_scan_1024(sum, s_w, t);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { hw[4 * tid + x] = run; run += c4[x]; }
+    __syncthreads();
+    for (u32 i = tid; i < m; i += 1024) P[atomicAdd(&hw[rg_bucket((u32)(A[i] >> 32), smax, scale, 4096)], 1u)] = (u16)i;
+    __syncthreads();
+    u64* __restrict__ dst = sorted + (i64)q * crow + lo;
+    for (u32 a = tid; a < m; a += 1024) {
+        const u64 rec = A[P[a]];
+        const u32 bk = rg_bucket((u32)(rec >> 32), smax, scale, 4096);
+        const u32 b0 = bk ? hw[bk - 1] : 0u, b1 = hw[bk];    // (after the scatter hw[b] is the END of bucket b)
+        u32 before = 0;
+        for (u32 e = b0; e < b1; ++e) before += A[P[e]] < rec ? 1u : 0u;
+        dst[b0 + before] = rec;
+    }
+}
+
 // The guess with the sample in LDS (k_real_guess reads its M samples three times from global memory with 256 threads):
 // 1024 threads copy the query's samples (as order-preserving keys) once, then the same 11 + 11 + 10 bit radix select of
 // the rank_s-th largest runs out of LDS.  M <= RG_MMAX.

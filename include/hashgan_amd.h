@@ -265,13 +265,15 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  * "real_mfma" (real-valued select pass -- 2, default: bfloat16 matrix-core filter with a rigorous margin, then the exact
  * float32 chain for the rows it keeps; 1: every pair exactly on the float32 matrix-core instruction; 0: vector ALU; same
  * lists either way), "real_sort_lds" (1, default: after the filter a query's records are ranked by one LDS-resident
- * kernel when they fit; 0: always the global-memory radix passes),
+ * kernel when they fit; 0: always the global-memory radix passes), "real_groups" (1, default: without a cut -- every row a
+ * record, R = N -- the rows are split by score range into LDS-sized groups and ordered group by group; the exact float32
+ * pair pass then stands in for filter + rescore; 0: the radix passes),
  * "real_queries_per_lane", "real_segment_bytes" (real-valued path), "step_graph" (0, default: always enqueue kernel
  * by kernel; 1: hg_map captures its one-shot sequence into a hipGraph the second time it sees the same problem and
  * replays it afterwards). */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
 /* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
- * (single queries rerun exactly after losing their bet), "optimistic_rebets" (second and widened bets), "cap_boost", "real_cap_boost" (the same for hg_map_real), "last_optimistic", "device_bytes", "segments",
+ * (single queries rerun exactly after losing their bet), "optimistic_rebets" (second and widened bets), "cap_boost", "real_cap_boost" (the same for hg_map_real), "real_grouped" (the last real-valued ranking ordered lists beyond the LDS group by group), "last_optimistic", "device_bytes", "segments",
  * "segment_rows", "slice_capacity", "record_row"; census of the float tables loaded by hg_set_*_f32 --
  * "db_nonbinary" / "q_nonbinary" (entries outside {-1,0,+1}), "db_zeros" / "q_zeros", "db_minus_ones" /
  * "q_minus_ones" -- from which the caller tells +-1 codes, {0,1} bits and real-valued features apart;

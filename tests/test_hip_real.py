@@ -63,6 +63,40 @@ def test_generic_float_features_match_oracle_bit_for_bit(Q, N, b, R, C, ctx):
     assert np.array_equal(ap, ap_ref, equal_nan=True)
 
 
+@pytest.mark.parametrize("kind", ["tanh", "grid"])
+def test_every_row_ranked_group_by_group(kind):
+    """R = N (the reference's CIFAR-10 setting) on real-valued features: every row is a record, far more than the LDS holds.
+    Continuous scores are split by score range into LDS-sized groups and ordered group by group (k_real_group_split /
+    k_real_group_sort, stat real_grouped); scores on a coarse grid pile up in the buckets and take the radix passes.  The
+    oracle's lists and APs either way, bit for bit."""
+    rng = np.random.default_rng(31)
+    Q, N, b, C = 6, 30000, 32, 10
+    R = N
+    if kind == "tanh":
+        dbf, qf = np.tanh(rng.standard_normal((N, b))).astype(np.float32), np.tanh(rng.standard_normal((Q, b))).astype(np.float32)
+    else:
+        dbf, qf = rng.integers(-1, 2, (N, b)).astype(np.float32), rng.integers(-1, 2, (Q, b)).astype(np.float32)
+    dl = (rng.random((N, C)) < 0.2).astype(np.int64)
+    ql = (rng.random((Q, C)) < 0.2).astype(np.int64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, ap_ref, idx_ref, score_ref = RM.map_from_features(qf, dbf, ql.astype(np.int8), dl.astype(np.int8), R)
+    c = _native.Context(0)
+    try:
+        c.set_database_f32(dbf, dl)
+        c.set_queries_f32(qf, ql)
+        idx, score = c.topr_real(R)
+        assert c.get_stat("real_grouped") == (1 if kind == "tanh" else 0)
+        assert np.array_equal(idx, idx_ref) and np.array_equal(score.view(np.uint32), score_ref.view(np.uint32))
+        ap, rel = c.map_real(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        c.set_option("real_groups", 0)                               # the radix passes: the same lists
+        idx2, _ = c.topr_real(R)
+        assert c.get_stat("real_grouped") == 0 and np.array_equal(idx2, idx_ref)
+    finally:
+        c.close()
+
+
 def test_features_that_follow_the_labels_in_a_class_sorted_database():
     """What a trained network hands over when the database is stored class by class: a query's top rows all sit in its
     class's tenth of the segments.  Both sampled cuts lose on slice capacity, the slices are widened (real_cap_boost) and
