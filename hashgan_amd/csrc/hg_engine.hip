@@ -2786,17 +2786,27 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
                            c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->tot.as<u32>(), c->sortA.as<u64>(), c->gtab.as<u32>(), c->crow, c->err.as<int>(), maxg, g);
         c->t_end();
         HG_TRY(c->check_launch("k_real_group_split"));
+        // the sort writes the ranked lists and the match bits itself (k_real_finish and k_match are for the radix passes)
+        HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+        HG_HIP(hipMemsetAsync(c->qbad.p, 0, (size_t)g.Qpad * 4, c->stream));
+        const GroupOut go{c->out_idx.as<u32>(), c->scores.as<float>(), c->mbits.as<u32>(), c->dblab.as<u64>(), c->qlab.as<u64>(), c->RW, g.R, g.LW, g.idx_base};
         c->t_begin(KI_RADIX);
         hipLaunchKernelGGL(k_real_group_sort, dim3(g.Q, maxg), dim3(1024), real_group_sort_lds(), c->stream, c->sortA.as<u64>(), c->gtab.as<u32>(),
-                           c->sortB.as<u64>(), c->crow, c->err.as<int>());
+                           go, c->crow, c->err.as<int>());
         c->t_end();
         HG_TRY(c->check_launch("k_real_group_sort"));
         int flag = 0;
         HG_TRY(read_plan_flag(c, &flag));
         if (flag & 4) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
-        else { grouped = true; in = c->sortB.as<u64>(); }
+        else grouped = true;
     }
     c->real_grouped = grouped ? 1 : 0;
+    if (grouped) {
+        c->stage = ST_DB | ST_Q | ST_SELECT | ST_MATCH;
+        if (with_ap) HG_TRY(do_ap(c));
+        HG_TRY(read_plan_flag(c, lost));
+        return HG_OK;
+    }
     for (int pass = 0; pass < 4 && !grouped; ++pass) {
         RadixArgs ra{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, c->crow, pass == 0, 32 + 8 * pass};
         u64* out = bufs[pass & 1];

@@ -883,14 +883,24 @@ __global__ __launch_bounds__(1024) void k_real_group_split(const u64* __restrict
     if (tid == 0) tot[q] = n;
 }
 
-constexpr size_t real_group_sort_lds() { return (size_t)RG_CAP * 8 + (size_t)RG_CAP * 2 + 4096 * 4; }
+constexpr int RG_BMW = RG_CAP / 32 + 2;                     // dwords of match bits a group's ranks can touch
+constexpr size_t real_group_sort_lds() { return (size_t)RG_CAP * 8 + (size_t)RG_CAP * 2 + 4096 * 4 + (size_t)RG_BMW * 4; }
 
-__global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __restrict__ grouped, const u32* __restrict__ gtab, u64* __restrict__ sorted,
+// The ranked list leaves from here too (what k_real_finish and k_match do after the radix passes): a record's final rank is
+// known the moment it has counted its bucket's predecessors -- idx and score go to the ranked lists, the label-match bit
+// (metric.py:17-19) into the group's stretch of the query's bitmap (LDS, then OR-ed into the zeroed global words: the first
+// and last word of a stretch are shared with the neighbouring groups).
+struct GroupOut {
+    u32* out_idx; float* scores; u32* mbits32; const u64* dblab; const u64* qlab; i64 RW; i64 R; int LW; u32 idx_base;
+};
+
+__global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __restrict__ grouped, const u32* __restrict__ gtab, const GroupOut o,
                                                           i64 crow, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) u64 gso[];
     u64* A = gso;                                            // [RG_CAP] the group's records
     u16* P = (u16*)(A + RG_CAP);                             // [RG_CAP] positions, grouped by fine bucket
     u32* hw = (u32*)(P + RG_CAP);                            // [4096] fine bucket counts -> starts -> ends
+    u32* bm = hw + 4096;                                     // [RG_BMW] match bits of ranks lo .. hi, from dword lo / 32
     __shared__ u32 s_w[16], s_x[16];
     const int q = blockIdx.x, gi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -911,7 +921,7 @@ __global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __restrict_
         kmin = v < kmin ? v : kmin; kmax = w > kmax ? w : kmax;
     }
     if (lane == 0) { s_w[wave] = kmin; s_x[wave] = kmax; }
-    for (int i = tid; i < 4096; i += 1024) hw[i] = 0u;
+    for (int i = tid; i < 4096 + RG_BMW; i += 1024) hw[i] = 0u;
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < 16; ++w) { const u32 v = s_w[w], x = s_x[w]; kmin = v < kmin ? v : kmin; kmax = x > kmax ? x : kmax; }
@@ -931,14 +941,29 @@ __global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __restrict_
     __syncthreads();
     for (u32 i = tid; i < m; i += 1024) P[atomicAdd(&hw[rg_bucket((u32)(A[i] >> 32), smax, scale, 4096)], 1u)] = (u16)i;
     __syncthreads();
-    u64* __restrict__ dst = sorted + (i64)q * crow + lo;
+    const u64* __restrict__ ql = o.qlab + (i64)q * o.LW;
+    const u32 w0 = lo >> 5;
     for (u32 a = tid; a < m; a += 1024) {
         const u64 rec = A[P[a]];
         const u32 bk = rg_bucket((u32)(rec >> 32), smax, scale, 4096);
         const u32 b0 = bk ? hw[bk - 1] : 0u, b1 = hw[bk];    // (after the scatter hw[b] is the END of bucket b)
         u32 before = 0;
         for (u32 e = b0; e < b1; ++e) before += A[P[e]] < rec ? 1u : 0u;
-        dst[b0 + before] = rec;
+        const u32 rk = lo + b0 + before;                     // the record's rank in the query's list
+        if ((i64)rk < o.R) {
+            const u32 gi = (u32)rec;
+            o.out_idx[(i64)q * o.R + rk] = gi;
+            if (o.scores) o.scores[(i64)q * o.R + rk] = rg_score((u32)(rec >> 32));
+            const u64* __restrict__ dl = o.dblab + (i64)(gi - o.idx_base) * o.LW;
+            u64 any = 0;
+            for (int w = 0; w < o.LW; ++w) any |= dl[w] & ql[w];
+            if (any) atomicOr(&bm[(rk >> 5) - w0], 1u << (rk & 31));
+        }
+    }
+    __syncthreads();
+    if (tid < RG_BMW) {
+        const u32 v = bm[tid];
+        if (v) atomicOr(&o.mbits32[(i64)q * 2 * o.RW + w0 + tid], v);
     }
 }
 
