@@ -833,7 +833,15 @@ __global__ __launch_bounds__(1024) void k_real_group_split(const u64* __restrict
     const bool dense = __syncthreads_and((int)dense_ok) != 0;
     auto for_records = [&](auto&& body) {
         if (dense) {
-            for (u32 a = tid; a < n; a += 1024) body(row[a]);
+            // four loads in flight per thread: one at a time, a walk was 53 dependent trips to memory at C1 (the body's LDS
+            // atomic keeps the compiler from overlapping them itself)
+            for (u32 a = tid; a < n; a += 4096) {
+                u64 r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = a + 1024u * k < n ? row[a + 1024u * k] : 0ull;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (a + 1024u * k < n) body(r[k]);
+            }
         } else {
             for (int s = 0; s < g.S; ++s) {
                 const u32 c = off[s + 1] - off[s];
@@ -858,20 +866,38 @@ __global__ __launch_bounds__(1024) void k_real_group_split(const u64* __restrict
     const float scale = (float)RG_COARSE / width;
     for_records([&](const u64 rec) { atomicAdd(&ch[rg_bucket((u32)(rec >> 32), smax, scale, RG_COARSE)], 1u); });
     __syncthreads();
-    if (tid == 0) {                                          // consecutive coarse buckets -> groups of at most RG_CAP records
-        int ng = 0;
-        u32 in_group = 0, start = 0;
-        bool bad = flat || n == 0;
-        gstart[0] = 0;
-        for (int b = 0; b < RG_COARSE && !bad; ++b) {
-            const u32 c = ch[b];
-            if (c > (u32)RG_CAP) { bad = true; break; }
-            if (in_group + c > (u32)RG_CAP) { ++ng; start += in_group; in_group = 0; if (ng >= maxg) { bad = true; break; } gstart[ng] = start; }
-            gmap[b] = (u8)ng;
-            in_group += c;
+    {   // consecutive coarse buckets -> groups of at most RG_CAP records, every bucket for itself: bucket b, whose records
+        // start at cumulative count ex_b, goes to group ex_b / T with T = RG_CAP - (largest bucket) -- a group then spans less
+        // than T + the largest bucket records, and with buckets of at most T no group number is skipped.  (A single thread
+        // packing the buckets greedily held the other 1023 at a barrier for a third of the block's life.)
+        const u32 cb = ch[tid];                              // (RG_COARSE == blockDim.x)
+        u32 mx = cb;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const u32 v = (u32)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
+        if (lane == 0) s_x[wave] = mx;
+        u32 t;
+        const u32 ex = block_excl_scan_1024(cb, s_w, t);    // (its barriers publish s_x too)
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const u32 v = s_x[w]; mx = v > mx ? v : mx; }
+        const bool bad = flat || n == 0 || mx > (u32)RG_CAP / 2u;
+        const u32 T = bad ? 1u : (u32)RG_CAP - mx;
+        const u32 gid = ex / T;
+        u32 lastg = cb ? gid : 0u;                           // the last group that holds a record
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const u32 v = (u32)__shfl_xor((int)lastg, o); lastg = v > lastg ? v : lastg; }
+        __syncthreads();                                     // (s_x is read above by everybody)
+        if (lane == 0) s_x[wave] = lastg;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const u32 v = s_x[w]; lastg = v > lastg ? v : lastg; }
+        const int ngroups = bad ? -1 : (int)lastg + 1;
+        if (!bad && ngroups <= maxg) {
+            gmap[tid] = (u8)gid;
+            const u32 gprev = tid ? (ex - ch[tid - 1]) / T : 0xFFFFFFFFu;
+            if (gid != gprev) gstart[gid] = ex;              // the group's first bucket
+            if (tid == 0) gstart[ngroups] = n;
         }
-        if (!bad) { ++ng; gstart[ng] = start + in_group; }
-        s_ng = bad ? -1 : ng;
+        if (tid == 0) s_ng = bad || ngroups > maxg ? -1 : ngroups;
     }
     __syncthreads();
     const int ng = s_ng;
