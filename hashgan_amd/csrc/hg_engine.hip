@@ -2773,7 +2773,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         // passes' four, 3.1 -> 0.85 ms at C1; piled-up scores come back as bit 2 of the flag.  (A bet's list beyond the LDS --
         // 19 000 records in 489 short slices at R = 10 000 -- stays with the radix passes: 3.9 ms against 5.7 this way.)
         HG_TRY(c->gtab.reserve((size_t)g.Q * (RG_MAXG + 1) * 4));
-        // (two consecutive groups of the greedy packing hold more than RG_CAP records together: at most 2 n / RG_CAP + 1 groups)
+        // (a group spans at least RG_CAP / 2 of cumulative count -- the largest bucket is at most RG_CAP / 2: at most 2 n / RG_CAP + 1 groups)
         const int maxg = (int)std::min<i64>(RG_MAXG, 2 * c->crow / RG_CAP + 2);
         static bool lds_set = false;
         if (!lds_set) {

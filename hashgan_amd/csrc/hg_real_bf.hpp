@@ -777,7 +777,7 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
 
 // ---- record lists beyond the LDS (R = N on a CIFAR-sized database: every row a record), two kernels instead of four radix
 // passes.  k_real_group_split: a query's records are split by SCORE RANGE into groups of at most RG_CAP records (1024 coarse
-// buckets of equal score width, consecutive buckets packed greedily) and written group by group; k_real_group_sort: one
+// buckets of equal score width, consecutive buckets, cut where the cumulative count passes a multiple of RG_CAP - the largest bucket) and written group by group; k_real_group_sort: one
 // block per (query, group) orders its group in LDS -- the bucket pass of k_real_rank_lds on 4096 fine score buckets,
 // ranks by counting the bucket's predecessors, the record's own 64 bits (key, idx) being the order -- and writes it to its
 // place in the sorted row.  Scores that pile up (a coarse bucket beyond RG_CAP, a fine one beyond RG_PILE, more than RG_MAXG
