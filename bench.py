@@ -119,13 +119,13 @@ def cpu_baseline(spec, packed, budget_s=12.0, chunk=128):
 
 
 def kernel_sources_sha():
-    """Fingerprint of the device code of the path this benchmark runs (the kernel headers; hg_engine.hip and
-    hg_host_pack.hpp are host code, hg_real_*.hpp is the real-valued path, which no line of this file launches): the
-    committed PMC traffic figure is only quoted for the kernels it was measured on."""
+    """Fingerprint of the device code of the path this benchmark's headline step runs (the kernel headers; the .hip units,
+    hg_ctx.hpp and hg_host_pack.hpp are host code, hg_real_*.hpp is the real-valued path): the committed PMC traffic figure
+    is only quoted for the kernels it was measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "hashgan_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if not f.endswith(".hpp") or f == "hg_host_pack.hpp" or f.startswith("hg_real_"):
+        if not f.endswith(".hpp") or f in ("hg_host_pack.hpp", "hg_ctx.hpp") or f.startswith("hg_real_"):
             continue
         with open(os.path.join(d, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())

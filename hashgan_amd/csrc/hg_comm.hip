@@ -1,0 +1,168 @@
+// libhashgan_amd.so -- collectives: RCCL over xGMI on the context's own stream, the library dlopen'ed on first use.
+#include "hg_ctx.hpp"
+
+#include <dlfcn.h>
+#include <mutex>
+#include <unistd.h>
+
+namespace {
+// ---- RCCL, loaded on first use.  The product links no collective library: a single-GPU process never pays for it. ----
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+std::mutex g_rccl_mu;                              // contexts of several threads may initialise communicators at once
+
+int rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.handle) return HG_OK;
+    const char* cands[] = {getenv("HG_RCCL_LIBRARY"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    std::string tried;
+    for (const char* name : cands) {
+        if (!name || !*name) continue;
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+        const char* why = dlerror();
+        tried += std::string(name) + ": " + (why ? why : "?") + "; ";
+    }
+    if (!h) return fail(HG_ERR_STATE, "RCCL not found (%s)", tried.c_str());
+    RcclApi a;
+    a.handle = h;
+#define HG_SYM(field, name)                                                             \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));                      \
+    if (!a.field) { dlclose(h); return fail(HG_ERR_STATE, "RCCL: symbol %s missing", name); }
+    HG_SYM(GetUniqueId, "ncclGetUniqueId")
+    HG_SYM(CommInitRank, "ncclCommInitRank")
+    HG_SYM(CommDestroy, "ncclCommDestroy")
+    HG_SYM(AllGather, "ncclAllGather")
+    HG_SYM(AllReduce, "ncclAllReduce")
+    HG_SYM(GetErrorString, "ncclGetErrorString")
+#undef HG_SYM
+    g_rccl = a;
+    return HG_OK;
+}
+
+#define HG_NCCL(expr)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess)                                                                         \
+            return fail(HG_ERR_HIP, "%s: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+}  // namespace
+
+void comm_release(hg_ctx* c) {
+    if (c->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+}
+
+extern "C" {
+
+// ---- collectives: RCCL over xGMI, on the context's own stream (no PyTorch anywhere) ----------------------------
+int hg_comm_unique_id(uint8_t* id) {
+    if (!id) return fail(HG_ERR_ARG, "hg_comm_unique_id: null pointer");
+    HG_TRY(rccl_load());
+    ncclUniqueId u;
+    HG_NCCL(g_rccl.GetUniqueId(&u));
+    static_assert(sizeof u == HG_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, sizeof u);
+    return HG_OK;
+}
+
+int hg_comm_init(hg_ctx* c, const uint8_t* id, int rank, int world) {
+    if (!c || !id) return fail(HG_ERR_ARG, "hg_comm_init: null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(HG_ERR_ARG, "hg_comm_init: rank %d of %d", rank, world);
+    if (c->comm) return fail(HG_ERR_STATE, "hg_comm_init: the context already has a communicator (hg_comm_destroy first)");
+    HG_TRY(c->use());
+    HG_TRY(rccl_load());
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    // RCCL prints a version banner on stdout when a communicator comes up; stdout belongs to the caller (bench.py's
+    // one JSON line): send whatever the library prints during the call to stderr instead
+    fflush(stdout);
+    const int saved = dup(1);
+    if (saved >= 0) (void)dup2(2, 1);
+    const ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    fflush(stdout);
+    if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
+    if (r != ncclSuccess) { c->comm = nullptr; return fail(HG_ERR_HIP, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return HG_OK;
+}
+
+int hg_comm_destroy(hg_ctx* c) {
+    if (!c) return fail(HG_ERR_ARG, "hg_comm_destroy: null context");
+    if (!c->comm) return HG_OK;
+    HG_TRY(c->use());
+    HG_TRY(c->sync());
+    ncclComm_t k = c->comm;
+    c->comm = nullptr;
+    c->comm_rank = 0; c->comm_world = 1;
+    HG_NCCL(g_rccl.CommDestroy(k));
+    return HG_OK;
+}
+
+int hg_comm_info(hg_ctx* c, int* rank, int* world) {
+    if (!c) return fail(HG_ERR_ARG, "hg_comm_info: null context");
+    if (rank) *rank = c->comm ? c->comm_rank : 0;
+    if (world) *world = c->comm ? c->comm_world : 0;      // 0: no communicator
+    return HG_OK;
+}
+
+int hg_allgather(hg_ctx* c, int slot, const void* dev_src, int64_t nbytes, void** dev_gathered) {
+    if (!c || !dev_src || !dev_gathered || nbytes < 1) return fail(HG_ERR_ARG, "hg_allgather: bad argument");
+    if (slot < 0 || slot >= 4) return fail(HG_ERR_ARG, "hg_allgather: slot %d outside 0..3", slot);
+    if (!c->comm) return fail(HG_ERR_STATE, "hg_allgather: no communicator (hg_comm_init)");
+    HG_TRY(c->use());
+    DevBuf& out = c->gathered[slot];
+    HG_TRY(out.reserve((size_t)nbytes * c->comm_world));
+    c->t_begin(KI_COMM);
+    HG_NCCL(g_rccl.AllGather(dev_src, out.p, (size_t)nbytes, ncclUint8, c->comm, c->stream));
+    c->t_end();
+    *dev_gathered = out.p;
+    return c->stage_end();
+}
+
+// The north star's exchange: every shard's ranked (dist, idx) lists all-gathered and merged (exactly one shard owns a
+// slot, the others hold HG_IDX_NONE / 0xFF there).  hg_get_topr then returns the global lists on every rank.
+int hg_allgather_topr(hg_ctx* c) {
+    HG_TRY(need(c, ST_SELECT, "hg_allgather_topr", "hg_select / hg_rank"));
+    if (!c->lists_valid) return fail(HG_ERR_STATE, "hg_allgather_topr: ranked lists were not materialised by the last call");
+    if (!c->comm) return fail(HG_ERR_STATE, "hg_allgather_topr: no communicator (hg_comm_init)");
+    const i64 n = (i64)c->geo.Q * c->geo.R;
+    const int G = c->comm_world;
+    HG_TRY(c->gath_idx.reserve((size_t)n * 4 * G));       // own landing zones: hg_allgather's slots may hold live data
+    HG_TRY(c->gath_dist.reserve((size_t)n * G));
+    c->t_begin(KI_COMM);
+    HG_NCCL(g_rccl.AllGather(c->out_idx.p, c->gath_idx.p, (size_t)n * 4, ncclUint8, c->comm, c->stream));
+    HG_NCCL(g_rccl.AllGather(c->out_dist.p, c->gath_dist.p, (size_t)n, ncclUint8, c->comm, c->stream));
+    c->t_end();
+    HG_TRY(launch_min_topr(c, c->gath_idx.as<u32>(), c->gath_dist.as<u8>(), n, G));
+    return c->stage_end();
+}
+
+// max over the ranks of one host double (step times of a benchmark), and a barrier: both one tiny all-reduce
+int hg_allreduce_max_f64(hg_ctx* c, double* host_inout) {
+    if (!c || !host_inout) return fail(HG_ERR_ARG, "hg_allreduce_max_f64: null argument");
+    if (!c->comm) return fail(HG_ERR_STATE, "hg_allreduce_max_f64: no communicator (hg_comm_init)");
+    HG_TRY(c->use());
+    HG_TRY(c->comm_tmp.reserve(16));
+    HG_HIP(hipMemcpyAsync(c->comm_tmp.p, host_inout, 8, hipMemcpyHostToDevice, c->stream));
+    HG_NCCL(g_rccl.AllReduce(c->comm_tmp.p, c->comm_tmp.as<char>() + 8, 1, ncclFloat64, ncclMax, c->comm, c->stream));
+    HG_HIP(hipMemcpyAsync(host_inout, c->comm_tmp.as<char>() + 8, 8, hipMemcpyDeviceToHost, c->stream));
+    return c->sync();
+}
+
+int hg_barrier(hg_ctx* c) {
+    double x = 0.0;
+    return hg_allreduce_max_f64(c, &x);
+}
+
+}  // extern "C"

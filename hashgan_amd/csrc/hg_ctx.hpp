@@ -1,0 +1,433 @@
+// Host side of libhashgan_amd.so, shared by its translation units: error plumbing, device buffers, the context
+// (struct hg_ctx, opaque in include/hashgan_amd.h) and the handful of host functions one unit calls in another.
+//
+//   hg_core.hip        context, tables (hg_set_*), options / statistics / timing, label match, AP, downloads
+//   hg_seq.hip         the Hamming sequences: geometry, histogram -> plan -> select -> rank, staged (sharded) and one-shot forms
+//   hg_pairs_valu.hip  launchers of the vector-ALU pair passes (k_hist, k_select, k_select_dense)
+//   hg_pairs_mx.hip    launchers of the matrix-core pair passes (k_select_mx2 / mx3, k_hist_mx, k_hist_i8) and their images
+//   hg_pairs_mx1.hip   launcher of k_select_mx (every code length: the longest compile)
+//   hg_real.hip        real-valued (float32 inner product) ranking
+//   hg_comm.hip        RCCL collectives (library dlopen'ed on first use)
+//
+// No torch, no CPU compute path: every entry point either runs HIP kernels or fails.
+#pragma once
+#include "hg_kernels.hpp"
+#pragma GCC visibility push(default)     // the library is built with -fvisibility=hidden: only the C ABI is exported
+#include "../../include/hashgan_amd.h"
+#pragma GCC visibility pop
+
+#include <rccl/rccl.h>     // types and enums only: the library itself is dlopen'ed by hg_comm_init (573 MB, not every process needs it)
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hg;
+
+extern thread_local std::string g_err;          // hg_last_error(): per thread
+int fail(int code, const char* fmt, ...);       // sets g_err, returns code
+
+#define HG_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? HG_ERR_NOMEM : HG_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                          \
+    } while (0)
+
+#define HG_TRY(expr)                \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != HG_OK) return rc_; \
+    } while (0)
+
+
+// Bumped whenever a device buffer moves: captured graphs hold raw addresses and die with the epoch they were built in.
+extern std::atomic<unsigned long long> g_alloc_epoch;   // bumped by every context's buffers (one MAPs object per thread is supported): atomic
+
+// HG_EFENCE=1 (debugging): every device buffer ends 64..127 bytes before an UNMAPPED 2 MiB page of its own virtual range
+// (hipMemAddressReserve / hipMemMap), so a kernel reading or writing past a buffer -- beyond the 64 bytes of slack the
+// kernels are allowed -- faults at once instead of only when hipMalloc happens to place the buffer at the end of a mapping;
+// and every new buffer starts out filled with 0xCB, so nothing can rely on fresh memory being zero.  HG_EFENCE=2: the
+// fill only, on plain allocations; HG_EFENCE=3: the unmapped page in FRONT of every buffer.  (tools/fuzz_*.py and the gpu
+// tests run under all three.)
+struct Fence { void* va = nullptr; void* map_at = nullptr; size_t va_size = 0, map_size = 0; hipMemGenericAllocationHandle_t h{}; };
+inline int efence_mode() { static const int m = getenv("HG_EFENCE") ? atoi(getenv("HG_EFENCE")) : 0; return m; }
+inline bool efence_on() { return efence_mode() != 0; }
+inline hipError_t fence_alloc(Fence& f, void** out, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;
+    f.map_size = (bytes + gran - 1) / gran * gran;
+    f.va_size = f.map_size + gran;                                   // the last granule stays unmapped
+    e = hipMemAddressReserve(&f.va, f.va_size, gran, nullptr, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemCreate(&f.h, f.map_size, &prop, 0);
+    if (e != hipSuccess) return e;
+    // HG_EFENCE=3: the unmapped granule comes FIRST and the buffer starts right behind it (reads before a buffer)
+    const bool front = efence_mode() == 3;
+    f.map_at = (char*)f.va + (front ? gran : 0);
+    e = hipMemMap(f.map_at, f.map_size, 0, f.h, 0);
+    if (e != hipSuccess) return e;
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess(f.map_at, f.map_size, &acc, 1);
+    if (e != hipSuccess) return e;
+    *out = front ? f.map_at : (char*)f.va + ((f.map_size - bytes) & ~(size_t)63);       // 64-byte aligned, ends < 64 bytes before the fence
+    return hipSuccess;
+}
+inline void fence_free(Fence& f) {
+    if (!f.va) return;
+    (void)hipDeviceSynchronize();                                    // hipFree waits for the device; unmapping does not
+    (void)hipMemUnmap(f.map_at, f.map_size);
+    (void)hipMemRelease(f.h);
+    // (the virtual range is NOT returned: a later buffer at the same address could meet stale cache lines of this one)
+    f = Fence{};
+}
+
+// A device buffer that only ever grows.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool borrowed = false;      // points into another context's allocation
+    Fence fence;                // HG_EFENCE: the buffer's own virtual range
+    void drop() {
+        if (p && !borrowed) { if (fence.va) fence_free(fence); else (void)hipFree(p); }
+    }
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return HG_OK;
+        drop();
+        p = nullptr; cap = 0; borrowed = false;
+        // slack: 16-byte wide copies may read past the last row of a table
+        if (efence_mode() == 2) {                           // plain allocation, poisoned
+            HG_HIP(hipMalloc(&p, bytes + 64));
+            HG_HIP(hipMemset(p, 0xCB, bytes + 64));
+            HG_HIP(hipDeviceSynchronize());                  // (the fill runs on the null stream; the context's stream does not wait for it)
+        } else if (efence_on()) {
+            HG_HIP(fence_alloc(fence, &p, bytes + 64));
+            HG_HIP(hipMemset(p, 0xCB, bytes + 64));
+            HG_HIP(hipDeviceSynchronize());
+        } else {
+            HG_HIP(hipMalloc(&p, bytes + 64));
+        }
+        cap = bytes;
+        ++g_alloc_epoch;
+        return HG_OK;
+    }
+    void borrow(const DevBuf& o) {
+        drop();
+        if (p != o.p) ++g_alloc_epoch;
+        p = o.p; cap = o.cap; borrowed = true;
+    }
+    void release() { drop(); if (p) ++g_alloc_epoch; p = nullptr; cap = 0; borrowed = false; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum KernelId { KI_HIST = 0, KI_HIST_REDUCE, KI_PLAN, KI_SEG_COUNTS, KI_SEG_LAYOUT, KI_GUESS, KI_SELECT, KI_CAND_HIST,
+                KI_ORDER, KI_RANK_FUSED, KI_MATCH, KI_AP, KI_MERGE, KI_PACK, KI_REAL_SAMPLE, KI_REAL_GUESS, KI_REAL_SELECT,
+                KI_RADIX, KI_REAL_FINISH, KI_SELECT_MX, KI_RANK_LDS, KI_COMM, KI_STEP, KI_REAL_RESCORE, KI_COUNT };
+enum Stage { ST_NONE = 0, ST_DB = 1, ST_Q = 2, ST_HIST = 4, ST_PLAN = 8, ST_SELECT = 16, ST_MATCH = 32, ST_AP = 64 };
+extern const char* const kKernelNames[KI_COUNT];
+
+void build_shape(int n, ApShape& sh);           // NumPy's pairwise-summation tree of an n-element chunk, flattened (hg_core.hip)
+
+struct Pending { int id; hipEvent_t a, b; };
+
+struct hg_ctx {
+    int device = 0;
+    int n_cu = 256;            // compute units of the device
+    hipStream_t stream = nullptr;
+    bool own_stream = true;    // false: the stream belongs to the caller (hg_set_stream) or to the parent context
+    bool stage_sync = true;    // staged calls synchronise the stream before returning
+    unsigned stage = ST_NONE;
+
+    // problem
+    i64 N = 0, Q = 0, R = 0, n_total = 0;
+    int b = 0, C = 0, NW = 0, NB = 0, LW = 0;
+    u32 idx_base = 0;
+    int G = 1, rank = 0;
+    Geo geo{};
+    i64 RW = 0;
+
+    // options
+    i64 target_units = 16384;
+    i64 min_segment = 256;
+    i64 opt_max_segments = 2048;   // "max_segments"
+    i64 opt_enable = 1;        // one-shot calls may bet on a sampled threshold (verified, exact fallback)
+    i64 opt_stride = 0;        // sampling stride in row batches, 0 = auto
+    i64 opt_sigma = 5;         // safety margin of the guess, in standard deviations of the sample count (5: a query loses its bet
+                               // about once in 3 million -- it is then rerun alone; 6 -> 5 keeps ~4 % fewer surplus records)
+    i64 staged_lists = 1;      // staged hg_select materialises the idx/dist lists
+    i64 cand_budget_x10 = 40;  // optimistic record budget per query, in tenths of R
+    i64 opt_real_seg_bytes = 512 * 1024;   // real-valued path: bytes of feature rows per segment
+    i64 opt_real_qpl = 1;      // real-valued path: queries per lane (1 or 2)
+    i64 opt_rank_waves = 0;    // k_rank_fused wavefronts per query: 0 = by list length, else 4 or 16
+    i64 opt_select_mfma = 1;   // optimistic select: 1 = matrix-core kernel (k_select_mx), 0 = vector-ALU k_select
+    i64 opt_probe = 0;         // measurement probes of the matrix-core select kernels (SelArgs::probe)
+    i64 opt_select_packed = 3; // codes of <= 64 bits, several distances per MFMA accumulator: 1 = k_select_mx2 (two) for <= 32 bits,
+                               // 2 = k_select_mx2 up to 64 bits, 3 = k_select_mx3 (three, batched drain) for compact records, else like 1
+    i64 opt_sample_ratio = 2;  // the sampled pass works on segments this many times longer than the select pass's
+    i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
+    i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
+    i64 opt_rank_cnt = 1;      // ... and ranks them with the per-thread counting sort (k_rank_cnt) where it applies
+    i64 real_grouped = 0;      // stat: the last real-valued ranking ordered its record lists group by group (k_real_group_*)
+    i64 opt_real_groups = 1;   // "real_groups": record lists beyond the LDS are split by score range and ordered group by group in LDS (0: the four radix passes)
+    i64 real_cap_boost = 1;    // the same for the real-valued ranking's slices (run_real)
+    i64 cap_boost = 1;         // slice capacity multiplier a lost bet escalated to on this database (run_oneshot); 1 after every load
+    i64 opt_rank_direct_lds = 80;    // "rank_direct_lds": KB of LDS a k_rank_direct block may take (80: two blocks per CU -- C1 0.25 ms vs 0.31 with 160 and one)
+    i64 opt_rank_direct = 1;   // "rank_direct": R = N on one shard in one counting-sort kernel, k_rank_direct, when its LDS fits (2: also N/8 < R < N)
+    i64 opt_rank_wave = 40;    // "rank_wave": one wavefront per query (k_rank_wave) for SHORT lists of one-byte records; the value is the
+                               // record capacity of a query's LDS share in tenths of the shard's share of R (+ 256; lists beyond it
+                               // go to k_rank_fused); 0 = off
+    i64 opt_rank_wave_max = 4608;   // "rank_wave_max": ... used when that capacity is at most this many records (<= 16128)
+    i64 opt_select_qt = 2;     // k_select_mx query tiles per wavefront (2: 4 wavefronts per SIMD, 4: 2)
+
+    // run state
+    bool optimistic = false;   // records come from a guessed threshold (fixed-capacity slices)
+    bool want_lists = true;
+    bool lists_valid = false;
+    u32 cap = 0;               // optimistic slice capacity
+    i64 crow = 0;              // record-row stride
+    i64 opt_runs = 0, opt_fallbacks = 0, opt_requeried = 0;
+    int opt_consecutive_fail = 0;   // one-shot bets lost in a row (this context only)
+    int shard_bet_fail = 0;         // sharded bets lost in a row: identical on every rank by construction
+    hg_ctx* sub = nullptr;     // child context (shares the database) that reruns single lost queries exactly
+    bool is_sub = false;
+
+    // device state
+    DevBuf db, dblab, qc, qlab;
+    DevBuf dbx, qx;            // fp4 images of db / qc in MFMA fragment order for k_select_mx (built on first use)
+    bool dbx_valid = false, qx_valid = false;
+    DevBuf dbx2, qx2;          // the same for k_select_mx2 (two rows per accumulator, codes of <= 64 bits)
+    bool dbx2_valid = false, qx2_valid = false;
+    DevBuf dbx8;               // i8 image of the database codes in A-fragment order (k_hist_i8), built on first use
+    bool dbx8_valid = false;
+    DevBuf dbx3;               // fp4 image for k_select_mx3 (48-row supertiles, three rows per accumulator), built on first use
+    bool dbx3_valid = false;
+    bool direct_rank = false;  // R = N: k_rank_fused computes distance and match bit per row itself (no records)
+    i64 opt_hist_mfma = 2;     // "hist_mfma": histograms (sampled pass; full pass of the one-shot exact sequence) on the matrix cores -- 2: the integer instruction delivers the counter address (k_hist_i8, codes of <= 128 bits), 1: fp4 distances (k_hist_mx), 0: vector ALU
+    bool hist_pairs = false;   // the last FULL histogram pass ran per segment pair (k_hist_mx)
+    bool exact_mx = false;     // the matrix-core select runs with the EXACT threshold (hg_hist + k_plan) instead of a guess
+    i64 opt_exact_mfma = 1;    // "exact_mfma": the one-shot exact sequence selects on the matrix cores when R << N
+    bool rec8 = false;         // the record rows hold one-byte compact records (matrix-core select, no lists wanted)
+    i64 opt_compact = 1;       // "compact_records": allow them
+    i64 opt_second_bet = 1;    // "second_bet": a lost one-shot bet is retried once with a wider margin before the exact sequence
+    i64 opt_rebets = 0;
+    i64 opt_lds_pad = 0;       // "lds_pad": extra dynamic LDS per block of the matrix-core select (occupancy experiments)
+    bool err_zeroed = false;   // the guess kernel of a one-shot bet already cleared err
+    i64 defer_verdict = 0;     // hg_rank does not wait for the bet's verdict; hg_bet_verdict reads it later
+    bool verdict_pending = false, verdict_known = false;
+    int verdict_flag = 0;
+    // pinned landing zone for a one-shot call's results: AP, hit counts and the lost-bet flag come back with the
+    // call's single synchronisation instead of three blocking copies into pageable memory afterwards
+    void* pin = nullptr;
+    size_t pin_cap = 0;
+    bool ap_staged = false;
+    DevBuf hist, hown, posbase, seglt, segtie;
+    DevBuf t, tguess, sstar, cnt_lt, quota, tie_before, n_lt, err;
+    DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
+    DevBuf mbits2;             // hg_merge_ranked's output (swapped with mbits)
+    DevBuf part;               // hg_merge_ap_part's output: {AP, hits} of this rank's queries + its verdict
+    bool ranked_local = false; // mbits holds this shard's bitmap in LOCAL rank order (hg_select_ranked)
+    DevBuf cand, out_idx, out_dist, mbits, shapes, ap_recip, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
+    DevBuf dbf, qf, samp, thr, sortA, sortB, scores, gtab;   // real-valued path
+    DevBuf dbfx;               // float features of the database in MFMA A-fragment order (k_real_select_mx), built on first use
+    bool dbfx_valid = false;
+    DevBuf sampx;              // float features of the sampled rows in MFMA A-fragment order (k_real_sample_mx), rebuilt per call
+    DevBuf dbfb, thr2, xmax2;  // filter + rescore path (hg_real_bf.hpp): bf16 image of the database, lowered cuts, max row norm^2
+    bool dbfb_valid = false;
+    i64 opt_real_sample_hits = 64;   // "real_sample_hits": the real-valued bet samples so that this many of a query's top R rows are in the sample
+    i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit
+    bool real_no_cut = false;     // the current real_attempt takes every row (thr = -inf)
+    bool real_filtered = false;   // the last real_select left unscored candidates that k_real_rescore completed
+    i64 real_attempts = 0;        // statistics of the last real-valued ranking: attempts made (1 = the first bet held) ...
+    i64 real_lds_ranked = 0;      // ... and whether the LDS-resident rank kernel produced its lists
+    i64 opt_real_mfma = 2;     // "real_mfma": 2 = bf16 filter on the matrix cores + exact rescoring of the survivors, 1 = exact float32 MFMA pass, 0 = vector ALU
+    int bpad = 0;              // feature count padded to a multiple of 16 (0: no float tables loaded)
+    i64 census_db[3] = {0, 0, 0}, census_q[3] = {0, 0, 0};
+    // hand-over of float32 / int64 arrays: packed on the host by a thread pool before the upload (hg_host_pack.hpp)
+    i64 opt_host_pack = 1;     // "host_pack": 0 = upload the raw arrays and pack on the GPU (k_pack_*)
+    i64 opt_keep_floats = 2;   // "keep_floats": database float table on the GPU -- 0 never, 1 always, 2 only if it is not a +-1 code
+    i64 opt_pack_threads = 0;  // "pack_threads": 0 = from the hardware (up to 96)
+    hipStream_t stream2 = nullptr;   // the float table's uploads while the packing pool works (pack_on_host)
+    hipEvent_t stream2_ev = nullptr;
+    void* fstage = nullptr;    // 4 x 16 MB of pinned staging for float tables on their way to the GPU (pack_on_host)
+    hipEvent_t fstage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* hpk = nullptr;       // pinned staging for the packed tables
+    size_t hpk_cap = 0;
+    bool dbf_resident = false, qf_resident = false;   // float tables as loaded: entries outside {-1,0,+1}, zeros, minus ones
+    bool real_lists = false;
+    i64 shapes_for_R = -1;
+    i64 recip_for_R = -1;      // ap_recip holds RN(1 / k) for k = 1 .. this
+    i64 opt_ap_recip = 1;      // "ap_recip": k_ap divides through the table of reciprocals (bit for bit the division; 0: divide)
+
+    // collectives (RCCL over xGMI), one communicator per context; gathered[] are the landing zones of hg_allgather
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    DevBuf gathered[4], scratch[4], comm_tmp, gath_idx, gath_dist;
+
+    // one-shot step as a hipGraph: the bet's whole sequence (memsets, ~7 kernels, the result download) is captured the
+    // second time hg_map sees the same problem and replayed afterwards -- one launch per step instead of ~15 enqueues,
+    // so the step time no longer depends on how fast the host can feed the stream
+    struct StepGraph {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        unsigned long long epoch = 0, cfg = 0, seen_epoch = 0, seen_cfg = 0;   // key of exec / of the last eager step
+        i64 R = -1, seen_R = -1;
+        int timing = -1, seen_timing = -1;
+        // host-side state the captured enqueue functions leave behind
+        unsigned stage = 0; bool optimistic = false, lists_valid = false; u32 cap = 0; i64 crow = 0, RW = 0; Geo geo{};
+        std::vector<Pending> evs;          // event-record nodes inside the graph (kernel timing)
+    } sg;
+    i64 opt_graph = 0;         // "step_graph": 1 = hg_map captures and replays its step (see run_oneshot); off by default
+    unsigned long long cfg_epoch = 1;      // bumped by everything that changes what a step enqueues (tables, options, stream)
+    bool capturing = false;
+    i64 graph_replays = 0, graph_captures = 0;
+
+    // timing
+    int timing = 0;            // 0 off, 1 the pair passes only (hist, select), 2 every kernel
+    double t_ms[KI_COUNT] = {0};
+    i64 t_n[KI_COUNT] = {0};
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+
+    int use() { HG_HIP(hipSetDevice(device)); return HG_OK; }
+
+    hipEvent_t get_event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    bool t_wanted(int id) const {
+        // 1: the select pass (the roofline kernel) and the step's span only -- every event pair costs the stream ~2-4 us
+        // and only on one step in "timing_every" (the averages are over the sampled launches)
+        return timing >= 2 || (timing == 1 && (id == KI_SELECT || id == KI_SELECT_MX || id == KI_STEP) &&
+                               (capturing || opt_timing_every <= 1 || t_seq % opt_timing_every == 0));
+    }
+    i64 opt_timing_every = 1;  // "timing_every": level-1 timing records its events on every n-th one-shot step only
+    i64 t_seq = 0;             // one-shot steps since timing was enabled
+    // while a step is being captured the events become event-record nodes of the graph and stay with it
+    std::vector<Pending>& t_list() { return capturing ? sg.evs : pending; }
+    bool t_open = false;
+    void t_begin(int id) {
+        t_open = t_wanted(id);
+        if (!t_open) return;
+        Pending p{id, get_event(), get_event()};
+        (void)hipEventRecord(p.a, stream);
+        t_list().push_back(p);
+    }
+    void t_end() {
+        if (!t_open) return;
+        t_open = false;
+        (void)hipEventRecord(t_list().back().b, stream);
+    }
+    // the whole step's span on the GPU (first enqueue to the last byte of the download): nests around the kernels' pairs
+    int step_slot = -1;
+    void t_step_begin() {
+        step_slot = -1;
+        ++t_seq;
+        if (!t_wanted(KI_STEP)) return;
+        Pending p{KI_STEP, get_event(), get_event()};
+        (void)hipEventRecord(p.a, stream);
+        step_slot = (int)t_list().size();
+        t_list().push_back(p);
+    }
+    void t_step_end() {
+        if (step_slot < 0) return;
+        (void)hipEventRecord(t_list()[step_slot].b, stream);
+        step_slot = -1;
+    }
+    void t_collect_graph() {   // after a replay has completed
+        for (auto& p : sg.evs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { t_ms[p.id] += ms; t_n[p.id] += 1; }
+        }
+    }
+    void drop_graph() {
+        if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
+        if (sg.graph) (void)hipGraphDestroy(sg.graph);
+        sg.exec = nullptr; sg.graph = nullptr;
+        for (auto& p : sg.evs) { pool.push_back(p.a); pool.push_back(p.b); }
+        sg.evs.clear();
+    }
+    void t_collect() {   // after a stream sync
+        for (auto& p : pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { t_ms[p.id] += ms; t_n[p.id] += 1; }
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+    int sync() {
+        HG_HIP(hipStreamSynchronize(stream));
+        if (pending.size() > 4096) t_collect();       // otherwise the elapsed times are read when somebody asks for them
+        return HG_OK;
+    }
+    // end of a staged call that only enqueued work: synchronise unless the caller orders everything on
+    // one stream itself (hg_set_stream + stage_sync = 0, e.g. torch's current stream in sharded mode)
+    int stage_end() { return stage_sync ? sync() : HG_OK; }
+    int check_launch(const char* what) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(HG_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+        return HG_OK;
+    }
+};
+
+
+inline int grid_for(i64 n, int per_block = 256) { return (int)((n + per_block - 1) / per_block); }
+inline int padded_grid(int nBlk) { return (nBlk + 7) / 8 * 8; }
+
+// ---- across translation units --------------------------------------------------------------------------------------
+// hg_core.hip
+int need(hg_ctx* c, unsigned st, const char* who, const char* what);     // stage check + hipSetDevice
+int upload_codes(hg_ctx* c, DevBuf& dst, const uint64_t* host, i64 n, int W, int NW);
+int ensure_pin(hg_ctx* c, size_t need_b);
+int do_match(hg_ctx* c);                         // k_match through the ranked idx list (> 128 classes, real-valued lists)
+int do_ap_range(hg_ctx* c, i64 q0, i64 nq);      // k_ap on queries [q0, q0 + nq)
+inline int do_ap(hg_ctx* c) { return do_ap_range(c, 0, c->geo.Q); }
+int read_plan_flag(hg_ctx* c, int* flag);        // *err back to the host (synchronises)
+int launch_min_topr(hg_ctx* c, const u32* idx_all, const u8* dist_all, i64 n, int G);
+// hg_seq.hip
+void make_geometry(hg_ctx* c);
+Geo hist_geometry(const hg_ctx* c);
+int set_R(hg_ctx* c, int64_t R, int G, int rank);
+// hg_pairs_valu.hip
+int launch_hist(hg_ctx* c);                      // k_hist<NW>
+int launch_select_valu(hg_ctx* c, int lw, bool optimistic);   // k_select<NW, LW, OPT>
+int launch_select_dense(hg_ctx* c, int lw);      // k_select_dense<NW, LW>
+// hg_pairs_mx.hip (k_select_mx: hg_pairs_mx1.hip)
+int ensure_mx_images(hg_ctx* c, bool need_db);  // fp4 images of database / query codes, built on first use
+int launch_hist_mx(hg_ctx* c);                   // k_hist_i8 / k_hist_mx
+int launch_select_mx(hg_ctx* c, int lw);         // k_select_mx<NW, LW, QT, COMPACT>
+int launch_select_mx2(hg_ctx* c, int lw);        // k_select_mx2 (codes of <= 64 bits)
+int launch_select_mx3(hg_ctx* c, int lw);        // k_select_mx3 (codes of <= 64 bits, one-byte records)
+// hg_comm.hip
+void comm_release(hg_ctx* c);                    // destroys the context's communicator, if any
+
+#define HG_DISPATCH_NW(fn, c, ...)                              \
+    switch ((c)->NW) {                                          \
+        case 1: return fn<1>(c, ##__VA_ARGS__);                 \
+        case 2: return fn<2>(c, ##__VA_ARGS__);                 \
+        case 3: return fn<3>(c, ##__VA_ARGS__);                 \
+        case 4: return fn<4>(c, ##__VA_ARGS__);                 \
+        case 5: return fn<5>(c, ##__VA_ARGS__);                 \
+        case 6: return fn<6>(c, ##__VA_ARGS__);                 \
+        case 7: return fn<7>(c, ##__VA_ARGS__);                 \
+        case 8: return fn<8>(c, ##__VA_ARGS__);                 \
+        default: return fail(HG_ERR_ARG, "unsupported code length: %d words", (c)->NW); \
+    }

@@ -22,6 +22,16 @@ namespace hg {
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) u32 lds_u32;
 
+// fire-and-forget LDS add whose address operand is a register holding the 32-bit LDS byte address (device pass only: on the
+// host an LDS pointer has no 32-bit form and the cast would only earn a warning per instantiation)
+__device__ __forceinline__ void lds_add_at(const u32 addr, const u32 inc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_add((lds_u32*)addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    (void)addr; (void)inc;
+#endif
+}
+
 __device__ __forceinline__ uint4 bits16_to_bytes(const u32 bits, const u32 one, const u32 zero) {   // bit i -> byte i: `one` or `zero`
     u32 w[4];
 #pragma unroll
@@ -38,7 +48,7 @@ __device__ __forceinline__ uint4 bits16_to_bytes(const u32 bits, const u32 one, 
 // (((G * NW + m) * 2 + hh) * 16 + r) * 16: byte i = 8 x bit (32 m + 16 hh + i) of row 16 G + r.  (A and B fragments of
 // the instruction map a lane's 16 bytes to the same 16 values of k, so any fixed bit -> byte assignment works as long
 // as the queries use the same one.)
-__global__ __launch_bounds__(256) void k_expand_db_i8(const u32* __restrict__ db, uint4* __restrict__ img, i64 N, i64 n16, int NW) {
+static __global__ __launch_bounds__(256) void k_expand_db_i8(const u32* __restrict__ db, uint4* __restrict__ img, i64 N, i64 n16, int NW) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n16 * NW * 2) return;
     const i64 row = i / (NW * 2);
@@ -131,11 +141,11 @@ void k_hist_i8(const u32* __restrict__ qc, const u8* __restrict__ dbx8, u32* __r
             if (whole) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    __hip_atomic_fetch_add((lds_u32*)(u32)acc[r], inc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    lds_add_at((u32)acc[r], inc[t]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if ((i64)r < left) __hip_atomic_fetch_add((lds_u32*)(u32)acc[r], inc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((i64)r < left) lds_add_at((u32)acc[r], inc[t]);
             }
         }
 #pragma unroll

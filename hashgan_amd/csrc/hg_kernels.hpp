@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_hist(const u32* __restrict__ qc, const 
 }
 
 // K2a  Hown[d][q] = sum over segments of hist[s][d][q].
-__global__ __launch_bounds__(256) void k_hist_reduce(const u32* __restrict__ hist, u32* __restrict__ hown, const Geo g) {
+static __global__ __launch_bounds__(256) void k_hist_reduce(const u32* __restrict__ hist, u32* __restrict__ hown, const Geo g) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 plane = (i64)g.NB * g.Qpad;
     if (i >= plane) return;
@@ -191,7 +191,7 @@ struct Plan {
     int* err;        // set when R exceeds the total row count
 };
 
-__global__ __launch_bounds__(256) void k_plan(const u32* __restrict__ hown, const u32* __restrict__ hall, int G, int rank,
+static __global__ __launch_bounds__(256) void k_plan(const u32* __restrict__ hown, const u32* __restrict__ hall, int G, int rank,
                                               Plan pl, const Geo g) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     const i64 plane = (i64)g.NB * g.Qpad + TAIL_WORDS;     // stride between the gathered shard histograms
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_plan(const u32* __restrict__ hown, cons
 }
 
 // K2c  per (segment, query): rows closer than t and rows at t in that segment.
-__global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ hist, const int* __restrict__ tq,
+static __global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ hist, const int* __restrict__ tq,
                                                     u32* __restrict__ seglt, u32* __restrict__ segtie, const Geo g) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;  // over S * Qpad
     if (i >= (i64)g.S * g.Qpad) return;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_seg_counts(const u32* __restrict__ hist
 // (closer-than-t rows + kept ties) at sl_start[s][q]; sl_tie[s][q] = how many of
 // the segment's ties are still inside the quota (ties are ranked shard-globally:
 // lower-ranked shards first, then index order).  tot[q] = records of the row.
-__global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ seglt, const u32* __restrict__ segtie,
+static __global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ seglt, const u32* __restrict__ segtie,
                                                     const u32* __restrict__ quota, const u32* __restrict__ tie_before,
                                                     u32* __restrict__ sl_start, u32* __restrict__ sl_tie,
                                                     u32* __restrict__ tot, int* __restrict__ sstar, int ratio, const Geo g) {
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_seg_layout(const u32* __restrict__ segl
 // records come up short of R and the bet is lost.
 // hseg: this shard's per-segment sample histograms [Sh][NB][Qpad] (k_hist's raw output), Sh segments
 // of `ratio` select-segments each.
-__global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, const u32* __restrict__ hall, int G, int rank,
+static __global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs, const u32* __restrict__ hall, int G, int rank,
                                                const u32* __restrict__ hseg, int Sh, int ratio,
                                                double sigma, i64 n_total, int* __restrict__ T, int* __restrict__ sstar,
                                                const Geo g) {
@@ -708,7 +708,7 @@ struct OrdArgs {
     i64 RW;                // 64-bit words per bit row
 };
 
-__global__ __launch_bounds__(256) void k_order(const u64* __restrict__ cand, const OrdArgs a,
+static __global__ __launch_bounds__(256) void k_order(const u64* __restrict__ cand, const OrdArgs a,
                                                u32* __restrict__ out_idx, u8* __restrict__ out_dist,
                                                u32* __restrict__ mbits32, int nbits, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
 // use_lds: the G local bitmap rows of the query are first copied into LDS with all loads in flight (the
 // stitching reads them bit range by bit range, one dependent load per 64 bits otherwise).
 // q0, q1: the queries this launch merges (a rank of the sharded bet takes its own share of them: hg_merge_ap_part).
-__global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restrict__ hall, const u64* __restrict__ ball, int G,
+static __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restrict__ hall, const u64* __restrict__ ball, int G,
                                                       i64 RW, u64* __restrict__ out, int* __restrict__ err,
                                                       u32* __restrict__ qbad, int use_lds, const Geo g, const int q0, const int q1) {
     extern __shared__ __attribute__((aligned(16))) u64 mrows[];       // [WPB][G][RW] when use_lds
@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restrict__ ha
 // row shares a positive label with the query.  One bit per slot, 64 slots per
 // wavefront via ballot.  Slots owned by another shard (IDX_NONE) give 0.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_match(const u32* __restrict__ out_idx, const u64* __restrict__ dblab,
+static __global__ __launch_bounds__(256) void k_match(const u32* __restrict__ out_idx, const u64* __restrict__ dblab,
                                                const u64* __restrict__ qlab, u64* __restrict__ mbits,
                                                i64 RW, int nKB, const Geo g) {
     const int q = (int)(blockIdx.x / (u32)nKB);          // nKB = ceil(R / 256) blocks per query
@@ -1200,12 +1200,12 @@ __global__ __launch_bounds__(256) void k_match(const u32* __restrict__ out_idx, 
 }
 
 // tail of an exported histogram: [0] overflow flag (cleared), [1] rows the pass visited, the rest 0
-__global__ void k_set_tail(u32* __restrict__ tail, u32 visited) {
+static __global__ void k_set_tail(u32* __restrict__ tail, u32 visited) {
     if (threadIdx.x < TAIL_WORDS) tail[threadIdx.x] = threadIdx.x == 1 ? visited : 0u;
 }
 
 // OR of G shards' bit rows (disjoint by construction).
-__global__ __launch_bounds__(256) void k_or_bits(const u64* __restrict__ all, u64* __restrict__ out, i64 n, int G) {
+static __global__ __launch_bounds__(256) void k_or_bits(const u64* __restrict__ all, u64* __restrict__ out, i64 n, int G) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     u64 v = 0;
@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(256) void k_or_bits(const u64* __restrict__ all, u6
 }
 
 // min over G shards' ranked lists: exactly one shard owns a slot, the others hold IDX_NONE / 0xFF.
-__global__ __launch_bounds__(256) void k_min_topr(const u32* __restrict__ idx_all, const u8* __restrict__ dist_all,
+static __global__ __launch_bounds__(256) void k_min_topr(const u32* __restrict__ idx_all, const u8* __restrict__ dist_all,
                                                   u32* __restrict__ idx, u8* __restrict__ dist, i64 n, int G) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1264,12 +1264,12 @@ __device__ __forceinline__ u32 count_bits_below(const u64* cw, int e) {  // bits
 }
 
 // recip[k] = RN(1 / k), k = 1 .. n: what turns k_ap's division into three multiply-adds (below)
-__global__ __launch_bounds__(256) void k_recip_table(double* __restrict__ recip, i64 n) {
+static __global__ __launch_bounds__(256) void k_recip_table(double* __restrict__ recip, i64 n) {
     const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
     if (k <= n) recip[k] = k ? 1.0 / (double)k : 0.0;
 }
 
-__global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits, i64 RW, i64 R,
+static __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits, i64 RW, i64 R,
                                                    const ApShape* __restrict__ shapes,  // [0] full chunk, [1] last chunk
                                                    const double* __restrict__ recip,    // [R + 1] or null
                                                    double* __restrict__ ap, u32* __restrict__ rel) {
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits
 // the host can tell +-1 codes from {0,1} bits from anything else (mixtures rank differently under np.dot than
 // under a Hamming distance -- metric.py:13) instead of silently ranking something else.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_sign_f32(const float* __restrict__ x, i64 ld, u32* __restrict__ out, i64 n, int b,
+static __global__ __launch_bounds__(256) void k_pack_sign_f32(const float* __restrict__ x, i64 ld, u32* __restrict__ out, i64 n, int b,
                                                        int NW, unsigned long long* __restrict__ bad) {
     const int lane = threadIdx.x & 63;
     const i64 r = (i64)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(256) void k_pack_sign_f32(const float* __restrict__
     if (nneg) atomicAdd(bad + 3, (unsigned long long)nneg);
 }
 
-__global__ __launch_bounds__(256) void k_pack_labels_i64(const long long* __restrict__ lab, u64* __restrict__ out, i64 n, int C,
+static __global__ __launch_bounds__(256) void k_pack_labels_i64(const long long* __restrict__ lab, u64* __restrict__ out, i64 n, int C,
                                                          int LW, unsigned long long* __restrict__ bad) {
     const int lane = threadIdx.x & 63;
     const i64 r = (i64)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -1440,7 +1440,7 @@ __global__ __launch_bounds__(256) void k_pack_labels_i64(const long long* __rest
 
 // Row gather / scatter between a full query set and the compacted set of queries whose bet
 // was lost: block i moves row (gather ? list[i] -> i : i -> list[i]) of `rowbytes` bytes.
-__global__ __launch_bounds__(256) void k_move_rows(const u8* __restrict__ src, u8* __restrict__ dst,
+static __global__ __launch_bounds__(256) void k_move_rows(const u8* __restrict__ src, u8* __restrict__ dst,
                                                    const u32* __restrict__ list, i64 rowbytes, int gather) {
     const i64 i = blockIdx.x;
     const i64 r = list[i];
@@ -1456,14 +1456,14 @@ __global__ __launch_bounds__(256) void k_move_rows(const u8* __restrict__ src, u
 }
 
 // fill helpers
-__global__ __launch_bounds__(256) void k_fill_u32(u32* __restrict__ p, u32 v, i64 n) {
+static __global__ __launch_bounds__(256) void k_fill_u32(u32* __restrict__ p, u32 v, i64 n) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
 }
 
 // What a rank of the sharded bet hands to the all-gather after merging + evaluating ITS queries [q0, q0 + nq): pairs of
 // doubles, pair i < nq = {AP, hit count} of query q0 + i, pairs nq .. width - 1 zero, pair `width` = {lost-bet flag, nq}.
-__global__ __launch_bounds__(256) void k_pack_part(const double* __restrict__ ap, const u32* __restrict__ rel, const int* __restrict__ err,
+static __global__ __launch_bounds__(256) void k_pack_part(const double* __restrict__ ap, const u32* __restrict__ rel, const int* __restrict__ err,
                                                    const i64 q0, const i64 nq, const i64 width, double* __restrict__ out) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i > width) return;

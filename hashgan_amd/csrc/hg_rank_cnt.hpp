@@ -42,7 +42,7 @@ __host__ __device__ inline RankCntLds rank_cnt_layout(int NB, i64 RW, int S, int
     return l;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_rank_cnt(const u64* __restrict__ cand, const RankLdsArgs a,
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_rank_cnt(const u64* __restrict__ cand, const RankLdsArgs a,
                                                   u32* __restrict__ out_idx, u8* __restrict__ out_dist,
                                                   u32* __restrict__ mbits32, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 rlds[];

@@ -50,7 +50,7 @@ __host__ __device__ inline RankDirectLds rank_direct_layout(int NB, i64 RW, int 
     return l;
 }
 
-__global__ __launch_bounds__(256) void k_rank_direct(const RankDirectArgs a, u32* __restrict__ out_idx, u8* __restrict__ out_dist,
+static __global__ __launch_bounds__(256) void k_rank_direct(const RankDirectArgs a, u32* __restrict__ out_idx, u8* __restrict__ out_dist,
                                                      u32* __restrict__ mbits32, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 dlds[];
     const int q = blockIdx.x;

@@ -36,7 +36,7 @@ __host__ __device__ inline RankWaveLds rank_wave_layout(int NB, i64 RW, int S, i
 }
 
 // Blocks are `blockDim.x / 64` independent wavefronts (the launcher picks 1 or 2: whatever packs the CU's LDS best).
-__global__ __launch_bounds__(256) void k_rank_wave(const u8* __restrict__ cand8, const RankLdsArgs a, u32* __restrict__ mbits32, const Geo g) {
+static __global__ __launch_bounds__(256) void k_rank_wave(const u8* __restrict__ cand8, const RankLdsArgs a, u32* __restrict__ mbits32, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 wlds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

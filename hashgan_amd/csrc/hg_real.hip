@@ -1,0 +1,442 @@
+// libhashgan_amd.so -- real-valued (float32 inner product) ranking, what main.py:157,164 feeds lib/metric.py:13-14:
+// sampled cut -> bf16 filter on the matrix cores -> exact float32 rescoring -> LDS ranking.
+#include "hg_ctx.hpp"
+#include "hg_real_kernels.hpp"
+#include "hg_real_mx.hpp"
+#include "hg_real_bf.hpp"
+
+namespace {
+template <int BP> int real_launch_sample(hg_ctx* c, i64 M, i64 stride) {
+    const Geo& g = c->geo;
+    const i64 units = (M + 63) / 64 * g.nQT;
+    c->t_begin(KI_REAL_SAMPLE);
+    hipLaunchKernelGGL(k_real_sample<BP>, dim3(grid_for(units, WPB)), dim3(256), (size_t)WPB * 64 * 65 * 4, c->stream,
+                       c->qf.as<float>(), c->dbf.as<float>(), c->samp.as<float>(), M, stride, g);
+    c->t_end();
+    return c->check_launch("k_real_sample");
+}
+template <int BP, int QPL> int real_launch_select_q(hg_ctx* c) {
+    Geo g = c->geo;
+    g.nQT = (g.Q + 64 * QPL - 1) / (64 * QPL);
+    g.nUnits = (i64)g.S * g.nQT;
+    g.wpb = WPB;
+    g.nBlk = (int)((g.nUnits + WPB - 1) / WPB);
+    RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
+    c->t_begin(KI_REAL_SELECT);
+    hipLaunchKernelGGL((k_real_select<BP, QPL>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(),
+                       c->dbf.as<float>(), a, c->cand.as<u64>(), g);
+    c->t_end();
+    return c->check_launch("k_real_select");
+}
+template <int BP> int real_launch_select(hg_ctx* c) {
+    // queries per lane (see k_real_select): two while their features fit the register file comfortably
+    if (BP <= 32 && c->opt_real_qpl == 2) return real_launch_select_q<BP, (BP <= 32 ? 2 : 1)>(c);
+    return real_launch_select_q<BP, 1>(c);
+}
+// real-valued select on the matrix cores: blocks = (pair of segments) x (256 queries)
+template <int KP> int real_launch_select_mx(hg_ctx* c) {
+    if (!c->dbfx_valid) {
+        const i64 n16 = (c->N + 15) / 16 * 16;
+        HG_TRY(c->dbfx.reserve((size_t)n16 * KP * 4));
+        const i64 items = n16 * (KP / 4);
+        c->t_begin(KI_PACK);
+        hipLaunchKernelGGL(k_expand_dbf, dim3(grid_for(items)), dim3(256), 0, c->stream, c->dbf.as<float>(), c->dbfx.as<float4>(),
+                           (i64)c->N, n16, KP, (i64)1);
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_dbf"));
+        c->dbfx_valid = true;
+    }
+    Geo g = c->geo;
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + WPB * 32 * RMX_QT - 1) / (WPB * 32 * RMX_QT);
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
+    c->t_begin(KI_REAL_SELECT);
+    hipLaunchKernelGGL((k_real_select_mx<KP>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream,
+                       c->qf.as<float>(), c->dbfx.as<u8>(), a, c->cand.as<u64>(), g);
+    c->t_end();
+    return c->check_launch("k_real_select_mx");
+}
+// filter + rescore (hg_real_bf.hpp): bf16 pair pass with a rigorous margin, then the exact chain for the survivors
+template <int KP> int real_launch_select_bf(hg_ctx* c) {
+    constexpr int QT = KP <= 128 ? 2 : 1;
+    if (!c->dbfb_valid) {
+        const i64 n16 = (c->N + 15) / 16 * 16;
+        HG_TRY(c->dbfb.reserve((size_t)n16 * KP * 2));
+        HG_TRY(c->xmax2.reserve(4));
+        HG_HIP(hipMemsetAsync(c->xmax2.p, 0, 4, c->stream));
+        c->t_begin(KI_PACK);
+        hipLaunchKernelGGL(k_expand_dbf_bf16, dim3(grid_for(n16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
+                           c->dbfb.as<uint4>(), (i64)c->N, n16, KP);
+        hipLaunchKernelGGL(k_row_norm_max, dim3(grid_for(c->N)), dim3(256), 0, c->stream, c->dbf.as<float>(), (i64)c->N, KP, c->xmax2.as<u32>());
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_dbf_bf16"));
+        c->dbfb_valid = true;
+    }
+    Geo g = c->geo;
+    HG_TRY(c->thr2.reserve((size_t)g.Qpad * 4));
+    c->t_begin(KI_REAL_GUESS);
+    hipLaunchKernelGGL(k_real_thr2, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->qf.as<float>(), c->thr.as<float>(),
+                       c->xmax2.as<u32>(), c->thr2.as<float>(), g.Q, KP);
+    c->t_end();
+    HG_TRY(c->check_launch("k_real_thr2"));
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + WPB * 32 * QT - 1) / (WPB * 32 * QT);
+    Geo gs = g;
+    gs.nQT = nQB;
+    gs.nUnits = (i64)nSP * nQB;
+    gs.wpb = WPB;
+    gs.nBlk = (int)gs.nUnits;
+    RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
+    c->t_begin(KI_REAL_SELECT);
+    if (real_bf_lds_bytes(KP) > 64 * 1024)
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_select_bf<KP, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, real_bf_lds_bytes(KP)));
+    hipLaunchKernelGGL((k_real_select_bf<KP, QT>), dim3(padded_grid(gs.nBlk)), dim3(256), real_bf_lds_bytes(KP), c->stream,
+                       c->qf.as<float>(), c->dbfb.as<u8>(), c->thr2.as<float>(), a, c->cand.as<u64>(), gs);
+    c->t_end();
+    HG_TRY(c->check_launch("k_real_select_bf"));
+    // slices per wavefront of the rescoring pass: about one round of 64 kept rows (the filter keeps ~2 R per query)
+    const double per_slice = 2.0 * (double)c->R / (double)g.S;
+    const int SG = per_slice * 8 <= 60 ? 8 : per_slice * 4 <= 60 ? 4 : per_slice * 3 <= 60 ? 3 : per_slice * 2 <= 60 ? 2 : 1;
+    const i64 waves = (i64)((g.S + SG - 1) / SG) * g.Q;
+    c->t_begin(KI_REAL_RESCORE);
+#define HG_RESCORE(sg)                                                                                                                   \
+    case sg:                                                                                                                             \
+        hipLaunchKernelGGL((k_real_rescore<(KP <= 128 ? KP : 0), sg>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(),  \
+                           c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(),               \
+                           c->sl_cnt.as<u32>(), KP, g);                                                                                  \
+        break;
+    switch (SG) { HG_RESCORE(8) HG_RESCORE(4) HG_RESCORE(3) HG_RESCORE(2) HG_RESCORE(1) }
+#undef HG_RESCORE
+    c->t_end();
+    c->real_filtered = true;
+    return c->check_launch("k_real_rescore");
+}
+int real_select_bf(hg_ctx* c) {
+    switch (c->bpad) {
+        case 16: return real_launch_select_bf<16>(c);
+        case 32: return real_launch_select_bf<32>(c);
+        case 48: return real_launch_select_bf<48>(c);
+        case 64: return real_launch_select_bf<64>(c);
+        case 80: return real_launch_select_bf<80>(c);
+        case 96: return real_launch_select_bf<96>(c);
+        case 112: return real_launch_select_bf<112>(c);
+        case 128: return real_launch_select_bf<128>(c);
+        case 144: return real_launch_select_bf<144>(c);
+        case 160: return real_launch_select_bf<160>(c);
+        case 176: return real_launch_select_bf<176>(c);
+        case 192: return real_launch_select_bf<192>(c);
+        case 208: return real_launch_select_bf<208>(c);
+        case 224: return real_launch_select_bf<224>(c);
+        case 240: return real_launch_select_bf<240>(c);
+        case 256: return real_launch_select_bf<256>(c);
+        default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 256 features (have %d)", c->b);
+    }
+}
+int real_select_mx(hg_ctx* c) {
+    switch (c->bpad) {
+        case 16: return real_launch_select_mx<16>(c);
+        case 32: return real_launch_select_mx<32>(c);
+        case 48: return real_launch_select_mx<48>(c);
+        case 64: return real_launch_select_mx<64>(c);
+        case 80: return real_launch_select_mx<80>(c);
+        case 96: return real_launch_select_mx<96>(c);
+        case 112: return real_launch_select_mx<112>(c);
+        case 128: return real_launch_select_mx<128>(c);
+        default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 128 features (have %d)", c->b);
+    }
+}
+
+#define HG_DISPATCH_BP(fn, c, ...)                                  \
+    switch ((c)->bpad / 2) {                                        \
+        case 8: return fn<8>(c, ##__VA_ARGS__);                     \
+        case 16: return fn<16>(c, ##__VA_ARGS__);                   \
+        case 24: return fn<24>(c, ##__VA_ARGS__);                   \
+        case 32: return fn<32>(c, ##__VA_ARGS__);                   \
+        case 40: return fn<40>(c, ##__VA_ARGS__);                   \
+        case 48: return fn<48>(c, ##__VA_ARGS__);                   \
+        case 56: return fn<56>(c, ##__VA_ARGS__);                   \
+        case 64: return fn<64>(c, ##__VA_ARGS__);                   \
+        default: return fail(HG_ERR_ARG, "real-valued ranking supports up to 128 features (have %d)", (c)->b); \
+    }
+// sample pass on the float32 MFMA: image of the M sampled rows (rebuilt per call: a few MB), 16 segments
+template <int KP> int real_launch_sample_mx(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
+    const i64 m16 = (M + 15) / 16 * 16;
+    HG_TRY(c->sampx.reserve((size_t)m16 * KP * 4));
+    c->t_begin(KI_REAL_SAMPLE);
+    hipLaunchKernelGGL(k_expand_dbf, dim3(grid_for(m16 * (KP / 4))), dim3(256), 0, c->stream, c->dbf.as<float>(), c->sampx.as<float4>(),
+                       M, m16, KP, stride);
+    Geo g = c->geo;
+    g.N = M;
+    i64 L = (M + 31) / 32;                               // ~32 segments (16 pairs) of a multiple of 16 rows
+    L = (L + 15) / 16 * 16;
+    g.L = L;
+    g.S = (int)((M + L - 1) / L);
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + WPB * 32 * RMX_QT - 1) / (WPB * 32 * RMX_QT);
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    hipLaunchKernelGGL((k_real_sample_mx<KP>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
+                       c->samp.as<float>(), mstride, g);
+    c->t_end();
+    return c->check_launch("k_real_sample_mx");
+}
+int real_sample_mx(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
+    switch (c->bpad) {
+        case 16: return real_launch_sample_mx<16>(c, M, stride, mstride);
+        case 32: return real_launch_sample_mx<32>(c, M, stride, mstride);
+        case 48: return real_launch_sample_mx<48>(c, M, stride, mstride);
+        case 64: return real_launch_sample_mx<64>(c, M, stride, mstride);
+        case 80: return real_launch_sample_mx<80>(c, M, stride, mstride);
+        case 96: return real_launch_sample_mx<96>(c, M, stride, mstride);
+        case 112: return real_launch_sample_mx<112>(c, M, stride, mstride);
+        default: return real_launch_sample_mx<128>(c, M, stride, mstride);
+    }
+}
+int real_sample(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
+    if (c->bpad <= 128 && c->opt_real_mfma) return real_sample_mx(c, M, stride, mstride);
+    if (c->bpad > 128) {                                 // k_real_sample keeps the query in registers: the staged form beyond
+        const Geo& g = c->geo;
+        const i64 units = (M + 63) / 64 * g.nQT;
+        const size_t lds = (size_t)WPB * (64 * 65 * 4 + 16 * 128);
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_sample_any), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->t_begin(KI_REAL_SAMPLE);
+        hipLaunchKernelGGL(k_real_sample_any, dim3(grid_for(units, WPB)), dim3(256), lds, c->stream, c->qf.as<float>(), c->dbf.as<float>(),
+                           c->samp.as<float>(), M, stride, c->bpad, g);
+        c->t_end();
+        return c->check_launch("k_real_sample_any");
+    }
+    (void)mstride;                                       // (the vector kernels write samp[q][M] densely: the caller passes mstride = M)
+    HG_DISPATCH_BP(real_launch_sample, c, M, stride)
+}
+int real_select(hg_ctx* c) {
+    c->real_filtered = false;
+    // without a cut (every row a record: R = N, or after lost bets) a filter filters nothing and every pair would be rescored:
+    // the exact float32 MFMA pass gives the scores at once (C1: 4.6 -> 4.0 ms per call)
+    const bool filter = c->opt_real_mfma == 2 && !(c->real_no_cut && c->bpad <= 128);
+    if ((filter || c->bpad > 128) && c->geo.L % 16 == 0) return real_select_bf(c);   // (the only pass for > 128 features)
+    if (c->opt_real_mfma && c->geo.L % 16 == 0) return real_select_mx(c);
+    HG_DISPATCH_BP(real_launch_select, c)
+}
+
+
+}  // namespace
+
+extern "C" {
+
+// ---- real-valued ranking: sample -> guess -> select -> 4-pass radix sort -> finish ----
+// one attempt; *lost = some query came up short of R records or overflowed a slice (bet mode only)
+static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double budget, bool with_ap, int* lost) {
+    ++c->real_attempts;
+    c->real_lds_ranked = 0;
+    c->real_no_cut = !bet;
+    make_geometry(c);
+    {   // Float rows are 4*bpad bytes (32x a 64-bit code): keep a segment's rows within ~512 KB so the few
+        // segments an XCD works on at a time stay in its 4 MiB L2 while all query tiles pass over them.
+        Geo& gg = c->geo;
+        i64 L = (i64)c->opt_real_seg_bytes / ((i64)c->bpad * 4);
+        L = L / 16 * 16;
+        if (L < 64) L = 64;
+        if (gg.L > L) {
+            gg.L = L;
+            gg.S = (int)((gg.N + L - 1) / L);
+            gg.nUnits = (i64)gg.S * gg.nQT;
+            gg.nBlk = (int)((gg.nUnits + WPB - 1) / WPB);
+        }
+    }
+    HG_TRY(set_R(c, R, 1, 0));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(c->thr.reserve(qb)); HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->failq.reserve(qb));
+    HG_TRY(c->tot.reserve(qb)); HG_TRY(c->err.reserve(4)); HG_TRY(c->qbad.reserve(qb));
+    HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
+    HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+    if (bet) {
+        // sample so that about 64 of a query's top R rows are in it; guess the cut `sigma` deviations deep
+        i64 stride = (i64)((double)R / (double)c->opt_real_sample_hits);
+        if (stride < 1) stride = 1;
+        const i64 M = (c->N + stride - 1) / stride;
+        const double fr = (double)R * (double)M / (double)c->N;
+        const u32 rank_s = (u32)std::ceil(fr + sigma * std::sqrt(fr)) + 1u;
+        // samp[q][mstride]: the matrix-core sample pass stores 16 samples at a time (rows 64-byte aligned), the vector kernels M densely
+        const i64 mstride = c->bpad <= 128 && c->opt_real_mfma ? (M + 15) / 16 * 16 : M;
+        HG_TRY(c->samp.reserve((size_t)g.Q * mstride * 4));
+        HG_TRY(real_sample(c, M, stride, mstride));
+        c->t_begin(KI_REAL_GUESS);
+        if (M <= RG_MMAX) hipLaunchKernelGGL(k_real_guess_lds, dim3(g.Q), dim3(1024), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
+        else hipLaunchKernelGGL(k_real_guess, dim3(g.Q), dim3(256), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
+        c->t_end();
+        HG_TRY(c->check_launch("k_real_guess"));
+        const double mean = budget * (double)R / (double)g.S;
+        u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
+        cap = (cap + 15u) & ~15u;                         // a multiple of the compact records' ring (16) and flush piece (8)
+        const u32 whole = (u32)((g.L + 15) & ~15ll);      // (a slice never needs more than its segment's rows)
+        c->cap = cap < whole ? cap : whole;
+    } else {
+        // no bet: every row becomes a record (thr = -inf), slices are whole segments
+        std::vector<float> ninf((size_t)g.Q, -INFINITY);
+        HG_HIP(hipMemcpyAsync(c->thr.p, ninf.data(), (size_t)g.Q * 4, hipMemcpyHostToDevice, c->stream));
+        HG_HIP(hipStreamSynchronize(c->stream));
+        c->cap = (u32)g.L;
+    }
+    c->crow = (i64)g.S * c->cap;
+    const size_t rows = (size_t)g.Q * c->crow * 8;
+    // the record rows; the global-memory ranking passes (a query whose records exceed the LDS, the exhaustive mode) need two
+    // more buffers of that size -- a widened bet (run_real) only goes as far as the rows alone stay moderate
+    if (bet && rows > (size_t)64 << 30) { *lost = 1; return HG_OK; }
+    if (!bet && rows * 3 > (size_t)200 << 30)
+        return fail(HG_ERR_NOMEM, "real-valued ranking: %zu GB of records needed (Q=%d, %lld per query)", rows * 3 >> 30, g.Q, (long long)c->crow);
+    HG_TRY(c->cand.reserve(rows));
+    HG_TRY(real_select(c));
+    const size_t slots = (size_t)g.Q * g.R;
+    HG_TRY(c->out_idx.reserve(slots * 4));
+    HG_TRY(c->scores.reserve(slots * 4));
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    if (c->real_filtered && bet && c->opt_real_sort_lds && g.S <= RK_SMAX && R <= RK_RMAX) {
+        // a query's records fit the LDS of one workgroup: copy + select + counting passes + ranked list in one kernel
+        constexpr int NA = 14336;
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_rank_lds<NA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)real_rank_lds_bytes<NA>()));
+        c->t_begin(KI_RADIX);
+        hipLaunchKernelGGL(k_real_rank_lds<NA>, dim3(g.Q), dim3(1024), real_rank_lds_bytes<NA>(), c->stream, c->cand.as<u64>(), c->crow, c->cap,
+                           c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->thr.as<float>(), c->out_idx.as<u32>(), c->scores.as<float>(),
+                           c->dblab.as<u64>(), c->qlab.as<u64>(), c->mbits.as<u64>(), c->RW, c->err.as<int>(), c->qbad.as<u32>(), g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_real_rank_lds"));
+        int flag = 0;
+        HG_TRY(read_plan_flag(c, &flag));
+        if (!(flag & 2)) {
+            c->real_lds_ranked = 1;
+            *lost = flag & 1;
+            c->stage = ST_DB | ST_Q | ST_SELECT;
+            if (*lost) return HG_OK;
+            c->stage |= ST_MATCH;                          // the rank kernel left the match bits too
+            if (with_ap) HG_TRY(do_ap(c));
+            return c->sync();
+        }
+        HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));    // some query's records exceed the LDS: the global-memory passes rank them all
+    }
+    if (rows * 3 > (size_t)200 << 30) {
+        if (bet) { *lost = 1; return HG_OK; }
+        return fail(HG_ERR_NOMEM, "real-valued ranking: %zu GB of records needed (Q=%d, %lld per query)", rows * 3 >> 30, g.Q, (long long)c->crow);
+    }
+    HG_TRY(c->sortA.reserve(rows)); HG_TRY(c->sortB.reserve(rows));
+    const int nwav = c->crow >= 16384 ? 16 : 4;
+    const size_t lds = (size_t)(nwav + 1) * 256 * 4;
+    u64* bufs[2] = {c->sortA.as<u64>(), c->sortB.as<u64>()};
+    const u64* in = c->cand.as<u64>();
+    bool grouped = false;
+    if (c->opt_real_groups && g.S <= 8192 && !bet && c->crow <= (i64)RG_MAXG * RG_CAP) {
+        // every row a record (R = N on a CIFAR-sized database): split by score range into LDS-sized groups, order each group
+        // in LDS (k_real_group_split / k_real_group_sort) -- two trips of the records through memory instead of the radix
+        // passes' four, 3.1 -> 0.85 ms at C1; piled-up scores come back as bit 2 of the flag.  (A bet's list beyond the LDS --
+        // 19 000 records in 489 short slices at R = 10 000 -- stays with the radix passes: 3.9 ms against 5.7 this way.)
+        HG_TRY(c->gtab.reserve((size_t)g.Q * (RG_MAXG + 1) * 4));
+        // (a group spans at least RG_CAP / 2 of cumulative count -- the largest bucket is at most RG_CAP / 2: at most 2 n / RG_CAP + 1 groups)
+        const int maxg = (int)std::min<i64>(RG_MAXG, 2 * c->crow / RG_CAP + 2);
+        // (per launch like everywhere else: the attribute is per DEVICE, and a process may hold contexts on several)
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_group_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)real_group_sort_lds()));
+        c->t_begin(KI_RADIX);
+        hipLaunchKernelGGL(k_real_group_split, dim3(g.Q), dim3(1024), real_group_split_lds(g.S), c->stream, c->cand.as<u64>(), c->crow, c->cap,
+                           c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->tot.as<u32>(), c->sortA.as<u64>(), c->gtab.as<u32>(), c->crow, c->err.as<int>(), maxg, g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_real_group_split"));
+        // the sort writes the ranked lists and the match bits itself (k_real_finish and k_match are for the radix passes)
+        HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+        HG_HIP(hipMemsetAsync(c->qbad.p, 0, (size_t)g.Qpad * 4, c->stream));
+        const GroupOut go{c->out_idx.as<u32>(), c->scores.as<float>(), c->mbits.as<u32>(), c->dblab.as<u64>(), c->qlab.as<u64>(), c->RW, g.R, g.LW, g.idx_base};
+        c->t_begin(KI_RADIX);
+        hipLaunchKernelGGL(k_real_group_sort, dim3(g.Q, maxg), dim3(1024), real_group_sort_lds(), c->stream, c->sortA.as<u64>(), c->gtab.as<u32>(),
+                           go, c->crow, c->err.as<int>());
+        c->t_end();
+        HG_TRY(c->check_launch("k_real_group_sort"));
+        int flag = 0;
+        HG_TRY(read_plan_flag(c, &flag));
+        if (flag & 4) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+        else grouped = true;
+    }
+    c->real_grouped = grouped ? 1 : 0;
+    if (grouped) {
+        c->stage = ST_DB | ST_Q | ST_SELECT | ST_MATCH;
+        if (with_ap) HG_TRY(do_ap(c));
+        HG_TRY(read_plan_flag(c, lost));
+        return HG_OK;
+    }
+    for (int pass = 0; pass < 4 && !grouped; ++pass) {
+        RadixArgs ra{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, c->crow, pass == 0, 32 + 8 * pass};
+        u64* out = bufs[pass & 1];
+        c->t_begin(KI_RADIX);
+        if (nwav == 16) hipLaunchKernelGGL(k_radix_pass<16>, dim3(g.Q), dim3(1024), lds, c->stream, in, out, ra, g);
+        else hipLaunchKernelGGL(k_radix_pass<4>, dim3(g.Q), dim3(256), lds, c->stream, in, out, ra, g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_radix_pass"));
+        in = out;
+    }
+    c->t_begin(KI_REAL_FINISH);
+    const i64 nKB = grid_for(g.R);
+    if (nKB * g.Q > 0x7FFFFFFFll) return fail(HG_ERR_ARG, "real-valued ranking: Q*R too large for one launch");
+    hipLaunchKernelGGL(k_real_finish, dim3((unsigned)(nKB * g.Q)), dim3(256), 0, c->stream, in, c->crow, c->tot.as<u32>(),
+                       c->out_idx.as<u32>(), c->scores.as<float>(), c->err.as<int>(), c->qbad.as<u32>(), (int)nKB,
+                       c->real_filtered ? c->thr.as<float>() : nullptr, g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_real_finish"));
+    c->stage = ST_DB | ST_Q | ST_SELECT;
+    HG_TRY(do_match(c));                               // label gather through the ranked idx list
+    if (with_ap) HG_TRY(do_ap(c));
+    HG_TRY(read_plan_flag(c, lost));
+    return HG_OK;
+}
+
+static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
+    if (!c->bpad || !c->dbf.p || !c->qf.p || !c->dbf_resident || !c->qf_resident)
+        return fail(HG_ERR_STATE, "real-valued ranking needs the float features on the GPU: load them with hg_set_database_f32 / "
+                                  "hg_set_queries_f32 (option keep_floats = 1 if the database is a +-1 code)");
+    if (c->n_total != c->N) return fail(HG_ERR_STATE, "real-valued ranking is single-shard");
+    if (R < 1 || R > c->N) return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->N);
+    int lost = 0;
+    c->real_attempts = 0;
+    if (R * 8 <= c->N && c->N >= 65536) {              // bet on a sampled cut; retry once deeper, then give up betting
+        const double boost0 = (double)c->real_cap_boost;
+        HG_TRY(real_attempt(c, R, true, 6.0, 3.0 * boost0, with_ap, &lost));
+        if (!lost) { c->real_lists = true; return HG_OK; }
+        // a deeper cut with twice the budget; then -- features that follow the labels in a database stored class by class
+        // put a query's top rows into a tenth of its slices -- eight and sixty-four times the slices' capacity, kept for
+        // the next calls on this database (the exhaustive mode below writes EVERY pair down: 80 GB at 10k x 1M)
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            if (attempt > 0) {
+                if (c->cap >= (u32)((c->geo.L + 15) & ~15ll)) break;      // a slice already holds its segment
+                c->real_cap_boost = c->real_cap_boost * 8 > 4096 ? 4096 : c->real_cap_boost * 8;
+            }
+            HG_TRY(real_attempt(c, R, true, 16.0, 6.0 * (double)c->real_cap_boost, with_ap, &lost));
+            if (!lost) {
+                if (attempt > 0 && c->real_cap_boost < 4096) c->real_cap_boost *= 2;     // (the budget that held: 6 = 2 x 3; a held plain retry changes nothing)
+                c->real_lists = true;
+                return HG_OK;
+            }
+        }
+        c->real_cap_boost = (i64)boost0;
+    }
+    HG_TRY(real_attempt(c, R, false, 0.0, 0.0, with_ap, &lost));
+    if (lost) return fail(HG_ERR_HIP, "real-valued ranking: internal error, exhaustive pass came up short");
+    c->real_lists = true;
+    return HG_OK;
+}
+
+int hg_topr_real(hg_ctx* c, int64_t R) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_topr_real", "hg_set_database_f32 + hg_set_queries_f32"));
+    return run_real(c, R, false);
+}
+
+int hg_map_real(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_map_real", "hg_set_database_f32 + hg_set_queries_f32"));
+    HG_TRY(run_real(c, R, true));
+    return hg_get_ap(c, host_ap, host_rel);
+}
+
+}  // extern "C"

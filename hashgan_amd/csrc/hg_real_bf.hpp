@@ -39,7 +39,7 @@ __device__ __forceinline__ u32 pack_bf16x2(float lo, float hi) {      // v_cvt_p
 // Database image in A-fragment order of v_mfma_f32_32x32x16_bf16: groups of 16 rows; chunk (group G, MFMA m, k-half
 // hh, row r) = 16 bytes at (((G * (KP/16) + m) * 2 + hh) * 16 + r) * 16 holding bf16 features 16 m + 8 hh .. + 7 of
 // row 16 G + r.
-__global__ __launch_bounds__(256) void k_expand_dbf_bf16(const float* __restrict__ dbf, uint4* __restrict__ img, i64 N, i64 n16, int KP) {
+static __global__ __launch_bounds__(256) void k_expand_dbf_bf16(const float* __restrict__ dbf, uint4* __restrict__ img, i64 N, i64 n16, int KP) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     const int per_row = KP / 8;
     if (i >= n16 * per_row) return;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_expand_dbf_bf16(const float* __restrict
 
 // max over the rows of |x|_2^2 (float32 sum of squares; the caller inflates it), as float bits (non-negative floats
 // order like unsigned integers).  out must be zeroed.
-__global__ __launch_bounds__(256) void k_row_norm_max(const float* __restrict__ dbf, i64 N, int KP, u32* __restrict__ out) {
+static __global__ __launch_bounds__(256) void k_row_norm_max(const float* __restrict__ dbf, i64 N, int KP, u32* __restrict__ out) {
     const i64 row = (i64)blockIdx.x * 256 + threadIdx.x;
     float s = 0.0f;
     if (row < N) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_row_norm_max(const float* __restrict__ 
 }
 
 // thr2[q] = thr[q] - eps[q], rounded down (see the header).  One thread per query, double arithmetic.
-__global__ __launch_bounds__(256) void k_real_thr2(const float* __restrict__ qf, const float* __restrict__ thr, const u32* __restrict__ xmax2,
+static __global__ __launch_bounds__(256) void k_real_thr2(const float* __restrict__ qf, const float* __restrict__ thr, const u32* __restrict__ xmax2,
                                                    float* __restrict__ thr2, int Q, int KP) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= Q) return;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
 // (64 sampled rows, 64 queries), lane = query.  16 rows at a time, 32 features at a time: the rows' pieces are staged
 // coalesced in LDS and read back as broadcasts, the lane's query piece sits in registers; each of the 16 accumulators
 // runs the float32 fma chain over k ascending, across the pieces.
-__global__ __launch_bounds__(256) void k_real_sample_any(const float* __restrict__ qf, const float* __restrict__ dbf, float* __restrict__ samp,
+static __global__ __launch_bounds__(256) void k_real_sample_any(const float* __restrict__ qf, const float* __restrict__ dbf, float* __restrict__ samp,
                                                          i64 M, i64 stride, const int KP, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 slds[];
     const int lane = threadIdx.x & 63;
@@ -798,7 +798,7 @@ __device__ __forceinline__ u32 rg_bucket(const u32 key, const float smax, const 
 }
 inline size_t real_group_split_lds(int S) { return ((size_t)S + 1 + RG_COARSE + RG_COARSE / 4 + 2 * (RG_MAXG + 1)) * 4; }
 
-__global__ __launch_bounds__(1024) void k_real_group_split(const u64* __restrict__ cand, i64 crow_in, u32 cap, const u32* __restrict__ sl_cnt,
+static __global__ __launch_bounds__(1024) void k_real_group_split(const u64* __restrict__ cand, i64 crow_in, u32 cap, const u32* __restrict__ sl_cnt,
                                                            const u32* __restrict__ fail, u32* __restrict__ tot, u64* __restrict__ grouped,
                                                            u32* __restrict__ gtab, i64 crow_out, int* __restrict__ err, const int maxg, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u32 gsl[];
@@ -920,7 +920,7 @@ struct GroupOut {
     u32* out_idx; float* scores; u32* mbits32; const u64* dblab; const u64* qlab; i64 RW; i64 R; int LW; u32 idx_base;
 };
 
-__global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __restrict__ grouped, const u32* __restrict__ gtab, const GroupOut o,
+static __global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __restrict__ grouped, const u32* __restrict__ gtab, const GroupOut o,
                                                           i64 crow, int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) u64 gso[];
     u64* A = gso;                                            // [RG_CAP] the group's records
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __restrict_
 // 1024 threads copy the query's samples (as order-preserving keys) once, then the same 11 + 11 + 10 bit radix select of
 // the rank_s-th largest runs out of LDS.  M <= RG_MMAX.
 constexpr int RG_MMAX = 16384;
-__global__ __launch_bounds__(1024) void k_real_guess_lds(const float* __restrict__ samp, i64 M, i64 mstride, u32 rank_s,
+static __global__ __launch_bounds__(1024) void k_real_guess_lds(const float* __restrict__ samp, i64 M, i64 mstride, u32 rank_s,
                                                          float* __restrict__ thr) {
     __shared__ u32 keys[RG_MMAX];
     __shared__ u32 hist[2048];

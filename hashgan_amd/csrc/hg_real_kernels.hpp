@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_real_sample(const float* __restrict__ q
 // pass keeps ip > thr[q], thr = the next float below that value (so ip >= it qualifies).
 // rank_s > M: everything qualifies (thr = -inf).
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_real_guess(const float* __restrict__ samp, i64 M, i64 mstride, u32 rank_s,
+static __global__ __launch_bounds__(256) void k_real_guess(const float* __restrict__ samp, i64 M, i64 mstride, u32 rank_s,
                                                     float* __restrict__ thr) {
     __shared__ u32 hist[2048];
     __shared__ u32 s_prefix, s_rank, s_wsum[4];
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NWAV * 64) void k_radix_pass(const u64* __restrict_
 // fewer than R records (guess too high) or an overflowed slice is flagged for the host.  thr (filter + rescore path,
 // hg_real_bf.hpp): the records are a superset of the rows scoring above thr[q], so the first R are the top R of all rows
 // only if the R-th still scores above it.
-__global__ __launch_bounds__(256) void k_real_finish(const u64* __restrict__ sorted, i64 crow, const u32* __restrict__ tot,
+static __global__ __launch_bounds__(256) void k_real_finish(const u64* __restrict__ sorted, i64 crow, const u32* __restrict__ tot,
                                                      u32* __restrict__ out_idx, float* __restrict__ scores,
                                                      int* __restrict__ err, u32* __restrict__ qbad, int nKB, const float* __restrict__ thr,
                                                      const Geo g) {

@@ -25,7 +25,7 @@ constexpr int RMX_QT = 2;                // query tiles (of 32) per wavefront
 // Database image in A-fragment order: groups of 16 rows; chunk (group G, m4, parity h, row r) = 16 bytes at
 // (((G * (KP/8) + m4) * 2 + h) * 16 + r) * 16 holding features 8 m4 + 2 u + h, u = 0..3, of row 16 G + r.
 // (rstride > 1: image row i is table row i * rstride -- the sample pass's image of every rstride-th row)
-__global__ __launch_bounds__(256) void k_expand_dbf(const float* __restrict__ dbf, float4* __restrict__ img, i64 N, i64 n16, int KP, i64 rstride) {
+static __global__ __launch_bounds__(256) void k_expand_dbf(const float* __restrict__ dbf, float4* __restrict__ img, i64 N, i64 n16, int KP, i64 rstride) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     const int per_row = KP / 4;                              // chunks per row: (KP / 8) m4 x 2 parities
     if (i >= n16 * per_row) return;

@@ -82,7 +82,7 @@ __device__ __forceinline__ uint4 expand_word(u32 x, bool query_side) {
 
 // Database image, in A-fragment order: rows in groups of 16; chunk (group G, mfma m, k-half kb, row ar)
 // = 16 bytes at (((G * NM + m) * 2 + kb) * 16 + ar) * 16 holding code word 2 m + kb of row 16 G + ar.
-__global__ __launch_bounds__(256) void k_expand_db(const u32* __restrict__ db, uint4* __restrict__ dbx, i64 N, i64 n16, int NW, int NM) {
+static __global__ __launch_bounds__(256) void k_expand_db(const u32* __restrict__ db, uint4* __restrict__ dbx, i64 N, i64 n16, int NW, int NM) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     const int wpr = 2 * NM;
     if (i >= n16 * wpr) return;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_expand_db(const u32* __restrict__ db, u
 }
 
 // Query image, in B-fragment order: chunk (query tile qt, mfma m, lane = 32 kb + j) at ((qt * NM + m) * 64 + lane) * 16
-__global__ __launch_bounds__(256) void k_expand_queries(const u32* __restrict__ qc, uint4* __restrict__ qx, i64 Q, i64 qpad, int NW, int NM) {
+static __global__ __launch_bounds__(256) void k_expand_queries(const u32* __restrict__ qc, uint4* __restrict__ qx, i64 Q, i64 qpad, int NW, int NM) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     const int wpr = 2 * NM;
     if (i >= qpad * wpr) return;

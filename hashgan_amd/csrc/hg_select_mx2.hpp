@@ -42,7 +42,7 @@ __host__ __device__ inline void m2_place(int rho, int& r, int& f) {
 
 // Database image: groups of 32 rows; chunk (group G, word w, field f, register r) = 16 bytes at
 // (((G * NW + w) * 2 + f) * 16 + r) * 16 holding code word w of the row that m2_place() puts at (r, f).
-__global__ __launch_bounds__(256) void k_expand_db2(const u32* __restrict__ db, uint4* __restrict__ dbx, i64 N, i64 n32, int NW) {
+static __global__ __launch_bounds__(256) void k_expand_db2(const u32* __restrict__ db, uint4* __restrict__ dbx, i64 N, i64 n32, int NW) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n32 * NW) return;
     const i64 row = i / NW;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_expand_db2(const u32* __restrict__ db, 
 
 // Query image: chunk (query tile qt, word w, lane = 32 kb + j) = word w of query 32 qt + j for BOTH k-halves,
 // as s = 2 q - 1: bit 1 -> +1.0 (0x2), bit 0 -> -1.0 (0xA).
-__global__ __launch_bounds__(256) void k_expand_queries2(const u32* __restrict__ qc, uint4* __restrict__ qx, i64 Q, i64 qpad, int NW) {
+static __global__ __launch_bounds__(256) void k_expand_queries2(const u32* __restrict__ qc, uint4* __restrict__ qx, i64 Q, i64 qpad, int NW) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= qpad * NW) return;
     const i64 q = i / NW;

@@ -65,7 +65,7 @@ __host__ __device__ inline void m3_place(int rho, int& f, int& r) {     // the i
 
 // Database image: supertiles of 48 rows; chunk (supertile G, tile f, k-half kb, register r) = 16 bytes at
 // (((G * 3 + f) * 2 + kb) * 16 + r) * 16 holding code word kb of row 48 G + m3_row(f, r) as 0.0 / -1.0 (fp4 0x0 / 0xA).
-__global__ __launch_bounds__(256) void k_expand_db3(const u32* __restrict__ db, uint4* __restrict__ dbx, i64 N, i64 n48, int NW) {
+static __global__ __launch_bounds__(256) void k_expand_db3(const u32* __restrict__ db, uint4* __restrict__ dbx, i64 N, i64 n48, int NW) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n48 * 2) return;
     const i64 row = i >> 1;

@@ -1,0 +1,1155 @@
+// libhashgan_amd.so -- the Hamming sequences: segment geometry, histogram -> plan -> select -> rank, in their staged
+// (sharded) and one-shot forms (lib/metric.py:13-19 as a counting selection).
+#include "hg_ctx.hpp"
+#include "hg_select_mx.hpp"
+#include "hg_select_mx3.hpp"
+#include "hg_hist_mx.hpp"
+#include "hg_rank_lds.hpp"
+#include "hg_rank_cnt.hpp"
+#include "hg_rank_wave.hpp"
+#include "hg_rank_direct.hpp"
+
+// Segment geometry of the pair passes: ~target_units wavefront-sized units.
+void make_geometry(hg_ctx* c) {
+    Geo& g = c->geo;
+    g.Q = (int)c->Q;
+    g.nQT = (int)((c->Q + 63) / 64);
+    g.Qpad = g.nQT * 64;
+    g.NW = c->NW; g.NB = c->NB; g.LW = c->LW;
+    g.N = c->N; g.R = c->R; g.idx_base = c->idx_base;
+    i64 S = (c->target_units + g.nQT - 1) / g.nQT;
+    // few queries: more segments than fill the GPU twice only make every query's record row longer to walk
+    // (Q = 64, N = 10M: 12500 slices per query cost the rank stage 3.4 ms; 2048 cost 0.1)
+    if (S > c->opt_max_segments) S = c->opt_max_segments;
+    const i64 maxS = (c->N + c->min_segment - 1) / c->min_segment;
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    i64 L = (c->N + S - 1) / S;
+    const i64 lq = (c->opt_select_packed >= 3 && c->NW <= 2) ? 96 : 32;   // k_select_mx2 walks segments in 32-row tiles, k_select_mx3 in 48-row supertiles
+    L = (L + lq - 1) / lq * lq;
+    if (L < lq) L = lq;
+    S = (c->N + L - 1) / L;
+    if (S < 1) S = 1;
+    if (c->opt_enable && c->opt_select_mfma && S >= 4) {
+        // k_select_mx runs (S / 2) x ceil(Q / 256 or 512) equal blocks, 4 or 2 resident per CU: pick the S near the
+        // target that fills a whole number of such rounds, so the last round is not a nearly empty one
+        const bool qt2 = c->NW <= 4;                                // mirrors launch_select_mx_t
+        const bool mx3 = c->opt_select_packed == 3 && c->NW <= 2;   // k_select_mx3: blocks of M3_WPB wavefronts x 64 queries
+        const i64 qblk = mx3 ? 64 * M3_WPB : qt2 ? 256 : 512;
+        const i64 nQB = (c->Q + qblk - 1) / qblk;
+        const i64 slots = (i64)c->n_cu * (mx3 ? 16 / M3_WPB : qt2 ? 4 : 2);
+        i64 k = (S / 2 * nQB + slots / 2) / slots;
+        if (k < 1) k = 1;
+        i64 S2 = 2 * (slots * k / nQB);
+        if (S2 > maxS) S2 = maxS / 2 * 2;
+        for (; S2 >= 4; S2 -= 2) {                 // rounding L up to 16 rows can drop segments: land on an even count
+            i64 L2 = (c->N + S2 - 1) / S2;
+            L2 = (L2 + lq - 1) / lq * lq;
+            const i64 Sr = (c->N + L2 - 1) / L2;
+            if (Sr * 4 < S * 3) break;             // too far from the target: keep the plain choice
+            if (Sr % 2 == 0 && Sr * 4 <= S * 5 && (Sr / 2) * nQB <= slots * k) { S = Sr; L = L2; break; }
+        }
+    }
+    g.S = (int)S; g.L = L;
+    g.nUnits = (i64)g.S * g.nQT;
+    g.hist_stride = 1;
+    g.hcap = 0;
+    g.wpb = WPB;
+    g.nBlk = (int)((g.nUnits + WPB - 1) / WPB);
+}
+
+// The sampled pass only needs the shard total: use 2x longer segments so the per-segment
+// histogram array (and its reduction) shrinks with the work.
+Geo hist_geometry(const hg_ctx* c) {
+    Geo g = c->geo;
+    if (g.hist_stride > 1 || c->hist_pairs) {
+        const i64 L = g.L * (c->hist_pairs ? 2 : c->opt_sample_ratio);
+        g.L = L;
+        g.S = (int)((g.N + L - 1) / L);
+        g.nUnits = (i64)g.S * g.nQT;
+    }
+    return g;
+}
+
+// histogram on the matrix cores: blocks = (pair of segments) x (256 queries); stride in tiles of 16 rows
+bool hist_mx_applies(const hg_ctx* c, int stride, bool pairs_ok) {
+    if (!c->opt_hist_mfma || !c->opt_select_mfma || c->NW > 8 || c->is_sub) return false;
+    {   // long segments (>= 65536 visited rows per pair) need one dword counter per query tile: with long codes the four
+        // wavefronts' columns then exceed the CU's LDS -- the vector kernel, which shrinks its block, takes those
+        const Geo& g = c->geo;
+        const i64 tiles_per_half = ((g.L + 15) / 16 + stride - 1) / stride;
+        const bool pack16 = 2 * tiles_per_half * 16 < 65536;
+        if ((size_t)WPB * (pack16 ? 1 : 2) * g.NB * 32 * 4 > 160u * 1024u) return false;
+    }
+    return stride > 1 ? c->opt_sample_ratio == 2 : pairs_ok;
+}
+// The record pass of the current sequence: which kernel takes it (the launchers live in hg_pairs_valu.hip / hg_pairs_mx.hip).
+int launch_select(hg_ctx* c) {
+    const int NW = c->NW;
+    const int lw = c->LW <= 2 ? c->LW : 0;           // > 128 classes: match bits come from k_match
+    // one-byte records (no index): only the matrix-core kernels of the bet produce them, and only when nobody wants the lists
+    const bool mx = c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS);
+    c->rec8 = mx && c->opt_compact && !c->want_lists && c->LW <= 2 && c->cap % 16 == 0 && c->crow * 64 < (1ll << 31);
+    if (!c->optimistic && c->R * 4 >= c->n_total) return launch_select_dense(c, lw);   // dense regime: most pairs are selected
+    // three rows per accumulator + batched drain: codes of <= 64 bits, one-byte records (<= 128 classes).  (For <= 32 bits the
+    // second k-half of every MFMA is empty, and it still beats k_select_mx2's two rows per accumulator: 0.69 vs 0.85 ms at b = 32.)
+    if (NW <= 2 && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) return launch_select_mx3(c, lw);
+    // two rows per accumulator: wins for one-word codes (half the MFMAs: 0.92 vs 1.02 ms at b = 32); for 33-64 bits
+    // its cheaper harvest (0.36 vs 0.44 ms) is eaten by the wider queue entries (select_packed = 2 forces it)
+    if (mx && c->geo.L % 32 == 0 &&
+        (((c->opt_select_packed == 1 || c->opt_select_packed >= 3) && NW == 1) || (c->opt_select_packed == 2 && NW <= 2)))
+        return launch_select_mx2(c, lw);
+    if (mx) return launch_select_mx(c, lw);
+    return launch_select_valu(c, lw, c->optimistic);
+}
+
+// rows k_hist visits with batch stride `stride` (mirrors its loop)
+template <int NW> i64 sampled_rows_t(Geo g, int stride, int ratio) {
+    g.hist_stride = stride;
+    {
+        const i64 L = g.L * ratio;                  // mirrors hist_geometry()
+        g.L = L;
+        g.S = (int)((g.N + L - 1) / L);
+    }
+    constexpr int B = Batch<NW>::rows;
+    i64 total = 0;
+    for (int s = 0; s < g.S; ++s) {
+        const i64 lo = (i64)s * g.L, hi = lo + g.L < g.N ? lo + g.L : g.N;
+        const i64 nb = (hi - lo) / B;
+        total += (nb + stride - 1) / stride * B;
+    }
+    return total;
+}
+i64 sampled_rows(hg_ctx* c, int stride) {
+    if (hist_mx_applies(c, stride, false)) return hist_mx_sampled_rows(c->geo, stride);
+    switch (c->NW) {
+        case 1: return sampled_rows_t<1>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 2: return sampled_rows_t<2>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 3: return sampled_rows_t<3>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 4: return sampled_rows_t<4>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 5: return sampled_rows_t<5>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 6: return sampled_rows_t<6>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 7: return sampled_rows_t<7>(c->geo, stride, (int)c->opt_sample_ratio);
+        default: return sampled_rows_t<8>(c->geo, stride, (int)c->opt_sample_ratio);
+    }
+}
+
+
+// =============================================================================
+extern "C" {
+
+static int do_hist(hg_ctx* c, int stride, bool reduce = true, bool pairs_ok = false, int hcap = 0) {
+    make_geometry(c);
+    c->geo.hist_stride = stride;
+    const bool mx = hist_mx_applies(c, stride, pairs_ok);
+    c->geo.hcap = mx && !reduce && stride > 1 ? hcap : 0;
+    c->hist_pairs = mx && stride == 1;                 // full pass per segment pair: the plan's per-segment steps follow suit
+    const Geo& g = c->geo;
+    const size_t plane = (size_t)g.NB * g.Qpad * 4;
+    HG_TRY(c->hist.reserve(plane * g.S));
+    HG_TRY(c->hown.reserve(plane + TAIL_WORDS * 4));
+    if (reduce) {   // tail of the exported histogram: [0] overflow flag, [1] rows this pass visited
+        const u32 visited = (u32)(stride == 1 ? g.N : sampled_rows(c, stride));
+        // written by a kernel: ordered with the kernels that read it, no pageable staging memory to keep alive
+        hipLaunchKernelGGL(k_set_tail, dim3(1), dim3(64), 0, c->stream, (u32*)(c->hown.as<char>() + plane), visited);
+        HG_TRY(c->check_launch("k_set_tail"));
+    }
+    HG_TRY(mx ? launch_hist_mx(c) : launch_hist(c));
+    if (!reduce) { c->stage = ST_DB | ST_Q; return HG_OK; }      // the caller reads the per-segment histograms itself
+    const Geo gh = hist_geometry(c);
+    c->t_begin(KI_HIST_REDUCE);
+    hipLaunchKernelGGL(k_hist_reduce, dim3(grid_for((i64)g.NB * g.Qpad)), dim3(256), 0, c->stream,
+                       c->hist.as<u32>(), c->hown.as<u32>(), gh);
+    c->t_end();
+    HG_TRY(c->check_launch("k_hist_reduce"));
+    c->stage = ST_DB | ST_Q | (stride == 1 ? ST_HIST : 0);
+    return HG_OK;
+}
+
+int hg_hist(hg_ctx* c) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_hist", "hg_set_database + hg_set_queries"));
+    HG_TRY(do_hist(c, 1));
+    return c->stage_end();
+}
+
+int hg_hist_buffer(hg_ctx* c, void** dev_ptr, int64_t* nbytes) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_hist_buffer", "hg_hist / hg_sample_hist / hg_select_candidates"));
+    if (!c->hown.p) return fail(HG_ERR_STATE, "hg_hist_buffer: no histogram computed yet");
+    if (dev_ptr) *dev_ptr = c->hown.p;
+    if (nbytes) *nbytes = ((int64_t)c->geo.NB * c->geo.Qpad + TAIL_WORDS) * 4;
+    return HG_OK;
+}
+
+extern "C++" int set_R(hg_ctx* c, int64_t R, int G, int rank) {
+    if (G < 1 || rank < 0 || rank >= G) return fail(HG_ERR_ARG, "rank %d of %d", rank, G);
+    if (R < 1 || R > c->n_total)
+        return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->n_total);
+    c->R = R; c->G = G; c->rank = rank;
+    c->geo.R = R;
+    c->RW = (R + 63) / 64;
+    return HG_OK;
+}
+
+// k_plan on c->hown (full histogram, or the records' histogram in optimistic mode)
+static int launch_plan(hg_ctx* c, const uint32_t* dev_hist_all) {
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(c->posbase.reserve((size_t)g.NB * qb));
+    HG_TRY(c->t.reserve(qb)); HG_TRY(c->cnt_lt.reserve(qb)); HG_TRY(c->quota.reserve(qb));
+    HG_TRY(c->tie_before.reserve(qb)); HG_TRY(c->n_lt.reserve(qb)); HG_TRY(c->err.reserve(4));
+    HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+    Plan pl{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->n_lt.as<u32>(),
+            c->posbase.as<u32>(), c->err.as<int>()};
+    c->t_begin(KI_PLAN);
+    hipLaunchKernelGGL(k_plan, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(),
+                       (const u32*)dev_hist_all, c->G, c->rank, pl, g);
+    c->t_end();
+    return c->check_launch("k_plan");
+}
+
+// exact plan: threshold from the full histogram, then the exact record-row layout
+static int do_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
+    if (G > 1 && !dev_hist_all) return fail(HG_ERR_ARG, "hg_plan: G > 1 needs the gathered histograms");
+    HG_TRY(set_R(c, R, G, rank));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(launch_plan(c, dev_hist_all));
+    HG_TRY(c->seglt.reserve((size_t)g.S * qb)); HG_TRY(c->segtie.reserve((size_t)g.S * qb));
+    HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
+    HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
+    HG_TRY(c->sstar.reserve(qb));
+    const Geo gp = hist_geometry(c);                   // per segment -- or per segment pair after k_hist_mx (then only sstar is used)
+    const int ratio = (int)(gp.L / g.L);
+    c->t_begin(KI_SEG_COUNTS);
+    hipLaunchKernelGGL(k_seg_counts, dim3(grid_for((i64)gp.S * g.Qpad)), dim3(256), 0, c->stream, c->hist.as<u32>(),
+                       c->t.as<int>(), c->seglt.as<u32>(), c->segtie.as<u32>(), gp);
+    c->t_end();
+    HG_TRY(c->check_launch("k_seg_counts"));
+    c->t_begin(KI_SEG_LAYOUT);
+    hipLaunchKernelGGL(k_seg_layout, dim3(grid_for(g.Qpad)), dim3(256), 0, c->stream, c->seglt.as<u32>(),
+                       c->segtie.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->sl_start.as<u32>(),
+                       c->sl_tie.as<u32>(), c->tot.as<u32>(), c->sstar.as<int>(), ratio, gp);
+    c->t_end();
+    HG_TRY(c->check_launch("k_seg_layout"));
+    c->optimistic = false;
+    c->crow = R;
+    c->cap = 0;
+    c->stage = ST_DB | ST_Q | ST_HIST | ST_PLAN;
+    return HG_OK;
+}
+
+static int check_plan_flag(hg_ctx* c) {
+    int err = 0;
+    HG_TRY(read_plan_flag(c, &err));
+    if (err) {
+        c->stage = ST_DB | ST_Q | ST_HIST;
+        return fail(HG_ERR_ARG, "R=%lld exceeds the rows present in the gathered histograms", (long long)c->R);
+    }
+    return HG_OK;
+}
+
+int hg_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
+    HG_TRY(need(c, ST_HIST, "hg_plan", "hg_hist"));
+    // a one-shot exact call may have left histograms per segment PAIR (k_hist_mx); the staged select lays its slices out
+    // per segment
+    if (c->hist_pairs) return fail(HG_ERR_STATE, "hg_plan called before hg_hist (the last histogram pass belonged to a one-shot call)");
+    HG_TRY(do_plan(c, R, dev_hist_all, G, rank));
+    // the device flag says "R exceeds the rows in the gathered histograms"; R <= n_total was checked on
+    // the host already, so an unsynchronised caller loses nothing by skipping the read-back
+    return c->stage_sync ? check_plan_flag(c) : HG_OK;
+}
+
+// k_rank_fused in one of its modes: 0 = histogram + plan + placement in one launch (single shard),
+// 1 = histogram phase (several shards, before the exchange), 2 = placement phase (after k_plan).
+// the dense regime in one kernel (k_rank_direct): fits when a block's LDS holds the counters, the R-bit bitmap and a tile of rows
+static i64 rank_direct_tile(const hg_ctx* c, int64_t R) {
+    if (!c->opt_rank_direct || c->LW > 2 || c->NW > 8 || c->b > 127) return 0;
+    const i64 RW = (R + 63) / 64;
+    const i64 fixed = rank_direct_layout(c->b + 1, RW, 0).total;
+    i64 tile = (c->opt_rank_direct_lds * 1024 - fixed) & ~(i64)15;
+    if (tile > 252 * 256) tile = 252 * 256;             // a thread's chunk must fit its byte counters
+    const i64 n8 = (c->N + 7) / 8 * 8;
+    if (tile > n8) tile = n8;
+    return tile >= 8192 || tile >= n8 ? tile : 0;
+}
+
+static int launch_rank(hg_ctx* c, int mode, int nbits) {
+    const Geo& g = c->geo;
+    if (c->direct_rank && mode == 0) {
+        const i64 tile = rank_direct_tile(c, g.R);
+        if (tile > 0) {
+            HG_TRY(c->err.reserve(4));
+            HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
+            const RankDirectLds L = rank_direct_layout(g.NB, c->RW, (int)tile);
+            if (L.total > 64 * 1024)
+                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_direct), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+            RankDirectArgs da{c->qc.as<u32>(), c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(),
+                              c->RW, (int)tile, c->want_lists ? 1 : 0};
+            c->t_begin(KI_RANK_FUSED);
+            hipLaunchKernelGGL(k_rank_direct, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, da, c->out_idx.as<u32>(), c->out_dist.as<u8>(),
+                               c->mbits.as<u32>(), g);
+            c->t_end();
+            return c->check_launch("k_rank_direct");
+        }
+    }
+    int nwav = c->opt_rank_waves ? (int)c->opt_rank_waves
+                                 : ((c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4);   // records per query ~ 3R / R
+    // k_rank_lds: the query's records resident in LDS -- room for ~2.5 R per query (the bet keeps 1.3-2 R),
+    // at most 64 KiB per block; queries with more are left to k_rank_fused (flagged in bigq)
+    bool use_lds = false;
+    i64 recs = 0;
+    const size_t fixed = ((size_t)5 * g.NB + 8 + 4 + 8 + 2 * (size_t)c->RW + (size_t)g.S + 2) * 4;
+    const size_t per_rec = c->want_lists ? 6 : 2;
+    if (c->optimistic && c->opt_rank_lds) {
+        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);    // this shard's part of the list
+        recs = (i64)(2.5 * (double)c->R * share) + 2048;   // small R: the guess's safety margin is relatively larger (R = 100 keeps ~4 R)
+        const i64 fit = fixed < 64 * 1024 ? (i64)((64 * 1024 - fixed) / per_rec) : 0;
+        if (recs > fit) recs = fit;
+        recs = recs / 64 * 64;
+        use_lds = (double)recs >= 2.0 * (double)c->R * share && recs >= 64;
+        if (use_lds) nwav = 4;                        // the two kernels share hwq's [Q][4][NB] layout
+    }
+    const size_t fixed_words = (size_t)(nwav + 1) * g.NB + 8;
+    const int bits_lds = (fixed_words + 2 * (size_t)c->RW) * 4 <= 64 * 1024;
+    if (mode != 1 && !bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+    HG_TRY(c->err.reserve(4));
+    HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
+    if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
+#ifdef HG_RANK_PROFILE
+    HG_TRY(c->hwq.reserve((size_t)4096 * 16 * 4 + (size_t)g.Q * nwav * g.NB * 4));
+#endif
+    if (mode == 0) {
+        if (c->optimistic) { if (!c->err_zeroed) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream)); }
+        else HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
+        c->err_zeroed = false;
+    }
+    const u32* only = nullptr;
+    bool counted = false;
+    if (c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_wave > 0 && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
+        g.S <= RW_SMAX) {
+        // one wavefront per query (k_rank_wave): no block barriers, 5 KB + the records of LDS per query in flight
+        // ... which pays for SHORT lists only (a sharded rank's share of R, a small R): a wavefront walks its query's records
+        // with 64 lanes where k_rank_cnt has 256, and at C2's 6500 records (16 KB of LDS per query, 10 in flight per CU) it
+        // is slower, 0.23 vs 0.19 ms; at 800 records (7 KB, 22 in flight) it wins, 0.105 vs 0.134 ms.
+        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
+        i64 r2 = (i64)(0.1 * (double)c->opt_rank_wave * (double)c->R * share) + 256;
+        if (r2 < 1024) r2 = 1024;
+        r2 = (r2 + 63) / 64 * 64;
+        if (r2 > (i64)c->opt_rank_wave_max) r2 = 0;                 // long lists: k_rank_cnt below
+        const int nbc = (mode == 0 && !c->exact_mx && c->G == 1) ? g.NB / 2 + 2 : 0;
+        const RankWaveLds L = rank_wave_layout(g.NB, c->RW, g.S, (int)r2, nbc);
+        // wavefronts per block: the split that wastes the least of a CU's 160 KB
+        const int fit1 = (int)(160 * 1024 / L.per_wave), fit2 = 2 * (int)(160 * 1024 / (2 * L.per_wave));
+        const int wpb = fit2 >= fit1 ? 2 : 1;
+        if (r2 > 0 && fit1 >= 4) {
+            HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
+            RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
+                           c->cap, c->crow, 0, 1, c->RW, (int)r2, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
+                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc};
+            const size_t lds = (size_t)wpb * L.per_wave;
+            if (lds > 64 * 1024)
+                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            c->t_begin(KI_RANK_LDS);
+            hipLaunchKernelGGL(k_rank_wave, dim3(grid_for(g.Q, wpb)), dim3(64 * wpb), lds, c->stream, c->cand.as<u8>(), la, c->mbits.as<u32>(), g);
+            c->t_end();
+            HG_TRY(c->check_launch("k_rank_wave"));
+            only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
+            counted = true;
+        }
+    }
+    if (!counted && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
+        // per-thread counting sort (k_rank_cnt): byte counters for every distance + a tile of the records, <= 64 KiB per
+        // block; lists longer than a tile are ranked tile by tile
+        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
+        i64 r2 = (i64)(2.5 * (double)c->R * share) + 256;         // a tile of the records: the usual list (1.3 - 2 R) in one
+        if (r2 < 4096) r2 = 4096;                                  // (small R: the guess's margin is relatively larger)
+        r2 = r2 / 64 * 64;
+        // a one-shot bet's guess stops below b/2 + 2 (enqueue_optimistic), so its records need no counters beyond: the
+        // block fits 32 KB and five of them a CU; a query with farther records (thin sample: everything taken) goes to k_rank_fused
+        const int nbc = (mode == 0 && !c->exact_mx && c->G == 1) ? g.NB / 2 + 2 : 0;
+        RankCntLds L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0, nbc);
+        while (L.total > 64 * 1024 && r2 > 64) { r2 -= 64; L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0, nbc); }
+        if (L.total <= 64 * 1024 && r2 >= 4096) {
+            HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
+            RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
+                           c->cap, c->crow, c->want_lists ? 1 : 0, c->rec8 ? 1 : 0, c->RW, (int)r2, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
+                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc};
+            c->t_begin(KI_RANK_LDS);
+            hipLaunchKernelGGL(k_rank_cnt, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, c->cand.as<u64>(), la, c->out_idx.as<u32>(),
+                               c->out_dist.as<u8>(), c->mbits.as<u32>(), g);
+            c->t_end();
+            HG_TRY(c->check_launch("k_rank_cnt"));
+            only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
+            counted = true;
+        }
+    }
+    if (use_lds && !counted) {
+        {
+            HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
+            if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
+            RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
+                           c->cap, c->crow, c->want_lists ? 1 : 0, c->rec8 ? 1 : 0, c->RW, (int)recs, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
+                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), 0};
+            const size_t lb = fixed + (size_t)recs * per_rec;
+            c->t_begin(KI_RANK_LDS);
+            hipLaunchKernelGGL(k_rank_lds<4>, dim3(g.Q), dim3(256), lb, c->stream, c->cand.as<u64>(), la, c->out_idx.as<u32>(),
+                               c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+            c->t_end();
+            HG_TRY(c->check_launch("k_rank_lds"));
+            only = c->bigq.as<u32>();                // k_rank_fused below only ranks what did not fit
+        }
+    }
+    RankArgs ra{c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(),
+                mode, c->hwq.as<u32>(), c->hown.as<u32>(), c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(),
+                c->tie_before.as<u32>(), c->posbase.as<u32>(),
+                c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW, only,
+                c->direct_rank ? 1 : 0, c->rec8 ? 1 : 0, c->db.as<u32>(), c->dblab.as<u64>(), c->qc.as<u32>(), c->qlab.as<u64>()};
+    const size_t lds_bytes = (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4;
+    c->t_begin(mode == 1 ? KI_CAND_HIST : KI_RANK_FUSED);
+    if (nwav == 16)
+        hipLaunchKernelGGL(k_rank_fused<16>, dim3(g.Q), dim3(1024), lds_bytes, c->stream, c->cand.as<u64>(), ra,
+                           c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+    else
+        hipLaunchKernelGGL(k_rank_fused<4>, dim3(g.Q), dim3(256), lds_bytes, c->stream, c->cand.as<u64>(), ra,
+                           c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+    c->t_end();
+    return c->check_launch("k_rank_fused");
+}
+
+// record pass + ordering (+ gather-based label match when labels are too wide for the record pass)
+static int do_select(hg_ctx* c) {
+    const Geo& g = c->geo;
+    const size_t slots = (size_t)g.Q * g.R;
+    if (c->LW > 2) c->want_lists = true;                  // k_match gathers through the idx list
+    HG_TRY(c->cand.reserve((size_t)g.Q * c->crow * 8));
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    HG_TRY(c->out_idx.reserve(c->want_lists ? slots * 4 : 16));
+    HG_TRY(c->out_dist.reserve(c->want_lists ? slots : 16));
+    if (c->want_lists && c->G > 1) {  // slots of other shards stay IDX_NONE / 0xFF
+        HG_HIP(hipMemsetAsync(c->out_idx.p, 0xFF, slots * 4, c->stream));
+        HG_HIP(hipMemsetAsync(c->out_dist.p, 0xFF, slots, c->stream));
+    }
+    HG_TRY(launch_select(c));
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    if (c->optimistic || c->G == 1) {
+        // one block per query: verify (optimistic) + plan + order.  Exact single-shard rows hold
+        // precisely the top R, so the same counting plan reproduces t and the bucket starts.
+        HG_TRY(launch_rank(c, 0, nbits));
+    } else {
+        const size_t lds_words = (size_t)g.NB + 2 * (size_t)c->RW;
+        const int bits_lds = WPB * lds_words * 4 <= 64 * 1024;
+        if (!bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+        OrdArgs oa{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(),
+                   c->tot.as<u32>(), c->crow, c->want_lists ? 1 : 0, bits_lds, c->RW};
+        c->t_begin(KI_ORDER);
+        hipLaunchKernelGGL(k_order, dim3(grid_for(g.Q, WPB)), dim3(256),
+                           (size_t)WPB * (g.NB + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4, c->stream, c->cand.as<u64>(), oa,
+                           c->out_idx.as<u32>(), c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_order"));
+    }
+    c->lists_valid = c->want_lists;
+    c->stage = (c->stage & (ST_DB | ST_Q | ST_HIST | ST_PLAN)) | ST_PLAN | ST_SELECT;
+    if (c->LW <= 2) c->stage |= ST_MATCH;                 // match bits came with the records
+    else HG_TRY(do_match(c));
+    return HG_OK;
+}
+
+int hg_select(hg_ctx* c) {
+    HG_TRY(need(c, ST_PLAN, "hg_select", "hg_plan"));
+    c->want_lists = c->staged_lists != 0;
+    HG_TRY(do_select(c));
+    return c->stage_end();
+}
+
+// ---- staged optimistic sequence (multi-shard): sample -> [gather] -> guess -> candidates ->
+// [gather] -> rank.  Mirrors the one-shot bet, with the two histogram exchanges made explicit.
+// Sampling stride of the bet, in row batches.  One row batch in 24: a fixed 4 % of a pass (with the
+// matrix-core select the sampling pass is a visible share of the step; 16 -> 24 trades 0.05 ms of it for
+// ~3 % more surplus records).  The
+// guess's safety margin is relative to sqrt(sampled hits), so a small R only means relatively more
+// surplus records (R = 100: ~3.5 R of them) -- still far cheaper than a full histogram pass.
+// Capacity of a (segment, query) slice of the bet: the budgeted mean + 6 sigma, never more than the segment's rows, and
+// the record rows of all queries together stay below 64 GB ("cap_boost" may ask for more than is sensible).
+static u32 slice_capacity(const hg_ctx* c, double mean) {
+    const Geo& g = c->geo;
+    u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
+    cap = (cap + 15u) & ~15u;                      // a multiple of the compact records' ring (16) and flush piece (8)
+    const u32 whole = (u32)((g.L + 15) & ~15ll);
+    if (cap > whole) cap = whole;
+    while (cap > 64u && (double)g.Q * (double)g.S * (double)cap * 8.0 > 64e9) cap = (cap / 2u + 15u) & ~15u;
+    return cap;
+}
+
+static int auto_stride(hg_ctx* c, int64_t R) {
+    (void)R;
+    return c->opt_stride > 0 ? (int)c->opt_stride : 24;
+}
+
+int hg_bet_eligible(hg_ctx* c, int64_t R, int world, int* eligible) {
+    if (!c || !eligible || world < 1) return fail(HG_ERR_ARG, "hg_bet_eligible: bad argument");
+    // only quantities every rank shares: options, R, the size of the whole database, the world size -- and the count of
+    // consecutive SHARDED bets lost, which only hg_merge_ranked / hg_rank / hg_bet_verdict touch, with a verdict that is
+    // computed from gathered data and therefore the same on every rank (one-shot calls keep their own counter)
+    const int stride = auto_stride(c, R);
+    const i64 per_shard = c->n_total / world;
+    *eligible = c->opt_enable && c->shard_bet_fail < 2 && stride >= 2 && R * 8 <= c->n_total && per_shard >= 65536;
+    return HG_OK;
+}
+
+int hg_sample_hist(hg_ctx* c, int64_t R) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_sample_hist", "hg_set_database + hg_set_queries"));
+    const int stride = auto_stride(c, R);
+    if (stride < 2) return fail(HG_ERR_ARG, "hg_sample_hist: R=%lld is too small to sample for", (long long)R);
+    HG_TRY(do_hist(c, stride));
+    return c->stage_end();
+}
+
+int hg_guess(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_guess", "hg_sample_hist"));
+    if (G > 1 && !dev_hist_all) return fail(HG_ERR_ARG, "hg_guess: G > 1 needs the gathered sample histograms");
+    HG_TRY(set_R(c, R, G, rank));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(c->tguess.reserve(qb));
+    HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
+    HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
+    HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
+    c->t_begin(KI_GUESS);
+    const Geo gh = hist_geometry(c);                   // the sampled pass ran on coarser segments
+    HG_TRY(c->sstar.reserve(qb));
+    hipLaunchKernelGGL(k_guess, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->hown.as<u32>(), (const u32*)dev_hist_all, G,
+                       rank, c->hist.as<u32>(), gh.S, (int)(gh.L / g.L), (double)c->opt_sigma, (i64)c->n_total,
+                       c->tguess.as<int>(), c->sstar.as<int>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_guess"));
+    // a guessed cut keeps at most ~2.6 R rows over ALL shards; a shard's share is proportional to its size,
+    // with the same 6-sigma headroom per slice as the one-shot bet
+    const double share = (double)c->N / (double)c->n_total;
+    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)c->cap_boost * (double)R * share / (double)g.S;
+    u32 cap = slice_capacity(c, mean);
+    c->optimistic = true;
+    c->cap = cap;
+    c->crow = (i64)g.S * cap;
+    c->stage = ST_DB | ST_Q | ST_PLAN;
+    return c->stage_end();
+}
+
+int hg_select_candidates(hg_ctx* c) {
+    HG_TRY(need(c, ST_PLAN, "hg_select_candidates", "hg_guess"));
+    if (!c->optimistic) return fail(HG_ERR_STATE, "hg_select_candidates: no guess in force (use hg_select after hg_plan)");
+    const Geo& g = c->geo;
+    c->want_lists = c->staged_lists != 0 || c->LW > 2;  // decides the record format (hg_rank places them)
+    HG_TRY(c->cand.reserve((size_t)g.Q * c->crow * 8));
+    HG_TRY(launch_select(c));
+    const size_t plane = (size_t)g.NB * g.Qpad * 4;
+    HG_HIP(hipMemsetAsync(c->hown.as<char>() + plane, 0, TAIL_WORDS * 4, c->stream));
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    HG_TRY(launch_rank(c, 1, nbits));                // per-wave and shard histograms of the records
+    return c->stage_end();
+}
+
+// Sharded bet, AP only: select, then rank THIS shard's records locally (rank kernels' mode 3).  What leaves the
+// shard is its per-distance record counts (hg_hist_buffer) and its match bitmap in local rank order
+// (hg_match_buffer); hg_merge_ranked stitches the global bitmap from the gathered pairs.  One exchange and one
+// pass over the records fewer than hg_select_candidates + hg_rank.
+int hg_select_ranked(hg_ctx* c) {
+    HG_TRY(need(c, ST_PLAN, "hg_select_ranked", "hg_guess"));
+    if (!c->optimistic) return fail(HG_ERR_STATE, "hg_select_ranked: no guess in force");
+    const Geo& g = c->geo;
+    // > 128 classes: the record pass leaves the match bit 0 (launch_select_nw instantiates LW = 0); the local bitmap
+    // then comes from k_match gathering the labels through the LOCAL ranked index list, so that list is kept
+    const bool wide = c->LW > 2;
+    c->want_lists = wide;
+    const size_t slots = (size_t)g.Q * g.R;
+    HG_TRY(c->cand.reserve((size_t)g.Q * c->crow * 8));
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    HG_TRY(c->out_idx.reserve(wide ? slots * 4 : 16)); HG_TRY(c->out_dist.reserve(wide ? slots : 16));
+    if (wide) HG_HIP(hipMemsetAsync(c->out_idx.p, 0xFF, slots * 4, c->stream));    // slots past the shard's own records: IDX_NONE
+    HG_TRY(c->err.reserve(4));
+    HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+    HG_TRY(launch_select(c));
+    const size_t plane = (size_t)g.NB * g.Qpad * 4;
+    HG_HIP(hipMemsetAsync(c->hown.as<char>() + plane, 0, TAIL_WORDS * 4, c->stream));
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    HG_TRY(launch_rank(c, 3, nbits));
+    c->lists_valid = false;
+    c->ranked_local = true;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT;
+    if (wide) HG_TRY(do_match(c));                    // metric.py:17-19 through the local list
+    c->want_lists = false;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_MATCH;     // hg_match_buffer hands out the LOCAL bitmap until the merge
+    return c->stage_end();
+}
+
+static int merge_ranked_range(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, i64 q0, i64 nq, const char* who) {
+    HG_TRY(need(c, ST_MATCH, who, "hg_select_ranked"));
+    if (!c->ranked_local) return fail(HG_ERR_STATE, "%s: hg_select_ranked has not run", who);
+    if (G < 1 || G > 64 || (G > 1 && (!dev_hist_all || !dev_bits_all)))
+        return fail(HG_ERR_ARG, "%s: bad argument (1 <= G <= 64, gathered buffers for G > 1)", who);
+    const Geo& g = c->geo;
+    if (q0 < 0 || nq < 0 || q0 + nq > g.Q) return fail(HG_ERR_ARG, "%s: queries [%lld, %lld) of %d", who, (long long)q0, (long long)(q0 + nq), g.Q);
+    HG_TRY(c->mbits2.reserve((size_t)g.Q * c->RW * 8));
+    HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
+    const u32* hall = G > 1 ? (const u32*)dev_hist_all : c->hown.as<u32>();
+    const u64* ball = G > 1 ? (const u64*)dev_bits_all : c->mbits.as<u64>();
+    const size_t rows_lds = (size_t)WPB * G * c->RW * 8;       // the G local bitmap rows of a block's four queries
+    const size_t cnt_lds = (size_t)WPB * G * g.NB * 4;         // their per-distance counts: at most 4 * 64 * 256 * 4 = 256 KiB ...
+    const int use_lds = rows_lds + cnt_lds <= 64 * 1024;
+    const size_t merge_lds = (use_lds ? rows_lds : 0) + cnt_lds;
+    if (merge_lds > 160 * 1024)                                // ... which only many shards of long codes reach
+        return fail(HG_ERR_ARG, "hg_merge_ranked: G=%d shards of %d-bit codes need %zu bytes of LDS per block (160 KiB available): "
+                                "use the staged sequence (hg_select_candidates / hg_rank)", G, c->b, merge_lds);
+    if (merge_lds > 64 * 1024)
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_ranked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds));
+    c->t_begin(KI_MERGE);
+    if (nq > 0)
+        hipLaunchKernelGGL(k_merge_ranked, dim3(grid_for(nq, WPB)), dim3(256), merge_lds, c->stream, hall, ball, G,
+                           c->RW, c->mbits2.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(), use_lds, g, (int)q0, (int)(q0 + nq));
+    c->t_end();
+    HG_TRY(c->check_launch("k_merge_ranked"));
+    std::swap(c->mbits, c->mbits2);                    // the global bitmap is what hg_ap and hg_get_match see
+    c->ranked_local = false;
+    c->G = G;
+    return HG_OK;
+}
+
+int hg_merge_ranked(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, int* bet_lost) {
+    if (!bet_lost) return fail(HG_ERR_ARG, "hg_merge_ranked: null argument");
+    HG_TRY(merge_ranked_range(c, dev_hist_all, dev_bits_all, G, 0, c ? c->geo.Q : 0, "hg_merge_ranked"));
+    if (c->defer_verdict) {
+        *bet_lost = -1;
+        c->verdict_pending = true;
+        c->verdict_known = false;
+        c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
+        return c->stage_end();
+    }
+    int flag = 0;
+    HG_TRY(read_plan_flag(c, &flag));
+    *bet_lost = flag;
+    c->opt_runs++;
+    if (flag) {
+        c->opt_fallbacks++;
+        c->shard_bet_fail++;
+        c->stage = ST_DB | ST_Q;
+        return HG_OK;
+    }
+    c->shard_bet_fail = 0;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
+    return HG_OK;
+}
+
+// bookkeeping after the verdict of a staged bet is known
+static int settle_bet(hg_ctx* c, int flag) {
+    c->opt_runs++;
+    if (flag) {
+        c->opt_fallbacks++;
+        c->shard_bet_fail++;
+        c->stage = ST_DB | ST_Q;
+        return HG_OK;
+    }
+    c->shard_bet_fail = 0;
+    c->lists_valid = c->want_lists;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT;
+    if (c->LW <= 2) c->stage |= ST_MATCH;
+    else HG_TRY(do_match(c));
+    return c->sync();
+}
+
+int hg_rank(hg_ctx* c, const uint32_t* dev_hist_all, int G, int rank, int* bet_lost) {
+    HG_TRY(need(c, ST_PLAN, "hg_rank", "hg_select_candidates"));
+    if (!c->optimistic) return fail(HG_ERR_STATE, "hg_rank: no guess in force");
+    if (!bet_lost || G < 1 || (G > 1 && !dev_hist_all)) return fail(HG_ERR_ARG, "hg_rank: bad argument");
+    const Geo& g = c->geo;
+    c->G = G; c->rank = rank;
+    c->want_lists = c->staged_lists != 0 || c->LW > 2;
+    const size_t slots = (size_t)g.Q * g.R;
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    HG_TRY(c->out_idx.reserve(c->want_lists ? slots * 4 : 16));
+    HG_TRY(c->out_dist.reserve(c->want_lists ? slots : 16));
+    if (c->want_lists && G > 1) {
+        HG_HIP(hipMemsetAsync(c->out_idx.p, 0xFF, slots * 4, c->stream));
+        HG_HIP(hipMemsetAsync(c->out_dist.p, 0xFF, slots, c->stream));
+    }
+    HG_TRY(launch_plan(c, dev_hist_all));
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    HG_TRY(launch_rank(c, 2, nbits));                // placement with the shared plan
+    if (c->defer_verdict) {
+        // the caller goes on as if the bet held (match bits, exchange, AP) and asks hg_bet_verdict at the end,
+        // together with its final download: no host round trip in the middle of the step
+        *bet_lost = -1;
+        c->verdict_pending = true;
+        c->verdict_known = false;
+        c->lists_valid = c->want_lists;
+        c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT;
+        if (c->LW <= 2) c->stage |= ST_MATCH;
+        else HG_TRY(do_match(c));
+        return c->stage_end();
+    }
+    int flag = 0;
+    HG_TRY(read_plan_flag(c, &flag));
+    *bet_lost = flag;
+    return settle_bet(c, flag);
+}
+
+int hg_bet_verdict(hg_ctx* c, int* bet_lost) {
+    if (!c || !bet_lost) return fail(HG_ERR_ARG, "hg_bet_verdict: null argument");
+    if (!c->verdict_pending) return fail(HG_ERR_STATE, "hg_bet_verdict: no deferred hg_rank outstanding");
+    c->verdict_pending = false;
+    int flag = 0;
+    if (c->verdict_known) flag = c->verdict_flag;      // came over with hg_get_ap's download
+    else HG_TRY(read_plan_flag(c, &flag));
+    c->verdict_known = false;
+    *bet_lost = flag;
+    if (!flag) { c->opt_runs++; c->shard_bet_fail = 0; return HG_OK; }
+    c->opt_runs++;
+    c->opt_fallbacks++;
+    c->shard_bet_fail++;
+    c->lists_valid = false;
+    c->stage = ST_DB | ST_Q;
+    return HG_OK;
+}
+
+// The sharded bet with the per-query stages SPLIT over the ranks: after the all-gather of record counts and local bitmaps
+// every rank merges and evaluates only its own queries [q0, q0 + nq) (instead of all Q on every rank), packs {AP, hits}
+// and its verdict into `part`; one small all-gather later hg_unpack_parts gives every rank all of it.
+int hg_merge_ap_part(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, int64_t q0, int64_t nq,
+                     int64_t width, void** dev_part, int64_t* nbytes) {
+    if (!c || !dev_part || !nbytes || width < nq || width < 1) return fail(HG_ERR_ARG, "hg_merge_ap_part: bad argument");
+    HG_TRY(merge_ranked_range(c, dev_hist_all, dev_bits_all, G, q0, nq, "hg_merge_ap_part"));
+    const Geo& g = c->geo;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
+    // AP of the merged rows only: k_ap's block index is the query
+    {
+        const i64 Qsave = c->geo.Q;
+        HG_TRY(c->ap.reserve((size_t)Qsave * 8));
+        HG_TRY(c->rel.reserve((size_t)Qsave * 4));
+        HG_TRY(do_ap_range(c, q0, nq));
+    }
+    if (!(q0 == 0 && nq == g.Q)) c->stage &= ~(unsigned)ST_MATCH;   // the merged bitmap holds rows [q0, q0 + nq) only: hg_get_match has nothing whole to hand out
+    const size_t pb = (size_t)(width + 1) * 16;
+    HG_TRY(c->part.reserve(pb));
+    hipLaunchKernelGGL(k_pack_part, dim3(grid_for(width + 1)), dim3(256), 0, c->stream, c->ap.as<double>(), c->rel.as<u32>(),
+                       c->err.as<int>(), (i64)q0, (i64)nq, (i64)width, c->part.as<double>());
+    HG_TRY(c->check_launch("k_pack_part"));
+    (void)g;
+    *dev_part = c->part.p;
+    *nbytes = (int64_t)pb;
+    return c->stage_end();
+}
+
+int hg_unpack_parts(hg_ctx* c, const void* dev_parts_all, int G, int64_t width, double* host_ap, int64_t* host_rel, int* bet_lost) {
+    if (!c || !dev_parts_all || G < 1 || width < 1 || !host_ap || !host_rel || !bet_lost) return fail(HG_ERR_ARG, "hg_unpack_parts: bad argument");
+    HG_TRY(c->use());
+    const i64 Q = c->geo.Q;
+    const size_t pb = (size_t)(width + 1) * 16, total = pb * (size_t)G;
+    HG_TRY(ensure_pin(c, total));
+    HG_HIP(hipMemcpyAsync(c->pin, dev_parts_all, total, hipMemcpyDeviceToHost, c->stream));
+    HG_TRY(c->sync());
+    int flag = 0;
+    i64 done = 0;
+    for (int r = 0; r < G; ++r) {
+        const double* p = (const double*)((const char*)c->pin + (size_t)r * pb);
+        const i64 n = (i64)p[2 * width + 1];
+        if (n < 0 || n > width || done + n > Q) return fail(HG_ERR_ARG, "hg_unpack_parts: rank %d reports %lld queries (width %lld, %lld of %lld placed)",
+                                                            r, (long long)n, (long long)width, (long long)done, (long long)Q);
+        flag |= p[2 * width] != 0.0;
+        for (i64 i = 0; i < n; ++i) { host_ap[done + i] = p[2 * i]; host_rel[done + i] = (int64_t)p[2 * i + 1]; }
+        done += n;
+    }
+    if (done != Q) return fail(HG_ERR_ARG, "hg_unpack_parts: the parts cover %lld of %lld queries", (long long)done, (long long)Q);
+    *bet_lost = flag;
+    c->verdict_pending = false;
+    c->verdict_known = false;
+    c->opt_runs++;                                     // the verdict comes from gathered data: the same on every rank
+    if (flag) {
+        c->opt_fallbacks++;
+        c->shard_bet_fail++;
+        c->lists_valid = false;
+        c->stage = ST_DB | ST_Q;
+    } else {
+        c->shard_bet_fail = 0;
+    }
+    return HG_OK;
+}
+
+// ---- one-shot forms: every stage enqueued back to back, one synchronisation ----
+// Optimistic bet (single shard, R << N): instead of a full histogram pass, sample
+// every stride-th row batch, guess the threshold a few sigma high, select a
+// superset with it, then verify: the records' exact histogram must contain R rows
+// and no slice may have overflowed.  The verified result is identical to the
+// exact path's; a failed bet reruns the exact path.
+static bool optimistic_eligible(hg_ctx* c, int64_t R, int* stride_out, u32* need_out) {
+    if (!c->opt_enable || c->opt_consecutive_fail >= 2) return false;
+    if (R * 8 > c->N || c->N < 65536) return false;
+    make_geometry(c);
+    const int stride = auto_stride(c, R);
+    if (stride < 2) return false;
+    const i64 sampled = sampled_rows(c, stride);
+    const double fr = (double)R * (double)sampled / (double)c->N;   // expected sample count at the true cut
+    const double need = fr + (double)c->opt_sigma * std::sqrt(fr) + 1.0;
+    *stride_out = stride;
+    *need_out = (u32)std::ceil(need);
+    return true;
+}
+
+// R = N on one shard (the reference's CIFAR-10 setting): every row is a member of every ranked list, so nothing
+// has to be selected or written down -- the ranking kernel walks the shard's rows directly, computing each row's
+// distance and match bit from the codes and labels in both of its passes (counting, then stable placement).
+static int enqueue_all_rows(hg_ctx* c, int64_t R) {
+    make_geometry(c);
+    HG_TRY(set_R(c, R, 1, 0));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    const size_t slots = (size_t)g.Q * g.R;
+    HG_TRY(c->err.reserve(4)); HG_TRY(c->failq.reserve(qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->sl_cnt.reserve(qb));
+    HG_TRY(c->cand.reserve(64));
+    HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    HG_TRY(c->out_idx.reserve(c->want_lists ? slots * 4 : 16));
+    HG_TRY(c->out_dist.reserve(c->want_lists ? slots : 16));
+    HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+    c->optimistic = false;
+    c->crow = R;
+    c->cap = 0;
+    int nbits = 1;
+    while ((1 << nbits) < g.NB) ++nbits;
+    c->direct_rank = true;
+    c->rec8 = false;
+    const int rc = launch_rank(c, 0, nbits);
+    c->direct_rank = false;
+    HG_TRY(rc);
+    c->lists_valid = c->want_lists;
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
+    return HG_OK;
+}
+
+static int enqueue_exact(hg_ctx* c, int64_t R) {
+    if (c->N == c->n_total && R == c->N && c->opt_all_rows && c->LW <= 2 && c->NW <= 8)
+        return enqueue_all_rows(c, R);                 // one-shot calls are single-shard
+    // (k_rank_direct ranks ANY R from the rows themselves, but with one block per query it re-reads the whole database per
+    // query and runs one wavefront per SIMD: measured against k_hist + k_select + k_rank_fused it loses for N/8 < R < N --
+    // 15.7 vs 12.3 ms at N = 200k, R = 100k; 82 vs 70 ms at N = 1M, R = 500k -- so only "rank_direct" = 2 routes that regime to it)
+    if (c->opt_rank_direct == 2 && c->N == c->n_total && R * 8 > c->N && c->opt_all_rows && !c->is_sub && rank_direct_tile(c, R) > 0)
+        return enqueue_all_rows(c, R);
+    HG_TRY(do_hist(c, 1));
+    HG_TRY(do_plan(c, R, nullptr, 1, 0));
+    return do_select(c);
+}
+
+// The exact sequence with its second pass on the matrix cores (one shard, R << N): full histogram -> plan (exact
+// threshold t, and sstar = the last segment whose ties at t are still inside the quota) -> k_select_mx with T = t,
+// fixed-capacity slices -> the bet's rank stage, which cuts the ties at the quota.  Nothing is guessed, so the only way
+// this can fail is a slice overflowing its capacity (clustered rows): *err then, and the caller runs enqueue_exact.
+static bool exact_mx_applies(const hg_ctx* c, int64_t R) {
+    return c->opt_exact_mfma && c->opt_select_mfma && c->N == c->n_total && R * 8 <= c->N && c->N >= 65536 && !c->is_sub;
+}
+static int enqueue_exact_mx(hg_ctx* c, int64_t R) {
+    HG_TRY(do_hist(c, 1, true, true));                 // per segment pair on the matrix cores where that applies
+    HG_TRY(do_plan(c, R, nullptr, 1, 0));              // c->t, c->sstar; leaves optimistic = false, crow = R
+    const Geo& g = c->geo;
+    // in all the slices hold R records + the ties of one segment beyond the quota, but unevenly: segments up to sstar carry
+    // ALL their rows at distance t (the cut bucket is typically the fullest), later ones none -- budget like the bet does
+    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)R / (double)g.S;
+    u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
+    cap = (cap + 15u) & ~15u;
+    c->optimistic = true;
+    c->exact_mx = true;
+    c->cap = cap;
+    c->crow = (i64)g.S * cap;
+    HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
+    const int rc = do_select(c);
+    c->exact_mx = false;
+    return rc;
+}
+
+static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
+    (void)need_cnt;
+    // the guess stops at the cut, far below b/2 when R <= N/8 on any data whose queries resemble the database: the
+    // sampled pass writes only those planes (130 -> 68 MB per launch at C2).  A cut beyond them reads as a thin
+    // sample -- everything is taken, the slices overflow, the exact sequence answers.
+    HG_TRY(do_hist(c, stride, false, false, c->NB / 2 + 2));
+    HG_TRY(set_R(c, R, 1, 0));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(c->tguess.reserve(qb));
+    HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
+    HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
+    HG_TRY(c->err.reserve(4));
+    HG_TRY(c->sstar.reserve(qb));
+    c->t_begin(KI_GUESS);
+    const Geo gh = hist_geometry(c);                   // the sampled pass ran on coarser segments
+    {   // lanes per query by the number of sampled segments each has to sum
+        const int ratio = (int)(gh.L / g.L);
+        const u32 srows = (u32)sampled_rows(c, stride);
+#define HG_GUESS(P)                                                                                                     \
+        hipLaunchKernelGGL(k_guess_direct<P>, dim3(grid_for(g.Qpad, WPB * (64 / P))), dim3(256), 0, c->stream,          \
+                           c->hist.as<u32>(), gh.S, ratio, (double)c->opt_sigma, (i64)c->n_total, srows,                \
+                           c->tguess.as<int>(), c->sstar.as<int>(), c->failq.as<u32>(), c->err.as<int>(), g)
+        // (more lanes per query shorten a lane's share of a plane but scatter a wavefront's loads over more lines: with 64
+        // lanes for every query that the chip has room for, Q = 1000 went 0.068 -> 0.090 ms, C3 0.032 -> 0.061)
+        if (gh.S <= 64) HG_GUESS(4);
+        else if (gh.S <= 512) HG_GUESS(16);
+        else HG_GUESS(64);
+#undef HG_GUESS
+    }
+    c->t_end();
+    HG_TRY(c->check_launch("k_guess_direct"));
+    c->err_zeroed = true;                              // launch_rank need not clear the lost-bet flag again
+    // slice capacity: a guessed cut typically keeps 1.3-3 R rows (the guess overshoots by at most one
+    // distance bucket, and cumulative counts grow ~2x per bucket in the tail where the cut lies; clustered
+    // codes grow faster) -- budget 4 R per query over the S segments plus 6 sigma per slice.  HBM is
+    // plentiful (2.5 GB at C2); an overflow only costs the exact rerun.
+    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)c->cap_boost * (double)R / (double)g.S;
+    u32 cap = slice_capacity(c, mean);
+    c->optimistic = true;
+    c->cap = cap;
+    c->crow = (i64)g.S * cap;
+    c->stage = ST_DB | ST_Q | ST_PLAN;
+    return do_select(c);
+}
+
+static int enqueue_exact(hg_ctx* c, int64_t R);
+
+// Lost bets are per query (a short superset, an overflowed slice).  When only a few queries lost,
+// rerun just those through the exact sequence in a child context that borrows the database
+// tables, and patch their results into place.  *handled = false: too many, caller reruns all.
+static int rerun_lost_queries(hg_ctx* c, int64_t R, bool lists, bool with_ap, bool* handled) {
+    *handled = false;
+    const Geo g = c->geo;
+    std::vector<u32> bad((size_t)g.Q);
+    HG_HIP(hipMemcpyAsync(bad.data(), c->qbad.p, (size_t)g.Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HG_TRY(c->sync());
+    std::vector<u32> lost;
+    for (int q = 0; q < g.Q; ++q) if (bad[(size_t)q]) lost.push_back((u32)q);
+    const i64 nF = (i64)lost.size();
+    if (nF == 0 || nF * 8 > g.Q) return HG_OK;
+    if (!c->sub) {
+        c->sub = new hg_ctx();
+        c->sub->is_sub = true;
+        c->sub->device = c->device;
+        c->sub->stream = c->stream;                  // same stream: ordered with the parent's work
+    }
+    hg_ctx* s = c->sub;
+    s->N = c->N; s->b = c->b; s->C = c->C; s->n_total = c->n_total; s->NW = c->NW; s->NB = c->NB; s->LW = c->LW;
+    s->idx_base = c->idx_base;
+    s->target_units = c->target_units; s->min_segment = c->min_segment; s->opt_enable = 0;
+    // a handful of queries: the per-segment bookkeeping (k_hist_reduce, k_seg_layout walk S segments per query) costs more than
+    // the pair passes themselves -- 2048 segments: 0.8 ms of a 1 ms rerun; 256 keep every CU busy and cost 0.1
+    s->opt_max_segments = 256;
+    s->timing = 0;
+    s->db.borrow(c->db);
+    s->dblab.borrow(c->dblab);
+    s->Q = nF;
+    HG_TRY(c->flist.reserve((size_t)nF * 4));
+    HG_HIP(hipMemcpyAsync(c->flist.p, lost.data(), (size_t)nF * 4, hipMemcpyHostToDevice, c->stream));
+    HG_TRY(s->qc.reserve((size_t)nF * c->NW * 4 + 64 * 4));
+    HG_TRY(s->qlab.reserve((size_t)nF * c->LW * 8));
+    auto move = [&](const void* src, void* dst, i64 rowbytes, int gather) {
+        hipLaunchKernelGGL(k_move_rows, dim3((unsigned)nF), dim3(256), 0, c->stream, (const u8*)src, (u8*)dst,
+                           c->flist.as<u32>(), rowbytes, gather);
+    };
+    move(c->qc.p, s->qc.p, (i64)c->NW * 4, 1);
+    move(c->qlab.p, s->qlab.p, (i64)c->LW * 8, 1);
+    HG_TRY(c->check_launch("k_move_rows"));
+    s->stage = ST_DB | ST_Q;
+    s->want_lists = lists;
+    HG_TRY(enqueue_exact(s, R));
+    if (with_ap) HG_TRY(do_ap(s));
+    move(s->mbits.p, c->mbits.p, c->RW * 8, 0);
+    if (with_ap) {
+        move(s->ap.p, c->ap.p, 8, 0);
+        move(s->rel.p, c->rel.p, 4, 0);
+    }
+    if (lists) {
+        move(s->out_idx.p, c->out_idx.p, R * 4, 0);
+        move(s->out_dist.p, c->out_dist.p, R, 0);
+    }
+    HG_TRY(c->check_launch("k_move_rows"));
+    HG_TRY(c->sync());                               // `lost` (the H2D source) must outlive the copy
+    c->opt_requeried += nF;
+    *handled = true;
+    return HG_OK;
+}
+
+// The bet's sequence for hg_map, enqueued on the stream: sampled histogram -> guess -> select -> verify + order ->
+// AP -> flag, AP and hit counts into pinned memory.  Pure enqueue (no synchronisation, no allocation once the
+// buffers are warm), so it can run under stream capture.
+static int enqueue_bet_with_ap(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
+    c->t_step_begin();
+    HG_TRY(enqueue_optimistic(c, R, stride, need_cnt));
+    HG_TRY(do_ap(c));
+    const size_t Q = (size_t)c->geo.Q;
+    char* pb = (char*)c->pin;                  // [flag 16 B][ap Q x 8][rel Q x 4]
+    HG_HIP(hipMemcpyAsync(pb, c->err.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(hipMemcpyAsync(pb + 16, c->ap.p, Q * 8, hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(hipMemcpyAsync(pb + 16 + Q * 8, c->rel.p, Q * 4, hipMemcpyDeviceToHost, c->stream));
+    c->t_step_end();
+    return HG_OK;
+}
+
+// Second sighting of the same step (same tables, options, R, timing level; no buffer moved since): capture it.
+static int capture_step(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
+    c->drop_graph();
+    const unsigned long long epoch0 = g_alloc_epoch.load();
+    HG_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    c->capturing = true;
+    const int rc = enqueue_bet_with_ap(c, R, stride, need_cnt);
+    c->capturing = false;
+    hipGraph_t gr = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->stream, &gr);
+    if (rc != HG_OK || e != hipSuccess || !gr || g_alloc_epoch != epoch0) {
+        if (gr) (void)hipGraphDestroy(gr);
+        c->drop_graph();
+        (void)hipGetLastError();
+        if (rc != HG_OK) return rc;
+        return fail(HG_ERR_HIP, "step capture failed: %s", e != hipSuccess ? hipGetErrorString(e) : "a buffer moved during capture");
+    }
+    hipGraphExec_t ex = nullptr;
+    const hipError_t e2 = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+    if (e2 != hipSuccess) {
+        (void)hipGraphDestroy(gr);
+        c->drop_graph();
+        return fail(HG_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2));
+    }
+    auto& sg = c->sg;
+    sg.graph = gr; sg.exec = ex;
+    sg.epoch = g_alloc_epoch; sg.cfg = c->cfg_epoch; sg.R = R; sg.timing = c->timing;
+    sg.stage = c->stage; sg.optimistic = c->optimistic; sg.lists_valid = c->lists_valid; sg.cap = c->cap; sg.crow = c->crow;
+    sg.RW = c->RW; sg.geo = c->geo;
+    c->graph_captures++;
+    return HG_OK;
+}
+
+static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
+    c->real_lists = false;
+    int stride = 0;
+    u32 need_cnt = 0;
+    if (R < 1 || R > c->n_total)
+        return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->n_total);
+    c->want_lists = lists;
+    const bool bet = optimistic_eligible(c, R, &stride, &need_cnt);
+    int flag = 0;
+    if (bet) {
+        c->opt_runs++;
+        if (with_ap) {
+            HG_TRY(ensure_pin(c, (size_t)c->Q * 12 + 16));
+            auto& sg = c->sg;
+            bool launched = false;
+            // event-record nodes inside a graph turned out slow and unreliable on ROCm 7.2 (a replayed step took 1.9 ms
+            // instead of 1.55, elapsed times came back for one replay in twenty): with kernel timing on, steps stay eager
+            if (c->opt_graph && !lists && !c->is_sub && c->timing == 0) {
+                const bool same = sg.exec && sg.epoch == g_alloc_epoch && sg.cfg == c->cfg_epoch && sg.R == R && sg.timing == c->timing;
+                const bool seen = sg.seen_epoch == g_alloc_epoch && sg.seen_cfg == c->cfg_epoch && sg.seen_R == R && sg.seen_timing == c->timing;
+                if (!same && seen) {
+                    if (capture_step(c, R, stride, need_cnt) != HG_OK) c->opt_graph = 0;      // not fatal: stay eager from now on
+                }
+                if (c->sg.exec && c->sg.epoch == g_alloc_epoch && c->sg.cfg == c->cfg_epoch && c->sg.R == R && c->sg.timing == c->timing) {
+                    HG_HIP(hipGraphLaunch(sg.exec, c->stream));
+                    HG_TRY(c->sync());
+                    c->t_collect_graph();
+                    // what the captured enqueue functions leave behind on the host side
+                    HG_TRY(set_R(c, R, 1, 0));
+                    c->geo = sg.geo; c->RW = sg.RW; c->stage = sg.stage; c->optimistic = sg.optimistic; c->lists_valid = sg.lists_valid;
+                    c->cap = sg.cap; c->crow = sg.crow; c->err_zeroed = false;
+                    c->graph_replays++;
+                    launched = true;
+                }
+            }
+            if (!launched) {
+                HG_TRY(enqueue_bet_with_ap(c, R, stride, need_cnt));
+                HG_TRY(c->sync());
+                sg.seen_epoch = g_alloc_epoch; sg.seen_cfg = c->cfg_epoch; sg.seen_R = R; sg.seen_timing = c->timing;
+            }
+            flag = *(const int*)c->pin;
+            c->ap_staged = flag == 0;
+        } else {
+            HG_TRY(enqueue_optimistic(c, R, stride, need_cnt));
+            HG_TRY(read_plan_flag(c, &flag));
+        }
+        if (!flag) { c->opt_consecutive_fail = 0; return HG_OK; }
+        bool handled = false;                      // some queries lost their bet
+        HG_TRY(rerun_lost_queries(c, R, lists, with_ap, &handled));
+        if (handled) { c->opt_consecutive_fail = 0; return HG_OK; }
+        // many queries lost.  Before paying for the exact two-pass sequence (3x the bet at C2), bet once more with
+        // twice the safety margin and twice the record budget -- the verification is what makes either bet exact.
+        // Still lost: the hits crowd into few segments (a database stored class by class: ten classes put ten times the
+        // mean into a query's slices), which no margin on the CUT cures -- escalate the slices' capacity (x8, x64, until a
+        // slice would hold its whole segment) and remember what worked for the next calls on this database.
+        if (c->opt_second_bet) {
+            const i64 sigma0 = c->opt_sigma, budget0 = c->cand_budget_x10, boost0 = c->cap_boost;
+            for (int attempt = 0; attempt < 3; ++attempt) {
+                if (attempt > 0) {
+                    if (c->cap >= (u32)((c->geo.L + 15) & ~15ll)) break;               // a slice already holds a segment
+                    if ((double)c->geo.Q * (double)c->crow * 8.0 * 8.0 > 64e9) break;  // the record rows would not fit comfortably
+                    c->cap_boost = c->cap_boost * 8 > 4096 ? 4096 : c->cap_boost * 8;
+                }
+                c->opt_sigma = 2 * sigma0 + 2;
+                c->cand_budget_x10 = 2 * budget0;
+                c->opt_rebets++;
+                c->want_lists = lists;
+                int rc;
+                if (with_ap) {
+                    rc = enqueue_bet_with_ap(c, R, stride, need_cnt);
+                    if (rc == HG_OK) rc = c->sync();
+                    flag = *(const int*)c->pin;
+                    c->ap_staged = rc == HG_OK && flag == 0;
+                } else {
+                    rc = enqueue_optimistic(c, R, stride, need_cnt);
+                    if (rc == HG_OK) rc = read_plan_flag(c, &flag);
+                }
+                c->opt_sigma = sigma0;
+                c->cand_budget_x10 = budget0;
+                if (rc != HG_OK) { c->cap_boost = boost0; return rc; }
+                // held with twice the budget of a first bet at this boost: the next call's first bet gets that budget
+                // (a class-sorted database of tight clusters lost every first bet at x8 and won every second one)
+                // -- only when a WIDENED attempt was the one that held: a held plain second bet (attempt 0) says the margin was
+                // short this once, not that the slices are too small, and must not ratchet every later first bet's budget up
+                auto keep = [&] {
+                    if (attempt > 0 && c->cap_boost < 4096) c->cap_boost *= 2;
+                    c->opt_consecutive_fail = 0;
+                    c->cfg_epoch++;
+                };
+                if (!flag) { keep(); return HG_OK; }
+                handled = false;
+                HG_TRY(rerun_lost_queries(c, R, lists, with_ap, &handled));
+                if (handled) { keep(); return HG_OK; }
+            }
+            c->cap_boost = boost0;                 // nothing helped: do not keep paying for big slices
+        }
+        c->opt_fallbacks++;                        // still too many: exact path for all
+        c->opt_consecutive_fail++;
+        c->want_lists = lists;
+    }
+    if (exact_mx_applies(c, R)) {
+        c->want_lists = lists;
+        c->t_step_begin();
+        HG_TRY(enqueue_exact_mx(c, R));
+        if (with_ap) HG_TRY(do_ap(c));
+        c->t_step_end();
+        HG_TRY(read_plan_flag(c, &flag));
+        if (!flag) return HG_OK;
+        c->want_lists = lists;                         // a slice overflowed: the vector-ALU select with exact-sized slices
+    }
+    c->t_step_begin();
+    HG_TRY(enqueue_exact(c, R));
+    if (with_ap) HG_TRY(do_ap(c));
+    c->t_step_end();
+    return check_plan_flag(c);
+}
+
+int hg_topr(hg_ctx* c, int64_t R) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_topr", "hg_set_database + hg_set_queries"));
+    return run_oneshot(c, R, true, false);
+}
+
+int hg_map(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_map", "hg_set_database + hg_set_queries"));
+    HG_TRY(run_oneshot(c, R, false, true));
+    return hg_get_ap(c, host_ap, host_rel);
+}
+
+}  // extern "C"

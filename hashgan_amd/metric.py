@@ -59,6 +59,7 @@ class RetrievalEngine:
     def __init__(self, device=0):
         self.ctx = _native.Context(device)
         self.b = self.C = self.N = self.db_kind = self.db_src = None
+        self.resident = None           # _evaluate's shortcut: (codes, labels, mode) of the arrays whose packed copy is on the GPU
 
     def close(self):
         self.ctx.close()
@@ -165,6 +166,7 @@ def _load_database(eng, db_codes, db_labels, mode="reference", floats=None):
     by inner product: never for the spellings that binarise or insist on binary codes, and in 'reference' mode only if
     the database is not a +-1 code (a +-1 database meeting real-valued queries is uploaded again with it, below)."""
     eng.b = eng.C = eng.N = eng.db_kind = eng.db_src = None      # nothing is resident until this load has succeeded
+    eng.resident = None                               # whoever loads another database (extra_metrics, MAPs) ends _evaluate's shortcut
     eng.ctx.set_option("keep_floats", floats if floats is not None else (2 if mode == "reference" else 0))
     bad_c, bad_l = eng.ctx.set_database_f32(db_codes, db_labels)
     if bad_l:
@@ -212,8 +214,11 @@ def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, mode):
     with eng.lock:
         # the same read-only arrays as the last call (an evaluation loop over one database): the packed copy on the GPU
         # is still theirs -- skip pack + upload, like MAPs does (a writable array may have changed in place: reload)
-        res = getattr(eng, "resident", None)
+        # (every load goes through _load_database, which clears `resident`: another database loaded into this shared
+        # engine in between -- extra_metrics -- can never be mistaken for this one)
+        res = eng.resident
         same = (res is not None and res[0] is db_codes and res[1] is db_labels and res[2] == mode
+                and eng.db_src is not None and eng.db_src[0] is db_codes and eng.db_src[1] is db_labels
                 and not db_codes.flags.writeable and not db_labels.flags.writeable)
         if not same:
             eng.resident = None

@@ -112,18 +112,40 @@ def exchange_id(rank, world, make_id, nbytes, timeout=300.0, path=None):
         return uid
     t0 = time.time()
     while True:
-        try:
-            if os.path.getmtime(path) >= _PROCESS_START - _LAUNCH_SKEW:
-                with open(path, "rb") as f:
-                    data = f.read()
-                if len(data) == nbytes + 8 and float(np.frombuffer(data[nbytes:], np.float64)[0]) >= _PROCESS_START - _LAUNCH_SKEW:
-                    return data[:nbytes]
-        except OSError:
-            pass
+        data = _read_id_file(path, nbytes)
+        if data is not None:
+            return data
         if time.time() - t0 > timeout:
             raise TimeoutError("rank %d of %d: no RCCL id from rank 0 in %s after %.0f s (is rank 0 running? do all ranks "
                                "share MASTER_ADDR / MASTER_PORT, or HG_COMM_ID_FILE?)" % (rank, world, path, timeout))
         time.sleep(0.02)
+
+
+def _read_id_file(path, nbytes):
+    """The id rank 0 published, or None.  Only a regular file of THIS user with mode 0600 counts (what rank 0 creates:
+    anything else at that path was planted or is debris), never through a symlink, and only if both its mtime and the
+    start time rank 0 wrote into it are no older than this process minus the tolerated launch skew."""
+    try:
+        fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+    except OSError:
+        return None
+    try:
+        st = os.fstat(fd)
+        import stat as _stat
+        if not _stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o777) != 0o600:
+            return None
+        if st.st_mtime < _PROCESS_START - _LAUNCH_SKEW or st.st_size != nbytes + 8:
+            return None
+        data = os.read(fd, nbytes + 8)
+    except OSError:
+        return None
+    finally:
+        os.close(fd)
+    if len(data) != nbytes + 8:
+        return None
+    if float(np.frombuffer(data[nbytes:], np.float64)[0]) < _PROCESS_START - _LAUNCH_SKEW:
+        return None
+    return data[:nbytes]
 
 
 def init_rccl(ctx, rank=None, world=None, timeout=300.0):
@@ -146,7 +168,9 @@ def init_rccl(ctx, rank=None, world=None, timeout=300.0):
     return comm
 
 
-_LAUNCH_SKEW = 120.0           # seconds one rank of a launch may start before another
+_LAUNCH_SKEW = 120.0           # seconds one rank of a launch may start before another (fresh boxes page the image in for a minute
+                               # or two, rank by rank).  A relaunch on the same port sooner than this after a CRASHED launch
+                               # should set HG_COMM_NONCE, or HG_COMM_ID_FILE in a private directory as bench.py does
 _PROCESS_START = time.time()
 
 
@@ -240,6 +264,9 @@ class HipShardEngine:
             self.ctx.set_option("cap_boost", 1)
             return False
         self.ctx.set_option("cap_boost", boost * 8)
+        # the lost attempt is retried within the same call: it does not count towards "two calls in a row lost their bets"
+        # (hg_bet_eligible) -- only the attempt a call gives up on does
+        self.ctx.set_option("forgive_lost_bet", 1)
         return True
 
     def ranked_merge_ok(self, world):

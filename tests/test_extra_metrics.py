@@ -32,3 +32,27 @@ def test_extra_metrics_match_bruteforce():
         ref = np.where(ball > 0, (inside & rel).sum(1) / np.maximum(ball, 1), 0.0).mean()
         got, balls = X.precision_within_radius(qb, db, ql, dl, radius)
         assert np.array_equal(balls, ball) and abs(got - ref) < 1e-15
+
+
+def test_map_between_extra_metrics_never_ranks_a_stale_database():
+    """MAP on read-only arrays keeps the packed database resident; extra_metrics loads ANOTHER database into the same
+    shared engine in between -- the next MAP on the first arrays must upload again, not rank against the other one."""
+    from hashgan_amd import MAP_per_query, extra_metrics as X, metric
+    rng = np.random.default_rng(11)
+    Q, N, b, C = 40, 3000, 32, 5
+    db1 = rng.integers(0, 2, (N, b), dtype=np.uint8)
+    db2 = rng.integers(0, 2, (N, b), dtype=np.uint8)
+    qb = db1[rng.integers(0, N, Q)] ^ (rng.random((Q, b)) < 0.1).astype(np.uint8)
+    dl1 = np.eye(C, dtype=np.int8)[rng.integers(0, C, N)]
+    dl2 = np.eye(C, dtype=np.int8)[rng.integers(0, C, N)]
+    ql = np.eye(C, dtype=np.int8)[rng.integers(0, C, Q)]
+    for a in (db1, dl1):
+        a.flags.writeable = False
+    m_ref, ap_ref, *_ = O.map_from_codes(qb, db1, ql, dl1, 500)
+    m1, ap1, _ = MAP_per_query(qb, db1, ql, dl1, 500)
+    assert metric._Shared.get(0).resident is not None
+    X.precision_recall_at_k(qb, db2, ql, dl2, [10])
+    assert metric._Shared.get(0).resident is None
+    m2, ap2, _ = MAP_per_query(qb, db1, ql, dl1, 500)
+    assert np.array_equal(ap1, ap_ref, equal_nan=True) and np.array_equal(ap2, ap_ref, equal_nan=True)
+    assert m1 == m_ref == m2

@@ -534,7 +534,7 @@ def test_longest_code_and_largest_distance(ctx):
 
 def test_queries_far_from_every_row_fall_back_exactly():
     """Queries on the other side of the code space (every distance > b/2): the cut lies beyond the distance planes the
-    bet's sampled pass writes (hg_engine.hip::enqueue_optimistic), the guess reads a thin sample, the bet is lost and the
+    bet's sampled pass writes (hg_seq.hip::enqueue_optimistic), the guess reads a thin sample, the bet is lost and the
     exact sequence must answer -- same AP as the oracle."""
     rng = np.random.default_rng(77)
     Q, N, b, R, C = 70, 300000, 64, 2000, 6

@@ -247,6 +247,25 @@ def test_rccl_id_rendezvous_ignores_a_stale_file_and_times_out(tmp_path):
     assert uid == b"\x02" * 128 and sharded.exchange_id(1, 2, None, 128, timeout=5.0, path=path) == uid
 
 
+def test_rccl_id_rendezvous_ignores_a_file_rank0_could_not_have_written(tmp_path):
+    """Rank 0 creates the id file exclusively with mode 0600: a fresh file with any other mode, or a symlink to one, was put
+    there by somebody else and is never read as the id."""
+    import time
+    from hashgan_amd import sharded
+    planted = str(tmp_path / "planted.id")
+    with open(planted, "wb") as f:
+        f.write(b"\x03" * 128 + np.float64(time.time()).tobytes())
+    os.chmod(planted, 0o644)
+    with pytest.raises(TimeoutError):
+        sharded.exchange_id(1, 2, None, 128, timeout=0.3, path=planted)
+    os.chmod(planted, 0o600)
+    link = str(tmp_path / "link.id")
+    os.symlink(planted, link)
+    with pytest.raises(TimeoutError):
+        sharded.exchange_id(1, 2, None, 128, timeout=0.3, path=link)
+    assert sharded.exchange_id(1, 2, None, 128, timeout=5.0, path=planted) == b"\x03" * 128     # mode 0600, own file, fresh: taken
+
+
 def test_bench_without_a_launcher_reports_instead_of_hanging():
     """`python bench.py --gpus 2` with no WORLD_SIZE spawns its own ranks; on a box where they cannot run (no GPU here)
     the parent prints ONE JSON line with an `error` key and exits non-zero.  A --gpus / WORLD_SIZE mismatch likewise."""

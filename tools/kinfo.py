@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Register / scratch / LDS usage of the kernels whose mangled name contains a pattern, from the device assembly
-(hipcc -S --cuda-device-only -o /tmp/hg_engine.s hashgan_amd/csrc/hg_engine.hip)."""
+(hipcc -S --cuda-device-only -o /tmp/hg_unit.s hashgan_amd/csrc/<unit>.hip)."""
 import re, sys
 pat = sys.argv[1] if len(sys.argv) > 1 else "k_select_mx"
-s = open(sys.argv[2] if len(sys.argv) > 2 else "/tmp/hg_engine.s").read()
+s = open(sys.argv[2] if len(sys.argv) > 2 else "/tmp/hg_unit.s").read()
 for blk in s.split("  - .agpr_count:")[1:]:
     m = re.search(r"\.name:\s+(\S+)", blk)
     if not m or pat not in m.group(1):
