@@ -41,6 +41,8 @@ sys.path.insert(0, ROOT)
 VALU_PEAK_TLANEOPS = 39.3
 VALU_NOMINAL_FP32_TLANEOPS = 78.6
 HBM_PEAK_GBS = 8000.0         # HBM3E spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+SETTLE_STEPS = 25             # untimed steps before the timed region, at least (see main)
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense MX-fp4 MFMA peak (MI355X_MICROARCH.md: ~10 PF dense; 9.1 PF measured)
 METRIC = "queries/sec (mAP@R of Q queries vs N-code database, Hamming ranking)"
 DTYPE = "fp4 (E2M1 0/+-1) x fp4 -> f32 exact distances; u32 xor+popcount elsewhere; f64 AP"
@@ -153,7 +155,33 @@ def traffic_from_profiles(kernel):
     return d[best].get("hbm_bytes_per_launch"), "rocprofv3 PMC pass of these sources (%s), kernel %s" % (d.get("_collected", "?"), best)
 
 
-def kernel_rooflines(timing, spec, rows, step_s, rec_bytes=1):
+SELECT_VARIANTS = {1: "k_select", 2: "k_select_dense", 3: "k_select_mx", 4: "k_select_mx2", 5: "k_select_mx3"}
+RANK_VARIANTS = {1: "k_rank_fused", 2: "k_rank_lds", 3: "k_rank_cnt", 4: "k_rank_wave", 5: "k_rank_direct"}
+
+
+def kernel_names(ctx, spec):
+    """The kernels behind the timing slots of the last step, by the names a rocprofv3 trace shows (the slots `k_select_mx`,
+    `k_rank_lds`, `k_hist` each cover several kernels; the library reports which one it launched)."""
+    NW, LW = (spec["b"] + 31) // 32, (spec["C"] + 63) // 64
+    sel = SELECT_VARIANTS.get(ctx.get_stat("select_variant"))
+    rank = RANK_VARIANTS.get(ctx.get_stat("rank_variant"))
+    names = {}
+    if sel == "k_select_mx3":
+        names["k_select_mx"] = "k_select_mx3<%d,%d>" % (2 if NW == 2 else 1, LW)
+    elif sel == "k_select_mx2":
+        names["k_select_mx"] = "k_select_mx2<%d,%d,compact>" % (NW, LW)
+    elif sel == "k_select_mx":
+        names["k_select_mx"] = "k_select_mx<%d,%d,%d,compact>" % (NW, LW if LW <= 2 else 0, 2 if NW <= 4 else 1)
+    elif sel:
+        names["k_select"] = "%s<%d,%d>" % (sel, NW, LW if LW <= 2 else 0)
+    if rank:
+        names["k_rank_lds" if rank in ("k_rank_lds", "k_rank_cnt", "k_rank_wave") else "k_rank_fused"] = rank
+    names["k_hist"] = "k_hist_i8<%d>" % NW if NW <= 4 else "k_hist_mx<%d>" % NW
+    names["k_guess"] = "k_guess_direct"
+    return names
+
+
+def kernel_rooflines(timing, spec, rows, step_s, rec_bytes=1, names=None):
     """Per-kernel average launch time -> roofline of the dominant kernel.  `rows` = database rows this GPU holds;
     rec_bytes: bytes per record the select pass writes (1: compact {match, dist}, hg_map's default; 8: with index)."""
     Q, b, C, R = spec["Q"], spec["b"], spec["C"], spec["R"]
@@ -183,7 +211,7 @@ def kernel_rooflines(timing, spec, rows, step_s, rec_bytes=1):
         # matrix-core select: one v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4) per 64 code bits and 32x32 tile of pairs
         K = 64 * ((NW + 1) // 2)
         flops = 2.0 * pairs * K
-        roof = {"bound": "mfma", "kernel": dom, "achieved": flops / t / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+        roof = {"bound": "mfma", "kernel": (names or {}).get(dom, dom), "timing_slot": dom, "achieved": flops / t / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / MFMA_FP4_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
                 "avg_launch_ms": out[dom]["avg_ms"], "algorithmic_flops": flops,
                 "note": "fp4 MFMA inner product over K=%d code bits per pair (2 flops per bit), against the dense fp4 peak; the "
@@ -194,7 +222,7 @@ def kernel_rooflines(timing, spec, rows, step_s, rec_bytes=1):
                 "valu_equiv_frac": valu_equiv, "hbm": hbm}
         return roof, out
     laneops = pairs * 2 * NW                      # one v_xor_b32 + one v_bcnt_u32_b32 per 32-bit word per pair
-    roof = {"bound": "valu", "kernel": dom, "achieved": laneops / t / 1e12, "peak": VALU_PEAK_TLANEOPS,
+    roof = {"bound": "valu", "kernel": (names or {}).get(dom, dom), "timing_slot": dom, "achieved": laneops / t / 1e12, "peak": VALU_PEAK_TLANEOPS,
             "unit": "Tlaneop/s", "frac": laneops / t / 1e12 / VALU_PEAK_TLANEOPS, "traffic": traffic, "traffic_source": traffic_note,
             "avg_launch_ms": out[dom]["avg_ms"], "algorithmic_laneops": laneops,
             "note": "integer bit-count path: xor+popcount lane-ops (2 per 32-bit code word per pair) against the "
@@ -266,9 +294,38 @@ def real_valued(spec, reps=5):
         for _ in range(reps):
             val2 = m.get_maps_by_feature(None, q)
         resident = (time.perf_counter() - t0) / reps
+        # per-kernel times of the resident call (HIP events around every kernel: a pass of its own) -> the call's roofline
+        roof = None
+        try:
+            ctx = m._eng.ctx
+            ctx.set_option("timing_every", 1)
+            ctx.timing_enable(2)
+            m.get_maps_by_feature(None, q)
+            ctx.timing_reset()
+            for _ in range(3):
+                m.get_maps_by_feature(None, q)
+            timing = ctx.timing_read()
+            ctx.timing_enable(False)
+            timing.pop("step_gpu_span", None)
+            real_names = {"k_real_select": "k_real_select_bf (bf16 MFMA filter)", "k_radix_pass": "k_real_rank_lds (select R-th key + order, in LDS)",
+                          "k_real_sample": "k_real_sample_mx", "k_real_guess": "k_real_guess_lds + k_real_thr2"}
+            kern = {real_names.get(k_, k_): round(ms / max(cnt, 1) * (cnt / 3.0), 5) for k_, (ms, cnt) in timing.items()}    # ms per call
+            flops = 2.0 * Q * N * b
+            filt = timing.get("k_real_select", (0.0, 1))
+            t_f = filt[0] / max(filt[1], 1) * 1e-3
+            dom = max(kern, key=kern.get)
+            roof = {"bound": "mfma (bf16)", "algorithmic_flops": flops, "definition": "2 * Q * N * b flop of the inner products (metric.py:13) / time / 2.5 PF dense bf16",
+                    "call": {"achieved": flops / resident / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / resident / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+                    "filter_kernel": {"kernel": "k_real_select_bf", "avg_launch_ms": t_f * 1e3, "achieved": flops / t_f / 1e12 if t_f else None,
+                                      "frac": flops / t_f / 1e12 / MFMA_BF16_PEAK_TFLOPS if t_f else None},
+                    "dominant_kernel": dom, "ms_per_call_by_kernel": kern,
+                    "rescore_bytes": "k_real_rescore gathers 4 * %d B of float32 row per kept (query, row) pair out of the L2; the filter keeps ~1.3-2 R rows per query" % (((b + 15) // 16) * 16)}
+        except Exception as e:      # noqa: BLE001
+            roof = {"error": "%s: %s" % (type(e).__name__, e)}
     finally:
         m.close()
     return {"call": "MAPs(R).get_maps_by_feature(database, query) on tanh(N(0,1)) float32 features, one-hot labels, Q=%d N=%d b=%d R=%d" % (Q, N, b, R),
+            "roofline": roof,
             "ranking": "float32 inner product (bf16 MFMA filter with a rigorous margin + exact float32 fma-chain rescoring), ties by index",
             "from_host": {"ms_per_call": full * 1e3, "queries_per_sec": Q / full,
                           "host_array_bytes": int(db.output.nbytes + db.label.nbytes + q.output.nbytes + q.label.nbytes)},
@@ -305,6 +362,90 @@ def c4_reference(opts, steps=5, warmup=2):
                 "pairs_per_sec": spec["Q"] * spec["N"] / dt, "map": float(m),
                 "parity_vs_reference_golden": bool(np.array_equal(a[:k], g["ap"], equal_nan=True)),
                 "optimistic_fallbacks": ctx.get_stat("optimistic_fallbacks")}
+    finally:
+        ctx.close()
+
+
+L2_PEAK_GBS = 34500.0         # aggregate L2 bandwidth, MI355X_MICROARCH.md section L2
+
+
+def config_leg(name, opts, steps=20, untimed=25, packed=None):
+    """One of the other BASELINE.json configurations (C1 = configs[0], C3 = configs[2], C5 = configs[4]) on this GPU, timed
+    like the headline step (inputs resident, K steps between synchronisations, untimed steps first), its per-kernel
+    breakdown from HIP events in a second short pass, parity against the reference's golden on the first queries, and the
+    roofline of ITS dominant kernel with the bound that applies to it.  Never `value`."""
+    from hashgan_amd import _native, metric
+    from tests import cases
+    spec = WORKLOADS[name]
+    Q, N, b, R, C = spec["Q"], spec["N"], spec["b"], spec["R"], spec["C"]
+    NW, LW = (b + 31) // 32, (C + 63) // 64
+    qw, ql, dw, dl = packed or build_packed(spec, 0, N)
+    ctx = _native.Context(0)
+    try:
+        for k_, v_ in opts:
+            ctx.set_option(k_, v_)
+        ctx.set_database(dw, dl, b, C)
+        ctx.set_queries(qw, ql)
+        for _ in range(untimed):
+            a, r = ctx.map(R)
+        ctx.synchronize()
+        each = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            a, r = ctx.map(R)
+            m = metric.mean_over_hits(a, r)
+            each.append(time.perf_counter() - t1)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ctx.set_option("timing_every", 1)
+        ctx.timing_enable(2)                               # every kernel between HIP events: a pass of its own (the events cost time)
+        for _ in range(4):
+            ctx.map(R)
+        ctx.timing_reset()
+        for _ in range(6):
+            ctx.map(R)
+        timing = ctx.timing_read()
+        ctx.timing_enable(False)
+        span = timing.pop("step_gpu_span", None)
+        names = kernel_names(ctx, spec)
+        kern = {names.get(k_, k_): {"avg_ms": round(ms / max(cnt, 1), 5), "launches_per_step": cnt / 6.0} for k_, (ms, cnt) in timing.items()}
+        slot = max(timing, key=lambda k_: timing[k_][0])
+        dom = names.get(slot, slot)
+        t = timing[slot][0] / max(timing[slot][1], 1) * 1e-3
+        pairs = Q * N
+        W = (b + 63) // 64
+        if slot == "k_select_mx":
+            flops = 2.0 * pairs * 64 * W
+            roof = {"bound": "mfma", "kernel": dom, "avg_launch_ms": t * 1e3, "algorithmic_flops": flops, "achieved": flops / t / 1e12,
+                    "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t / 1e12 / MFMA_FP4_PEAK_TFLOPS,
+                    "note": "fp4 MFMA inner product, 2 flops per code bit (K = %d) and pair; the kernel's other per-pair cost is the "
+                            "vector-ALU harvest of the accumulators (does not overlap the MFMAs on gfx950)" % (64 * W)}
+        elif dom == "k_rank_direct":
+            # R = N: no pair pass at all -- one block per query streams every row's code and label words (the whole table is
+            # L2-resident: N * (4 NW + 8 LW) bytes) and counting-sorts the N one-byte {match, dist} keys in LDS
+            ab = Q * N * (4 * NW + 8 * LW) + Q * ((R + 63) // 64) * 8
+            roof = {"bound": "l2", "kernel": dom, "avg_launch_ms": t * 1e3, "algorithmic_bytes": ab, "achieved": ab / t / 1e9,
+                    "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": ab / t / 1e9 / L2_PEAK_GBS,
+                    "note": "every query's block reads all N rows from L2 (Q * N * %d B) and writes R match bits; what bounds the "
+                            "kernel is the LDS counting sort's chain of dependent phases per tile of rows, not this stream" % (4 * NW + 8 * LW)}
+        else:
+            ab = (Q + N) * (NW * 4 + LW * 8) + Q * R
+            roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": t * 1e3, "algorithmic_bytes": ab, "achieved": ab / t / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / t / 1e9 / HBM_PEAK_GBS,
+                    "note": "latency chain of a short kernel: neither the HBM nor an ALU bound is near"}
+        roof["valu_equiv_frac"] = {"definition": "pairs * 4 * ceil(b/64) lane-ops / (t * 78.6e12)  (SURVEY.md 8d)",
+                                   "kernel": pairs * 4 * W / t / (VALU_NOMINAL_FP32_TLANEOPS * 1e12),
+                                   "step": pairs * 4 * W / dt / (VALU_NOMINAL_FP32_TLANEOPS * 1e12)}
+        g = cases.load_golden(spec["golden"])
+        k = g["ap"].shape[0]
+        return {"workload": "%s: Q=%d N=%d b=%d R=%d C=%d, %s codes" % (name.upper(), Q, N, b, R, C, spec["kind"]),
+                "steps": steps, "untimed_steps": untimed, "ms_per_step": dt * 1e3, "ms_per_step_min": min(each) * 1e3,
+                "ms_per_step_median": float(np.median(each)) * 1e3, "queries_per_sec": Q / dt, "pairs_per_sec": pairs / dt,
+                "map": float(m), "parity_vs_reference_golden": bool(np.array_equal(a[:k], g["ap"][:Q], equal_nan=True)), "golden_queries": int(min(k, Q)),
+                "bet": bool(ctx.get_stat("last_optimistic")), "optimistic_fallbacks": ctx.get_stat("optimistic_fallbacks"),
+                "dominant_kernel": dom, "roofline": roof, "kernels": kern,
+                "gpu_span_ms_with_events": round(span[0] / max(span[1], 1), 5) if span else None}
     finally:
         ctx.close()
 
@@ -456,6 +597,7 @@ def main():
     ap.add_argument("--no-sorted", action="store_true", help="skip the class-sorted database timing")
     ap.add_argument("--no-real", action="store_true", help="skip the real-valued (tanh features) call timing")
     ap.add_argument("--no-c4-ref", action="store_true", help="skip the one-GPU C4 point of the scaling curve")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C5 legs (the other BASELINE.json configurations)")
     ap.add_argument("--no-query-split", action="store_true", help="sharded runs: skip the replicated-database / split-queries leg")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (hg_set_option), repeatable")
     ap.add_argument("--timing-every", type=int, default=4,
@@ -524,16 +666,27 @@ def main():
         def fence():
             ctx.synchronize()                           # hipStreamSynchronize (every one-shot call also ends synchronised)
 
-    for _ in range(args.warmup):
-        m, a = step()
+    # Untimed steps first: the W the caller asked for, and at least SETTLE_STEPS in all -- a GPU that has idled (the inputs
+    # were generated on the host for seconds) needs ~20 ms of load before its clocks are back up (the first steps run 5-20 %
+    # slow: tools/step_probe.py), and the first steps after kernel timing is switched on pay a one-off ~8 ms inside the HIP
+    # runtime (event pools), so timing is on -- every step -- from the first untimed step.
     every = max(1, min(args.timing_every, args.steps)) if args.kernel_timing == "pair-passes" else 1
+    level = {"pair-passes": 1, "all": 2, "none": 0}[args.kernel_timing]
+    ctx.set_option("timing_every", 1)
+    ctx.timing_enable(level)
+    untimed = max(args.warmup, SETTLE_STEPS)
+    for _ in range(untimed):
+        m, a = step()
     ctx.set_option("timing_every", every)
-    ctx.timing_enable({"pair-passes": 1, "all": 2, "none": 0}[args.kernel_timing])
+    ctx.timing_enable(level)                            # restarts the every-n-th count
     ctx.timing_reset()
     fence()
+    each = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        m, a = step()
+        t1 = time.perf_counter()
+        m, a = step()                                   # (ends synchronised: the AP vector is on the host)
+        each.append(time.perf_counter() - t1)
     fence()
     dt = time.perf_counter() - t0
     if sharded_leg:
@@ -563,6 +716,8 @@ def main():
     out = {
         "metric": METRIC, "value": Q / per_step, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True,
+        "untimed_steps": untimed,
+        "ms_per_step_min": min(each) * 1e3, "ms_per_step_median": float(np.median(each)) * 1e3, "ms_per_step_max": max(each) * 1e3,
         "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "%s: Q=%d N=%d b=%d R=%d C=%d, %s codes" % (wl.upper(), Q, N, b, R, C, spec["kind"]),
                    "parallelism": ("database sharded over %d GPU%s (%d rows on rank 0); native RCCL all-gather of shard "
@@ -583,8 +738,8 @@ def main():
     if timing:
         span = timing.pop("step_gpu_span", None)
         rec_bytes = 8 if any(kv.replace(" ", "") == "compact_records=0" for kv in args.opt) else 1
-        roof, per_kernel = kernel_rooflines(timing, spec, rows, per_step, rec_bytes)
-        roof["launches_timed"] = per_kernel[roof["kernel"]]["launches"]
+        roof, per_kernel = kernel_rooflines(timing, spec, rows, per_step, rec_bytes, kernel_names(ctx, spec))
+        roof["launches_timed"] = per_kernel[roof["timing_slot"]]["launches"]
         roof["timed"] = "HIP events around the kernel on every %s step of the timed region" % ("" if every == 1 else "%d-th" % every)
         out["roofline"] = roof
         out["kernels"] = {k_: {"avg_ms": round(v["avg_ms"], 5), "launches": v["launches"]} for k_, v in per_kernel.items()}
@@ -617,6 +772,16 @@ def main():
             side("class_sorted_database", lambda: class_sorted(spec, packed))
         if not args.no_real:
             side("real_valued", lambda: real_valued(spec))
+        if not args.no_configs:
+            copts = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt]
+            out["configs"] = {}
+            for nm in ("c1", "c3", "c5"):
+                if nm == wl:
+                    continue
+                try:
+                    out["configs"][nm] = config_leg(nm, copts)
+                except Exception as e:      # noqa: BLE001
+                    out["configs"][nm] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_c4_ref and wl == "c2":
             side("scaling_reference_c4_one_gpu", lambda: c4_reference([(kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt]))
         if not args.no_cpu_baseline:

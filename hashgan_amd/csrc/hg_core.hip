@@ -512,8 +512,9 @@ int hg_merge_match(hg_ctx* c, const uint64_t* dev_bits_all, int G) {
     return c->stage_end();
 }
 
-extern "C++" int do_ap_range(hg_ctx* c, i64 q0, i64 nq) {      // k_ap's block index is the query: a range is a pointer offset
-    c->ap_staged = false;
+// k_ap's tables for the current R: the flattened summation trees and the reciprocals of the ranks (also read by
+// k_rank_cnt's AP epilogue); *use_recip: lists beyond 2^20 divide
+extern "C++" int ensure_ap_tables(hg_ctx* c, bool* use_recip_out) {
     const Geo& g = c->geo;
     if (c->shapes_for_R != g.R) {
         std::vector<ApShape> sh(2);
@@ -534,11 +535,21 @@ extern "C++" int do_ap_range(hg_ctx* c, i64 q0, i64 nq) {      // k_ap's block i
     }
     HG_TRY(c->ap.reserve((size_t)g.Q * 8));
     HG_TRY(c->rel.reserve((size_t)g.Q * 4));
+    *use_recip_out = use_recip;
+    return HG_OK;
+}
+
+// only: optional device flags [Q] -- evaluate just the flagged queries
+extern "C++" int do_ap_range(hg_ctx* c, i64 q0, i64 nq, const u32* only) {      // k_ap's block index is the query: a range is a pointer offset
+    c->ap_staged = false;
+    const Geo& g = c->geo;
+    bool use_recip = false;
+    HG_TRY(ensure_ap_tables(c, &use_recip));
     c->t_begin(KI_AP);
     if (nq > 0)
         hipLaunchKernelGGL(k_ap, dim3((unsigned)nq), dim3(AP_THREADS), 0, c->stream, c->mbits.as<u64>() + (size_t)q0 * c->RW, c->RW, g.R,
                            c->shapes.as<ApShape>(), use_recip ? c->ap_recip.as<double>() : (const double*)nullptr,
-                           c->ap.as<double>() + q0, c->rel.as<u32>() + q0);
+                           c->ap.as<double>() + q0, c->rel.as<u32>() + q0, only ? only + q0 : (const u32*)nullptr);
     c->t_end();
     HG_TRY(c->check_launch("k_ap"));
     c->stage |= ST_AP;
@@ -749,6 +760,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         // the caller retries the lost sharded bet within the same call (sharded.evaluate_shard widens the slices): that
         // attempt does not count towards hg_bet_eligible's "two calls in a row"
         if (value && c->shard_bet_fail > 0) c->shard_bet_fail--;
+    } else if (!strcmp(key, "fuse_ap")) {
+        c->opt_fuse_ap = value != 0;
     } else if (!strcmp(key, "rank_direct_lds")) {
         if (value < 32 || value > 160) return fail(HG_ERR_ARG, "rank_direct_lds must be 32..160 (KB)");
         c->opt_rank_direct_lds = value;
@@ -848,6 +861,10 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "optimistic_fallbacks")) *value = c->opt_fallbacks;
     else if (!strcmp(key, "optimistic_requeried")) *value = c->opt_requeried;
     else if (!strcmp(key, "optimistic_rebets")) *value = c->opt_rebets;
+    else if (!strcmp(key, "rank_leftovers")) *value = c->opt_leftover;
+    else if (!strcmp(key, "select_variant")) *value = c->last_select;
+    else if (!strcmp(key, "rank_variant")) *value = c->last_rank;
+    else if (!strcmp(key, "ap_fused")) *value = c->ap_fused ? 1 : 0;
     else if (!strcmp(key, "cap_boost")) *value = c->cap_boost;
     else if (!strcmp(key, "real_cap_boost")) *value = c->real_cap_boost;
     else if (!strcmp(key, "real_grouped")) *value = c->real_grouped;

@@ -202,6 +202,9 @@ struct hg_ctx {
     u32 cap = 0;               // optimistic slice capacity
     i64 crow = 0;              // record-row stride
     i64 opt_runs = 0, opt_fallbacks = 0, opt_requeried = 0;
+    int last_select = 0;       // stat "select_variant": 1 k_select, 2 k_select_dense, 3 k_select_mx, 4 k_select_mx2, 5 k_select_mx3
+    int last_rank = 0;         // stat "rank_variant": 1 k_rank_fused, 2 k_rank_lds, 3 k_rank_cnt, 4 k_rank_wave, 5 k_rank_direct
+    i64 opt_leftover = 0;      // stat "rank_leftovers": queries of fused steps that k_rank_cnt left to the general rank kernel
     int opt_consecutive_fail = 0;   // one-shot bets lost in a row (this context only)
     int shard_bet_fail = 0;         // sharded bets lost in a row: identical on every rank by construction
     hg_ctx* sub = nullptr;     // child context (shares the database) that reruns single lost queries exactly
@@ -228,6 +231,11 @@ struct hg_ctx {
     i64 opt_rebets = 0;
     i64 opt_lds_pad = 0;       // "lds_pad": extra dynamic LDS per block of the matrix-core select (occupancy experiments)
     bool err_zeroed = false;   // the guess kernel of a one-shot bet already cleared err
+    // AP from the rank kernel's epilogue (k_rank_cnt: the bitmap is still in LDS) -- one launch less per step, and the general
+    // rank kernel for the queries k_rank_cnt declines is launched only when the step's download says there are any
+    i64 opt_fuse_ap = 1;       // "fuse_ap"
+    bool fuse_ap = false;      // request of the current enqueue (hg_map's bet)
+    bool ap_fused = false;     // the last launch_rank left the AP of every query it ranked in c->ap / c->rel, leftovers counted in err[1]
     i64 defer_verdict = 0;     // hg_rank does not wait for the bet's verdict; hg_bet_verdict reads it later
     bool verdict_pending = false, verdict_known = false;
     int verdict_flag = 0;
@@ -289,7 +297,7 @@ struct hg_ctx {
         i64 R = -1, seen_R = -1;
         int timing = -1, seen_timing = -1;
         // host-side state the captured enqueue functions leave behind
-        unsigned stage = 0; bool optimistic = false, lists_valid = false; u32 cap = 0; i64 crow = 0, RW = 0; Geo geo{};
+        unsigned stage = 0; bool optimistic = false, lists_valid = false, ap_fused = false, rec8 = false; u32 cap = 0; i64 crow = 0, RW = 0; Geo geo{};
         std::vector<Pending> evs;          // event-record nodes inside the graph (kernel timing)
     } sg;
     i64 opt_graph = 0;         // "step_graph": 1 = hg_map captures and replays its step (see run_oneshot); off by default
@@ -398,7 +406,8 @@ int need(hg_ctx* c, unsigned st, const char* who, const char* what);     // stag
 int upload_codes(hg_ctx* c, DevBuf& dst, const uint64_t* host, i64 n, int W, int NW);
 int ensure_pin(hg_ctx* c, size_t need_b);
 int do_match(hg_ctx* c);                         // k_match through the ranked idx list (> 128 classes, real-valued lists)
-int do_ap_range(hg_ctx* c, i64 q0, i64 nq);      // k_ap on queries [q0, q0 + nq)
+int ensure_ap_tables(hg_ctx* c, bool* use_recip);   // summation trees + reciprocals for the current R, c->ap / c->rel sized
+int do_ap_range(hg_ctx* c, i64 q0, i64 nq, const u32* only = nullptr);      // k_ap on queries [q0, q0 + nq) (only: device flags [Q], just the flagged ones)
 inline int do_ap(hg_ctx* c) { return do_ap_range(c, 0, c->geo.Q); }
 int read_plan_flag(hg_ctx* c, int* flag);        // *err back to the host (synchronises)
 int launch_min_topr(hg_ctx* c, const u32* idx_all, const u8* dist_all, i64 n, int G);

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hs
     const int lane = threadIdx.x & 63, part = lane / QPW;
     const int q = (blockIdx.x * WPB + (threadIdx.x >> 6)) * QPW + (lane % QPW);
     if (part == 0 && q < g.Qpad) failq[q] = 0u;
-    if (q == 0 && part == 0) *err = 0;
+    if (q == 0 && part == 0) { err[0] = 0; err[1] = 0; }    // the lost-bet flag and the fused step's leftover count
     const bool live = q < g.Q;
     const int qq = live ? q : 0;                       // dead lanes follow query 0 (shuffles need every lane)
     const double fr = (double)g.R * (double)sampled / (double)n_total;
@@ -1269,17 +1269,35 @@ static __global__ __launch_bounds__(256) void k_recip_table(double* __restrict__
     if (k <= n) recip[k] = k ? 1.0 / (double)k : 0.0;
 }
 
-static __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits, i64 RW, i64 R,
-                                                   const ApShape* __restrict__ shapes,  // [0] full chunk, [1] last chunk
-                                                   const double* __restrict__ recip,    // [R + 1] or null
-                                                   double* __restrict__ ap, u32* __restrict__ rel) {
-    __shared__ u64 cw[AP_CHUNK / 64];
-    __shared__ double tree[2 * AP_LEAF];   // leaf sums, then the sums of the internal nodes
-    __shared__ u32 wpre[AP_CHUNK / 64 + 1];   // matches in the chunk's words before word w
-    __shared__ u32 s_before, s_w0;
-    const int q = blockIdx.x;
-    const int tid = threadIdx.x;
-    const u64* __restrict__ row = mbits + (i64)q * RW;
+// LDS of one AP evaluation (k_ap: static arrays; k_rank_cnt's epilogue: carved out of its counters, free by then)
+struct ApLds {
+    u64* cw;       // [AP_CHUNK / 64] the chunk's match bits
+    double* tree;  // [2 * AP_LEAF]   leaf sums, then the sums of the internal nodes
+    u32* wpre;     // [AP_CHUNK / 64 + 1] matches in the chunk's words before word w
+    u32* sb;       // [2] matches before the chunk; first wavefront's total
+};
+constexpr int AP_LDS_BYTES = AP_CHUNK / 8 + 2 * AP_LEAF * 8 + (AP_CHUNK / 64 + 1) * 4 + 12;    // cw, tree, wpre (+ pad to 8), sb
+__device__ __forceinline__ ApLds ap_lds_at(u8* base) {     // base 8-byte aligned
+    ApLds l;
+    l.cw = (u64*)base;
+    l.tree = (double*)(base + AP_CHUNK / 8);
+    l.wpre = (u32*)(base + AP_CHUNK / 8 + 2 * AP_LEAF * 8);
+    l.sb = l.wpre + AP_CHUNK / 64 + 2;
+    return l;
+}
+
+// The AP of one query by a block of NT threads (NT >= 128, every thread of the block calls this -- it has barriers);
+// word(w) = 64-bit word w of the query's match-bit row (0 beyond RW).  Thread 0 returns through *ap_out / *rel_out.
+template <int NT, class WordFn>
+__device__ __forceinline__ void ap_eval(const WordFn& word_at, const i64 RW, const i64 R, const ApShape* __restrict__ shapes,
+                                        const double* __restrict__ recip, const ApLds& L, const int tid,
+                                        double* __restrict__ ap_out, u32* __restrict__ rel_out) {
+    static_assert(NT >= AP_CHUNK / 64 && NT % 64 == 0, "one thread per word of a chunk");
+    u64* cw = L.cw;
+    double* tree = L.tree;
+    u32* wpre = L.wpre;
+    u32& s_before = L.sb[0];
+    u32& s_w0 = L.sb[1];
     if (tid == 0) s_before = 0;
     double total = 0.0;        // thread 0 only
     const i64 n_chunks = (R + AP_CHUNK - 1) / AP_CHUNK;
@@ -1288,9 +1306,9 @@ static __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict_
         const bool last = (c == n_chunks - 1);
         const ApShape* __restrict__ sh = shapes + ((last && (R - cb) != AP_CHUNK) ? 1 : 0);
         const int n = (int)(R - cb < AP_CHUNK ? R - cb : AP_CHUNK);
-        {   // load the chunk's words and prefix their popcounts (two wavefronts, 64 words each)
+        if (tid < AP_CHUNK / 64) {   // load the chunk's words and prefix their popcounts (two wavefronts, 64 words each)
             const i64 w = (cb >> 6) + tid;
-            const u64 word = (w < RW) ? row[w] : 0ull;        // AP_THREADS == AP_CHUNK / 64
+            const u64 word = (w < RW) ? word_at(w) : 0ull;
             cw[tid] = word;
             u32 incl = (u32)__popcll(word);
 #pragma unroll
@@ -1303,7 +1321,7 @@ static __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict_
             if (tid == 0) wpre[0] = 0u;
         }
         __syncthreads();
-        if (tid >= 64) wpre[tid + 1] += s_w0;
+        if (tid >= 64 && tid < AP_CHUNK / 64) wpre[tid + 1] += s_w0;
         __syncthreads();
         const u32 before = s_before;
         const bool sparse = wpre[AP_CHUNK / 64] * 4u < (u32)n;   // block-uniform: fewer than one slot in four matches
@@ -1327,7 +1345,7 @@ static __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict_
         // combines them as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  Lane j of a leaf's group owns r_j; the xor butterfly
         // 1, 2, 4 is exactly that tree (IEEE addition is commutative); lane 0 adds the < 8 tail elements in order.
         const int nl = sh->n_leaves;
-        for (int l0 = 0; l0 < nl; l0 += AP_THREADS / 8) {
+        for (int l0 = 0; l0 < nl; l0 += NT / 8) {
             const int leaf = l0 + (tid >> 3), j = tid & 7;
             const bool act = leaf < nl;
             const int ls = act ? sh->leaf_start[leaf] : 0, ll = act ? sh->leaf_len[leaf] : 0;
@@ -1382,9 +1400,21 @@ static __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict_
     }
     if (tid == 0) {
         const u32 r = s_before;
-        rel[q] = r;
-        ap[q] = r ? total / (double)r : __longlong_as_double(0x7FF8000000000000ll);
+        *rel_out = r;
+        *ap_out = r ? total / (double)r : __longlong_as_double(0x7FF8000000000000ll);
     }
+}
+
+// only: optional [Q] -- evaluate just the flagged queries (the rest got their AP from k_rank_cnt's epilogue)
+static __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits, i64 RW, i64 R,
+                                                   const ApShape* __restrict__ shapes,  // [0] full chunk, [1] last chunk
+                                                   const double* __restrict__ recip,    // [R + 1] or null
+                                                   double* __restrict__ ap, u32* __restrict__ rel, const u32* __restrict__ only) {
+    __shared__ __attribute__((aligned(8))) u8 aplds[AP_LDS_BYTES];
+    const int q = blockIdx.x;
+    if (only && !only[q]) return;
+    const u64* __restrict__ row = mbits + (i64)q * RW;
+    ap_eval<AP_THREADS>([&](const i64 w) { return row[w]; }, RW, R, shapes, recip, ap_lds_at(aplds), (int)threadIdx.x, ap + q, rel + q);
 }
 
 // ----------------------------------------------------------------------------

@@ -30,11 +30,11 @@ __host__ __device__ inline RankCntLds rank_cnt_layout(int NB, i64 RW, int S, int
     const int RC_MAXB = rank_cnt_maxb(NB);
     l.cnt = 0;                                   // [NB][64] u32: byte counter of thread 4 i + j = byte j of dword i
     const int NBc = nbc > 0 && nbc < (NB < 128 ? NB : 128) ? nbc : (NB < 128 ? NB : 128);
-    l.off = l.cnt + NBc * 256;                   // (distances beyond the counters never reach this path)   [RC_MAXB + 1][128] u32: 16-bit offset of thread 2 i + j = half j of dword i
+    l.off = l.cnt + (NBc * 256 > AP_LDS_BYTES + 8 ? NBc * 256 : (AP_LDS_BYTES + 15) & ~15);   // (distances beyond the counters never reach this path; the AP epilogue reuses the counters)   [RC_MAXB + 1][128] u32: 16-bit offset of thread 2 i + j = half j of dword i
     l.tot = l.off + (RC_MAXB + 1) * 512;         // [NB] u32   (offsets row RC_MAXB is a dummy: records beyond the cut add there)
     l.misc = l.tot + NB * 4;                     // [8] u32
     l.wsum = l.misc + 32;                        // [8] u32, then done[32] and tilecnt[32] (several tiles: per-bucket progress)
-    l.bm = l.wsum + 32 + 256;                    // [2 RW] u32
+    l.bm = (l.wsum + 32 + 256 + 7) & ~7;         // [2 RW] u32 (read as u64 words by the AP epilogue)
     l.pref = l.bm + (int)(2 * RW) * 4;           // [S + 2] u32
     l.rec = l.pref + ((S + 2) & ~1) * 4;         // [recs] u8 {match:1 | dist:7}
     l.idx = l.rec + ((recs + 7) & ~7);           // [recs] u32 (lists only)
@@ -42,7 +42,10 @@ __host__ __device__ inline RankCntLds rank_cnt_layout(int NB, i64 RW, int S, int
     return l;
 }
 
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_rank_cnt(const u64* __restrict__ cand, const RankLdsArgs a,
+#ifndef HG_RANK_WAVES
+#define HG_RANK_WAVES 5        // wavefronts per SIMD the kernel is compiled for (blocks per CU, with its LDS)
+#endif
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HG_RANK_WAVES, HG_RANK_WAVES))) void k_rank_cnt(const u64* __restrict__ cand, const RankLdsArgs a,
                                                   u32* __restrict__ out_idx, u8* __restrict__ out_dist,
                                                   u32* __restrict__ mbits32, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 rlds[];
@@ -52,7 +55,9 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NB = g.NB, S = g.S;
     const int NBall = NB < 128 ? NB : 128;
-    const int NBc = a.nbc > 0 && a.nbc < NBall ? a.nbc : NBall;   // distances that have counters (records beyond them leave this path)
+    const int NBc = a.nbc > 0 && a.nbc < NBall ? a.nbc : NBall;   // distances that have counters (records beyond them leave this path) ...
+    int wlo = 0;                                                  // ... starting at this one
+    if (a.cut) { const int T = a.cut[q]; wlo = T - (NBc - 1) > 0 ? T - (NBc - 1) : 0; }
     constexpr int nthr = 256, NWAV = 4;
     const int RC_MAXB = rank_cnt_maxb(NB);
     const int bmw = (int)(2 * a.RW);
@@ -317,7 +322,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
             for (int k = 0; k < 8; ++k) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const u32 d = (wv[k] >> (8 * j)) & 0x7Fu;
+                    const u32 d = ((wv[k] >> (8 * j)) & 0x7Fu) - (u32)wlo;      // relative to the first counter (wraps below it)
                     if (i0 + 4u * k + j < i1) {
                         if (d < (u32)NBc) atomicAdd(&cnt32[d * 64 + (tid >> 2)], one);
                         else misc[7] = 1u;
@@ -331,7 +336,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
             const u32 v = rec32[i >> 2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const u32 d = (v >> (8 * j)) & 0x7Fu;
+                const u32 d = ((v >> (8 * j)) & 0x7Fu) - (u32)wlo;
                 if (i + j < i1) {
                     if (d < (u32)NBc) atomicAdd(&cnt32[d * 64 + (tid >> 2)], one);
                     else misc[7] = 1u;                                   // a distance without a counter: the general kernel
@@ -350,7 +355,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
             }
             sm += (u32)__shfl_xor((int)sm, 1);
             sm += (u32)__shfl_xor((int)sm, 2);
-            if (d < NBc && j == 0) tot[d] += sm;
+            if (d < NBc && j == 0 && wlo + d < NB) tot[wlo + d] += sm;
         }
     };
     auto zero_counters = [&]() {
@@ -362,11 +367,11 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
         copy_all();
         __syncthreads();
         HG_TK();                                      // 1: copy
-        if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }        // a distance beyond 127: the general kernel
+        if (misc[7]) { if (tid == 0) { a.big[q] = 1u; if (a.nleft) atomicAdd(a.nleft, 1u); } return; }        // a distance beyond 127: the general kernel
         count_tile(n);
         __syncthreads();
         HG_TK();                                      // 2: count
-        if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }
+        if (misc[7]) { if (tid == 0) { a.big[q] = 1u; if (a.nleft) atomicAdd(a.nleft, 1u); } return; }
         add_totals();
         __syncthreads();
         HG_TK();                                      // 3: totals
@@ -375,10 +380,10 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
             const u32 T0 = tl * TC, T1 = T0 + TC < n ? T0 + TC : n;
             copy_tile(T0, T1);
             __syncthreads();
-            if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }
+            if (misc[7]) { if (tid == 0) { a.big[q] = 1u; if (a.nleft) atomicAdd(a.nleft, 1u); } return; }
             count_tile(T1 - T0);
             __syncthreads();
-            if (misc[7]) { if (tid == 0) a.big[q] = 1u; return; }
+            if (misc[7]) { if (tid == 0) { a.big[q] = 1u; if (a.nleft) atomicAdd(a.nleft, 1u); } return; }
             add_totals();
             __syncthreads();
             zero_counters();
@@ -404,8 +409,9 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
         int t = -1, dmin = -1;
         u32 cntlt = 0;
         for (int d0 = 0; d0 < NBc && t < 0 && want > 0; d0 += 64) {
-            const int d = d0 + lane;
-            const u32 c = d < NBc ? tot[d] : 0u;
+            const int d = wlo + d0 + lane;                  // (tot[] is indexed by the distance itself)
+            const bool has = d0 + lane < NBc && d < NB;
+            const u32 c = has ? tot[d] : 0u;
             u32 inc = c;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -414,15 +420,15 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
             }
             const u32 start = base + inc - c;         // global start of bucket d
             const u64 present = __ballot(c != 0u);
-            if (dmin < 0 && present) dmin = d0 + (int)__builtin_ctzll(present);
-            const u64 reached = __ballot((u64)base + inc >= want && d < NBc);
+            if (dmin < 0 && present) dmin = wlo + d0 + (int)__builtin_ctzll(present);
+            const u64 reached = __ballot((u64)base + inc >= want && has);
             if (reached) {
                 const int lt = (int)__builtin_ctzll(reached);
-                t = d0 + lt;
+                t = wlo + d0 + lt;
                 cntlt = (u32)__shfl((int)start, lt);
                 if (lane <= lt) tot[d] = start;       // starts of the buckets up to the cut
             } else {
-                if (d < NBc) tot[d] = start;
+                if (has) tot[d] = start;
                 base += (u32)__shfl((int)inc, 63);
             }
         }
@@ -448,7 +454,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
     const int dmin = (int)misc[3];
     const int nbk = t - dmin + 1;
     if (nbk > RC_MAXB) {                              // a list spanning many distances: the general kernel
-        if (tid == 0) { a.big[q] = 1u; if (a.mode == 0) a.qbad[q] = 0u; }
+        if (tid == 0) { a.big[q] = 1u; if (a.nleft) atomicAdd(a.nleft, 1u); if (a.mode == 0) a.qbad[q] = 0u; }
         return;
     }
 
@@ -464,7 +470,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
             __syncthreads();
         }
         for (int k = wave; k < nbk; k += NWAV) {
-            const u32 x = cnt32[(dmin + k) * 64 + lane];
+            const u32 x = cnt32[(dmin + k - wlo) * 64 + lane];
             const u32 sm = __builtin_amdgcn_sad_u8(x, 0u, 0u);
             u32 inc = sm;
 #pragma unroll
@@ -533,6 +539,12 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5
     }
     for (int w = tid; w < bmw; w += nthr) grow[w] = bm[w];
     HG_TK();                                          // 7: bitmap out
+    if (a.ap_shapes) {
+        // metric.py:20-23 while the bitmap is in LDS: k_ap's very arithmetic (ap_eval), its scratch carved out of the counters
+        __syncthreads();                              // the last tile's counters and offsets are no longer read
+        const u64* bm64 = (const u64*)bm;
+        ap_eval<nthr>([&](const i64 w) { return bm64[w]; }, a.RW, g.R, a.ap_shapes, a.ap_recip, ap_lds_at(rlds + L.cnt), tid, a.ap + q, a.rel + q);
+    }
 }
 
 }  // namespace hg

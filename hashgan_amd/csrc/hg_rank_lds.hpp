@@ -37,6 +37,16 @@ struct RankLdsArgs {
     const u32* xtie_before;
     const u32* xposbase;   // [NB][Qpad]
     int nbc;               // k_rank_cnt: distances that have counters (0: all up to 127); a record beyond them sends the query to k_rank_fused
+    // k_rank_cnt, mode 0: the AP of every query it ranks comes out of its epilogue (the bitmap is still in LDS) -- metric.py:20-23
+    const ApShape* ap_shapes;   // null: no AP here (k_ap runs later)
+    const double* ap_recip;     // [R + 1] or null
+    double* ap;                 // [Q]
+    u32* rel;                   // [Q]
+    u32* nleft;                 // count of queries left to the general kernel (big[q] = 1): the host launches it only if > 0
+    // k_rank_cnt: the nbc counters cover the distances [max(0, cut[q] - nbc + 1), cut[q]] -- every record of a bet is within
+    // its query's cut (the guess, or the exact threshold), and a list that reaches further down than the 16 (32) distances
+    // this kernel places leaves it anyway (null: the counters cover [0, nbc))
+    const int* cut;
 };
 
 template <int NWAV>

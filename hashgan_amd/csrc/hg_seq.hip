@@ -1,6 +1,7 @@
 // libhashgan_amd.so -- the Hamming sequences: segment geometry, histogram -> plan -> select -> rank, in their staged
 // (sharded) and one-shot forms (lib/metric.py:13-19 as a counting selection).
 #include "hg_ctx.hpp"
+#include <chrono>
 #include "hg_select_mx.hpp"
 #include "hg_select_mx3.hpp"
 #include "hg_hist_mx.hpp"
@@ -90,16 +91,17 @@ int launch_select(hg_ctx* c) {
     // one-byte records (no index): only the matrix-core kernels of the bet produce them, and only when nobody wants the lists
     const bool mx = c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS);
     c->rec8 = mx && c->opt_compact && !c->want_lists && c->LW <= 2 && c->cap % 16 == 0 && c->crow * 64 < (1ll << 31);
-    if (!c->optimistic && c->R * 4 >= c->n_total) return launch_select_dense(c, lw);   // dense regime: most pairs are selected
+    if (!c->optimistic && c->R * 4 >= c->n_total) { c->last_select = 2; return launch_select_dense(c, lw); }   // dense regime: most pairs are selected
     // three rows per accumulator + batched drain: codes of <= 64 bits, one-byte records (<= 128 classes).  (For <= 32 bits the
     // second k-half of every MFMA is empty, and it still beats k_select_mx2's two rows per accumulator: 0.69 vs 0.85 ms at b = 32.)
-    if (NW <= 2 && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) return launch_select_mx3(c, lw);
+    if (NW <= 2 && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 5; return launch_select_mx3(c, lw); }
     // two rows per accumulator: wins for one-word codes (half the MFMAs: 0.92 vs 1.02 ms at b = 32); for 33-64 bits
     // its cheaper harvest (0.36 vs 0.44 ms) is eaten by the wider queue entries (select_packed = 2 forces it)
     if (mx && c->geo.L % 32 == 0 &&
         (((c->opt_select_packed == 1 || c->opt_select_packed >= 3) && NW == 1) || (c->opt_select_packed == 2 && NW <= 2)))
-        return launch_select_mx2(c, lw);
-    if (mx) return launch_select_mx(c, lw);
+        { c->last_select = 4; return launch_select_mx2(c, lw); }
+    if (mx) { c->last_select = 3; return launch_select_mx(c, lw); }
+    c->last_select = 1;
     return launch_select_valu(c, lw, c->optimistic);
 }
 
@@ -196,7 +198,7 @@ static int launch_plan(hg_ctx* c, const uint32_t* dev_hist_all) {
     const size_t qb = (size_t)g.Qpad * 4;
     HG_TRY(c->posbase.reserve((size_t)g.NB * qb));
     HG_TRY(c->t.reserve(qb)); HG_TRY(c->cnt_lt.reserve(qb)); HG_TRY(c->quota.reserve(qb));
-    HG_TRY(c->tie_before.reserve(qb)); HG_TRY(c->n_lt.reserve(qb)); HG_TRY(c->err.reserve(4));
+    HG_TRY(c->tie_before.reserve(qb)); HG_TRY(c->n_lt.reserve(qb)); HG_TRY(c->err.reserve(8));
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     Plan pl{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->n_lt.as<u32>(),
             c->posbase.as<u32>(), c->err.as<int>()};
@@ -273,12 +275,14 @@ static i64 rank_direct_tile(const hg_ctx* c, int64_t R) {
     return tile >= 8192 || tile >= n8 ? tile : 0;
 }
 
-static int launch_rank(hg_ctx* c, int mode, int nbits) {
+// leftovers_only: the second half of a fused step -- k_rank_cnt has run (with its AP epilogue) and flagged in bigq the queries
+// it declined; rank just those with the general kernel
+static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = false) {
     const Geo& g = c->geo;
     if (c->direct_rank && mode == 0) {
         const i64 tile = rank_direct_tile(c, g.R);
         if (tile > 0) {
-            HG_TRY(c->err.reserve(4));
+            HG_TRY(c->err.reserve(8));
             HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
             const RankDirectLds L = rank_direct_layout(g.NB, c->RW, (int)tile);
             if (L.total > 64 * 1024)
@@ -289,6 +293,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
             hipLaunchKernelGGL(k_rank_direct, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, da, c->out_idx.as<u32>(), c->out_dist.as<u8>(),
                                c->mbits.as<u32>(), g);
             c->t_end();
+            c->last_rank = 5;
             return c->check_launch("k_rank_direct");
         }
     }
@@ -311,21 +316,24 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
     }
     const size_t fixed_words = (size_t)(nwav + 1) * g.NB + 8;
     const int bits_lds = (fixed_words + 2 * (size_t)c->RW) * 4 <= 64 * 1024;
-    if (mode != 1 && !bits_lds) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
-    HG_TRY(c->err.reserve(4));
+    if (mode != 1 && !bits_lds && !leftovers_only) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+    HG_TRY(c->err.reserve(8));
     HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
     if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
 #ifdef HG_RANK_PROFILE
     HG_TRY(c->hwq.reserve((size_t)4096 * 16 * 4 + (size_t)g.Q * nwav * g.NB * 4));
 #endif
-    if (mode == 0) {
-        if (c->optimistic) { if (!c->err_zeroed) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream)); }
+    if (mode == 0 && !leftovers_only) {
+        if (c->optimistic) { if (!c->err_zeroed) HG_HIP(hipMemsetAsync(c->err.p, 0, 8, c->stream)); }
         else HG_HIP(hipMemsetAsync(c->failq.p, 0, (size_t)g.Qpad * 4, c->stream));
         c->err_zeroed = false;
     }
     const u32* only = nullptr;
     bool counted = false;
-    if (c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_wave > 0 && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
+    c->ap_fused = false;
+    if (!leftovers_only) c->last_rank = 1;                // k_rank_fused unless one of the LDS-resident kernels takes the lists
+    if (leftovers_only) { only = c->bigq.as<u32>(); counted = true; }
+    if (!counted && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_wave > 0 && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
         g.S <= RW_SMAX) {
         // one wavefront per query (k_rank_wave): no block barriers, 5 KB + the records of LDS per query in flight
         // ... which pays for SHORT lists only (a sharded rank's share of R, a small R): a wavefront walks its query's records
@@ -353,6 +361,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
             hipLaunchKernelGGL(k_rank_wave, dim3(grid_for(g.Q, wpb)), dim3(64 * wpb), lds, c->stream, c->cand.as<u8>(), la, c->mbits.as<u32>(), g);
             c->t_end();
             HG_TRY(c->check_launch("k_rank_wave"));
+            c->last_rank = 4;
             only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
             counted = true;
         }
@@ -364,21 +373,43 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
         i64 r2 = (i64)(2.5 * (double)c->R * share) + 256;         // a tile of the records: the usual list (1.3 - 2 R) in one
         if (r2 < 4096) r2 = 4096;                                  // (small R: the guess's margin is relatively larger)
         r2 = r2 / 64 * 64;
-        // a one-shot bet's guess stops below b/2 + 2 (enqueue_optimistic), so its records need no counters beyond: the
-        // block fits 32 KB and five of them a CU; a query with farther records (thin sample: everything taken) goes to k_rank_fused
-        const int nbc = (mode == 0 && !c->exact_mx && c->G == 1) ? g.NB / 2 + 2 : 0;
+        // every record of a bet lies within its query's cut (the guess; the exact threshold of the exact_mx sequence), and a
+        // list reaching further down than the 16 (32) distances this kernel places leaves it anyway: byte counters for the
+        // 18 (34) distances up to the cut are all it needs (round 3: b/2 + 2 of them -- 8.7 KB of LDS at b = 64, 16.9 KB at
+        // b = 128); a query with a record below them goes to k_rank_fused
+        const int nbc = rank_cnt_maxb(g.NB) + 2 < g.NB ? rank_cnt_maxb(g.NB) + 2 : 0;
+        const int* cut = nbc ? (c->exact_mx ? c->t.as<int>() : c->tguess.as<int>()) : nullptr;
         RankCntLds L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0, nbc);
+        {   // one block more per CU when trimming the record tile by a few percent (never below 2.2 R) makes it fit
+            const int per_cu = (int)(160 * 1024 / ((L.total + 511) & ~511));
+            const i64 want = (160 * 1024 / (per_cu + 1)) & ~511ll;
+            const i64 r3 = (r2 - (L.total - want)) / 64 * 64;
+            // (the kernel is compiled for HG_RANK_WAVES wavefronts per SIMD = blocks per CU: more LDS room than that buys nothing)
+            if (per_cu + 1 <= HG_RANK_WAVES && L.total > want && r3 >= (i64)(2.2 * (double)c->R * share) + 256 && r3 >= 4096 && !c->want_lists) {
+                r2 = r3;
+                L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, 0, nbc);
+            }
+        }
         while (L.total > 64 * 1024 && r2 > 64) { r2 -= 64; L = rank_cnt_layout(g.NB, c->RW, g.S, (int)r2, c->want_lists ? 1 : 0, nbc); }
         if (L.total <= 64 * 1024 && r2 >= 4096) {
             HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
+            // hg_map's bet: the AP leaves with the ranking (the bitmap is in LDS), and the general kernel below is NOT launched --
+            // the step's download carries the number of queries this kernel declined (err[1]); the host launches it only then
+            const bool fuse = c->fuse_ap && c->opt_fuse_ap && mode == 0 && !c->want_lists && c->LW <= 2;
+            bool use_recip = false;
+            if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
             RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
                            c->cap, c->crow, c->want_lists ? 1 : 0, c->rec8 ? 1 : 0, c->RW, (int)r2, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
-                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc};
+                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc,
+                           fuse ? c->shapes.as<ApShape>() : nullptr, fuse && use_recip ? c->ap_recip.as<double>() : nullptr,
+                           c->ap.as<double>(), c->rel.as<u32>(), fuse ? c->err.as<u32>() + 1 : nullptr, cut};
             c->t_begin(KI_RANK_LDS);
             hipLaunchKernelGGL(k_rank_cnt, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, c->cand.as<u64>(), la, c->out_idx.as<u32>(),
                                c->out_dist.as<u8>(), c->mbits.as<u32>(), g);
             c->t_end();
             HG_TRY(c->check_launch("k_rank_cnt"));
+            c->last_rank = 3;
+            if (fuse) { c->ap_fused = true; return HG_OK; }
             only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
             counted = true;
         }
@@ -396,6 +427,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits) {
                                c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
             c->t_end();
             HG_TRY(c->check_launch("k_rank_lds"));
+            c->last_rank = 2;
             only = c->bigq.as<u32>();                // k_rank_fused below only ranks what did not fit
         }
     }
@@ -568,7 +600,7 @@ int hg_select_ranked(hg_ctx* c) {
     HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
     HG_TRY(c->out_idx.reserve(wide ? slots * 4 : 16)); HG_TRY(c->out_dist.reserve(wide ? slots : 16));
     if (wide) HG_HIP(hipMemsetAsync(c->out_idx.p, 0xFF, slots * 4, c->stream));    // slots past the shard's own records: IDX_NONE
-    HG_TRY(c->err.reserve(4));
+    HG_TRY(c->err.reserve(8));
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     HG_TRY(launch_select(c));
     const size_t plane = (size_t)g.NB * g.Qpad * 4;
@@ -806,7 +838,7 @@ static int enqueue_all_rows(hg_ctx* c, int64_t R) {
     const Geo& g = c->geo;
     const size_t qb = (size_t)g.Qpad * 4;
     const size_t slots = (size_t)g.Q * g.R;
-    HG_TRY(c->err.reserve(4)); HG_TRY(c->failq.reserve(qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->sl_cnt.reserve(qb));
+    HG_TRY(c->err.reserve(8)); HG_TRY(c->failq.reserve(qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->sl_cnt.reserve(qb));
     HG_TRY(c->cand.reserve(64));
     HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
     HG_TRY(c->out_idx.reserve(c->want_lists ? slots * 4 : 16));
@@ -819,6 +851,7 @@ static int enqueue_all_rows(hg_ctx* c, int64_t R) {
     while ((1 << nbits) < g.NB) ++nbits;
     c->direct_rank = true;
     c->rec8 = false;
+    c->last_select = 0;                                // no record pass at all
     const int rc = launch_rank(c, 0, nbits);
     c->direct_rank = false;
     HG_TRY(rc);
@@ -878,7 +911,7 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     HG_TRY(c->tguess.reserve(qb));
     HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
     HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
-    HG_TRY(c->err.reserve(4));
+    HG_TRY(c->err.reserve(8));
     HG_TRY(c->sstar.reserve(qb));
     c->t_begin(KI_GUESS);
     const Geo gh = hist_geometry(c);                   // the sampled pass ran on coarser segments
@@ -980,11 +1013,15 @@ static int rerun_lost_queries(hg_ctx* c, int64_t R, bool lists, bool with_ap, bo
 // buffers are warm), so it can run under stream capture.
 static int enqueue_bet_with_ap(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     c->t_step_begin();
-    HG_TRY(enqueue_optimistic(c, R, stride, need_cnt));
-    HG_TRY(do_ap(c));
+    c->fuse_ap = true;
+    const int rc = enqueue_optimistic(c, R, stride, need_cnt);
+    c->fuse_ap = false;
+    HG_TRY(rc);
+    if (c->ap_fused) { c->ap_staged = false; c->stage |= ST_AP; }     // k_rank_cnt's epilogue left the APs (leftovers: run_oneshot)
+    else HG_TRY(do_ap(c));
     const size_t Q = (size_t)c->geo.Q;
-    char* pb = (char*)c->pin;                  // [flag 16 B][ap Q x 8][rel Q x 4]
-    HG_HIP(hipMemcpyAsync(pb, c->err.p, 4, hipMemcpyDeviceToHost, c->stream));
+    char* pb = (char*)c->pin;                  // [flag, leftover count: 16 B][ap Q x 8][rel Q x 4]
+    HG_HIP(hipMemcpyAsync(pb, c->err.p, 8, hipMemcpyDeviceToHost, c->stream));
     HG_HIP(hipMemcpyAsync(pb + 16, c->ap.p, Q * 8, hipMemcpyDeviceToHost, c->stream));
     HG_HIP(hipMemcpyAsync(pb + 16 + Q * 8, c->rel.p, Q * 4, hipMemcpyDeviceToHost, c->stream));
     c->t_step_end();
@@ -1019,8 +1056,31 @@ static int capture_step(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     sg.graph = gr; sg.exec = ex;
     sg.epoch = g_alloc_epoch; sg.cfg = c->cfg_epoch; sg.R = R; sg.timing = c->timing;
     sg.stage = c->stage; sg.optimistic = c->optimistic; sg.lists_valid = c->lists_valid; sg.cap = c->cap; sg.crow = c->crow;
-    sg.RW = c->RW; sg.geo = c->geo;
+    sg.RW = c->RW; sg.geo = c->geo; sg.ap_fused = c->ap_fused; sg.rec8 = c->rec8;
     c->graph_captures++;
+    return HG_OK;
+}
+
+// After the synchronisation of a fused step (k_rank_cnt ranked AND evaluated): the queries it declined -- pin[1] of them,
+// flagged in bigq; a list spanning more than 16 distances, a record beyond its counters -- get the general rank kernel and
+// k_ap now, and the results come over again.  Rare by construction (none on any BASELINE workload), so the common step
+// carries neither launch.
+static int finish_leftovers(hg_ctx* c, int* flag) {
+    if (!c->ap_fused) return HG_OK;
+    const u32 nleft = ((const u32*)c->pin)[1];
+    if (!nleft) return HG_OK;
+    c->opt_leftover += nleft;
+    const size_t Q = (size_t)c->geo.Q;
+    int nbits = 1;
+    while ((1 << nbits) < c->geo.NB) ++nbits;
+    HG_TRY(launch_rank(c, 0, nbits, true));
+    HG_TRY(do_ap_range(c, 0, c->geo.Q, c->bigq.as<u32>()));
+    char* pb = (char*)c->pin;
+    HG_HIP(hipMemcpyAsync(pb, c->err.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(hipMemcpyAsync(pb + 16, c->ap.p, Q * 8, hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(hipMemcpyAsync(pb + 16 + Q * 8, c->rel.p, Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HG_TRY(c->sync());
+    *flag = *(const int*)c->pin;
     return HG_OK;
 }
 
@@ -1054,17 +1114,26 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
                     // what the captured enqueue functions leave behind on the host side
                     HG_TRY(set_R(c, R, 1, 0));
                     c->geo = sg.geo; c->RW = sg.RW; c->stage = sg.stage; c->optimistic = sg.optimistic; c->lists_valid = sg.lists_valid;
-                    c->cap = sg.cap; c->crow = sg.crow; c->err_zeroed = false;
+                    c->cap = sg.cap; c->crow = sg.crow; c->err_zeroed = false; c->ap_fused = sg.ap_fused; c->rec8 = sg.rec8;
                     c->graph_replays++;
                     launched = true;
                 }
             }
             if (!launched) {
+                static const bool trace = getenv("HG_STEP_TRACE") != nullptr;        // debugging: where a slow step spent its time
+                const auto tp0 = std::chrono::steady_clock::now();
                 HG_TRY(enqueue_bet_with_ap(c, R, stride, need_cnt));
+                const auto tp1 = std::chrono::steady_clock::now();
                 HG_TRY(c->sync());
+                if (trace) {
+                    const auto tp2 = std::chrono::steady_clock::now();
+                    const double e = std::chrono::duration<double, std::milli>(tp1 - tp0).count(), w = std::chrono::duration<double, std::milli>(tp2 - tp1).count();
+                    if (e + w > 2.0) fprintf(stderr, "[hg] slow step: enqueue %.3f ms, wait %.3f ms (t_seq %lld, pending events %zu, pool %zu)\n", e, w, (long long)c->t_seq, c->pending.size(), c->pool.size());
+                }
                 sg.seen_epoch = g_alloc_epoch; sg.seen_cfg = c->cfg_epoch; sg.seen_R = R; sg.seen_timing = c->timing;
             }
             flag = *(const int*)c->pin;
+            HG_TRY(finish_leftovers(c, &flag));
             c->ap_staged = flag == 0;
         } else {
             HG_TRY(enqueue_optimistic(c, R, stride, need_cnt));
@@ -1096,6 +1165,7 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
                     rc = enqueue_bet_with_ap(c, R, stride, need_cnt);
                     if (rc == HG_OK) rc = c->sync();
                     flag = *(const int*)c->pin;
+                    if (rc == HG_OK) rc = finish_leftovers(c, &flag);
                     c->ap_staged = rc == HG_OK && flag == 0;
                 } else {
                     rc = enqueue_optimistic(c, R, stride, need_cnt);

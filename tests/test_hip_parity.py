@@ -855,3 +855,55 @@ def test_dense_regime_ranks_the_rows_directly(Q, N, b, R, C):
         assert np.array_equal(ap2, ap_ref, equal_nan=True)
     finally:
         ctx.close()
+
+
+def test_fused_step_hands_wide_lists_to_the_general_kernel(ctx):
+    """hg_map's bet ranks AND evaluates in k_rank_cnt (the AP leaves from its epilogue) and launches the general rank
+    kernel only when the step's download reports queries k_rank_cnt declined.  Two queries here have rows planted at
+    EVERY distance 0..21 (30 each), so their top-2000 lists span more than the 16 distances k_rank_cnt places: they are
+    the leftovers, ranked by k_rank_fused and evaluated by k_ap afterwards; all APs equal the oracle's, with the fused
+    epilogue on and off."""
+    from hashgan_amd import synth
+    Q, N, b, R, C = 192, 100000, 64, 2000, 10              # (lists too long for k_rank_wave, which takes the short ones)
+    dl, _ = synth.onehot_labels(71, N, C)
+    ql, _ = synth.onehot_labels(72, Q, C)
+    db = synth.random_bits(73, N, b)
+    qb = synth.random_bits(74, Q, b)
+    rng = np.random.default_rng(75)
+    for qi, base in ((7, 20000), (130, 60000)):
+        k = 0
+        for d in range(22):
+            for _ in range(30):
+                row = qb[qi].copy()
+                row[rng.choice(b, d, replace=False)] ^= 1
+                db[base + 7 * k] = row                       # spread over several segments
+                k += 1
+    probe = [0, 7, 8, 129, 130, 191]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb[probe], db, ql[probe], dl, R)
+    ctx.set_option("optimistic", 1)
+    ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
+    ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
+    try:
+        l0, f0 = ctx.get_stat("rank_leftovers"), ctx.get_stat("optimistic_fallbacks")
+        ap, rel = ctx.map(R)
+        assert ctx.get_stat("last_optimistic") == 1 and ctx.get_stat("optimistic_fallbacks") == f0
+        assert ctx.get_stat("ap_fused") == 0 and ctx.get_stat("rank_leftovers") - l0 >= 2      # (the leftover pass clears ap_fused)
+        assert np.array_equal(ap[probe], ap_ref, equal_nan=True)
+        ctx.set_option("fuse_ap", 0)
+        ap2, rel2 = ctx.map(R)
+        assert np.array_equal(ap2, ap, equal_nan=True) and np.array_equal(rel2, rel)
+    finally:
+        ctx.set_option("fuse_ap", 1)
+    # an ordinary workload: every query evaluated in the epilogue, nothing left over
+    db2 = synth.random_bits(76, N, b)
+    ctx.set_database(metric.pack_codes(db2), metric.pack_labels(dl), b, C)
+    ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
+    l1 = ctx.get_stat("rank_leftovers")
+    ap3, _ = ctx.map(R)
+    assert ctx.get_stat("ap_fused") == 1 and ctx.get_stat("rank_leftovers") == l1
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap3_ref, *_ = O.map_from_codes(qb[probe], db2, ql[probe], dl, R)
+    assert np.array_equal(ap3[probe], ap3_ref, equal_nan=True)
