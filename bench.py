@@ -155,7 +155,7 @@ def traffic_from_profiles(kernel):
     return d[best].get("hbm_bytes_per_launch"), "rocprofv3 PMC pass of these sources (%s), kernel %s" % (d.get("_collected", "?"), best)
 
 
-SELECT_VARIANTS = {1: "k_select", 2: "k_select_dense", 3: "k_select_mx", 4: "k_select_mx2", 5: "k_select_mx3"}
+SELECT_VARIANTS = {1: "k_select", 2: "k_select_dense", 3: "k_select_mx", 4: "k_select_mx2", 5: "k_select_mx3", 6: "k_select_mx4"}
 RANK_VARIANTS = {1: "k_rank_fused", 2: "k_rank_lds", 3: "k_rank_cnt", 4: "k_rank_wave", 5: "k_rank_direct"}
 
 
@@ -168,6 +168,8 @@ def kernel_names(ctx, spec):
     names = {}
     if sel == "k_select_mx3":
         names["k_select_mx"] = "k_select_mx3<%d,%d>" % (2 if NW == 2 else 1, LW)
+    elif sel == "k_select_mx4":
+        names["k_select_mx"] = "k_select_mx4<%d,%d>" % (NW, LW)
     elif sel == "k_select_mx2":
         names["k_select_mx"] = "k_select_mx2<%d,%d,compact>" % (NW, LW)
     elif sel == "k_select_mx":
@@ -674,7 +676,7 @@ def main():
     level = {"pair-passes": 1, "all": 2, "none": 0}[args.kernel_timing]
     ctx.set_option("timing_every", 1)
     ctx.timing_enable(level)
-    untimed = max(args.warmup, SETTLE_STEPS)
+    untimed = args.warmup if dry_dir else max(args.warmup, SETTLE_STEPS)      # (a dry run through files measures nothing)
     for _ in range(untimed):
         m, a = step()
     ctx.set_option("timing_every", every)

@@ -154,7 +154,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip, &c->part};
+                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -210,6 +210,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     c->dbx_valid = false;
     c->dbx2_valid = false;
     c->dbx3_valid = false;
+    c->dbx4_valid = false;
     c->dbx8_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;    // a new database: earlier lost bets say nothing about it
     c->cap_boost = c->real_cap_boost = 1;
@@ -410,6 +411,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->dbx_valid = false;
     c->dbx2_valid = false;
     c->dbx3_valid = false;
+    c->dbx4_valid = false;
     c->dbx8_valid = false;
     c->dbfx_valid = false;
     c->dbfb_valid = false;
@@ -848,6 +850,7 @@ int hg_trim(hg_ctx* c) {
     c->dbx_valid = c->qx_valid = c->dbx2_valid = c->qx2_valid = false;
     c->dbx8.release(); c->dbx8_valid = false;
     c->dbx3.release(); c->dbx3_valid = false;
+    c->dbx4.release(); c->dbx4_valid = false;
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     c->stage &= (ST_DB | ST_Q);
     c->lists_valid = false;
@@ -878,7 +881,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
                          &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2,
-                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->sampx, &c->ap_recip, &c->part};
+                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
         *value = total;

@@ -202,7 +202,7 @@ struct hg_ctx {
     u32 cap = 0;               // optimistic slice capacity
     i64 crow = 0;              // record-row stride
     i64 opt_runs = 0, opt_fallbacks = 0, opt_requeried = 0;
-    int last_select = 0;       // stat "select_variant": 1 k_select, 2 k_select_dense, 3 k_select_mx, 4 k_select_mx2, 5 k_select_mx3
+    int last_select = 0;       // stat "select_variant": 1 k_select, 2 k_select_dense, 3 k_select_mx, 4 k_select_mx2, 5 k_select_mx3, 6 k_select_mx4
     int last_rank = 0;         // stat "rank_variant": 1 k_rank_fused, 2 k_rank_lds, 3 k_rank_cnt, 4 k_rank_wave, 5 k_rank_direct
     i64 opt_leftover = 0;      // stat "rank_leftovers": queries of fused steps that k_rank_cnt left to the general rank kernel
     int opt_consecutive_fail = 0;   // one-shot bets lost in a row (this context only)
@@ -220,6 +220,8 @@ struct hg_ctx {
     bool dbx8_valid = false;
     DevBuf dbx3;               // fp4 image for k_select_mx3 (48-row supertiles, three rows per accumulator), built on first use
     bool dbx3_valid = false;
+    DevBuf dbx4;               // fp4 image for k_select_mx4 (32-row supertiles, two rows per accumulator; codes of 65..128 bits), built on first use
+    bool dbx4_valid = false;
     bool direct_rank = false;  // R = N: k_rank_fused computes distance and match bit per row itself (no records)
     i64 opt_hist_mfma = 2;     // "hist_mfma": histograms (sampled pass; full pass of the one-shot exact sequence) on the matrix cores -- 2: the integer instruction delivers the counter address (k_hist_i8, codes of <= 128 bits), 1: fp4 distances (k_hist_mx), 0: vector ALU
     bool hist_pairs = false;   // the last FULL histogram pass ran per segment pair (k_hist_mx)
@@ -425,6 +427,7 @@ int launch_hist_mx(hg_ctx* c);                   // k_hist_i8 / k_hist_mx
 int launch_select_mx(hg_ctx* c, int lw);         // k_select_mx<NW, LW, QT, COMPACT>
 int launch_select_mx2(hg_ctx* c, int lw);        // k_select_mx2 (codes of <= 64 bits)
 int launch_select_mx3(hg_ctx* c, int lw);        // k_select_mx3 (codes of <= 64 bits, one-byte records)
+int launch_select_mx4(hg_ctx* c, int lw);        // k_select_mx4 (codes of 65..128 bits, one-byte records)
 // hg_comm.hip
 void comm_release(hg_ctx* c);                    // destroys the context's communicator, if any
 

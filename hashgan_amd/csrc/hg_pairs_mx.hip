@@ -5,6 +5,7 @@
 #include "hg_select_mx.hpp"
 #include "hg_select_mx2.hpp"
 #include "hg_select_mx3.hpp"
+#include "hg_select_mx4.hpp"
 #include "hg_hist_mx.hpp"
 #include "hg_hist_i8.hpp"
 
@@ -218,6 +219,48 @@ int launch_select_mx2(hg_ctx* c, int lw) {           // codes of <= 64 bits
         case 2: return launch_select_mx2_t<2, 2>(c);
         default: return launch_select_mx2_t<2, 0>(c);
     }
+}
+
+namespace {
+// codes of 65..128 bits, compact records: two rows per accumulator and the batched drain (k_select_mx4);
+// blocks = (pair of segments) x (512 queries); the query image is k_select_mx's
+template <int NW, int LW> int launch_select_mx4_t(hg_ctx* c) {
+    HG_TRY(ensure_mx_images(c, false));
+    if (!c->dbx4_valid) {
+        const i64 n32 = (c->N + M4_ROWS - 1) / M4_ROWS * M4_ROWS + M4_WS * M4_ROWS;     // + one window of zero rows: the last segment's last window may run past the end
+        HG_TRY(c->dbx4.reserve((size_t)n32 * 64));
+        const i64 items = n32 * 4;
+        c->t_begin(KI_PACK);
+        hipLaunchKernelGGL(k_expand_db4, dim3(grid_for(items)), dim3(256), 0, c->stream, c->db.as<u32>(), c->dbx4.as<uint4>(), (i64)c->N, n32, NW);
+        c->t_end();
+        HG_TRY(c->check_launch("k_expand_db4"));
+        c->dbx4_valid = true;
+    }
+    Geo g = c->geo;
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + 64 * M4_WPB - 1) / (64 * M4_WPB);
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = M4_WPB;
+    g.nBlk = (int)g.nUnits;
+    const Mx4Lds L = mx4_lds_layout(NW, LW);
+    if (L.total > 64 * 1024)
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx4<NW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
+              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), 0};
+    c->t_begin(KI_SELECT_MX);
+    hipLaunchKernelGGL((k_select_mx4<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(64 * M4_WPB), (size_t)L.total + (size_t)c->opt_lds_pad, c->stream, c->qc.as<u32>(),
+                       c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx4.as<u8>(), c->dblab.as<u64>(), a,
+                       c->cand.as<u8>(), g);
+    c->t_end();
+    return c->check_launch("k_select_mx4");
+}
+}  // namespace
+
+int launch_select_mx4(hg_ctx* c, int lw) {           // codes of 65..128 bits, one-byte records, <= 128 classes
+    if (c->NW < 3 || c->NW > 4 || lw < 1 || lw > 2) return fail(HG_ERR_ARG, "k_select_mx4 takes codes of 65..128 bits and 1..128 classes");
+    if (c->NW == 3) return lw == 1 ? launch_select_mx4_t<3, 1>(c) : launch_select_mx4_t<3, 2>(c);
+    return lw == 1 ? launch_select_mx4_t<4, 1>(c) : launch_select_mx4_t<4, 2>(c);
 }
 
 int launch_select_mx3(hg_ctx* c, int lw) {           // codes of <= 64 bits, one-byte records, <= 128 classes

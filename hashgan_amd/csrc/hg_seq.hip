@@ -4,6 +4,7 @@
 #include <chrono>
 #include "hg_select_mx.hpp"
 #include "hg_select_mx3.hpp"
+#include "hg_select_mx4.hpp"
 #include "hg_hist_mx.hpp"
 #include "hg_rank_lds.hpp"
 #include "hg_rank_cnt.hpp"
@@ -35,7 +36,7 @@ void make_geometry(hg_ctx* c) {
         // k_select_mx runs (S / 2) x ceil(Q / 256 or 512) equal blocks, 4 or 2 resident per CU: pick the S near the
         // target that fills a whole number of such rounds, so the last round is not a nearly empty one
         const bool qt2 = c->NW <= 4;                                // mirrors launch_select_mx_t
-        const bool mx3 = c->opt_select_packed == 3 && c->NW <= 2;   // k_select_mx3: blocks of M3_WPB wavefronts x 64 queries
+        const bool mx3 = c->opt_select_packed == 3 && c->NW <= 4;   // k_select_mx3 / k_select_mx4: blocks of 8 wavefronts x 64 queries, two per CU
         const i64 qblk = mx3 ? 64 * M3_WPB : qt2 ? 256 : 512;
         const i64 nQB = (c->Q + qblk - 1) / qblk;
         const i64 slots = (i64)c->n_cu * (mx3 ? 16 / M3_WPB : qt2 ? 4 : 2);
@@ -95,6 +96,8 @@ int launch_select(hg_ctx* c) {
     // three rows per accumulator + batched drain: codes of <= 64 bits, one-byte records (<= 128 classes).  (For <= 32 bits the
     // second k-half of every MFMA is empty, and it still beats k_select_mx2's two rows per accumulator: 0.69 vs 0.85 ms at b = 32.)
     if (NW <= 2 && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 5; return launch_select_mx3(c, lw); }
+    // codes of 65..128 bits: two rows per accumulator (8-bit fields) and the same drain
+    if ((NW == 3 || NW == 4) && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M4_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 6; return launch_select_mx4(c, lw); }
     // two rows per accumulator: wins for one-word codes (half the MFMAs: 0.92 vs 1.02 ms at b = 32); for 33-64 bits
     // its cheaper harvest (0.36 vs 0.44 ms) is eaten by the wider queue entries (select_packed = 2 forces it)
     if (mx && c->geo.L % 32 == 0 &&
@@ -299,6 +302,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
     }
     int nwav = c->opt_rank_waves ? (int)c->opt_rank_waves
                                  : ((c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4);   // records per query ~ 3R / R
+    if (leftovers_only && !c->opt_rank_waves && c->R >= 1024) nwav = 16;   // a handful of blocks: what counts is one block's latency
     // k_rank_lds: the query's records resident in LDS -- room for ~2.5 R per query (the bet keeps 1.3-2 R),
     // at most 64 KiB per block; queries with more are left to k_rank_fused (flagged in bigq)
     bool use_lds = false;

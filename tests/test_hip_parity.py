@@ -253,6 +253,23 @@ def test_bursts_of_hits_take_the_direct_route():
             assert np.array_equal(ap[:16], ap_ref, equal_nan=True), compact
         assert np.array_equal(out[0], out[1], equal_nan=True)
         assert ctx.get_stat("optimistic_runs") == 2 and ctx.get_stat("optimistic_fallbacks") == 0
+        # long codes: k_select_mx4 (two rows per accumulator) feeding its copy of the drain
+        rng = np.random.default_rng(55)
+        ext = (rng.random((N0, 64)) < 0.5).astype(np.uint8)              # 64 more bits per distinct row, shared by its near-copies
+        qext = (rng.random((Q, 64)) < 0.5).astype(np.uint8)
+        c128 = dict(c, qbits=np.concatenate([qb, qext], 1), dbbits=np.concatenate([db, np.repeat(ext, dup, axis=0)], 1), b=128)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, ap_ref128, *_ = O.map_from_codes(c128["qbits"][:8], c128["dbbits"], ql[:8], dl, R)
+        _load(ctx, c128)
+        res = []
+        for compact in (1, 0):
+            ctx.set_option("compact_records", compact)
+            res.append(ctx.map(R)[0])
+            assert np.array_equal(res[-1][:8], ap_ref128, equal_nan=True), compact
+            if compact:
+                assert ctx.get_stat("select_variant") == 6
+        assert np.array_equal(res[0], res[1], equal_nan=True)
         # and with short codes (k_select_mx2's harvest feeding the same drain)
         c32 = dict(c, qbits=qb[:, :32].copy(), dbbits=db[:, :32].copy(), b=32)
         _load(ctx, c32)
@@ -794,7 +811,7 @@ def test_a_database_stored_class_by_class_keeps_the_bet():
         ctx.close()
 
 
-@pytest.mark.parametrize("b", [64, 40])
+@pytest.mark.parametrize("b", [64, 40, 128, 72])
 def test_one_lane_bursts_while_its_neighbours_stay_sparse(b):
     """Inside ONE wavefront of the matrix-core select: a few queries meet long runs of rows at distance 0 (their slices'
     rings overflow: the lane walks its hits to global memory itself, then returns to the rings), runs that straddle
@@ -907,3 +924,38 @@ def test_fused_step_hands_wide_lists_to_the_general_kernel(ctx):
         warnings.simplefilter("ignore")
         _, ap3_ref, *_ = O.map_from_codes(qb[probe], db2, ql[probe], dl, R)
     assert np.array_equal(ap3[probe], ap3_ref, equal_nan=True)
+
+
+@pytest.mark.parametrize("b", [65, 80, 96, 97, 100, 127, 128])
+def test_long_codes_take_the_packed_matrix_core_select(b):
+    """Codes of 65..128 bits: hg_map's bet selects with k_select_mx4 (two rows per fp4 accumulator, 8-bit fields -- the
+    harvested sign bits must be exactly dist <= T for every row of a 32-row supertile, both lane halves, ragged segment
+    ends included).  APs equal the oracle's (the reference's canonical order) and the 8-byte-record kernel's."""
+    from hashgan_amd import synth
+    Q, N, R, C = 150, 140000 + b, 1100, 7
+    dl, _ = synth.onehot_labels(500 + b, N, C)
+    ql, _ = synth.onehot_labels(600 + b, Q, C)
+    db = synth.planted_codes(700 + b, dl, b, 0.33)
+    qb = synth.planted_codes(700 + b, ql, b, 0.33)
+    db[N - 40:] = qb[149]                                   # a run of duplicates at the database's ragged end
+    db[1000:1003] = qb[0]
+    probe = [0, 1, 31, 32, 63, 64, 100, 149]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb[probe], db, ql[probe], dl, R)
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        ap, rel = ctx.map(R)
+        assert ctx.get_stat("select_variant") == 6 and ctx.get_stat("last_optimistic") == 1
+        assert np.array_equal(ap[probe], ap_ref, equal_nan=True)
+        ctx.set_option("compact_records", 0)                # k_select_mx, one distance per accumulator, 8-byte records
+        ap2, rel2 = ctx.map(R)
+        assert ctx.get_stat("select_variant") == 3
+        assert np.array_equal(ap2, ap, equal_nan=True) and np.array_equal(rel2, rel)
+        ctx.set_option("compact_records", 1)
+        ctx.set_option("select_packed", 1)                  # k_select_mx with one-byte records
+        ap3, _ = ctx.map(R)
+        assert ctx.get_stat("select_variant") == 3 and np.array_equal(ap3, ap, equal_nan=True)
+    finally:
+        ctx.close()
