@@ -214,6 +214,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     c->dbx8_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;    // a new database: earlier lost bets say nothing about it
     c->cap_boost = c->real_cap_boost = 1;
+    c->crowd_probed = false;
     c->cfg_epoch++;
     return HG_OK;
 }
@@ -417,6 +418,7 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->dbfb_valid = false;
     c->opt_consecutive_fail = c->shard_bet_fail = 0;
     c->cap_boost = c->real_cap_boost = 1;
+    c->crowd_probed = false;
     c->cfg_epoch++;
     return HG_OK;
 }
@@ -762,6 +764,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         // the caller retries the lost sharded bet within the same call (sharded.evaluate_shard widens the slices): that
         // attempt does not count towards hg_bet_eligible's "two calls in a row"
         if (value && c->shard_bet_fail > 0) c->shard_bet_fail--;
+    } else if (!strcmp(key, "crowd_probe")) {
+        c->opt_crowd_probe = value != 0;
     } else if (!strcmp(key, "fuse_ap")) {
         c->opt_fuse_ap = value != 0;
     } else if (!strcmp(key, "rank_direct_lds")) {
@@ -869,6 +873,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "rank_variant")) *value = c->last_rank;
     else if (!strcmp(key, "ap_fused")) *value = c->ap_fused ? 1 : 0;
     else if (!strcmp(key, "cap_boost")) *value = c->cap_boost;
+    else if (!strcmp(key, "crowding_x100")) *value = c->crowd_x100;
     else if (!strcmp(key, "real_cap_boost")) *value = c->real_cap_boost;
     else if (!strcmp(key, "real_grouped")) *value = c->real_grouped;
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;

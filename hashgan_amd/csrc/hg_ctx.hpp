@@ -186,6 +186,9 @@ struct hg_ctx {
     i64 real_grouped = 0;      // stat: the last real-valued ranking ordered its record lists group by group (k_real_group_*)
     i64 opt_real_groups = 1;   // "real_groups": record lists beyond the LDS are split by score range and ordered group by group in LDS (0: the four radix passes)
     i64 real_cap_boost = 1;    // the same for the real-valued ranking's slices (run_real)
+    bool crowd_probed = false; // the first bet on this database has measured how its near rows crowd (k_guess_direct's probe)
+    i64 crowd_x100 = 0;        // stat "crowding_x100": that measure, x 100 (~200: rows in random order; ~100 x classes: stored class by class)
+    i64 opt_crowd_probe = 1;   // "crowd_probe"
     i64 cap_boost = 1;         // slice capacity multiplier a lost bet escalated to on this database (run_oneshot); 1 after every load
     i64 opt_rank_direct_lds = 80;    // "rank_direct_lds": KB of LDS a k_rank_direct block may take (80: two blocks per CU -- C1 0.25 ms vs 0.31 with 160 and one)
     i64 opt_rank_direct = 1;   // "rank_direct": R = N on one shard in one counting-sort kernel, k_rank_direct, when its LDS fits (2: also N/8 < R < N)

@@ -349,7 +349,7 @@ static __global__ __launch_bounds__(256) void k_guess(const u32* __restrict__ hs
 template <int PARTS>
 __global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hseg, int Sh, int ratio, double sigma,
                                                       i64 n_total, u32 sampled, int* __restrict__ T, int* __restrict__ sstar,
-                                                      u32* __restrict__ failq, int* __restrict__ err, const Geo g) {
+                                                      u32* __restrict__ failq, int* __restrict__ err, u32* __restrict__ crowd, const Geo g) {
     constexpr int QPW = 64 / PARTS;                    // lane = part * QPW + query-in-wave
     const int lane = threadIdx.x & 63, part = lane / QPW;
     const int q = (blockIdx.x * WPB + (threadIdx.x >> 6)) * QPW + (lane % QPW);
@@ -370,9 +370,11 @@ __global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hs
     // reading): two planes per step, eight segments of each in flight -- 16 loads per trip instead of 4 (0.038 -> 0.025 ms
     // at C2, where a lane sums 13 segments per plane and stops at the 19th; C5 0.083 -> 0.049).
     constexpr int PL = 4;                              // planes per trip (round 3: 2 -> 4, 32 loads in flight: 0.0255 -> 0.0205 ms at C2, C5 0.047 -> 0.034)
+    u32 gmax = 0, gtot = 0;                            // crowding probe: the fullest sampled segment of the last plane group, the group's total
     for (int d = 0; d < dn && !found; d += PL) {
         u32 cs[PL];
         const u32* __restrict__ col[PL];
+        gmax = 0;
 #pragma unroll
         for (int p = 0; p < PL; ++p) { cs[p] = 0; col[p] = hseg + (i64)(d + p < dn ? d + p : d) * g.Qpad + qq; }
         for (int sh = s0; sh < s1; sh += 8) {
@@ -384,22 +386,40 @@ __global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hs
                 for (int p = 0; p < PL; ++p) v[p][k] = col[p][o];
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < 8; ++k) {
+                u32 sk = 0;
 #pragma unroll
-                for (int p = 0; p < PL; ++p) cs[p] += sh + k < s1 ? v[p][k] : 0u;
+                for (int p = 0; p < PL; ++p) { const u32 x = sh + k < s1 ? v[p][k] : 0u; cs[p] += x; sk += x; }
+                gmax = sk > gmax ? sk : gmax;
+            }
         }
 #pragma unroll
         for (int off = QPW; off < 64; off <<= 1)                          // sums over the query's parts
 #pragma unroll
             for (int p = 0; p < PL; ++p) cs[p] += (u32)__shfl_xor((int)cs[p], off);
+        gtot = 0;
 #pragma unroll
         for (int p = 0; p < PL; ++p) {
+            gtot += cs[p];
             if (!found && d + p < dn) {
                 below = cum;
                 cum += cs[p];
                 if (cum >= need) { t = d + p; found = true; }
             }
         }
+    }
+    if (crowd) {
+        // How unevenly do the rows near this query spread over the database?  The plane group that holds the cut carries
+        // most of the sampled mass below it: its fullest segment against the group's total, summed over the queries --
+        // the host turns sum(max) * segments / sum(total) into the slices' width for this database (a database stored class
+        // by class puts a query's near rows into its class's tenth of the segments: run_oneshot used to find that out by
+        // losing two bets).  First call on a database only.
+#pragma unroll
+        for (int off = QPW; off < 64; off <<= 1) {
+            const u32 m = (u32)__shfl_xor((int)gmax, off);
+            gmax = gmax > m ? gmax : m;
+        }
+        if (live && found && part == 0) { atomicAdd(crowd, gmax); atomicAdd(crowd + 1, gtot); }
     }
     // all parts of a query agree on t; a wave's queries may stop at different d: the shuffles below only pair
     // lanes of the same query, which left the loop together

@@ -253,7 +253,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     const Geo& g = c->geo;
     const size_t qb = (size_t)g.Qpad * 4;
     HG_TRY(c->thr.reserve(qb)); HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->failq.reserve(qb));
-    HG_TRY(c->tot.reserve(qb)); HG_TRY(c->err.reserve(8)); HG_TRY(c->qbad.reserve(qb));
+    HG_TRY(c->tot.reserve(qb)); HG_TRY(c->err.reserve(16)); HG_TRY(c->qbad.reserve(qb));
     HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     if (bet) {

@@ -201,7 +201,7 @@ static int launch_plan(hg_ctx* c, const uint32_t* dev_hist_all) {
     const size_t qb = (size_t)g.Qpad * 4;
     HG_TRY(c->posbase.reserve((size_t)g.NB * qb));
     HG_TRY(c->t.reserve(qb)); HG_TRY(c->cnt_lt.reserve(qb)); HG_TRY(c->quota.reserve(qb));
-    HG_TRY(c->tie_before.reserve(qb)); HG_TRY(c->n_lt.reserve(qb)); HG_TRY(c->err.reserve(8));
+    HG_TRY(c->tie_before.reserve(qb)); HG_TRY(c->n_lt.reserve(qb)); HG_TRY(c->err.reserve(16));
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     Plan pl{c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->n_lt.as<u32>(),
             c->posbase.as<u32>(), c->err.as<int>()};
@@ -285,7 +285,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
     if (c->direct_rank && mode == 0) {
         const i64 tile = rank_direct_tile(c, g.R);
         if (tile > 0) {
-            HG_TRY(c->err.reserve(8));
+            HG_TRY(c->err.reserve(16));
             HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
             const RankDirectLds L = rank_direct_layout(g.NB, c->RW, (int)tile);
             if (L.total > 64 * 1024)
@@ -302,7 +302,6 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
     }
     int nwav = c->opt_rank_waves ? (int)c->opt_rank_waves
                                  : ((c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4);   // records per query ~ 3R / R
-    if (leftovers_only && !c->opt_rank_waves && c->R >= 1024) nwav = 16;   // a handful of blocks: what counts is one block's latency
     // k_rank_lds: the query's records resident in LDS -- room for ~2.5 R per query (the bet keeps 1.3-2 R),
     // at most 64 KiB per block; queries with more are left to k_rank_fused (flagged in bigq)
     bool use_lds = false;
@@ -318,10 +317,11 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
         use_lds = (double)recs >= 2.0 * (double)c->R * share && recs >= 64;
         if (use_lds) nwav = 4;                        // the two kernels share hwq's [Q][4][NB] layout
     }
+    if (leftovers_only && !c->opt_rank_waves && c->R >= 1024) nwav = 16;   // a handful of blocks (mode 0: no hwq): what counts is one block's latency
     const size_t fixed_words = (size_t)(nwav + 1) * g.NB + 8;
     const int bits_lds = (fixed_words + 2 * (size_t)c->RW) * 4 <= 64 * 1024;
     if (mode != 1 && !bits_lds && !leftovers_only) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
-    HG_TRY(c->err.reserve(8));
+    HG_TRY(c->err.reserve(16));
     HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
     if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
 #ifdef HG_RANK_PROFILE
@@ -604,7 +604,7 @@ int hg_select_ranked(hg_ctx* c) {
     HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
     HG_TRY(c->out_idx.reserve(wide ? slots * 4 : 16)); HG_TRY(c->out_dist.reserve(wide ? slots : 16));
     if (wide) HG_HIP(hipMemsetAsync(c->out_idx.p, 0xFF, slots * 4, c->stream));    // slots past the shard's own records: IDX_NONE
-    HG_TRY(c->err.reserve(8));
+    HG_TRY(c->err.reserve(16));
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     HG_TRY(launch_select(c));
     const size_t plane = (size_t)g.NB * g.Qpad * 4;
@@ -842,7 +842,7 @@ static int enqueue_all_rows(hg_ctx* c, int64_t R) {
     const Geo& g = c->geo;
     const size_t qb = (size_t)g.Qpad * 4;
     const size_t slots = (size_t)g.Q * g.R;
-    HG_TRY(c->err.reserve(8)); HG_TRY(c->failq.reserve(qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->sl_cnt.reserve(qb));
+    HG_TRY(c->err.reserve(16)); HG_TRY(c->failq.reserve(qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->sl_cnt.reserve(qb));
     HG_TRY(c->cand.reserve(64));
     HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
     HG_TRY(c->out_idx.reserve(c->want_lists ? slots * 4 : 16));
@@ -915,8 +915,12 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     HG_TRY(c->tguess.reserve(qb));
     HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
     HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
-    HG_TRY(c->err.reserve(8));
+    HG_TRY(c->err.reserve(16));
     HG_TRY(c->sstar.reserve(qb));
+    // first bet on this database: the guess kernel also measures how the near rows crowd (err[2], err[3]) -- see below
+    const bool probe = c->opt_crowd_probe && !c->crowd_probed && c->cap_boost == 1 && !c->capturing && !c->is_sub;
+    u32* crowd = probe ? c->err.as<u32>() + 2 : nullptr;
+    if (probe) HG_HIP(hipMemsetAsync(crowd, 0, 8, c->stream));
     c->t_begin(KI_GUESS);
     const Geo gh = hist_geometry(c);                   // the sampled pass ran on coarser segments
     {   // lanes per query by the number of sampled segments each has to sum
@@ -925,7 +929,7 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
 #define HG_GUESS(P)                                                                                                     \
         hipLaunchKernelGGL(k_guess_direct<P>, dim3(grid_for(g.Qpad, WPB * (64 / P))), dim3(256), 0, c->stream,          \
                            c->hist.as<u32>(), gh.S, ratio, (double)c->opt_sigma, (i64)c->n_total, srows,                \
-                           c->tguess.as<int>(), c->sstar.as<int>(), c->failq.as<u32>(), c->err.as<int>(), g)
+                           c->tguess.as<int>(), c->sstar.as<int>(), c->failq.as<u32>(), c->err.as<int>(), crowd, g)
         // (more lanes per query shorten a lane's share of a plane but scatter a wavefront's loads over more lines: with 64
         // lanes for every query that the chip has room for, Q = 1000 went 0.068 -> 0.090 ms, C3 0.032 -> 0.061)
         if (gh.S <= 64) HG_GUESS(4);
@@ -936,6 +940,24 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     c->t_end();
     HG_TRY(c->check_launch("k_guess_direct"));
     c->err_zeroed = true;                              // launch_rank need not clear the lost-bet flag again
+    if (probe) {
+        // One host round trip, once per database: sum over the queries of (fullest sampled segment) * segments / (their total)
+        // is ~2 for rows in random order (the maximum of ~50 small Poisson counts) and ~the number of classes for a database
+        // stored class by class, whose slices then need that many times the mean -- widen them NOW instead of losing the
+        // first two bets (round 3: first call 6.6 ms at C2, two lost bets per new context).
+        u32 cr[2] = {0u, 0u};
+        HG_HIP(hipMemcpyAsync(cr, crowd, 8, hipMemcpyDeviceToHost, c->stream));
+        HG_TRY(c->sync());
+        c->crowd_probed = true;
+        const double ratio = cr[1] ? (double)cr[0] * (double)gh.S / (double)cr[1] : 0.0;
+        c->crowd_x100 = (i64)(ratio * 100.0);
+        if (ratio > 4.0) {
+            i64 boost = 2;
+            while ((double)boost < ratio && boost < 64) boost *= 2;
+            c->cap_boost = boost;
+            c->cfg_epoch++;
+        }
+    }
     // slice capacity: a guessed cut typically keeps 1.3-3 R rows (the guess overshoots by at most one
     // distance bucket, and cumulative counts grow ~2x per bucket in the tail where the cut lies; clustered
     // codes grow faster) -- budget 4 R per query over the S segments plus 6 sigma per slice.  HBM is

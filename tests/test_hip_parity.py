@@ -772,9 +772,10 @@ def test_sampled_kernel_timing_counts_every_nth_step(case_cache):
 
 def test_a_database_stored_class_by_class_keeps_the_bet():
     """Rows sorted by label, codes that follow the labels: a query's near rows all sit in its class's tenth of the
-    segments, ten times what slices sized for an even spread hold.  The first call loses the bet twice, widens the slices
-    (cap_boost) and wins; later calls on the same database bet with the wide slices at once; a new database starts over.
-    Every answer is the oracle's."""
+    segments, ten times what slices sized for an even spread hold.  The first bet on a database measures that crowding in
+    its guess kernel (k_guess_direct's probe) and widens the slices BEFORE selecting: no bet is lost.  With the probe off
+    the first call loses the bet twice, widens (cap_boost) and wins, as it did until round 3.  Later calls on the same
+    database bet with the wide slices at once; a new database starts over.  Every answer is the oracle's."""
     rng = np.random.default_rng(4242)
     Q, N, R, C, b = 64, 200000, 3000, 10, 64
     cls = np.sort(rng.integers(0, C, N))
@@ -793,8 +794,15 @@ def test_a_database_stored_class_by_class_keeps_the_bet():
         ap, rel = ctx.map(R)
         assert np.array_equal(ap, ap_ref, equal_nan=True)
         assert ctx.get_stat("last_optimistic") == 1 and ctx.get_stat("optimistic_fallbacks") == 0
+        assert ctx.get_stat("cap_boost") >= 8 and ctx.get_stat("optimistic_rebets") == 0 and ctx.get_stat("crowding_x100") > 600
+        ctx.set_option("crowd_probe", 0)                       # the adaptive way: lose, widen, remember
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        ap, rel = ctx.map(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        assert ctx.get_stat("last_optimistic") == 1 and ctx.get_stat("optimistic_fallbacks") == 0
         boost, rebets = ctx.get_stat("cap_boost"), ctx.get_stat("optimistic_rebets")
         assert boost > 1 and rebets >= 2
+        ctx.set_option("crowd_probe", 1)
         ap, rel = ctx.map(R)                                   # the widened slices are remembered: no further lost bet
         assert np.array_equal(ap, ap_ref, equal_nan=True)
         assert ctx.get_stat("optimistic_rebets") == rebets and ctx.get_stat("last_optimistic") == 1
@@ -802,7 +810,7 @@ def test_a_database_stored_class_by_class_keeps_the_bet():
         _load(ctx, dict(qbits=qb, dbbits=db[perm], qlab=ql, dblab=dl[perm], b=b))
         assert ctx.get_stat("cap_boost") == 1
         ap2, _ = ctx.map(R)
-        assert ctx.get_stat("cap_boost") == 1 and ctx.get_stat("optimistic_rebets") == rebets
+        assert ctx.get_stat("cap_boost") == 1 and ctx.get_stat("optimistic_rebets") == rebets and ctx.get_stat("crowding_x100") < 400
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             _, ap_ref2, *_ = O.map_from_codes(qb, db[perm], ql, dl[perm], R)
