@@ -49,6 +49,11 @@ _SIGNATURES = {
     "hg_merge_ranked": [_p, _p, _p, C.c_int, C.POINTER(C.c_int)],
     "hg_merge_ap_part": [_p, _p, _p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.POINTER(_p), C.POINTER(C.c_int64)],
     "hg_unpack_parts": [_p, _p, C.c_int, C.c_int64, _p, _p, C.POINTER(C.c_int)],
+    "hg_pack_sample_by_owner": [_p, C.c_int, C.POINTER(_p), C.POINTER(C.c_int64)],
+    "hg_guess_owned": [_p, _i64, _p, C.c_int, C.c_int, C.POINTER(_p), C.POINTER(C.c_int64)],
+    "hg_guess_finish": [_p, _i64, _p, C.c_int, C.c_int],
+    "hg_pack_ranked_by_owner": [_p, C.c_int, C.POINTER(_p), C.POINTER(C.c_int64)],
+    "hg_merge_ap_owned": [_p, _p, C.c_int, C.c_int, C.POINTER(_p), C.POINTER(C.c_int64)],
     "hg_match": [_p],
     "hg_match_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
     "hg_merge_match": [_p, _p, C.c_int],
@@ -69,6 +74,7 @@ _SIGNATURES = {
     "hg_comm_destroy": [_p],
     "hg_comm_info": [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "hg_allgather": [_p, C.c_int, _p, _i64, C.POINTER(_p)],
+    "hg_alltoall": [_p, C.c_int, _p, _i64, C.POINTER(_p)],
     "hg_allgather_topr": [_p],
     "hg_allreduce_max_f64": [_p, C.POINTER(C.c_double)],
     "hg_barrier": [_p],
@@ -265,6 +271,31 @@ class Context:
         check(self._lib.hg_unpack_parts(self._h, _p(dev_parts_all), int(G), int(width), _ptr(ap), _ptr(rel), C.byref(lost)))
         return ap, rel, bool(lost.value)
 
+    # -- the same bet with its exchanges routed by query owner (hg_pack_sample_by_owner ... hg_merge_ap_owned)
+    def pack_sample_by_owner(self, G):
+        p, n = _p(), _i64()
+        check(self._lib.hg_pack_sample_by_owner(self._h, int(G), C.byref(p), C.byref(n)))
+        return p.value, n.value                      # (device address of [G] blocks, bytes per block)
+
+    def guess_owned(self, R, dev_recv, G, rank):
+        p, n = _p(), _i64()
+        check(self._lib.hg_guess_owned(self._h, int(R), _p(dev_recv), int(G), int(rank), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def guess_finish(self, R, dev_answers, G, rank):
+        check(self._lib.hg_guess_finish(self._h, int(R), _p(dev_answers), int(G), int(rank)))
+        self.R = int(R)
+
+    def pack_ranked_by_owner(self, G):
+        p, n = _p(), _i64()
+        check(self._lib.hg_pack_ranked_by_owner(self._h, int(G), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def merge_ap_owned(self, dev_recv, G, rank):
+        p, n = _p(), _i64()
+        check(self._lib.hg_merge_ap_owned(self._h, _p(dev_recv), int(G), int(rank), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
     def bet_verdict(self):
         lost = C.c_int()
         check(self._lib.hg_bet_verdict(self._h, C.byref(lost)))
@@ -360,6 +391,12 @@ class Context:
         """-> device address of [world][nbytes], owned by the context (slot 0..3)."""
         out = _p()
         check(self._lib.hg_allgather(self._h, int(slot), _p(dev_ptr), int(nbytes), C.byref(out)))
+        return out.value
+
+    def alltoall(self, slot, dev_ptr, nbytes_per_peer):
+        """dev_ptr = [world][nbytes_per_peer], block r to rank r -> device address of [world][nbytes_per_peer] received."""
+        out = _p()
+        check(self._lib.hg_alltoall(self._h, int(slot), _p(dev_ptr), int(nbytes_per_peer), C.byref(out)))
         return out.value
 
     def allgather_topr(self):

@@ -14,6 +14,10 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
@@ -44,6 +48,10 @@ int rccl_load() {
     HG_SYM(CommDestroy, "ncclCommDestroy")
     HG_SYM(AllGather, "ncclAllGather")
     HG_SYM(AllReduce, "ncclAllReduce")
+    HG_SYM(Send, "ncclSend")
+    HG_SYM(Recv, "ncclRecv")
+    HG_SYM(GroupStart, "ncclGroupStart")
+    HG_SYM(GroupEnd, "ncclGroupEnd")
     HG_SYM(GetErrorString, "ncclGetErrorString")
 #undef HG_SYM
     g_rccl = a;
@@ -127,6 +135,28 @@ int hg_allgather(hg_ctx* c, int slot, const void* dev_src, int64_t nbytes, void*
     HG_NCCL(g_rccl.AllGather(dev_src, out.p, (size_t)nbytes, ncclUint8, c->comm, c->stream));
     c->t_end();
     *dev_gathered = out.p;
+    return c->stage_end();
+}
+
+// The owner-routed exchanges of the sharded bet: block r of dev_src (nbytes each) goes to rank r, *dev_out = [world][nbytes],
+// block r = what rank r sent here.  One grouped ncclSend / ncclRecv per peer: point-to-point over xGMI, every link busy at once,
+// and a GPU receives only its own queries' share of the tables (an all-gather would deliver all of them to everybody).
+int hg_alltoall(hg_ctx* c, int slot, const void* dev_src, int64_t nbytes_per_peer, void** dev_out) {
+    if (!c || !dev_src || !dev_out || nbytes_per_peer < 1) return fail(HG_ERR_ARG, "hg_alltoall: bad argument");
+    if (slot < 0 || slot >= 4) return fail(HG_ERR_ARG, "hg_alltoall: slot %d outside 0..3", slot);
+    if (!c->comm) return fail(HG_ERR_STATE, "hg_alltoall: no communicator (hg_comm_init)");
+    HG_TRY(c->use());
+    DevBuf& out = c->gathered[slot];
+    HG_TRY(out.reserve((size_t)nbytes_per_peer * c->comm_world));
+    c->t_begin(KI_COMM);
+    HG_NCCL(g_rccl.GroupStart());
+    for (int r = 0; r < c->comm_world; ++r) {
+        HG_NCCL(g_rccl.Send((const char*)dev_src + (size_t)r * nbytes_per_peer, (size_t)nbytes_per_peer, ncclUint8, r, c->comm, c->stream));
+        HG_NCCL(g_rccl.Recv(out.as<char>() + (size_t)r * nbytes_per_peer, (size_t)nbytes_per_peer, ncclUint8, r, c->comm, c->stream));
+    }
+    HG_NCCL(g_rccl.GroupEnd());
+    c->t_end();
+    *dev_out = out.p;
     return c->stage_end();
 }
 

@@ -159,6 +159,7 @@ int hg_destroy(hg_ctx* c) {
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
     c->comm_tmp.release(); c->gath_idx.release(); c->gath_dist.release();
+    c->obuf[0].release(); c->obuf[1].release();
     comm_release(c);
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->pin) (void)hipHostFree(c->pin);
@@ -851,6 +852,7 @@ int hg_trim(hg_ctx* c) {
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
     c->gath_idx.release(); c->gath_dist.release();
+    c->obuf[0].release(); c->obuf[1].release();
     c->dbx_valid = c->qx_valid = c->dbx2_valid = c->qx2_valid = false;
     c->dbx8.release(); c->dbx8_valid = false;
     c->dbx3.release(); c->dbx3_valid = false;

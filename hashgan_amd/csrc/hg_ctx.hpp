@@ -254,6 +254,7 @@ struct hg_ctx {
     DevBuf sl_start, sl_tie, sl_cnt, tot, failq;
     DevBuf mbits2;             // hg_merge_ranked's output (swapped with mbits)
     DevBuf part;               // hg_merge_ap_part's output: {AP, hits} of this rank's queries + its verdict
+    DevBuf obuf[2];            // owner-routed exchanges: [0] the blocks this rank sends (hg_pack_*_by_owner), [1] its answers as an owner (hg_guess_owned)
     bool ranked_local = false; // mbits holds this shard's bitmap in LOCAL rank order (hg_select_ranked)
     DevBuf cand, out_idx, out_dist, mbits, shapes, ap_recip, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores, gtab;   // real-valued path

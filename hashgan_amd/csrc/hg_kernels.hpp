@@ -1112,9 +1112,18 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
 // use_lds: the G local bitmap rows of the query are first copied into LDS with all loads in flight (the
 // stitching reads them bit range by bit range, one dependent load per 64 bits otherwise).
 // q0, q1: the queries this launch merges (a rank of the sharded bet takes its own share of them: hg_merge_ap_part).
+// Where the gathered tables live: all-gathered whole tables (every rank holds every query's rows of every shard), or the
+// owner-routed blocks of an all-to-all (this rank holds only ITS queries' rows of every shard -- hg_pack_ranked_by_owner).
+struct MergeSrc {
+    i64 hstride;     // u32 words between two shards' count tables
+    int hq;          // queries per row of a count table (a table is [NB][hq], q fastest)
+    i64 tail_off;    // word offset of a shard's tail (overflow flag in word 0) inside its block
+    i64 bstride;     // u64 words between two shards' bitmap tables
+    int qoff;        // first query the tables hold (row index = q - qoff)
+};
 static __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restrict__ hall, const u64* __restrict__ ball, int G,
                                                       i64 RW, u64* __restrict__ out, int* __restrict__ err,
-                                                      u32* __restrict__ qbad, int use_lds, const Geo g, const int q0, const int q1) {
+                                                      u32* __restrict__ qbad, int use_lds, const Geo g, const int q0, const int q1, const MergeSrc ms) {
     extern __shared__ __attribute__((aligned(16))) u64 mrows[];       // [WPB][G][RW] when use_lds
     const int lane = threadIdx.x & 63;
     const int q = q0 + blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -1125,18 +1134,17 @@ static __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restri
     u32* lcnt = (u32*)(mrows + (use_lds ? (i64)WPB * G * RW : 0)) + (i64)wv * G * g.NB;
     for (int i = lane; i < G * g.NB; i += 64) {
         const int r = i / g.NB, d = i - r * g.NB;
-        lcnt[i] = hall[(i64)r * ((i64)g.NB * g.Qpad + TAIL_WORDS) + (i64)d * g.Qpad + q];
+        lcnt[i] = hall[(i64)r * ms.hstride + (i64)d * ms.hq + (q - ms.qoff)];
     }
     if (use_lds) {
         for (i64 i = lane; i < (i64)G * RW; i += 64) {
             const i64 r = i / RW, w = i - r * RW;
-            lrows[i] = ball[(r * g.Q + q) * RW + w];
+            lrows[i] = ball[r * ms.bstride + (i64)(q - ms.qoff) * RW + w];
         }
     }
     wave_lds_sync();
-    const i64 plane = (i64)g.NB * g.Qpad + TAIL_WORDS;
     const bool mine = lane < G;                                       // lane r speaks for shard r (G <= 64)
-    if (q == q0 && mine && hall[(i64)lane * plane + plane - TAIL_WORDS]) atomicExch(err, 1);   // a slice overflowed somewhere
+    if (q == q0 && mine && hall[(i64)lane * ms.hstride + ms.tail_off]) atomicExch(err, 1);   // a slice overflowed somewhere
     u64* __restrict__ orow = out + (i64)q * RW;
     u64 acc = 0;                // output bits not yet written (wave-uniform), `fill` of them
     int fill = 0;
@@ -1163,7 +1171,7 @@ static __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restri
         for (int r = 0; r < G; ++r) {                                  // append shard r's `take` bits of bucket d
             const u32 n = (u32)__builtin_amdgcn_readlane((int)take, r);
             const u32 so = (u32)__builtin_amdgcn_readlane((int)loff, r);
-            const u64* src = use_lds ? lrows + (i64)r * RW : ball + ((i64)r * g.Q + q) * RW;
+            const u64* src = use_lds ? lrows + (i64)r * RW : ball + (i64)r * ms.bstride + (i64)(q - ms.qoff) * RW;
             for (u32 k0 = 0; k0 < n; k0 += 64) {
                 const u32 k = k0 + lane;
                 const bool bit = k < n && ((src[(so + k) >> 6] >> ((so + k) & 63)) & 1ull);
@@ -1189,6 +1197,126 @@ static __global__ __launch_bounds__(256) void k_merge_ranked(const u32* __restri
         const bool lost = cum < (u64)g.R;                              // fewer than R records over all shards: bet lost
         qbad[q] = lost ? 1u : 0u;
         if (lost) atomicExch(err, 1);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// K4o  the sharded bet's exchanges ROUTED BY QUERY OWNER (round 4).  The queries are split over the ranks exactly like
+// the per-query stages (hashgan_amd.sharded.shard_bounds: rank o owns [q0(o), q0(o) + nq(o))); what a stage needs of a
+// query it needs from every shard, but only on the query's owner -- so the tables travel by all-to-all, one block per
+// destination, instead of every rank receiving every query's rows of every shard (80 MB of ingress per GPU and step at
+// C4 / 8 GPUs with all-gathers, 10.6 MB this way).
+// ----------------------------------------------------------------------------
+struct Owners { int G, per, extra, width; };          // shard_bounds(Q, G): per = Q / G, the first `extra` ranks own one more
+__host__ __device__ inline int owner_q0(const Owners& w, int o) { return o * w.per + (o < w.extra ? o : w.extra); }
+__host__ __device__ inline int owner_nq(const Owners& w, int o) { return w.per + (o < w.extra ? 1 : 0); }
+__host__ __device__ inline int owner_of(const Owners& w, int q) {
+    const int big = w.extra * (w.per + 1);            // queries owned by the ranks that own per + 1
+    return q < big ? q / (w.per + 1) : w.extra + (w.per ? (q - big) / w.per : 0);
+}
+inline Owners make_owners(i64 Q, int G) { Owners w; w.G = G; w.per = (int)(Q / G); w.extra = (int)(Q % G); w.width = w.per + (w.extra ? 1 : 0); return w; }
+
+// Exchange 1 out: the sampled shard histogram, cut by owner.  Block o = u32 [4 + HC * width]: [1] = rows this shard's sampled
+// pass visited, [4 + d * width + i] = sampled rows at distance d < HC of query q0(o) + i.
+static __global__ __launch_bounds__(256) void k_pack_sample_owner(const u32* __restrict__ hown, const Owners w, const int HC,
+                                                                   u32* __restrict__ out, const Geo g) {
+    const i64 blk = 4 + (i64)HC * w.width;
+    const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (i64)w.G * HC * w.width) return;
+    const int o = (int)(idx / ((i64)HC * w.width));
+    const int rem = (int)(idx - (i64)o * HC * w.width);
+    const int d = rem / w.width, i = rem - d * w.width;
+    out[o * blk + 4 + rem] = i < owner_nq(w, o) ? hown[(i64)d * g.Qpad + owner_q0(w, o) + i] : 0u;
+    if (rem < 4) out[o * blk + rem] = rem == 1 ? hown[(i64)g.NB * g.Qpad + 1] : 0u;
+}
+
+// On the owner: the guess of ITS queries from the G received blocks (k_guess's arithmetic), answered per shard -- block r
+// = u32 [width][4] {T, sampled rows below the cut's ties that precede shard r's own (= k_guess's `have` before its
+// segments), the sample count the cut must reach, found}.
+static __global__ __launch_bounds__(256) void k_guess_owner(const u32* __restrict__ recv, const Owners w, const int HC, const int nq,
+                                                             const double sigma, const i64 n_total, u32* __restrict__ out, const Geo g) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w.width) return;
+    const i64 blk = 4 + (i64)HC * w.width;
+    u64 sampled = 0;
+    for (int r = 0; r < w.G; ++r) sampled += recv[r * blk + 1];
+    const double fr = (double)g.R * (double)sampled / (double)n_total;
+    const u64 need = (u64)ceil(fr + sigma * sqrt(fr) + 1.0);
+    u64 cum = 0, below = 0;
+    int t = g.NB - 1;                                  // sample too thin (or the cut beyond the planes sent): take everything
+    bool found = false;
+    if (i < nq) {
+        for (int d = 0; d < HC; ++d) {
+            below = cum;
+            for (int r = 0; r < w.G; ++r) cum += recv[r * blk + 4 + (i64)d * w.width + i];
+            if (cum >= need) { t = d; found = true; break; }
+        }
+    }
+    u64 have = below;
+    for (int r = 0; r < w.G; ++r) {
+        u32* o4 = out + ((i64)r * w.width + i) * 4;
+        o4[0] = (u32)t;
+        o4[1] = (u32)(have > 0xFFFFFFFFull ? 0xFFFFFFFFull : have);
+        o4[2] = (u32)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need);
+        o4[3] = found ? 1u : 0u;
+        if (found) have += recv[r * blk + 4 + (i64)t * w.width + i];
+    }
+}
+
+// On every rank: the owners' answers (block o = the queries o owns) + this shard's per-segment sampled histograms ->
+// the shared cut T and this shard's sstar, exactly as k_guess derives them from all-gathered tables.
+static __global__ __launch_bounds__(256) void k_guess_finish(const u32* __restrict__ ans, const Owners w, const u32* __restrict__ hseg,
+                                                              const int Sh, const int ratio, int* __restrict__ T, int* __restrict__ sstar,
+                                                              const Geo g) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= g.Q) return;
+    const int o = owner_of(w, q), i = q - owner_q0(w, o);
+    const u32* a4 = ans + ((i64)o * w.width + i) * 4;
+    const int t = (int)a4[0];
+    const u64 need = a4[2];
+    int ss = g.S - 1;                                  // default: collect distance T everywhere
+    if (a4[3]) {
+        u64 have = a4[1];
+        if (have >= need) {
+            ss = -1;                                   // the lower shards already hold the prefix
+        } else {
+            for (int sh = 0; sh < Sh; ++sh) {
+                have += hseg[((i64)sh * g.NB + t) * g.Qpad + q];
+                if (have >= need) { ss = (sh + 1) * ratio - 1; break; }
+            }
+            if (ss > g.S - 1) ss = g.S - 1;
+        }
+    }
+    T[q] = t;
+    sstar[q] = ss;
+}
+
+// Exchange 2 out: this shard's per-distance record counts and its match bitmap in LOCAL rank order (hg_select_ranked), cut
+// by owner.  Block o = u32 counts [cw = NB * width rounded up to even], u32 tail [TAIL_WORDS] ([0] = this shard's overflow
+// flag), u64 bits [width][RW].
+static __global__ __launch_bounds__(256) void k_pack_ranked_owner(const u32* __restrict__ hown, const u64* __restrict__ mbits, const Owners w,
+                                                                   const i64 RW, const i64 cw, u32* __restrict__ out, const Geo g) {
+    const i64 blk32 = cw + TAIL_WORDS + 2 * (i64)w.width * RW;       // u32 words per block
+    const i64 ncnt = (i64)w.G * (cw + TAIL_WORDS), nbit = (i64)w.G * w.width * RW;
+    const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (idx < ncnt) {
+        const int o = (int)(idx / (cw + TAIL_WORDS));
+        const i64 rem = idx - (i64)o * (cw + TAIL_WORDS);
+        u32 v = 0;
+        if (rem < (i64)g.NB * w.width) {
+            const int d = (int)(rem / w.width), i = (int)(rem - (i64)d * w.width);
+            if (i < owner_nq(w, o)) v = hown[(i64)d * g.Qpad + owner_q0(w, o) + i];
+        } else if (rem >= cw) {
+            v = hown[(i64)g.NB * g.Qpad + (rem - cw)];               // the tail as it is
+        }
+        out[o * blk32 + rem] = v;
+    } else if (idx < ncnt + nbit) {
+        const i64 k = idx - ncnt;
+        const int o = (int)(k / ((i64)w.width * RW));
+        const i64 rem = k - (i64)o * w.width * RW;
+        const int i = (int)(rem / RW);
+        u64* bits = (u64*)(out + o * blk32 + cw + TAIL_WORDS);
+        bits[rem] = i < owner_nq(w, o) ? mbits[(i64)(owner_q0(w, o) + i) * RW + (rem - (i64)i * RW)] : 0ull;
     }
 }
 

@@ -621,7 +621,8 @@ int hg_select_ranked(hg_ctx* c) {
     return c->stage_end();
 }
 
-static int merge_ranked_range(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, i64 q0, i64 nq, const char* who) {
+static int merge_ranked_range(hg_ctx* c, const uint32_t* dev_hist_all, const uint64_t* dev_bits_all, int G, i64 q0, i64 nq, const char* who,
+                              const MergeSrc* routed = nullptr) {
     HG_TRY(need(c, ST_MATCH, who, "hg_select_ranked"));
     if (!c->ranked_local) return fail(HG_ERR_STATE, "%s: hg_select_ranked has not run", who);
     if (G < 1 || G > 64 || (G > 1 && (!dev_hist_all || !dev_bits_all)))
@@ -630,8 +631,8 @@ static int merge_ranked_range(hg_ctx* c, const uint32_t* dev_hist_all, const uin
     if (q0 < 0 || nq < 0 || q0 + nq > g.Q) return fail(HG_ERR_ARG, "%s: queries [%lld, %lld) of %d", who, (long long)q0, (long long)(q0 + nq), g.Q);
     HG_TRY(c->mbits2.reserve((size_t)g.Q * c->RW * 8));
     HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
-    const u32* hall = G > 1 ? (const u32*)dev_hist_all : c->hown.as<u32>();
-    const u64* ball = G > 1 ? (const u64*)dev_bits_all : c->mbits.as<u64>();
+    const u32* hall = G > 1 || routed ? (const u32*)dev_hist_all : c->hown.as<u32>();
+    const u64* ball = G > 1 || routed ? (const u64*)dev_bits_all : c->mbits.as<u64>();
     const size_t rows_lds = (size_t)WPB * G * c->RW * 8;       // the G local bitmap rows of a block's four queries
     const size_t cnt_lds = (size_t)WPB * G * g.NB * 4;         // their per-distance counts: at most 4 * 64 * 256 * 4 = 256 KiB ...
     const int use_lds = rows_lds + cnt_lds <= 64 * 1024;
@@ -643,8 +644,11 @@ static int merge_ranked_range(hg_ctx* c, const uint32_t* dev_hist_all, const uin
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_ranked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_lds));
     c->t_begin(KI_MERGE);
     if (nq > 0)
+    {   // all-gathered whole tables by default; `routed`: the owner's blocks of an all-to-all (hg_merge_ap_owned)
+        const MergeSrc whole{(i64)g.NB * g.Qpad + TAIL_WORDS, g.Qpad, (i64)g.NB * g.Qpad, (i64)g.Q * c->RW, 0};
         hipLaunchKernelGGL(k_merge_ranked, dim3(grid_for(nq, WPB)), dim3(256), merge_lds, c->stream, hall, ball, G,
-                           c->RW, c->mbits2.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(), use_lds, g, (int)q0, (int)(q0 + nq));
+                           c->RW, c->mbits2.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(), use_lds, g, (int)q0, (int)(q0 + nq), routed ? *routed : whole);
+    }
     c->t_end();
     HG_TRY(c->check_launch("k_merge_ranked"));
     std::swap(c->mbits, c->mbits2);                    // the global bitmap is what hg_ap and hg_get_match see
@@ -811,6 +815,126 @@ int hg_unpack_parts(hg_ctx* c, const void* dev_parts_all, int G, int64_t width, 
         c->shard_bet_fail = 0;
     }
     return HG_OK;
+}
+
+// ---- the sharded bet with its exchanges routed by query owner (all-to-all instead of all-gather): see k_pack_sample_owner ----
+static int owners_for(hg_ctx* c, int G, Owners* w, const char* who) {
+    if (G < 1 || G > 64) return fail(HG_ERR_ARG, "%s: 1 <= G <= 64", who);
+    *w = make_owners(c->geo.Q, G);
+    return HG_OK;
+}
+static int sample_planes(const hg_ctx* c) { const int NB = c->geo.NB; return NB / 2 + 2 < NB ? NB / 2 + 2 : NB; }   // what a guess can need (enqueue_optimistic)
+
+int hg_pack_sample_by_owner(hg_ctx* c, int G, void** dev_ptr, int64_t* nbytes_per_peer) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_pack_sample_by_owner", "hg_sample_hist"));
+    if (!dev_ptr || !nbytes_per_peer || !c->hown.p) return fail(HG_ERR_ARG, "hg_pack_sample_by_owner: bad argument (hg_sample_hist first)");
+    Owners w;
+    HG_TRY(owners_for(c, G, &w, "hg_pack_sample_by_owner"));
+    const Geo& g = c->geo;
+    const int HC = sample_planes(c);
+    const i64 blk = 4 + (i64)HC * w.width;
+    HG_TRY(c->obuf[0].reserve((size_t)G * blk * 4));
+    hipLaunchKernelGGL(k_pack_sample_owner, dim3(grid_for((i64)G * HC * w.width)), dim3(256), 0, c->stream, c->hown.as<u32>(), w, HC,
+                       c->obuf[0].as<u32>(), g);
+    HG_TRY(c->check_launch("k_pack_sample_owner"));
+    *dev_ptr = c->obuf[0].p;
+    *nbytes_per_peer = blk * 4;
+    return c->stage_end();
+}
+
+int hg_guess_owned(hg_ctx* c, int64_t R, const void* dev_recv, int G, int rank, void** dev_ptr, int64_t* nbytes_per_peer) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_guess_owned", "hg_sample_hist"));
+    if (!dev_recv || !dev_ptr || !nbytes_per_peer) return fail(HG_ERR_ARG, "hg_guess_owned: null argument");
+    Owners w;
+    HG_TRY(owners_for(c, G, &w, "hg_guess_owned"));
+    HG_TRY(set_R(c, R, G, rank));
+    const Geo& g = c->geo;
+    HG_TRY(c->obuf[1].reserve((size_t)G * w.width * 16));
+    c->t_begin(KI_GUESS);
+    hipLaunchKernelGGL(k_guess_owner, dim3(grid_for(w.width)), dim3(256), 0, c->stream, (const u32*)dev_recv, w, sample_planes(c),
+                       owner_nq(w, rank), (double)c->opt_sigma, (i64)c->n_total, c->obuf[1].as<u32>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_guess_owner"));
+    *dev_ptr = c->obuf[1].p;
+    *nbytes_per_peer = (int64_t)w.width * 16;
+    return c->stage_end();
+}
+
+int hg_guess_finish(hg_ctx* c, int64_t R, const void* dev_answers, int G, int rank) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_guess_finish", "hg_sample_hist"));
+    if (!dev_answers) return fail(HG_ERR_ARG, "hg_guess_finish: null argument");
+    Owners w;
+    HG_TRY(owners_for(c, G, &w, "hg_guess_finish"));
+    HG_TRY(set_R(c, R, G, rank));
+    const Geo& g = c->geo;
+    const size_t qb = (size_t)g.Qpad * 4;
+    HG_TRY(c->tguess.reserve(qb));
+    HG_TRY(c->sl_start.reserve((size_t)g.S * qb)); HG_TRY(c->sl_tie.reserve((size_t)g.S * qb));
+    HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
+    HG_TRY(c->sstar.reserve(qb));
+    HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
+    const Geo gh = hist_geometry(c);                   // the sampled pass ran on coarser segments
+    c->t_begin(KI_GUESS);
+    hipLaunchKernelGGL(k_guess_finish, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, (const u32*)dev_answers, w, c->hist.as<u32>(), gh.S,
+                       (int)(gh.L / g.L), c->tguess.as<int>(), c->sstar.as<int>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_guess_finish"));
+    // (the slices' budget: as hg_guess)
+    const double share = (double)c->N / (double)c->n_total;
+    const double mean = 0.1 * (double)c->cand_budget_x10 * (double)c->cap_boost * (double)R * share / (double)g.S;
+    c->optimistic = true;
+    c->cap = slice_capacity(c, mean);
+    c->crow = (i64)g.S * c->cap;
+    c->stage = ST_DB | ST_Q | ST_PLAN;
+    return c->stage_end();
+}
+
+int hg_pack_ranked_by_owner(hg_ctx* c, int G, void** dev_ptr, int64_t* nbytes_per_peer) {
+    HG_TRY(need(c, ST_MATCH, "hg_pack_ranked_by_owner", "hg_select_ranked"));
+    if (!c->ranked_local) return fail(HG_ERR_STATE, "hg_pack_ranked_by_owner: hg_select_ranked has not run");
+    if (!dev_ptr || !nbytes_per_peer) return fail(HG_ERR_ARG, "hg_pack_ranked_by_owner: null argument");
+    Owners w;
+    HG_TRY(owners_for(c, G, &w, "hg_pack_ranked_by_owner"));
+    const Geo& g = c->geo;
+    const i64 cw = ((i64)g.NB * w.width + 1) & ~1ll;
+    const i64 blk32 = cw + TAIL_WORDS + 2 * (i64)w.width * c->RW;
+    HG_TRY(c->obuf[0].reserve((size_t)G * blk32 * 4));
+    const i64 items = (i64)G * (cw + TAIL_WORDS) + (i64)G * w.width * c->RW;
+    hipLaunchKernelGGL(k_pack_ranked_owner, dim3(grid_for(items)), dim3(256), 0, c->stream, c->hown.as<u32>(), c->mbits.as<u64>(), w, c->RW, cw,
+                       c->obuf[0].as<u32>(), g);
+    HG_TRY(c->check_launch("k_pack_ranked_owner"));
+    *dev_ptr = c->obuf[0].p;
+    *nbytes_per_peer = blk32 * 4;
+    return c->stage_end();
+}
+
+int hg_merge_ap_owned(hg_ctx* c, const void* dev_recv, int G, int rank, void** dev_part, int64_t* nbytes) {
+    if (!c || !dev_recv || !dev_part || !nbytes) return fail(HG_ERR_ARG, "hg_merge_ap_owned: null argument");
+    Owners w;
+    HG_TRY(owners_for(c, G, &w, "hg_merge_ap_owned"));
+    if (rank < 0 || rank >= G) return fail(HG_ERR_ARG, "hg_merge_ap_owned: rank %d of %d", rank, G);
+    const Geo& g = c->geo;
+    const i64 cw = ((i64)g.NB * w.width + 1) & ~1ll;
+    const i64 blk32 = cw + TAIL_WORDS + 2 * (i64)w.width * c->RW;
+    const i64 q0 = owner_q0(w, rank), nq = owner_nq(w, rank);
+    const MergeSrc ms{blk32, w.width, cw, blk32 / 2, (int)q0};
+    const u32* hall = (const u32*)dev_recv;
+    const u64* ball = (const u64*)(hall + cw + TAIL_WORDS);
+    HG_TRY(merge_ranked_range(c, hall, ball, G, q0, nq, "hg_merge_ap_owned", &ms));
+    c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
+    HG_TRY(c->ap.reserve((size_t)g.Q * 8));
+    HG_TRY(c->rel.reserve((size_t)g.Q * 4));
+    HG_TRY(do_ap_range(c, q0, nq));
+    if (!(q0 == 0 && nq == g.Q)) c->stage &= ~(unsigned)ST_MATCH;
+    const i64 width = w.width;
+    const size_t pb = (size_t)(width + 1) * 16;
+    HG_TRY(c->part.reserve(pb));
+    hipLaunchKernelGGL(k_pack_part, dim3(grid_for(width + 1)), dim3(256), 0, c->stream, c->ap.as<double>(), c->rel.as<u32>(),
+                       c->err.as<int>(), (i64)q0, (i64)nq, (i64)width, c->part.as<double>());
+    HG_TRY(c->check_launch("k_pack_part"));
+    *dev_part = c->part.p;
+    *nbytes = (int64_t)pb;
+    return c->stage_end();
 }
 
 // ---- one-shot forms: every stage enqueued back to back, one synchronisation ----

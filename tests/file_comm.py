@@ -56,6 +56,20 @@ class FileComm:
         self.ctx.memcpy_htod(base, np.ascontiguousarray(allb), allb.size)
         return DevBuf(base, allb.size)
 
+    def all_to_all(self, buf):
+        host = np.empty(buf.nbytes, np.uint8)
+        self.ctx.memcpy_dtoh(host, buf.ptr, buf.nbytes)
+        self._publish("a2a", host.tobytes())
+        parts = self._collect("a2a")
+        self._n += 1
+        n = buf.nbytes // self.world
+        mine = np.frombuffer(b"".join(p[self.rank * n:(self.rank + 1) * n] for p in parts), np.uint8)
+        slot = self._slot
+        self._slot = (slot + 1) % 4
+        base = self.ctx.scratch(slot, buf.nbytes)
+        self.ctx.memcpy_htod(base, np.ascontiguousarray(mine), mine.size)
+        return DevBuf(base, mine.size)
+
     def barrier(self):
         self._publish("bar", b"x")
         self._collect("bar")

@@ -145,3 +145,73 @@ class NumpyRankedEngine(NumpyShardEngine):
         ap = np.concatenate([P[r, :ns[r], 0] for r in range(world)])
         rel = np.concatenate([P[r, :ns[r], 1] for r in range(world)]).astype(np.int64)
         return ap, rel, bool(P[:, width, 0].any())
+
+
+class NumpyRoutedEngine(NumpyRankedEngine):
+    """The same bet with its exchanges routed by query owner (HipShardEngine.pack_sample_by_owner ... merge_ap_owned over
+    comm.all_to_all): every table is cut into one block per owner of its queries, block o holding rows q0(o) .. of them, and
+    the owner stitches and evaluates only what it received.  Blocks are [world, ...] tensors, like the HIP engine's."""
+
+    def _owners(self, world):
+        from hashgan_amd.sharded import shard_bounds
+        b = shard_bounds(self.D.shape[0], world)
+        return b, max(n for _, n in b)
+
+    def sample_hist(self, R):
+        self.R = R
+        return self.hist()
+
+    def pack_sample_by_owner(self, world):
+        bounds, width = self._owners(world)
+        out = np.zeros((world, width, self.NB), np.int32)
+        for o, (q0, nq) in enumerate(bounds):
+            out[o, :nq] = self.h[q0:q0 + nq]
+        return torch.from_numpy(out)
+
+    def guess_owned(self, R, received, world, rank):
+        # (the stand-in's "guess" keeps every row: the answers carry nothing, but they make the second all-to-all happen)
+        _, width = self._owners(world)
+        assert tuple(received.shape) == (world, width, self.NB)
+        return torch.zeros((world, width, 4), dtype=torch.int32)
+
+    def guess_finish(self, R, answers, world, rank):
+        _, width = self._owners(world)
+        assert tuple(answers.shape) == (world, width, 4)
+        self.R = R
+
+    def pack_ranked_by_owner(self, world):
+        bounds, width = self._owners(world)
+        nbyte = (self.R + 7) // 8
+        packed = np.packbits(self.local_bits, axis=1, bitorder="little")
+        out = np.zeros((world, width, self.NB * 4 + nbyte), np.uint8)
+        for o, (q0, nq) in enumerate(bounds):
+            out[o, :nq, :self.NB * 4] = self.h[q0:q0 + nq].astype(np.int32).view(np.uint8).reshape(nq, self.NB * 4)
+            out[o, :nq, self.NB * 4:] = packed[q0:q0 + nq]
+        return torch.from_numpy(out)
+
+    def merge_ap_owned(self, received, world, rank):
+        bounds, width = self._owners(world)
+        q0, nq = bounds[rank]
+        blk = received.numpy()
+        R = self.R
+        part = np.zeros((width + 1, 2), dtype=np.float64)
+        lost = False
+        for i in range(nq):
+            H = np.stack([blk[r, i, :self.NB * 4].copy().view(np.int32) for r in range(world)]).astype(np.int64)     # [world, NB]
+            loc = [np.unpackbits(blk[r, i, self.NB * 4:], bitorder="little")[:R].astype(bool) for r in range(world)]
+            out = np.zeros(R, dtype=bool)
+            off = [0] * world
+            pos = 0
+            for d in range(self.NB):
+                for r in range(world):
+                    take = min(int(H[r, d]), R - pos)
+                    out[pos:pos + take] = loc[r][off[r]:off[r] + take]
+                    pos += take
+                    off[r] += int(H[r, d])
+                if pos >= R:
+                    break
+            lost = lost or pos < R
+            a, rel = O.average_precision(out, R)
+            part[i] = (np.nan if a is None else a, rel)
+        part[width] = (1.0 if lost else 0.0, nq)
+        return torch.from_numpy(part)

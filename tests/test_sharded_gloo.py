@@ -15,7 +15,7 @@ def _worker(rank, world, port, name, out_dir, ranked=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from tests import cases
-    from tests.numpy_shard_engine import NumpyShardEngine, NumpyRankedEngine
+    from tests.numpy_shard_engine import NumpyShardEngine, NumpyRankedEngine, NumpyRoutedEngine
     from hashgan_amd import sharded
     from tests.torch_comm import TorchComm
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -24,7 +24,7 @@ def _worker(rank, world, port, name, out_dir, ranked=False):
     c = cases.build_case(name)
     N = c["dbbits"].shape[0]
     base, rows = sharded.shard_bounds(N, world)[rank]
-    cls = NumpyRankedEngine if ranked else NumpyShardEngine
+    cls = NumpyRoutedEngine if ranked == "routed" else NumpyRankedEngine if ranked else NumpyShardEngine
     eng = cls(c["qbits"], c["qlab"], c["dbbits"][base:base + rows], c["dblab"][base:base + rows], base)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -58,6 +58,21 @@ def test_two_rank_gloo_merged_local_rankings(name, tmp_path):
     r1 = np.load(tmp_path / "rank1.npz")
     assert np.array_equal(r0["ap"], r1["ap"], equal_nan=True)
     assert np.array_equal(r0["ap"], g["ap"], equal_nan=True)
+
+
+@pytest.mark.parametrize("name,world", [("e_b8", 2), ("e_some_skipped", 3), ("e_dups_alleq", 2)])
+def test_gloo_owner_routed_exchanges(name, world, tmp_path):
+    """The bet with its tables routed by query owner (evaluate_shard's all_to_all branch: sampled histograms -> owner's
+    guess -> answers back -> record counts + local bitmaps -> the owner stitches and evaluates its queries) over a gloo
+    group of 2 and 3 processes: every rank ends up with every query's AP, equal to the unmodified reference's golden."""
+    from tests import cases
+    port = 29100 + (os.getpid() % 150)
+    mp.spawn(_worker, args=(world, port, name, str(tmp_path), "routed"), nprocs=world, join=True)
+    g = cases.load_golden(name)
+    rs = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    for r in rs[1:]:
+        assert np.array_equal(rs[0]["ap"], r["ap"], equal_nan=True) and np.array_equal(rs[0]["rel"], r["rel"])
+    assert np.array_equal(rs[0]["ap"], g["ap"], equal_nan=True)
 
 
 def test_shard_bounds():

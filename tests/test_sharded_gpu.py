@@ -12,7 +12,7 @@ from hashgan_amd import _native, metric, sharded
 pytestmark = pytest.mark.gpu
 
 
-def _run_virtual(c, G, gather_topr, defer=False):
+def _run_virtual(c, G, gather_topr, defer=False, routed=True):
     N = c["dbbits"].shape[0]
     qw, ql = metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"])
     comms = sharded.LocalComm.create(G)
@@ -32,7 +32,7 @@ def _run_virtual(c, G, gather_topr, defer=False):
             eng = sharded.HipShardEngine(ctx, want_lists=gather_topr)
             if defer:
                 ctx.set_option("defer_verdict", 1)      # hg_rank does not wait; the verdict comes with the AP download
-            results[r] = sharded.evaluate_shard(eng, comms[r], c["R"], gather_topr=gather_topr)
+            results[r] = sharded.evaluate_shard(eng, comms[r], c["R"], gather_topr=gather_topr, route_by_owner=routed)
             stats[r] = (ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks"))
             boosts[r] = ctx.get_stat("cap_boost")
             ctx.close()
@@ -82,11 +82,13 @@ def test_virtual_shards_optimistic_sequence(name, G, case_cache):
     AP of the unmodified reference, and really have taken the one-pass route."""
     c = case_cache(name)
     g = cases.load_golden(name)
-    for defer in (False, True):
-        res = _run_virtual(c, G, gather_topr=False, defer=defer)
+    # routed: the bet's tables by all-to-all to the owner of their queries (the default); else the all-gather form
+    combos = ((False, True), (False, False)) if name == "c4_n10m_q8" else ((False, True), (True, True), (False, False))
+    for defer, routed in combos:
+        res = _run_virtual(c, G, gather_topr=False, defer=defer, routed=routed)
         for r in range(G):
             ap, rel = res[r]
-            assert np.array_equal(ap, g["ap"], equal_nan=True), (name, G, r, defer)
+            assert np.array_equal(ap, g["ap"], equal_nan=True), (name, G, r, defer, routed)
         assert sharded.mean_ap(*res[0]) == g["map"]
         assert all(st == (1, 0) for st in _run_virtual.last_stats), _run_virtual.last_stats
 
@@ -197,12 +199,14 @@ def test_sharded_product_path_is_torch_free():
     assert r.returncode == 0 and "TORCH_FREE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("world,workload", [(2, "c3"), (3, "c3")])
+@pytest.mark.parametrize("world,workload", [(2, "c3"), (3, "c3"), (8, "c3")])
 def test_bench_multi_rank_control_flow(world, workload, tmp_path):
     """bench.py --gpus G as the driver launches it (one process per rank, RANK / WORLD_SIZE / LOCAL_RANK in the
     environment), dry-run on ONE GPU with the file communicator standing in for RCCL: rendezvous of the processes, shard
     bounds, the orchestration over real process boundaries, max-over-ranks clock, only rank 0 prints -- one JSON line
-    whose AP matches the reference's golden.  (world 2: the merged-ranking bet; world 3: shards too small, exact sequence.)"""
+    whose AP matches the reference's golden.  (world 2: the merged-ranking bet, its tables routed by query owner; world 3
+    and 8 -- the driver's full node: rendezvous of eight processes, shard_bounds(N, 8), eight slots -- shards too small for
+    the bet, exact sequence.)"""
     import json
     import os
     import subprocess

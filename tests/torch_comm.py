@@ -18,6 +18,13 @@ class TorchComm:
         dist.all_gather_into_tensor(out, flat, group=self.group)
         return out.view((self.world,) + tuple(t.shape))
 
+    def all_to_all(self, t):
+        """t = [world, ...]: block r goes to rank r -> [world, ...], block r = what rank r sent here."""
+        t = t.contiguous()
+        out = torch.empty_like(t)
+        dist.all_to_all_single(out.view(-1), t.view(-1), group=self.group)
+        return out
+
     def barrier(self):
         dist.barrier(group=self.group)
 
