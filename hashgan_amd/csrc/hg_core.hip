@@ -784,6 +784,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_rank_lds = value != 0;
     } else if (!strcmp(key, "rank_cnt")) {
         c->opt_rank_cnt = value != 0;
+    } else if (!strcmp(key, "rank_lean")) {
+        c->opt_rank_lean = value != 0;
     } else if (!strcmp(key, "host_pack")) {
         c->opt_host_pack = value != 0;
     } else if (!strcmp(key, "keep_floats")) {

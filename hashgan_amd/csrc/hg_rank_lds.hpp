@@ -47,6 +47,7 @@ struct RankLdsArgs {
     // its query's cut (the guess, or the exact threshold), and a list that reaches further down than the 16 (32) distances
     // this kernel places leaves it anyway (null: the counters cover [0, nbc))
     const int* cut;
+    int spec_pieces;       // k_rank_lean: 16-byte pieces of every slice fetched before the slice counts are known
 };
 
 template <int NWAV>

@@ -9,6 +9,7 @@
 #include "hg_rank_lds.hpp"
 #include "hg_rank_cnt.hpp"
 #include "hg_rank_wave.hpp"
+#include "hg_rank_lean.hpp"
 #include "hg_rank_direct.hpp"
 
 // Segment geometry of the pair passes: ~target_units wavefront-sized units.
@@ -366,6 +367,49 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
             c->t_end();
             HG_TRY(c->check_launch("k_rank_wave"));
             c->last_rank = 4;
+            only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
+            counted = true;
+        }
+    }
+    if (!counted && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_lean && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
+        g.S <= 256 && (c->cap & 15u) == 0 && c->cap <= 1024 && g.R <= 60000) {
+        // the lean counting sort (k_rank_lean): the whole record row in one coalesced read, piecewise compaction, chunks in registers
+        const int nbc = rank_cnt_maxb(g.NB) + 2 < g.NB ? rank_cnt_maxb(g.NB) + 2 : 0;
+        const int nbc_eff = nbc ? nbc : (g.NB < 128 ? g.NB : 128);
+        const int* cut = nbc ? (c->exact_mx ? c->t.as<int>() : c->tguess.as<int>()) : nullptr;
+        // room for every piece of the row when that fits HG_RANK_WAVES blocks per CU; else for the usual list (2.2 R + padding)
+        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
+        const i64 all = (i64)g.S * c->cap;
+        // pieces of a slice fetched up front: what it holds but for a 4-sigma exception, when the select keeps ~0.7 of the budgeted
+        // mean (cap = mean + 6 sqrt(mean) + 16, inverted); at most what four loads per thread cover
+        const double mb = std::pow(std::sqrt((double)c->cap > 7.0 ? (double)c->cap - 7.0 : 0.0) - 3.0, 2.0), est = 0.7 * mb;
+        int psp = (int)std::ceil((est + 4.0 * std::sqrt(est) + 1.0) / 16.0);
+        if (psp > (int)(c->cap >> 4)) psp = (int)(c->cap >> 4);
+        if (psp > RL_MAX_PIECES / g.S) psp = RL_MAX_PIECES / g.S;
+        if (psp < 1) psp = 1;
+        const i64 room = ((160 * 1024 / HG_RANK_WAVES) & ~511ll) - rank_lean_layout(g.NB, c->RW, g.S, 0, nbc).total;
+        i64 rb = all <= room ? all : room & ~15ll;
+        const i64 least = ((i64)(2.2 * (double)c->R * share) + 256 + 16 * (i64)g.S + 15) & ~15ll;
+        if (rb < least && least <= all) rb = least;
+        if (rb > all) rb = all;
+        if (rb > 16 * RL_MAX_PIECES) rb = 16 * RL_MAX_PIECES;      // a thread keeps at most four pieces of its query's list
+        const RankLeanLds L = rank_lean_layout(g.NB, c->RW, g.S, (int)rb, nbc);
+        if (nbc_eff <= 63 && L.total <= 64 * 1024 && rb >= 16 && (rb >= least || rb == all)) {
+            HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
+            const bool fuse = c->fuse_ap && c->opt_fuse_ap && mode == 0 && c->LW <= 2;
+            bool use_recip = false;
+            if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
+            RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
+                           c->cap, c->crow, 0, 1, c->RW, (int)rb, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
+                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc,
+                           fuse ? c->shapes.as<ApShape>() : nullptr, fuse && use_recip ? c->ap_recip.as<double>() : nullptr,
+                           c->ap.as<double>(), c->rel.as<u32>(), fuse ? c->err.as<u32>() + 1 : nullptr, cut, psp};
+            c->t_begin(KI_RANK_LDS);
+            hipLaunchKernelGGL(k_rank_lean, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, c->cand.as<u8>(), la, c->mbits.as<u32>(), g);
+            c->t_end();
+            HG_TRY(c->check_launch("k_rank_lean"));
+            c->last_rank = 6;
+            if (fuse) { c->ap_fused = true; return HG_OK; }
             only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
             counted = true;
         }
