@@ -533,8 +533,9 @@ extern "C++" int ensure_ap_tables(hg_ctx* c, bool* use_recip_out) {
     // reciprocals of the ranks 1 .. R (k_ap's division in three multiply-adds); lists beyond 2^20 divide
     const bool use_recip = c->opt_ap_recip && g.R <= (1ll << 20);
     if (use_recip && c->recip_for_R != g.R) {
-        HG_TRY(c->ap_recip.reserve((size_t)(g.R + 1) * 8));
-        hipLaunchKernelGGL(k_recip_table, dim3(grid_for(g.R + 1)), dim3(256), 0, c->stream, c->ap_recip.as<double>(), (i64)g.R);
+        // (AP_RECIP_SLACK more: ap_eval2's masked slots past the last rank still load a -- finite -- entry)
+        HG_TRY(c->ap_recip.reserve((size_t)(g.R + 1 + AP_RECIP_SLACK) * 8));
+        hipLaunchKernelGGL(k_recip_table, dim3(grid_for(g.R + 1 + AP_RECIP_SLACK)), dim3(256), 0, c->stream, c->ap_recip.as<double>(), (i64)g.R + AP_RECIP_SLACK);
         HG_TRY(c->check_launch("k_recip_table"));
         c->recip_for_R = g.R;
     }

@@ -1553,6 +1553,152 @@ __device__ __forceinline__ void ap_eval(const WordFn& word_at, const i64 RW, con
     }
 }
 
+// ap_eval with a third of the instructions (round 4; k_rank_lean's epilogue).  Same arithmetic, same order of additions:
+//   * a lane (leaf, j) walks its stride-8 elements incrementally: 32 window bits per step come from two LDS reads and a
+//     funnel shift, the running match count from v_bcnt of the window's bytes (no per-element prefix lookup, no 64-bit
+//     masks), the rank as a double from b += 8.0, the reciprocal through an immediate offset from one per-lane pointer;
+//     a slot without a match contributes a = 0 -> q = 0 -> +0.0, and r + 0.0 == r exactly, so no branch per element;
+//   * the < 8 tail elements of a leaf are evaluated by lanes 0..6 of its group at once and added by lane 0 in order (DPP);
+//   * the eight accumulators combine through DPP (xor 1, xor 2, half mirror) instead of ds_bpermute;
+//   * the tree above the leaves is walked by wavefront 0 alone (its tables prefetched at the start): no block barrier per level.
+// Needs the reciprocal table (with AP_RECIP_SLACK finite entries past R: masked slots still load); without one, ap_eval.
+constexpr int AP_RECIP_SLACK = 160;
+template <int CTRL> __device__ __forceinline__ double ap_dpp_mov(const double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int NT, class WordFn>
+__device__ __forceinline__ void ap_eval2(const WordFn& word_at, const i64 RW, const i64 R, const ApShape* __restrict__ shapes,
+                                         const double* __restrict__ recip, const ApLds& L, const int tid,
+                                         double* __restrict__ ap_out, u32* __restrict__ rel_out) {
+    static_assert(NT >= AP_CHUNK / 64 && NT % 64 == 0, "one thread per word of a chunk");
+    u64* cw = L.cw;
+    const u32* cw32 = (const u32*)L.cw;
+    double* tree = L.tree;
+    u32* wpre = L.wpre;
+    u32& s_before = L.sb[0];
+    u32& s_w0 = L.sb[1];
+    if (tid == 0) s_before = 0;
+    double total = 0.0;        // thread 0 only
+    const i64 n_chunks = (R + AP_CHUNK - 1) / AP_CHUNK;
+    for (i64 c = 0; c < n_chunks; ++c) {
+        const i64 cb = c * AP_CHUNK;
+        const bool last = (c == n_chunks - 1);
+        const ApShape* __restrict__ sh = shapes + ((last && (R - cb) != AP_CHUNK) ? 1 : 0);
+        const int n = (int)(R - cb < AP_CHUNK ? R - cb : AP_CHUNK);
+        // the tree's tables (wavefront 0 walks it at the end) and the first leaves, requested before anything waits
+        const int nn = sh->n_nodes, nlv = sh->n_leaves, max_h = sh->max_h;
+        int tl[2] = {0, 0}, tr[2] = {0, 0}, th[2] = {0, 0};
+        if (tid < 64) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (tid + 64 * k < nn) { tl[k] = sh->nl[tid + 64 * k]; tr[k] = sh->nr[tid + 64 * k]; th[k] = sh->nh[tid + 64 * k]; }
+        }
+        if (tid < AP_CHUNK / 64) {   // load the chunk's words and prefix their popcounts (two wavefronts, 64 words each)
+            const i64 w = (cb >> 6) + tid;
+            const u64 word = (w < RW) ? word_at(w) : 0ull;
+            cw[tid] = word;
+            u32 incl = (u32)__popcll(word);
+            incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);
+            incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);
+            incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);
+            incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);
+            incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);
+            incl += (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);
+            if (tid == 63) s_w0 = incl;
+            wpre[tid + 1] = incl;                              // the second wave's values still lack the first's total
+            if (tid == 0) wpre[0] = 0u;
+        }
+        __syncthreads();
+        const u32 before = s_before;
+        const u32 w0tot = s_w0;
+        for (int l0 = 0; l0 < nlv; l0 += NT / 8) {
+            const int leaf = l0 + (tid >> 3), j = tid & 7;
+            const bool act = leaf < nlv;
+            const int ls = act ? sh->leaf_start[leaf] : 0, ll = act ? sh->leaf_len[leaf] : 0;
+            const int body = ll - (ll % 8);
+            // matches before the leaf: (earlier chunks) + (words before its first) + (bits below it in that word); ls is a multiple of 8
+            const int wi = ls >> 6;
+            const u64 fw = cw[wi];
+            u32 P = before + wpre[wi] + (wi > 64 ? w0tot : 0u) + (u32)__popcll(fw & ((1ull << (ls & 63)) - 1ull));
+            const u32 lmask = (2u << j) - 1u;                  // bits 0..j of a byte: the elements of a group of eight up to the lane's
+            const int wd = ls >> 5, bs = ls & 31;              // the leaf's first dword of the bitmap, its first bit inside it
+            const double* __restrict__ rp = recip + (cb + ls + j + 1);
+            double b = (double)(cb + ls + j + 1);
+            double r = 0.0;
+            for (int i4 = 0; __any(32 * i4 < body); ++i4) {    // 32 elements of the leaf = 4 of the lane's per step
+                const u32 lo = cw32[wd + i4], hi = cw32[wd + i4 + 1];
+                u32 W = __builtin_amdgcn_alignbit(hi, lo, (u32)bs);      // elements 32 i4 .. 32 i4 + 31 of the leaf
+                const int nb = body - 32 * i4;
+                W = nb >= 32 ? W : nb <= 0 ? 0u : W & ((1u << nb) - 1u);
+                const double y0 = rp[0], y1 = rp[8], y2 = rp[16], y3 = rp[24];
+                const double ys[4] = {y0, y1, y2, y3};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32 byte = (W >> (8 * k)) & 0xFFu;
+                    const u32 cnt = P + (u32)__builtin_popcount(byte & lmask);
+                    P += (u32)__builtin_popcount(byte);
+                    const u32 bit = (byte >> j) & 1u;
+                    const double a = (double)(cnt * bit);
+                    const double q = a * ys[k];
+                    r += __builtin_fma(__builtin_fma(-q, b, a), ys[k], q);
+                    b += 8.0;
+                }
+                rp += 32;
+            }
+            r += ap_dpp_mov<0xB1>(r);                          // quad_perm [1, 0, 3, 2]: lane ^ 1
+            r += ap_dpp_mov<0x4E>(r);                          // quad_perm [2, 3, 0, 1]: lane ^ 2
+            r += ap_dpp_mov<0x141>(r);                         // row_half_mirror: the other quad of the eight
+            // tail: element body + j of the leaf, for j < ll - body
+            {
+                const int tw = (ls + body) >> 5, tb = (ls + body) & 31;
+                const u32 byte = __builtin_amdgcn_alignbit(cw32[tw + 1], cw32[tw], (u32)tb) & ((1u << (ll - body)) - 1u);
+                const u32 cnt = P + (u32)__builtin_popcount(byte & lmask);
+                const u32 bit = (byte >> j) & 1u;
+                const double a = (double)(cnt * bit);
+                const double bt = (double)(cb + ls + body + j + 1);
+                const double y = recip[cb + ls + body + j + 1];
+                const double q = a * y;
+                const double v = __builtin_fma(__builtin_fma(-q, bt, a), y, q);      // +0.0 where there is no element
+                double res = r;                                // (ll < 8: r is 0.0)
+                res += v;                                      // lane 0 of the group: element body + 0
+                res += ap_dpp_mov<0x101>(v);                   // row_shl:1 .. 7: the values of lanes j + 1 .. j + 7
+                res += ap_dpp_mov<0x102>(v);
+                res += ap_dpp_mov<0x103>(v);
+                res += ap_dpp_mov<0x104>(v);
+                res += ap_dpp_mov<0x105>(v);
+                res += ap_dpp_mov<0x106>(v);
+                res += ap_dpp_mov<0x107>(v);
+                if (act && j == 0) tree[leaf] = res;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // the tree, level by level: all nodes of one height are independent; every addition is left + right exactly as in
+            // NumPy's recursion, only the schedule differs
+            for (int hgt = 1; hgt <= max_h; ++hgt) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (tid + 64 * k < nn && th[k] == hgt) tree[nlv + tid + 64 * k] = tree[tl[k]] + tree[tr[k]];
+                wave_lds_sync();
+            }
+            if (tid == 0) {
+                const double chunk_sum = tree[nlv + nn - 1];    // the root is the last node (or the only leaf)
+                total = (c == 0) ? chunk_sum : total + chunk_sum;
+                s_before = before + wpre[n >> 6] + ((n >> 6) > 64 ? w0tot : 0u) + ((n & 63) ? (u32)__popcll(cw[n >> 6] & ((1ull << (n & 63)) - 1ull)) : 0u);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const u32 r = s_before;
+        *rel_out = r;
+        *ap_out = r ? total / (double)r : __longlong_as_double(0x7FF8000000000000ll);
+    }
+}
+
 // only: optional [Q] -- evaluate just the flagged queries (the rest got their AP from k_rank_cnt's epilogue)
 static __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits, i64 RW, i64 R,
                                                    const ApShape* __restrict__ shapes,  // [0] full chunk, [1] last chunk

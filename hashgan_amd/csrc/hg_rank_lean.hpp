@@ -302,7 +302,9 @@ void k_rank_lean(const u8* __restrict__ cand8, const RankLdsArgs a, u32* __restr
     if (a.ap_shapes) {
         // metric.py:20-23 while the bitmap is in LDS: k_ap's very arithmetic (ap_eval), its scratch carved out of the counters
         const u64* bm64 = (const u64*)bm;
-        ap_eval<nthr>([&](const i64 w) { return bm64[w]; }, a.RW, g.R, a.ap_shapes, a.ap_recip, ap_lds_at(rlds + L.cnt), tid, a.ap + q, a.rel + q);
+        if (a.ap_recip) ap_eval2<nthr>([&](const i64 w) { return bm64[w]; }, a.RW, g.R, a.ap_shapes, a.ap_recip, ap_lds_at(rlds + L.cnt), tid, a.ap + q, a.rel + q);
+        else ap_eval<nthr>([&](const i64 w) { return bm64[w]; }, a.RW, g.R, a.ap_shapes, a.ap_recip, ap_lds_at(rlds + L.cnt), tid, a.ap + q, a.rel + q);
+        HG_TKL();                                     // 7: AP
     }
 }
 

@@ -18,7 +18,7 @@ t = host.reshape(4096, 16)[:, :8].astype(np.float64)
 print("rank variant", ctx.get_stat("rank_variant"))
 names = ["counts+prefix", "copy", "count", "totals", "plan", "offsets", "place", "bitmap out"]
 if ctx.get_stat("rank_variant") == 6:      # k_rank_lean's phases
-    names = ["loads + slice prefix", "compaction", "count", "totals", "plan + ranks", "place", "bitmap out"]
+    names = ["loads + slice prefix", "compaction", "count", "totals", "plan + ranks", "place", "bitmap out", "AP"]
 prev = np.zeros(4096)
 print("phase            median cycles (cumulative)   median of the phase")
 for k, n in enumerate(names):
