@@ -1,5 +1,5 @@
-"""BASELINE.json's single-GPU configurations at FULL size (C2: Q=10k, N=1M, b=64, R=5000; C3: Q=2.1k, N=190k,
-b=48, 81 multi-hot classes; C5: b=128), where the oracle would take hours: size-independent properties of the
+"""BASELINE.json's configurations at FULL size on one GPU (C2: Q=10k, N=1M, b=64, R=5000; C3: Q=2.1k, N=190k,
+b=48, 81 multi-hot classes; C5: b=128; C4: N=10M, all 10 000 queries), where the oracle would take hours: size-independent properties of the
 HIP result plus a golden anchor on the first queries."""
 import numpy as np
 import pytest
@@ -10,7 +10,7 @@ from hashgan_amd import _native, metric
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["c2_q64", "c3_nus_q64", "c5_b128_q32"])
+@pytest.mark.parametrize("name", ["c2_q64", "c3_nus_q64", "c5_b128_q32", "c4_n10m_q8"])
 def test_full_size_properties(name):
     spec = dict(cases.CASES[name])
     spec.pop("q_take")
