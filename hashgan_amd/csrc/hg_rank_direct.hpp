@@ -31,14 +31,19 @@ struct RankDirectArgs {
     i64 RW;                // 64-bit words per bitmap row
     int tile_rows;         // rows per tile (a multiple of 8, <= 252 * 256)
     int want_lists;
+    // hg_map: the AP of the query leaves with its ranking, out of the bitmap in LDS (metric.py:20-23; ap_eval2) -- no k_ap launch
+    const ApShape* ap_shapes;   // null: no AP here
+    const double* ap_recip;     // [R + 1 + AP_RECIP_SLACK]
+    double* ap;                 // [Q]
+    u32* rel;                   // [Q]
 };
 
 struct RankDirectLds { int cnt, off, tot, misc, done, tilecnt, qsh, bm, rec, total; };      // byte offsets
 __host__ __device__ inline RankDirectLds rank_direct_layout(int NB, i64 RW, int tile_rows) {
     RankDirectLds l;
     const int NBc = NB < 128 ? NB : 128;
-    l.cnt = 0;                                    // [NBc][64] u32: byte counter of thread 4 i + j = byte j of dword i
-    l.off = l.cnt + NBc * 256;                    // [NBc + 1][128] u32: 16-bit offset of thread 2 i + j (row NBc: dummy for rows beyond the cut)
+    l.cnt = 0;                                    // [NBc][64] u32: byte counter of thread 4 i + j = byte j of dword i   (the AP epilogue's scratch afterwards)
+    l.off = l.cnt + (NBc * 256 > AP_LDS_BYTES + 8 ? NBc * 256 : (AP_LDS_BYTES + 8 + 15) & ~15);   // [NBc + 1][128] u32: 16-bit offset of thread 2 i + j (row NBc: dummy for rows beyond the cut)
     l.tot = l.off + (NBc + 1) * 512;              // [NBc] u32: totals, then bucket starts
     l.misc = l.tot + NBc * 4;                     // [16] u32
     l.done = l.misc + 64;                         // [NBc + 1] u32: rows of each bucket placed by earlier tiles
@@ -285,6 +290,11 @@ static __global__ __launch_bounds__(256) void k_rank_direct(const RankDirectArgs
         }
     }
     for (int w = tid; w < bmw; w += nthr) grow[w] = bm[w];
+    if (a.ap_shapes) {
+        __syncthreads();                                 // (the counters -- the AP's scratch from here on -- are no longer read)
+        const u64* bm64 = (const u64*)bm;
+        ap_eval2<nthr>([&](const i64 w) { return bm64[w]; }, a.RW, g.R, a.ap_shapes, a.ap_recip, ap_lds_at(dlds + L.cnt), tid, a.ap + q, a.rel + q);
+    }
 }
 
 }  // namespace hg

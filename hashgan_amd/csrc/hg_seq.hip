@@ -291,13 +291,20 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
             const RankDirectLds L = rank_direct_layout(g.NB, c->RW, (int)tile);
             if (L.total > 64 * 1024)
                 HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_direct), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+            // hg_map: the AP comes out of the kernel's epilogue (one launch less, the bitmap never re-read)
+            bool use_recip = false;
+            const bool fuse = c->fuse_ap && c->opt_fuse_ap && !c->want_lists && L.bm % 8 == 0;
+            if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
+            const bool fused = fuse && use_recip;
             RankDirectArgs da{c->qc.as<u32>(), c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(),
-                              c->RW, (int)tile, c->want_lists ? 1 : 0};
+                              c->RW, (int)tile, c->want_lists ? 1 : 0, fused ? c->shapes.as<ApShape>() : nullptr,
+                              fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>()};
             c->t_begin(KI_RANK_FUSED);
             hipLaunchKernelGGL(k_rank_direct, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, da, c->out_idx.as<u32>(), c->out_dist.as<u8>(),
                                c->mbits.as<u32>(), g);
             c->t_end();
             c->last_rank = 5;
+            c->ap_fused = fused;
             return c->check_launch("k_rank_direct");
         }
     }
@@ -1399,8 +1406,16 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
         c->want_lists = lists;                         // a slice overflowed: the vector-ALU select with exact-sized slices
     }
     c->t_step_begin();
-    HG_TRY(enqueue_exact(c, R));
-    if (with_ap) HG_TRY(do_ap(c));
+    c->ap_fused = false;
+    c->fuse_ap = with_ap && !lists;
+    const int rce = enqueue_exact(c, R);
+    c->fuse_ap = false;
+    HG_TRY(rce);
+    if (with_ap) {
+        if (c->ap_fused) { c->ap_staged = false; c->stage |= ST_AP; }     // k_rank_direct's epilogue left the APs
+        else HG_TRY(do_ap(c));
+    }
+    c->ap_fused = false;                               // (no leftovers on this path: nothing for finish_leftovers)
     c->t_step_end();
     return check_plan_flag(c);
 }
