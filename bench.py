@@ -156,7 +156,7 @@ def traffic_from_profiles(kernel):
 
 
 SELECT_VARIANTS = {1: "k_select", 2: "k_select_dense", 3: "k_select_mx", 4: "k_select_mx2", 5: "k_select_mx3", 6: "k_select_mx4"}
-RANK_VARIANTS = {1: "k_rank_fused", 2: "k_rank_lds", 3: "k_rank_cnt", 4: "k_rank_wave", 5: "k_rank_direct", 6: "k_rank_lean"}
+RANK_VARIANTS = {1: "k_rank_fused", 2: "k_rank_lds", 3: "k_rank_cnt", 4: "k_rank_wave", 5: "k_rank_direct", 6: "k_rank_lean", 7: "k_rank_dense"}
 
 
 def kernel_names(ctx, spec):
@@ -176,6 +176,8 @@ def kernel_names(ctx, spec):
         names["k_select_mx"] = "k_select_mx<%d,%d,%d,compact>" % (NW, LW if LW <= 2 else 0, 2 if NW <= 4 else 1)
     elif sel:
         names["k_select"] = "%s<%d,%d>" % (sel, NW, LW if LW <= 2 else 0)
+    if rank == "k_rank_dense":
+        names["k_select"] = "k_dense_bytes<%d,%d>" % (NW, LW)
     if rank:
         names["k_rank_lds" if rank in ("k_rank_lds", "k_rank_cnt", "k_rank_wave", "k_rank_lean") else "k_rank_fused"] = rank
     names["k_hist"] = "k_hist_i8<%d>" % NW if NW <= 4 else "k_hist_mx<%d>" % NW
@@ -431,6 +433,15 @@ def config_leg(name, opts, steps=20, untimed=25, packed=None):
                     "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": ab / t / 1e9 / L2_PEAK_GBS,
                     "note": "every query's block reads all N rows from L2 (Q * N * %d B) and writes R match bits; what bounds the "
                             "kernel is the LDS counting sort's chain of dependent phases per tile of rows, not this stream" % (4 * NW + 8 * LW)}
+        elif dom == "k_rank_dense":
+            # N/8 < R <= N: k_dense_bytes wrote one byte {match, dist} per pair; one block per query streams its N bytes twice
+            # (count, then place) and writes R match bits -- each row costs two LDS atomics on its thread's counter column
+            ab = 2 * Q * N + Q * ((R + 63) // 64) * 8
+            roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": t * 1e3, "algorithmic_bytes": ab, "achieved": ab / t / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / t / 1e9 / HBM_PEAK_GBS,
+                    "note": "two streams over the query's row of the byte matrix (2 * Q * N bytes; at this size it is cache "
+                            "resident) + R match bits; what bounds the kernel is the rate of LDS atomics (two per row on the "
+                            "thread's own counter column, ~4 lanes per clock and CU measured), not this stream"}
         else:
             ab = (Q + N) * (NW * 4 + LW * 8) + Q * R
             roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": t * 1e3, "algorithmic_bytes": ab, "achieved": ab / t / 1e9,

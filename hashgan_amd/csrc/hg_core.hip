@@ -154,7 +154,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part};
+                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part, &c->dbytes};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -776,6 +776,15 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_direct")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "rank_direct must be 0, 1 (R = N) or 2 (also N/8 < R < N)");
         c->opt_rank_direct = value;
+    } else if (!strcmp(key, "rank_dense")) {
+        if (value < 0 || value > 2) return fail(HG_ERR_ARG, "rank_dense must be 0 or 1 (2 is accepted and means 1)");
+        c->opt_rank_dense = value;
+    } else if (!strcmp(key, "rank_dense_gbm")) {
+        if (value < -1 || value > 1) return fail(HG_ERR_ARG, "rank_dense_gbm must be -1, 0 or 1");
+        c->opt_rank_dense_gbm = value;
+    } else if (!strcmp(key, "dense_budget_mb")) {
+        if (value < 1) return fail(HG_ERR_ARG, "dense_budget_mb must be >= 1");
+        c->opt_dense_budget_mb = value;
     } else if (!strcmp(key, "rank_wave_max")) {
         if (value < 0 || value > 16128) return fail(HG_ERR_ARG, "rank_wave_max must be 0..16128 (a lane's chunk must fit its byte counters)");
         c->opt_rank_wave_max = value;
@@ -848,7 +857,7 @@ int hg_trim(hg_ctx* c) {
     HG_TRY(c->sync());
     DevBuf* work[] = {&c->hist, &c->seglt, &c->segtie, &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->cand, &c->out_idx,
                       &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->bigq, &c->mbits2,
-                      &c->dbx, &c->qx, &c->dbx2, &c->qx2, &c->dbfx, &c->dbfb, &c->sampx};   // the images are rebuilt on demand
+                      &c->dbx, &c->qx, &c->dbx2, &c->qx2, &c->dbfx, &c->dbfb, &c->sampx, &c->dbytes};   // the images are rebuilt on demand
     for (auto* d : work) d->release();
     c->dbfx_valid = false;
     c->dbfb_valid = false;

@@ -193,6 +193,10 @@ struct hg_ctx {
     i64 cap_boost = 1;         // slice capacity multiplier a lost bet escalated to on this database (run_oneshot); 1 after every load
     i64 opt_rank_direct_lds = 80;    // "rank_direct_lds": KB of LDS a k_rank_direct block may take (80: two blocks per CU -- C1 0.25 ms vs 0.31 with 160 and one)
     i64 opt_rank_direct = 1;   // "rank_direct": R = N on one shard in one counting-sort kernel, k_rank_direct, when its LDS fits (2: also N/8 < R < N)
+    i64 opt_rank_dense = 1;    // "rank_dense": N/8 < R <= N on one shard through the byte matrix (k_dense_bytes + k_rank_dense, hg_rank_dense.hpp; codes of <= 126 bits, <= 128 classes); 0: off
+    i64 opt_rank_dense_gbm = -1;   // "rank_dense_gbm": k_rank_dense's bitmap in global memory (1) or LDS (0, where it fits); -1: by the blocks per CU
+    i64 opt_dense_budget_mb = 16384;   // "dense_budget_mb": the byte matrix D holds at most this much (queries are chunked)
+    bool dense_rank = false;   // run state of enqueue_all_rows: rank through the byte matrix
     i64 opt_rank_wave = 40;    // "rank_wave": one wavefront per query (k_rank_wave) for SHORT lists of one-byte records; the value is the
                                // record capacity of a query's LDS share in tenths of the shard's share of R (+ 256; lists beyond it
                                // go to k_rank_fused); 0 = off
@@ -207,7 +211,7 @@ struct hg_ctx {
     i64 crow = 0;              // record-row stride
     i64 opt_runs = 0, opt_fallbacks = 0, opt_requeried = 0;
     int last_select = 0;       // stat "select_variant": 1 k_select, 2 k_select_dense, 3 k_select_mx, 4 k_select_mx2, 5 k_select_mx3, 6 k_select_mx4
-    int last_rank = 0;         // stat "rank_variant": 1 k_rank_fused, 2 k_rank_lds, 3 k_rank_cnt, 4 k_rank_wave, 5 k_rank_direct, 6 k_rank_lean
+    int last_rank = 0;         // stat "rank_variant": 1 k_rank_fused, 2 k_rank_lds, 3 k_rank_cnt, 4 k_rank_wave, 5 k_rank_direct, 6 k_rank_lean, 7 k_rank_dense
     i64 opt_leftover = 0;      // stat "rank_leftovers": queries of fused steps that k_rank_cnt left to the general rank kernel
     int opt_consecutive_fail = 0;   // one-shot bets lost in a row (this context only)
     int shard_bet_fail = 0;         // sharded bets lost in a row: identical on every rank by construction
@@ -258,6 +262,7 @@ struct hg_ctx {
     DevBuf obuf[2];            // owner-routed exchanges: [0] the blocks this rank sends (hg_pack_*_by_owner), [1] its answers as an owner (hg_guess_owned)
     bool ranked_local = false; // mbits holds this shard's bitmap in LOCAL rank order (hg_select_ranked)
     DevBuf cand, out_idx, out_dist, mbits, shapes, ap_recip, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
+    DevBuf dbytes;             // the byte matrix D[q][Npad] of the dense regime (k_dense_bytes)
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores, gtab;   // real-valued path
     DevBuf dbfx;               // float features of the database in MFMA A-fragment order (k_real_select_mx), built on first use
     bool dbfx_valid = false;

@@ -11,6 +11,7 @@
 #include "hg_rank_wave.hpp"
 #include "hg_rank_lean.hpp"
 #include "hg_rank_direct.hpp"
+#include "hg_rank_dense.hpp"
 
 // Segment geometry of the pair passes: ~target_units wavefront-sized units.
 void make_geometry(hg_ctx* c) {
@@ -279,10 +280,88 @@ static i64 rank_direct_tile(const hg_ctx* c, int64_t R) {
     return tile >= 8192 || tile >= n8 ? tile : 0;
 }
 
+// the dense regime through the byte matrix (hg_rank_dense.hpp): the counter columns always fit a block's LDS for codes of <= 126 bits
+static bool rank_dense_fits(const hg_ctx* c, int64_t R) {
+    (void)R;
+    return c->opt_rank_dense && c->LW <= 2 && c->NW <= 4 && c->b <= 126 && c->N == c->n_total && !c->is_sub;
+}
+
+static void launch_dense_bytes(hg_ctx* c, u8* D, i64 Npad, int q0, int nq) {
+    const int qper = 64;
+    const dim3 grid((unsigned)(Npad / 1024), (unsigned)((nq + qper - 1) / qper));
+    const u32 padbyte = (u32)(c->b + 1);               // = NB: the distance of the rows past N
+#define HG_DENSE_BYTES(NW_, LW_)                                                                                                      \
+    hipLaunchKernelGGL((k_dense_bytes<NW_, LW_>), grid, dim3(256), 0, c->stream, c->qc.as<u32>(), c->qlab.as<u64>(), c->db.as<u32>(), \
+                       c->dblab.as<u64>(), D, c->N, Npad, q0, nq, qper, padbyte)
+    const int key = c->NW * 2 + (c->LW <= 1 ? 0 : 1);
+    switch (key) {
+        case 2: HG_DENSE_BYTES(1, 1); break;
+        case 3: HG_DENSE_BYTES(1, 2); break;
+        case 4: HG_DENSE_BYTES(2, 1); break;
+        case 5: HG_DENSE_BYTES(2, 2); break;
+        case 6: HG_DENSE_BYTES(3, 1); break;
+        case 7: HG_DENSE_BYTES(3, 2); break;
+        case 8: HG_DENSE_BYTES(4, 1); break;
+        default: HG_DENSE_BYTES(4, 2); break;
+    }
+#undef HG_DENSE_BYTES
+}
+
+static int launch_rank_dense(hg_ctx* c) {
+    const Geo& g = c->geo;
+    HG_TRY(c->err.reserve(16));
+    HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
+    // Where the R-bit bitmap lives.  LDS while two blocks still share a CU, and the AP then leaves from the epilogue (C1: 0.12 ms
+    // for ranking + AP).  A bitmap that leaves room for one block only: in global memory while the members are few (R < N/4:
+    // the atomic ORs of the matching members cost ~3.6 ms per 10^9; two to four blocks per CU), else in LDS with one block per CU --
+    // and k_ap afterwards either way (an epilogue on four wavefronts per CU is a latency chain: 62 chunks at R = 500k, 0.3 ms per query).
+    // Q = 10k, N = 1M, b = 64, ranking + AP: R = 130k 7.4 ms global / 11.5 LDS; 200k 9.7 / 12.0; 500k 22.7 / 13.7.
+    const int lds_cu = 160 * 1024;
+    const int tot_lds = rank_dense_layout(g.NB, c->RW, false).total, tot_gbm = rank_dense_layout(g.NB, c->RW, true).total;
+    const int blocks_lds = (c->RW * 8 + 4096 < lds_cu && tot_lds <= lds_cu) ? lds_cu / tot_lds : 0;
+    const bool gbm = c->opt_rank_dense_gbm >= 0 ? c->opt_rank_dense_gbm != 0 || blocks_lds == 0 : (blocks_lds == 0 || (blocks_lds < 2 && g.R * 4 < c->N));
+    const int total = gbm ? tot_gbm : tot_lds;
+    const i64 Npad = rank_dense_pieces(c->N) * RD_THREADS * 16;
+    i64 qchunk = (c->opt_dense_budget_mb << 20) / Npad;
+    if (qchunk < 1) qchunk = 1;
+    if (qchunk > g.Q) qchunk = g.Q;
+    HG_TRY(c->dbytes.reserve((size_t)qchunk * Npad));
+    bool use_recip = false;
+    const bool fuse = !gbm && blocks_lds >= 2 && c->fuse_ap && c->opt_fuse_ap && !c->want_lists;
+    if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
+    const bool fused = fuse && use_recip;
+    if (gbm) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
+    for (i64 q0 = 0; q0 < g.Q; q0 += qchunk) {
+        const int nq = (int)(q0 + qchunk < g.Q ? qchunk : g.Q - q0);
+        c->t_begin(KI_SELECT);
+        launch_dense_bytes(c, c->dbytes.as<u8>(), Npad, (int)q0, nq);
+        c->t_end();
+        HG_TRY(c->check_launch("k_dense_bytes"));
+        RankDenseArgs da{c->dbytes.as<u8>(), Npad, (int)q0, c->err.as<int>(), c->qbad.as<u32>(), c->RW,
+                         fused ? c->shapes.as<ApShape>() : nullptr, fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>()};
+        c->t_begin(KI_RANK_FUSED);
+#define HG_RANK_DENSE(LISTS_, GBM_)                                                                                                              \
+    do {                                                                                                                                         \
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_dense<LISTS_, GBM_>), hipFuncAttributeMaxDynamicSharedMemorySize, total)); \
+        hipLaunchKernelGGL((k_rank_dense<LISTS_, GBM_>), dim3(nq), dim3(RD_THREADS), (size_t)total, c->stream, da, c->out_idx.as<u32>(),         \
+                           c->out_dist.as<u8>(), c->mbits.as<u32>(), g);                                                                         \
+    } while (0)
+        if (c->want_lists) { if (gbm) HG_RANK_DENSE(true, true); else HG_RANK_DENSE(true, false); }
+        else { if (gbm) HG_RANK_DENSE(false, true); else HG_RANK_DENSE(false, false); }
+#undef HG_RANK_DENSE
+        c->t_end();
+        HG_TRY(c->check_launch("k_rank_dense"));
+    }
+    c->last_rank = 7;
+    c->ap_fused = fused;
+    return HG_OK;
+}
+
 // leftovers_only: the second half of a fused step -- k_rank_cnt has run (with its AP epilogue) and flagged in bigq the queries
 // it declined; rank just those with the general kernel
 static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = false) {
     const Geo& g = c->geo;
+    if (c->dense_rank && mode == 0) return launch_rank_dense(c);
     if (c->direct_rank && mode == 0) {
         const i64 tile = rank_direct_tile(c, g.R);
         if (tile > 0) {
@@ -1033,6 +1112,7 @@ static int enqueue_all_rows(hg_ctx* c, int64_t R) {
     c->last_select = 0;                                // no record pass at all
     const int rc = launch_rank(c, 0, nbits);
     c->direct_rank = false;
+    c->dense_rank = false;
     HG_TRY(rc);
     c->lists_valid = c->want_lists;
     c->stage = ST_DB | ST_Q | ST_PLAN | ST_SELECT | ST_MATCH;
@@ -1040,6 +1120,12 @@ static int enqueue_all_rows(hg_ctx* c, int64_t R) {
 }
 
 static int enqueue_exact(hg_ctx* c, int64_t R) {
+    // N/8 < R <= N through the byte matrix (k_dense_bytes + k_rank_dense: R = N/2 of N = 1M 68.8 -> 16.3 ms, C1 0.35 -> 0.19 ms);
+    // "rank_direct" = 2 keeps the round-3 kernel for that regime
+    if (R * 8 > c->N && c->opt_all_rows && c->opt_rank_direct != 2 && rank_dense_fits(c, R)) {
+        c->dense_rank = true;
+        return enqueue_all_rows(c, R);
+    }
     if (c->N == c->n_total && R == c->N && c->opt_all_rows && c->LW <= 2 && c->NW <= 8)
         return enqueue_all_rows(c, R);                 // one-shot calls are single-shard
     // (k_rank_direct ranks ANY R from the rows themselves, but with one block per query it re-reads the whole database per

@@ -879,9 +879,30 @@ def test_dense_regime_ranks_the_rows_directly(Q, N, b, R, C):
         ctx.topr(R)
         idx, dist = ctx.get_topr()
         assert np.array_equal(idx.astype(np.int64), idx_ref) and np.array_equal(dist.astype(np.int64), dist_ref)
+        ctx.set_option("rank_direct", 1)                  # the default: N/8 < R <= N through the byte matrix (k_dense_bytes + k_rank_dense)
+        ap3, _ = ctx.map(R)
+        assert np.array_equal(ap3, ap_ref, equal_nan=True)
+        assert ctx.get_stat("rank_variant") == 7
+        ctx.topr(R)
+        idx, dist = ctx.get_topr()
+        assert np.array_equal(idx.astype(np.int64), idx_ref) and np.array_equal(dist.astype(np.int64), dist_ref)
+        ctx.set_option("dense_budget_mb", 1)              # the byte matrix in several chunks of queries
+        ap5, _ = ctx.map(R)
+        assert np.array_equal(ap5, ap_ref, equal_nan=True)
+        for gbm in (1, 0):                                # the R-bit bitmap in global memory (k_ap afterwards) / in LDS (AP from the epilogue)
+            ctx.set_option("rank_dense_gbm", gbm)
+            ap6, _ = ctx.map(R)
+            assert np.array_equal(ap6, ap_ref, equal_nan=True)
+            assert ctx.get_stat("rank_variant") == 7
+            ctx.topr(R)
+            idx, dist = ctx.get_topr()
+            assert np.array_equal(idx.astype(np.int64), idx_ref) and np.array_equal(dist.astype(np.int64), dist_ref)
+        ctx.set_option("rank_dense_gbm", -1)
+        ctx.set_option("rank_dense", 0)
         ctx.set_option("rank_direct", 0)                  # the older sequences give the same
         ap2, _ = ctx.map(R)
         assert np.array_equal(ap2, ap_ref, equal_nan=True)
+        assert ctx.get_stat("rank_variant") != 7
     finally:
         ctx.close()
 
