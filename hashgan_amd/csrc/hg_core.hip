@@ -776,6 +776,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_direct")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "rank_direct must be 0, 1 (R = N) or 2 (also N/8 < R < N)");
         c->opt_rank_direct = value;
+    } else if (!strcmp(key, "interleave_records")) {
+        c->opt_interleave = value != 0;
     } else if (!strcmp(key, "rank_dense")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "rank_dense must be 0 or 1 (2 is accepted and means 1)");
         c->opt_rank_dense = value;
@@ -885,6 +887,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "rank_leftovers")) *value = c->opt_leftover;
     else if (!strcmp(key, "select_variant")) *value = c->last_select;
     else if (!strcmp(key, "rank_variant")) *value = c->last_rank;
+    else if (!strcmp(key, "records_interleaved")) *value = c->rec_il ? 1 : 0;
     else if (!strcmp(key, "ap_fused")) *value = c->ap_fused ? 1 : 0;
     else if (!strcmp(key, "cap_boost")) *value = c->cap_boost;
     else if (!strcmp(key, "crowding_x100")) *value = c->crowd_x100;

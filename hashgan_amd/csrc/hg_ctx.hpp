@@ -237,6 +237,10 @@ struct hg_ctx {
     i64 opt_exact_mfma = 1;    // "exact_mfma": the one-shot exact sequence selects on the matrix cores when R << N
     bool rec8 = false;         // the record rows hold one-byte compact records (matrix-core select, no lists wanted)
     i64 opt_compact = 1;       // "compact_records": allow them
+    bool rec_il = false;       // ... with the 16-byte pieces of 32 queries' slices interleaved (rec8_at): k_select_mx3 / mx4 -> k_rank_lean
+    i64 opt_interleave = 0;    // "interleave_records": allow that.  Off: measured at C2 (profiles/r04_interleaved_records.txt) the select's HBM traffic
+                               // falls 440 -> 368 MB and k_rank_lean's 164 -> 91 MB per launch, but the step gets 1 % slower (0.926 -> 0.936 ms) -- the L2
+                               // does not merge 8-byte stores that arrive tens of microseconds apart in either layout (33 bytes written per store)
     i64 opt_second_bet = 1;    // "second_bet": a lost one-shot bet is retried once with a wider margin before the exact sequence
     i64 opt_rebets = 0;
     i64 opt_lds_pad = 0;       // "lds_pad": extra dynamic LDS per block of the matrix-core select (occupancy experiments)
@@ -309,7 +313,7 @@ struct hg_ctx {
         i64 R = -1, seen_R = -1;
         int timing = -1, seen_timing = -1;
         // host-side state the captured enqueue functions leave behind
-        unsigned stage = 0; bool optimistic = false, lists_valid = false, ap_fused = false, rec8 = false; u32 cap = 0; i64 crow = 0, RW = 0; Geo geo{};
+        unsigned stage = 0; bool optimistic = false, lists_valid = false, ap_fused = false, rec8 = false, rec_il = false; u32 cap = 0; i64 crow = 0, RW = 0; Geo geo{};
         std::vector<Pending> evs;          // event-record nodes inside the graph (kernel timing)
     } sg;
     i64 opt_graph = 0;         // "step_graph": 1 = hg_map captures and replays its step (see run_oneshot); off by default

@@ -145,7 +145,7 @@ template <int NW, int LW> int launch_select_mx3_t(hg_ctx* c) {
     if (L.total > 64 * 1024)
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx3<NW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
     SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
-              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
+              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe, c->rec_il ? 1 : 0};
     c->t_begin(KI_SELECT_MX);
     hipLaunchKernelGGL((k_select_mx3<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(64 * M3_WPB), (size_t)L.total + (size_t)c->opt_lds_pad, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx3.as<u8>(), c->dblab.as<u64>(), a,
@@ -247,7 +247,7 @@ template <int NW, int LW> int launch_select_mx4_t(hg_ctx* c) {
     if (L.total > 64 * 1024)
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx4<NW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
     SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
-              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), 0};
+              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), 0, c->rec_il ? 1 : 0};
     c->t_begin(KI_SELECT_MX);
     hipLaunchKernelGGL((k_select_mx4<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(64 * M4_WPB), (size_t)L.total + (size_t)c->opt_lds_pad, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx4.as<u8>(), c->dblab.as<u64>(), a,

@@ -48,6 +48,7 @@ struct RankLdsArgs {
     // this kernel places leaves it anyway (null: the counters cover [0, nbc))
     const int* cut;
     int spec_pieces;       // k_rank_lean: 16-byte pieces of every slice fetched before the slice counts are known
+    int il;                // k_rank_lean: the record rows are interleaved (rec8_at)
 };
 
 template <int NWAV>

@@ -126,25 +126,41 @@ struct Mx3Drain {
     u8* tb0;                             // the wavefront's first slice (t = 0, lane 0); tile t adds t * 32 * crow
     i64 crow;
     u32 lane_off;                        // byte offset of the lane's slices relative to that (the launcher keeps 64 * crow below 2^31)
+    u32 ilk;                             // 1: a slice is `cap` contiguous bytes; 32: its 16-byte pieces interleave with the tile's other 31 queries' (rec_off)
     u32 cnt[QT];                         // records of slice (t, lane) pushed so far (may exceed cap: the surplus is dropped at the flush)
     u32 prev[QT];                        // ... pushed before the current window: those are in the rings for sure
     u32 flushed[QT];                     // ... written to global memory (a multiple of 8)
     u32 qhead, qfill, old;               // queue: first entry, entries, entries pushed before the current window (wave-uniform)
     int probe;
 
-    __device__ __forceinline__ void init(u8* lds_, const Mx3Lds& L_, int wave_, int lane_, int qb, int sp, u32 cap_, i64 crow_, u8* cand8, int probe_) {
+    __device__ __forceinline__ void init(u8* lds_, const Mx3Lds& L_, int wave_, int lane_, int qb, int sp, u32 cap_, i64 crow_, u8* cand8, int probe_, int il) {
         lds = lds_; L = L_; wave = wave_; lane = lane_; cap = cap_; crow = crow_; probe = probe_;
         qab = (u64*)(lds + L.qab) + wave * M3_QCAP;
         qc = (u32*)(lds + L.qc) + wave * M3_QCAP;
         rings = lds + L.rings + wave * (64 * QT * M3_RING);
         const int h = lane >> 5, j = lane & 31;
-        lane_off = (u32)j * (u32)crow + (u32)h * cap;
-        tb0 = cand8 + (i64)(qb * M3_WPB + wave) * 64 * crow + (i64)(2 * sp) * cap;
+        // Interleaved record rows (SelArgs::il): the 32 queries of a tile share a region of 32 * crow bytes in which piece p16
+        // of slice s of query j sits at ((s * cap/16 + p16) * 32 + j) * 16 -- the lanes of a half-wavefront that flush the same
+        // piece of their slices write side by side, and the L2 sees whole lines instead of 8 bytes of a 128-byte line per slice
+        // (4.8x write amplification at C2, profiles/r03_pmc_traffic.json).
+        ilk = il ? 32u : 1u;
+        if (il) {
+            lane_off = (u32)(2 * sp + h) * cap * 32u + (u32)j * 16u;
+            tb0 = cand8 + (i64)(qb * M3_WPB + wave) * 64 * crow;
+        } else {
+            lane_off = (u32)j * (u32)crow + (u32)h * cap;
+            tb0 = cand8 + (i64)(qb * M3_WPB + wave) * 64 * crow + (i64)(2 * sp) * cap;
+        }
         qhead = qfill = old = 0;
 #pragma unroll
         for (int t = 0; t < QT; ++t) cnt[t] = prev[t] = flushed[t] = 0;
     }
     __device__ __forceinline__ u8* slice(const int t) const { return tb0 + (i64)t * 32 * crow + lane_off; }
+    // byte offset of record p inside the lane's slice: whole 16-byte pieces are `ilk` pieces apart
+    __device__ __forceinline__ u32 rec_off(const u32 p) const {
+        if (__builtin_expect(ilk == 1u, 1)) return p;              // (wave-uniform: plain rows pay nothing for the other layout)
+        return (p & ~15u) * 32u + (p & 15u);
+    }
 
     // ---- owner side: completed 8-record pieces below limit[t] leave the ring with one aligned 8-byte store each ----
     // (a slice that is already full keeps advancing: its surplus pieces land on its last piece -- the query is flagged
@@ -161,7 +177,7 @@ struct Mx3Drain {
                 if (limit[t] - f >= 8u) {
                     const u8* ring = rings + (t * 64 + lane) * M3_RING;
                     u8* tb = tb0 + (i64)t * 32 * crow;                // wave-uniform base; the lane's part fits 32 bits
-                    *(u64*)(tb + (lane_off + min(f, cap - 8u))) = *(const u64*)(ring + (f & 8u));
+                    *(u64*)(tb + (lane_off + rec_off(min(f, cap - 8u)))) = *(const u64*)(ring + (f & 8u));
                     flushed[t] = f + 8u;
                     need |= limit[t] - f >= 16u;
                 }
@@ -226,7 +242,7 @@ struct Mx3Drain {
         const u8* ring_r = rings + (t * 64 + lane) * M3_RING;
         u8* ring = rings + (t * 64 + lane) * M3_RING;
         u8* out = slice(t);
-        for (u32 p = flushed[t]; p < cnt[t]; ++p) if (p < cap) out[p] = ring_r[p & (M3_RING - 1)];
+        for (u32 p = flushed[t]; p < cnt[t]; ++p) if (p < cap) out[rec_off(p)] = ring_r[p & (M3_RING - 1)];
         const u32 a21 = (wa >> 6) & 0x1FFFFFu, b21 = (wb >> 6) & 0x1FFFFFu, c6 = ((wc * 0x421u) >> 16) & 0x3Fu;
         u64 x = (u64)a21 | ((u64)b21 << 21) | ((u64)c6 << 42);
         const int ql = wave * 64 + t * 32 + (lane & 31);
@@ -251,7 +267,7 @@ struct Mx3Drain {
 #pragma unroll
             for (int k = 0; k < LW; ++k) any |= lp[k] & qlw[k];
             const u8 rec = make_rec8(d, any != 0);
-            if (pos < cap) out[pos] = rec;
+            if (pos < cap) out[rec_off(pos)] = rec;
             ring[pos & (M3_RING - 1)] = rec;
             ++pos;
         }
@@ -345,7 +361,7 @@ struct Mx3Drain {
             const u32 f = flushed[t];
             if (cnt[t] > f) {
                 const u8* ring = rings + (t * 64 + lane) * M3_RING;
-                *(u64*)(slice(t) + min(f, cap - 8u)) = *(const u64*)(ring + (f & 8u));
+                *(u64*)(slice(t) + rec_off(min(f, cap - 8u))) = *(const u64*)(ring + (f & 8u));
             }
         }
     }
@@ -405,7 +421,7 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
     u32 K[QT][3];
     bool far[QT];
     Mx3Drain<NW, LW> dr;
-    dr.init(mxlds, L, wave, lane, qb, sp, a.cap, a.crow, cand8, a.probe);
+    dr.init(mxlds, L, wave, lane, qb, sp, a.cap, a.crow, cand8, a.probe, a.il);
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = q0w + t * 32 + j;

@@ -87,6 +87,8 @@ bool hist_mx_applies(const hg_ctx* c, int stride, bool pairs_ok) {
     }
     return stride > 1 ? c->opt_sample_ratio == 2 : pairs_ok;
 }
+static bool records_may_interleave(const hg_ctx* c);
+
 // The record pass of the current sequence: which kernel takes it (the launchers live in hg_pairs_valu.hip / hg_pairs_mx.hip).
 int launch_select(hg_ctx* c) {
     const int NW = c->NW;
@@ -94,12 +96,13 @@ int launch_select(hg_ctx* c) {
     // one-byte records (no index): only the matrix-core kernels of the bet produce them, and only when nobody wants the lists
     const bool mx = c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS);
     c->rec8 = mx && c->opt_compact && !c->want_lists && c->LW <= 2 && c->cap % 16 == 0 && c->crow * 64 < (1ll << 31);
+    c->rec_il = false;
     if (!c->optimistic && c->R * 4 >= c->n_total) { c->last_select = 2; return launch_select_dense(c, lw); }   // dense regime: most pairs are selected
     // three rows per accumulator + batched drain: codes of <= 64 bits, one-byte records (<= 128 classes).  (For <= 32 bits the
     // second k-half of every MFMA is empty, and it still beats k_select_mx2's two rows per accumulator: 0.69 vs 0.85 ms at b = 32.)
-    if (NW <= 2 && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 5; return launch_select_mx3(c, lw); }
+    if (NW <= 2 && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 5; c->rec_il = records_may_interleave(c); return launch_select_mx3(c, lw); }
     // codes of 65..128 bits: two rows per accumulator (8-bit fields) and the same drain
-    if ((NW == 3 || NW == 4) && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M4_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 6; return launch_select_mx4(c, lw); }
+    if ((NW == 3 || NW == 4) && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M4_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 6; c->rec_il = records_may_interleave(c); return launch_select_mx4(c, lw); }
     // two rows per accumulator: wins for one-word codes (half the MFMAs: 0.92 vs 1.02 ms at b = 32); for 33-64 bits
     // its cheaper harvest (0.36 vs 0.44 ms) is eaten by the wider queue entries (select_packed = 2 forces it)
     if (mx && c->geo.L % 32 == 0 &&
@@ -357,6 +360,65 @@ static int launch_rank_dense(hg_ctx* c) {
     return HG_OK;
 }
 
+// Which LDS-resident rank kernel a bet's one-byte records will meet -- decided from what is known BEFORE the select runs (R, the
+// slices' capacity, the segment count, options), because the select writes the interleaved record layout (SelArgs::il) only for
+// the kernel that reads it, k_rank_lean (k_rank_fused, the general kernel behind every path, reads both layouts).
+struct WavePlan { bool ok; i64 r2; int nbc, wpb; size_t lds; };
+static WavePlan rank_wave_plan(const hg_ctx* c, int mode) {
+    const Geo& g = c->geo;
+    WavePlan w{false, 0, 0, 1, 0};
+    if (!(c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_wave > 0 && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
+          g.S <= RW_SMAX)) return w;
+    const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
+    i64 r2 = (i64)(0.1 * (double)c->opt_rank_wave * (double)c->R * share) + 256;
+    if (r2 < 1024) r2 = 1024;
+    r2 = (r2 + 63) / 64 * 64;
+    if (r2 > (i64)c->opt_rank_wave_max) r2 = 0;                 // long lists: k_rank_cnt / k_rank_lean
+    w.nbc = (mode == 0 && !c->exact_mx && c->G == 1) ? g.NB / 2 + 2 : 0;
+    const RankWaveLds L = rank_wave_layout(g.NB, c->RW, g.S, (int)r2, w.nbc);
+    // wavefronts per block: the split that wastes the least of a CU's 160 KB
+    const int fit1 = (int)(160 * 1024 / L.per_wave), fit2 = 2 * (int)(160 * 1024 / (2 * L.per_wave));
+    w.wpb = fit2 >= fit1 ? 2 : 1;
+    w.r2 = r2;
+    w.lds = (size_t)w.wpb * L.per_wave;
+    w.ok = r2 > 0 && fit1 >= 4;
+    return w;
+}
+struct LeanPlan { bool ok; int nbc, psp; i64 rb; };
+static LeanPlan rank_lean_plan(const hg_ctx* c, int mode) {
+    const Geo& g = c->geo;
+    LeanPlan l{false, 0, 1, 0};
+    if (!(c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_lean && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
+          g.S <= 256 && (c->cap & 15u) == 0 && c->cap <= 1024 && g.R <= 60000)) return l;
+    const int nbc = rank_cnt_maxb(g.NB) + 2 < g.NB ? rank_cnt_maxb(g.NB) + 2 : 0;
+    const int nbc_eff = nbc ? nbc : (g.NB < 128 ? g.NB : 128);
+    // room for every piece of the row when that fits HG_RANK_WAVES blocks per CU; else for the usual list (2.2 R + padding)
+    const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
+    const i64 all = (i64)g.S * c->cap;
+    // pieces of a slice fetched up front: what it holds but for a 4-sigma exception, when the select keeps ~0.7 of the budgeted
+    // mean (cap = mean + 6 sqrt(mean) + 16, inverted); at most what four loads per thread cover
+    const double mb = std::pow(std::sqrt((double)c->cap > 7.0 ? (double)c->cap - 7.0 : 0.0) - 3.0, 2.0), est = 0.7 * mb;
+    int psp = (int)std::ceil((est + 4.0 * std::sqrt(est) + 1.0) / 16.0);
+    if (psp > (int)(c->cap >> 4)) psp = (int)(c->cap >> 4);
+    if (psp > RL_MAX_PIECES / g.S) psp = RL_MAX_PIECES / g.S;
+    if (psp < 1) psp = 1;
+    const i64 room = ((160 * 1024 / HG_RANK_WAVES) & ~511ll) - rank_lean_layout(g.NB, c->RW, g.S, 0, nbc).total;
+    i64 rb = all <= room ? all : room & ~15ll;
+    const i64 least = ((i64)(2.2 * (double)c->R * share) + 256 + 16 * (i64)g.S + 15) & ~15ll;
+    if (rb < least && least <= all) rb = least;
+    if (rb > all) rb = all;
+    if (rb > 16 * RL_MAX_PIECES) rb = 16 * RL_MAX_PIECES;      // a thread keeps at most four pieces of its query's list
+    const RankLeanLds L = rank_lean_layout(g.NB, c->RW, g.S, (int)rb, nbc);
+    l.nbc = nbc; l.psp = psp; l.rb = rb;
+    l.ok = nbc_eff <= 63 && L.total <= 64 * 1024 && rb >= 16 && (rb >= least || rb == all);
+    return l;
+}
+// (called by launch_select once rec8, cap and crow are set): the records may interleave iff k_rank_lean will read them
+static bool records_may_interleave(const hg_ctx* c) {
+    if (!c->opt_interleave || !c->rec8) return false;
+    return !rank_wave_plan(c, 0).ok && !rank_wave_plan(c, 3).ok && rank_lean_plan(c, 0).ok;
+}
+
 // leftovers_only: the second half of a fused step -- k_rank_cnt has run (with its AP epilogue) and flagged in bigq the queries
 // it declined; rank just those with the general kernel
 static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = false) {
@@ -424,28 +486,20 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
     c->ap_fused = false;
     if (!leftovers_only) c->last_rank = 1;                // k_rank_fused unless one of the LDS-resident kernels takes the lists
     if (leftovers_only) { only = c->bigq.as<u32>(); counted = true; }
-    if (!counted && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_wave > 0 && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
-        g.S <= RW_SMAX) {
+    if (!counted && !c->rec_il) {
         // one wavefront per query (k_rank_wave): no block barriers, 5 KB + the records of LDS per query in flight
         // ... which pays for SHORT lists only (a sharded rank's share of R, a small R): a wavefront walks its query's records
         // with 64 lanes where k_rank_cnt has 256, and at C2's 6500 records (16 KB of LDS per query, 10 in flight per CU) it
         // is slower, 0.23 vs 0.19 ms; at 800 records (7 KB, 22 in flight) it wins, 0.105 vs 0.134 ms.
-        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
-        i64 r2 = (i64)(0.1 * (double)c->opt_rank_wave * (double)c->R * share) + 256;
-        if (r2 < 1024) r2 = 1024;
-        r2 = (r2 + 63) / 64 * 64;
-        if (r2 > (i64)c->opt_rank_wave_max) r2 = 0;                 // long lists: k_rank_cnt below
-        const int nbc = (mode == 0 && !c->exact_mx && c->G == 1) ? g.NB / 2 + 2 : 0;
-        const RankWaveLds L = rank_wave_layout(g.NB, c->RW, g.S, (int)r2, nbc);
-        // wavefronts per block: the split that wastes the least of a CU's 160 KB
-        const int fit1 = (int)(160 * 1024 / L.per_wave), fit2 = 2 * (int)(160 * 1024 / (2 * L.per_wave));
-        const int wpb = fit2 >= fit1 ? 2 : 1;
-        if (r2 > 0 && fit1 >= 4) {
+        const WavePlan wp = rank_wave_plan(c, mode);
+        const i64 r2 = wp.r2;
+        const int nbc = wp.nbc, wpb = wp.wpb;
+        if (wp.ok) {
             HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
             RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
                            c->cap, c->crow, 0, 1, c->RW, (int)r2, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
                            c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc};
-            const size_t lds = (size_t)wpb * L.per_wave;
+            const size_t lds = wp.lds;
             if (lds > 64 * 1024)
                 HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             c->t_begin(KI_RANK_LDS);
@@ -457,30 +511,14 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
             counted = true;
         }
     }
-    if (!counted && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_lean && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
-        g.S <= 256 && (c->cap & 15u) == 0 && c->cap <= 1024 && g.R <= 60000) {
+    if (!counted) {
         // the lean counting sort (k_rank_lean): the whole record row in one coalesced read, piecewise compaction, chunks in registers
-        const int nbc = rank_cnt_maxb(g.NB) + 2 < g.NB ? rank_cnt_maxb(g.NB) + 2 : 0;
-        const int nbc_eff = nbc ? nbc : (g.NB < 128 ? g.NB : 128);
+        const LeanPlan lp = rank_lean_plan(c, mode);
+        const int nbc = lp.nbc, psp = lp.psp;
+        const i64 rb = lp.rb;
         const int* cut = nbc ? (c->exact_mx ? c->t.as<int>() : c->tguess.as<int>()) : nullptr;
-        // room for every piece of the row when that fits HG_RANK_WAVES blocks per CU; else for the usual list (2.2 R + padding)
-        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
-        const i64 all = (i64)g.S * c->cap;
-        // pieces of a slice fetched up front: what it holds but for a 4-sigma exception, when the select keeps ~0.7 of the budgeted
-        // mean (cap = mean + 6 sqrt(mean) + 16, inverted); at most what four loads per thread cover
-        const double mb = std::pow(std::sqrt((double)c->cap > 7.0 ? (double)c->cap - 7.0 : 0.0) - 3.0, 2.0), est = 0.7 * mb;
-        int psp = (int)std::ceil((est + 4.0 * std::sqrt(est) + 1.0) / 16.0);
-        if (psp > (int)(c->cap >> 4)) psp = (int)(c->cap >> 4);
-        if (psp > RL_MAX_PIECES / g.S) psp = RL_MAX_PIECES / g.S;
-        if (psp < 1) psp = 1;
-        const i64 room = ((160 * 1024 / HG_RANK_WAVES) & ~511ll) - rank_lean_layout(g.NB, c->RW, g.S, 0, nbc).total;
-        i64 rb = all <= room ? all : room & ~15ll;
-        const i64 least = ((i64)(2.2 * (double)c->R * share) + 256 + 16 * (i64)g.S + 15) & ~15ll;
-        if (rb < least && least <= all) rb = least;
-        if (rb > all) rb = all;
-        if (rb > 16 * RL_MAX_PIECES) rb = 16 * RL_MAX_PIECES;      // a thread keeps at most four pieces of its query's list
-        const RankLeanLds L = rank_lean_layout(g.NB, c->RW, g.S, (int)rb, nbc);
-        if (nbc_eff <= 63 && L.total <= 64 * 1024 && rb >= 16 && (rb >= least || rb == all)) {
+        if (lp.ok) {
+            const RankLeanLds L = rank_lean_layout(g.NB, c->RW, g.S, (int)rb, nbc);
             HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
             const bool fuse = c->fuse_ap && c->opt_fuse_ap && mode == 0 && c->LW <= 2;
             bool use_recip = false;
@@ -489,9 +527,9 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
                            c->cap, c->crow, 0, 1, c->RW, (int)rb, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
                            c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc,
                            fuse ? c->shapes.as<ApShape>() : nullptr, fuse && use_recip ? c->ap_recip.as<double>() : nullptr,
-                           c->ap.as<double>(), c->rel.as<u32>(), fuse ? c->err.as<u32>() + 1 : nullptr, cut, psp};
+                           c->ap.as<double>(), c->rel.as<u32>(), fuse ? c->err.as<u32>() + 1 : nullptr, cut, psp, c->rec_il ? 1 : 0};
             c->t_begin(KI_RANK_LDS);
-            hipLaunchKernelGGL(k_rank_lean, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, c->cand.as<u8>(), la, c->mbits.as<u32>(), g);
+            hipLaunchKernelGGL(k_rank_lean, dim3(padded_grid(g.Q)), dim3(256), (size_t)L.total, c->stream, c->cand.as<u8>(), la, c->mbits.as<u32>(), g);
             c->t_end();
             HG_TRY(c->check_launch("k_rank_lean"));
             c->last_rank = 6;
@@ -500,7 +538,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
             counted = true;
         }
     }
-    if (!counted && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
+    if (!counted && !c->rec_il && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
         // per-thread counting sort (k_rank_cnt): byte counters for every distance + a tile of the records, <= 64 KiB per
         // block; lists longer than a tile are ranked tile by tile
         const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
@@ -569,7 +607,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
                 mode, c->hwq.as<u32>(), c->hown.as<u32>(), c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(),
                 c->tie_before.as<u32>(), c->posbase.as<u32>(),
                 c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW, only,
-                c->direct_rank ? 1 : 0, c->rec8 ? 1 : 0, c->db.as<u32>(), c->dblab.as<u64>(), c->qc.as<u32>(), c->qlab.as<u64>()};
+                c->direct_rank ? 1 : 0, c->rec8 ? 1 : 0, c->db.as<u32>(), c->dblab.as<u64>(), c->qc.as<u32>(), c->qlab.as<u64>(), c->rec_il ? 1 : 0};
     const size_t lds_bytes = (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4;
     c->t_begin(mode == 1 ? KI_CAND_HIST : KI_RANK_FUSED);
     if (nwav == 16)
@@ -1343,7 +1381,7 @@ static int capture_step(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     sg.graph = gr; sg.exec = ex;
     sg.epoch = g_alloc_epoch; sg.cfg = c->cfg_epoch; sg.R = R; sg.timing = c->timing;
     sg.stage = c->stage; sg.optimistic = c->optimistic; sg.lists_valid = c->lists_valid; sg.cap = c->cap; sg.crow = c->crow;
-    sg.RW = c->RW; sg.geo = c->geo; sg.ap_fused = c->ap_fused; sg.rec8 = c->rec8;
+    sg.RW = c->RW; sg.geo = c->geo; sg.ap_fused = c->ap_fused; sg.rec8 = c->rec8; sg.rec_il = c->rec_il;
     c->graph_captures++;
     return HG_OK;
 }
@@ -1401,7 +1439,7 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
                     // what the captured enqueue functions leave behind on the host side
                     HG_TRY(set_R(c, R, 1, 0));
                     c->geo = sg.geo; c->RW = sg.RW; c->stage = sg.stage; c->optimistic = sg.optimistic; c->lists_valid = sg.lists_valid;
-                    c->cap = sg.cap; c->crow = sg.crow; c->err_zeroed = false; c->ap_fused = sg.ap_fused; c->rec8 = sg.rec8;
+                    c->cap = sg.cap; c->crow = sg.crow; c->err_zeroed = false; c->ap_fused = sg.ap_fused; c->rec8 = sg.rec8; c->rec_il = sg.rec_il;
                     c->graph_replays++;
                     launched = true;
                 }

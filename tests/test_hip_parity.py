@@ -907,6 +907,37 @@ def test_dense_regime_ranks_the_rows_directly(Q, N, b, R, C):
         ctx.close()
 
 
+@pytest.mark.parametrize("Q,N,b,R,C", [(4200, 200000, 64, 1500, 10), (4130, 150000, 100, 2000, 100), (5000, 131072, 48, 1200, 81)])
+def test_interleaved_record_rows_match_plain(Q, N, b, R, C):
+    """The bet's one-byte records reach k_rank_lean through record rows in which the 16-byte pieces of 32 queries' slices
+    interleave (rec8_at: whole cache lines leave the select instead of 8 bytes per slice).  Same APs as
+    with plain rows, and as the oracle's -- bet and the ranked lists' path (which keeps plain 8-byte records) alike."""
+    rng = np.random.default_rng(Q + N)
+    proto = (rng.random((C, b)) < 0.5).astype(np.uint8)
+    lab_db, lab_q = rng.integers(0, C, N), rng.integers(0, C, Q)
+    db = proto[lab_db] ^ (rng.random((N, b)) < 0.35).astype(np.uint8)
+    qb = proto[lab_q] ^ (rng.random((Q, b)) < 0.35).astype(np.uint8)
+    dl = np.eye(C, dtype=np.int8)[lab_db]
+    ql = np.eye(C, dtype=np.int8)[lab_q]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb, db, ql, dl, R)
+    ctx = _native.Context(0)
+    try:
+        ctx.set_option("interleave_records", 1)           # (off by default: traffic falls, the step does not get faster)
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        ap, rel = ctx.map(R)
+        assert ctx.get_stat("last_optimistic") == 1 and ctx.get_stat("rank_variant") == 6
+        assert ctx.get_stat("records_interleaved") == 1
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        ctx.set_option("interleave_records", 0)
+        ap2, _ = ctx.map(R)
+        assert ctx.get_stat("records_interleaved") == 0 and ctx.get_stat("rank_variant") == 6
+        assert np.array_equal(ap2, ap_ref, equal_nan=True)
+    finally:
+        ctx.close()
+
+
 def test_fused_step_hands_wide_lists_to_the_general_kernel(ctx):
     """hg_map's bet ranks AND evaluates in k_rank_cnt (the AP leaves from its epilogue) and launches the general rank
     kernel only when the step's download reports queries k_rank_cnt declined.  Two queries here have rows planted at
