@@ -156,7 +156,7 @@ def traffic_from_profiles(kernel):
 
 
 SELECT_VARIANTS = {1: "k_select", 2: "k_select_dense", 3: "k_select_mx", 4: "k_select_mx2", 5: "k_select_mx3", 6: "k_select_mx4"}
-RANK_VARIANTS = {1: "k_rank_fused", 2: "k_rank_lds", 3: "k_rank_cnt", 4: "k_rank_wave", 5: "k_rank_direct", 6: "k_rank_lean", 7: "k_rank_dense"}
+RANK_VARIANTS = {1: "k_rank_fused", 2: "k_rank_lds", 3: "k_rank_cnt", 4: "k_rank_wave", 5: "k_rank_direct", 6: "k_rank_lean", 7: "k_rank_dense", 8: "k_rank_dense<slices>"}
 
 
 def kernel_names(ctx, spec):
@@ -179,7 +179,7 @@ def kernel_names(ctx, spec):
     if rank == "k_rank_dense":
         names["k_select"] = "k_dense_bytes<%d,%d>" % (NW, LW)
     if rank:
-        names["k_rank_lds" if rank in ("k_rank_lds", "k_rank_cnt", "k_rank_wave", "k_rank_lean") else "k_rank_fused"] = rank
+        names["k_rank_lds" if rank in ("k_rank_lds", "k_rank_cnt", "k_rank_wave", "k_rank_lean", "k_rank_dense<slices>") else "k_rank_fused"] = rank
     names["k_hist"] = "k_hist_i8<%d>" % NW if NW <= 4 else "k_hist_mx<%d>" % NW
     names["k_guess"] = "k_guess_direct"
     return names

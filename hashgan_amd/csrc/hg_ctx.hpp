@@ -194,6 +194,8 @@ struct hg_ctx {
     i64 opt_rank_direct_lds = 80;    // "rank_direct_lds": KB of LDS a k_rank_direct block may take (80: two blocks per CU -- C1 0.25 ms vs 0.31 with 160 and one)
     i64 opt_rank_direct = 1;   // "rank_direct": R = N on one shard in one counting-sort kernel, k_rank_direct, when its LDS fits (2: also N/8 < R < N)
     i64 opt_rank_dense = 1;    // "rank_dense": N/8 < R <= N on one shard through the byte matrix (k_dense_bytes + k_rank_dense, hg_rank_dense.hpp; codes of <= 126 bits, <= 128 classes); 0: off
+    i64 opt_rank_slices = 7000;    // "rank_slices": a bet's one-byte records with R >= this are ranked by k_rank_dense<slices>; 0: off (k_rank_cnt's tiles).
+                                   // Q = 10k, N = 1M: R = 5000 0.274 ms against k_rank_lean's 0.139 (fixed costs of the counter columns); R = 8000 0.318 / 0.372; R = 50 000 1.38 / 3.83
     i64 opt_rank_dense_gbm = -1;   // "rank_dense_gbm": k_rank_dense's bitmap in global memory (1) or LDS (0, where it fits); -1: by the blocks per CU
     i64 opt_dense_budget_mb = 16384;   // "dense_budget_mb": the byte matrix D holds at most this much (queries are chunked)
     bool dense_rank = false;   // run state of enqueue_all_rows: rank through the byte matrix
@@ -211,7 +213,7 @@ struct hg_ctx {
     i64 crow = 0;              // record-row stride
     i64 opt_runs = 0, opt_fallbacks = 0, opt_requeried = 0;
     int last_select = 0;       // stat "select_variant": 1 k_select, 2 k_select_dense, 3 k_select_mx, 4 k_select_mx2, 5 k_select_mx3, 6 k_select_mx4
-    int last_rank = 0;         // stat "rank_variant": 1 k_rank_fused, 2 k_rank_lds, 3 k_rank_cnt, 4 k_rank_wave, 5 k_rank_direct, 6 k_rank_lean, 7 k_rank_dense
+    int last_rank = 0;         // stat "rank_variant": 1 k_rank_fused, 2 k_rank_lds, 3 k_rank_cnt, 4 k_rank_wave, 5 k_rank_direct, 6 k_rank_lean, 7 k_rank_dense, 8 k_rank_dense<slices>
     i64 opt_leftover = 0;      // stat "rank_leftovers": queries of fused steps that k_rank_cnt left to the general rank kernel
     int opt_consecutive_fail = 0;   // one-shot bets lost in a row (this context only)
     int shard_bet_fail = 0;         // sharded bets lost in a row: identical on every rank by construction

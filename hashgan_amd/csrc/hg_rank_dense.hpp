@@ -97,13 +97,22 @@ struct RankDenseArgs {
     const double* ap_recip;     // [R + 1 + AP_RECIP_SLACK]
     double* ap;                 // [Q]
     u32* rel;                   // [Q]
+    // SLICES: the rows are the one-byte records of a bet (k_select_mx3 / mx4) instead of the byte matrix -- slice s of query q
+    // is sl_cnt[s][q] bytes at cand8 + q * crow + s * cap, in index order; thread = (slice, part of it)
+    const u8* cand8;
+    const u32* sl_cnt;          // [S][Qpad]
+    const u32* fail;            // [Qpad]: a slice of the query overflowed (the bet is lost for it)
+    u32 cap;
+    i64 crow;
+    int nrows;                  // counter rows (distances 0 .. nrows - 1; row `nrows`: pad bytes).  DENSE: b + 1.  SLICES: the bet's cut never exceeds
+                                // b/2 + 1 (the sampled pass stops there; a thinner sample takes everything, overflows and is flagged): b/2 + 2 rows
 };
 
 // GBM: the R-bit bitmap stays in global memory (zeroed by the caller; members' match bits arrive by fire-and-forget
 // atomic ORs -- ~5 % of the rows -- and k_ap evaluates it afterwards) instead of LDS: the block is then its counter
 // columns alone, (b + 2) KB, and two to four blocks share a CU where a 62 KB bitmap (R = 500k) leaves room for one.
 struct RankDenseLds { int cnt, tot, misc, bm, total; };              // byte offsets
-__host__ __device__ inline RankDenseLds rank_dense_layout(int NB, i64 RW, bool gbm) {
+__host__ __device__ inline RankDenseLds rank_dense_layout(int NB, i64 RW, bool gbm) {     // NB: counter rows (RankDenseArgs::nrows)
     RankDenseLds l;
     l.cnt = 0;                                   // [NB + 1][256] u32: thread tid's counter of distance d at d * 256 + tid; row NB: pad rows (the AP epilogue's scratch afterwards)
     int cb = (NB + 1) * RD_THREADS * 4;
@@ -115,7 +124,11 @@ __host__ __device__ inline RankDenseLds rank_dense_layout(int NB, i64 RW, bool g
     return l;
 }
 
-template <bool LISTS, bool GBM>
+// SLICES (the bet with a long list, R beyond k_rank_lean's LDS): the same two passes over the query's RECORDS.  The record rows
+// are a superset of the top R by construction of the bet; what this kernel verifies is what every rank kernel of the bet
+// verifies -- no slice overflowed, and the records number at least R (else the plan finds no cut: the bet is lost and the
+// caller escalates).  k_rank_cnt ranks such lists tile by tile (compaction, per-tile scans: 2.8 ms at Q = 10k, R = 50 000).
+template <bool LISTS, bool GBM, bool SLICES>
 static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDenseArgs a, u32* __restrict__ out_idx, u8* __restrict__ out_dist,
                                                                   u32* __restrict__ mbits32, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 dlds[];
@@ -124,7 +137,7 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NB = g.NB;
+    const int NB = a.nrows;                          // distances with a counter row; row NB takes the pad bytes
     const int bmw = (int)(2 * a.RW);
     const RankDenseLds L = rank_dense_layout(NB, a.RW, GBM);
     u32* cnt = (u32*)(dlds + L.cnt);
@@ -137,9 +150,49 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
     if (!GBM) for (int i = tid; i <= bmw; i += nthr) bm[i] = 0u;
     if (tid < NB) tot[tid] = 0u;
 
-    // thread tid owns rows [tid Lr, (tid + 1) Lr), Lr = 16 P: piece p of its range is the uint4 at p * 256 + tid of the query's row of D
-    const i64 P = a.Npad / (nthr * 16);
-    const uint4* __restrict__ drow = (const uint4*)(a.D + (i64)blockIdx.x * a.Npad) + tid;
+    // DENSE: thread tid owns rows [tid Lr, (tid + 1) Lr), Lr = 16 P: piece p of its range is the uint4 at p * 256 + tid of the query's row of D.
+    // SLICES: thread tid = (slice tid / parts, part tid % parts) owns a run of whole 16-byte pieces of that slice, contiguous in memory.
+    i64 P, pstride;
+    const uint4* __restrict__ drow;
+    u32 tailkeep[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // SLICES: the valid bytes of the thread's LAST piece
+    if (SLICES) {
+        if (a.fail[q]) {                                 // (block-uniform) a slice overflowed: lost
+            if (tid == 0) { atomicExch(a.err, 1); a.qbad[q] = 1u; }
+            return;
+        }
+        const int parts = nthr / g.S > 0 ? nthr / g.S : 1;             // the launcher keeps S <= 256
+        const int sl = tid / parts, part = tid - sl * parts;
+        const u32 c = sl < g.S ? a.sl_cnt[(i64)sl * g.Qpad + q] : 0u;
+        const u32 np = (c + 15u) >> 4;                                 // pieces of the slice (c <= cap: the select clamps the count)
+        const u32 pa = np * (u32)part / (u32)parts, pb = np * (u32)(part + 1) / (u32)parts;
+        P = (i64)(pb - pa);
+        pstride = 1;
+        drow = (const uint4*)(a.cand8 + (i64)q * a.crow + (i64)(sl < g.S ? sl : 0) * a.cap) + pa;
+        if (pb == np && (c & 15u)) {                                   // the slice's last piece is partial: bytes past the count become pad rows
+            const int valid = (int)(c & 15u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nb = valid - 4 * i;
+                tailkeep[i] = nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : (1u << (8 * nb)) - 1u;
+            }
+        }
+    } else {
+        P = a.Npad / (nthr * 16);
+        pstride = nthr;
+        drow = (const uint4*)(a.D + (i64)blockIdx.x * a.Npad) + tid;
+    }
+    const u32 padw = (u32)NB * 0x01010101u;
+    // (SLICES: a record beyond the counter rows cannot come from a bet that holds -- it would index past the columns: clamp it onto the pad row)
+    auto rowof = [&](const u32 d) -> u32 { return SLICES ? (d < (u32)NB ? d : (u32)NB) : d; };
+    // piece p of the thread's range, pad bytes in place
+    auto piece = [&](const i64 p) -> uint4 {
+        uint4 v = drow[(p < P ? p : 0) * pstride];
+        if (SLICES && p == P - 1) {
+            v.x = (v.x & tailkeep[0]) | (padw & ~tailkeep[0]); v.y = (v.y & tailkeep[1]) | (padw & ~tailkeep[1]);
+            v.z = (v.z & tailkeep[2]) | (padw & ~tailkeep[2]); v.w = (v.w & tailkeep[3]) | (padw & ~tailkeep[3]);
+        }
+        return v;
+    };
     u32* mycnt = cnt + tid;
     __syncthreads();
 
@@ -147,17 +200,17 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
     {
         uint4 v[RD_PF], nx[RD_PF];
 #pragma unroll
-        for (int k = 0; k < RD_PF; ++k) v[k] = drow[(i64)(k < P ? k : 0) * nthr];
+        for (int k = 0; k < RD_PF; ++k) v[k] = piece(k);
         for (i64 p0 = 0; p0 < P; p0 += RD_PF) {
 #pragma unroll
-            for (int k = 0; k < RD_PF; ++k) nx[k] = drow[(p0 + RD_PF + k < P ? p0 + RD_PF + k : 0) * nthr];
+            for (int k = 0; k < RD_PF; ++k) nx[k] = piece(p0 + RD_PF + k);
 #pragma unroll
             for (int k = 0; k < RD_PF; ++k) {
                 if (p0 + k < P) {
                     const u32 w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
                     u32* ad[16];                                        // (addresses first, adds after: sixteen independent chains for the one wavefront a SIMD has)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) ad[e] = mycnt + ((w4[e >> 2] >> (8 * (e & 3))) & 0x7Fu) * nthr;
+                    for (int e = 0; e < 16; ++e) ad[e] = mycnt + rowof((w4[e >> 2] >> (8 * (e & 3))) & 0x7Fu) * nthr;
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int e = 0; e < 16; ++e) atomicAdd(ad[e], 1u);
@@ -251,10 +304,10 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
         const u32 row0 = g.idx_base + (u32)((i64)tid * P * 16);
         uint4 v[RD_PF], nx[RD_PF];
 #pragma unroll
-        for (int k = 0; k < RD_PF; ++k) v[k] = drow[(i64)(k < P ? k : 0) * nthr];
+        for (int k = 0; k < RD_PF; ++k) v[k] = piece(k);
         for (i64 p0 = 0; p0 < P; p0 += RD_PF) {
 #pragma unroll
-            for (int k = 0; k < RD_PF; ++k) nx[k] = drow[(p0 + RD_PF + k < P ? p0 + RD_PF + k : 0) * nthr];
+            for (int k = 0; k < RD_PF; ++k) nx[k] = piece(p0 + RD_PF + k);
 #pragma unroll
             for (int k = 0; k < RD_PF; ++k) {
                 if (p0 + k < P) {
@@ -262,7 +315,7 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
                     u32 pos[16];
                     u32* ad[16];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) ad[e] = mycnt + ((w4[e >> 2] >> (8 * (e & 3))) & 0x7Fu) * nthr;
+                    for (int e = 0; e < 16; ++e) ad[e] = mycnt + rowof((w4[e >> 2] >> (8 * (e & 3))) & 0x7Fu) * nthr;
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int e = 0; e < 16; ++e) pos[e] = atomicAdd(ad[e], 1u);

@@ -341,12 +341,13 @@ static int launch_rank_dense(hg_ctx* c) {
         c->t_end();
         HG_TRY(c->check_launch("k_dense_bytes"));
         RankDenseArgs da{c->dbytes.as<u8>(), Npad, (int)q0, c->err.as<int>(), c->qbad.as<u32>(), c->RW,
-                         fused ? c->shapes.as<ApShape>() : nullptr, fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>()};
+                         fused ? c->shapes.as<ApShape>() : nullptr, fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>(),
+                         nullptr, nullptr, nullptr, 0u, 0, g.NB};
         c->t_begin(KI_RANK_FUSED);
 #define HG_RANK_DENSE(LISTS_, GBM_)                                                                                                              \
     do {                                                                                                                                         \
-        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_dense<LISTS_, GBM_>), hipFuncAttributeMaxDynamicSharedMemorySize, total)); \
-        hipLaunchKernelGGL((k_rank_dense<LISTS_, GBM_>), dim3(nq), dim3(RD_THREADS), (size_t)total, c->stream, da, c->out_idx.as<u32>(),         \
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_dense<LISTS_, GBM_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, total)); \
+        hipLaunchKernelGGL((k_rank_dense<LISTS_, GBM_, false>), dim3(nq), dim3(RD_THREADS), (size_t)total, c->stream, da, c->out_idx.as<u32>(),  \
                            c->out_dist.as<u8>(), c->mbits.as<u32>(), g);                                                                         \
     } while (0)
         if (c->want_lists) { if (gbm) HG_RANK_DENSE(true, true); else HG_RANK_DENSE(true, false); }
@@ -537,6 +538,29 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
             only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
             counted = true;
         }
+    }
+    // (the bet's cut never exceeds b/2 + 1 -- enqueue_optimistic's sampled pass stops there --, so b/2 + 2 counter rows cover its records)
+    const int sl_rows = (!c->exact_mx && g.NB / 2 + 2 < g.NB) ? g.NB / 2 + 2 : g.NB;
+    if (!counted && !c->rec_il && c->optimistic && c->opt_rank_slices > 0 && mode == 0 && c->rec8 && !c->want_lists && g.S <= RD_THREADS && g.NB <= 127 &&
+        g.R >= c->opt_rank_slices && rank_dense_layout(sl_rows, c->RW, false).total <= 160 * 1024) {
+        // long lists of a bet (beyond k_rank_lean's LDS): k_rank_dense's two passes over the query's record slices, thread = part of a slice
+        const int total = rank_dense_layout(sl_rows, c->RW, false).total;
+        const bool fuse = c->fuse_ap && c->opt_fuse_ap && 160 * 1024 / total >= 2;
+        bool use_recip = false;
+        if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
+        const bool fused = fuse && use_recip;
+        RankDenseArgs da{nullptr, 0, 0, c->err.as<int>(), c->qbad.as<u32>(), c->RW,
+                         fused ? c->shapes.as<ApShape>() : nullptr, fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>(),
+                         c->cand.as<u8>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, sl_rows};
+        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_dense<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, total));
+        c->t_begin(KI_RANK_LDS);
+        hipLaunchKernelGGL((k_rank_dense<false, false, true>), dim3(g.Q), dim3(RD_THREADS), (size_t)total, c->stream, da, c->out_idx.as<u32>(),
+                           c->out_dist.as<u8>(), c->mbits.as<u32>(), g);
+        c->t_end();
+        HG_TRY(c->check_launch("k_rank_dense<slices>"));
+        c->last_rank = 8;
+        c->ap_fused = fused;
+        return HG_OK;
     }
     if (!counted && !c->rec_il && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
         // per-thread counting sort (k_rank_cnt): byte counters for every distance + a tile of the records, <= 64 KiB per

@@ -938,6 +938,42 @@ def test_interleaved_record_rows_match_plain(Q, N, b, R, C):
         ctx.close()
 
 
+@pytest.mark.parametrize("Q,N,b,R,C,by_class", [(4200, 200000, 64, 20000, 10, False), (4100, 150000, 100, 15000, 100, False),
+                                                (4300, 262144, 48, 30000, 12, True)])
+def test_long_lists_of_a_bet_are_ranked_slice_by_slice(Q, N, b, R, C, by_class):
+    """N/100 < R <= N/8: the bet's record lists no longer fit k_rank_lean's LDS; k_rank_dense<slices> ranks them in two passes
+    with thread = part of a slice (private counter columns, one returning LDS add per record) instead of k_rank_cnt's tiles.
+    Same APs as the oracle and as the tiled kernel; a database stored class by class loses its first bets (overflowing
+    slices are flagged by the select and make this kernel leave the query) and still ends exact."""
+    rng = np.random.default_rng(Q + N + R)
+    proto = (rng.random((C, b)) < 0.5).astype(np.uint8)
+    lab_db, lab_q = rng.integers(0, C, N), rng.integers(0, C, Q)
+    if by_class:
+        lab_db = np.sort(lab_db)
+    db = proto[lab_db] ^ (rng.random((N, b)) < 0.3).astype(np.uint8)
+    qb = proto[lab_q] ^ (rng.random((Q, b)) < 0.3).astype(np.uint8)
+    dl = np.eye(C, dtype=np.int8)[lab_db]
+    ql = np.eye(C, dtype=np.int8)[lab_q]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb, db, ql, dl, R)
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
+        ap, rel = ctx.map(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        ap, rel = ctx.map(R)                              # (a second call: the widened slices of a class-sorted database are in force)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        if ctx.get_stat("last_optimistic") == 1:
+            assert ctx.get_stat("rank_variant") == 8
+        ctx.set_option("rank_slices", 0)
+        ap2, _ = ctx.map(R)
+        assert np.array_equal(ap2, ap_ref, equal_nan=True)
+        assert ctx.get_stat("rank_variant") != 8
+    finally:
+        ctx.close()
+
+
 def test_fused_step_hands_wide_lists_to_the_general_kernel(ctx):
     """hg_map's bet ranks AND evaluates in k_rank_cnt (the AP leaves from its epilogue) and launches the general rank
     kernel only when the step's download reports queries k_rank_cnt declined.  Two queries here have rows planted at
