@@ -32,7 +32,7 @@ constexpr int RD_THREADS = 256;
 #define HG_RD_PF 8
 #endif
 constexpr int RD_PF = HG_RD_PF;           // 16-byte pieces a thread has in flight while it works on as many (16 measured the same: the loads' latency is covered)
-// (a row past N carries the distance NB = b + 1, which no row has and no cut reaches: one more counter row, no test per row; codes of <= 126 bits)
+// (a row past N carries the distance b with the match bit clear: see padrow in k_rank_dense; no test per row; codes of <= 126 bits)
 
 // rows per thread range (a multiple of 16) for a database of N rows
 __host__ __device__ inline i64 rank_dense_pieces(i64 N) { return ((N + RD_THREADS - 1) / RD_THREADS + 15) / 16; }
@@ -112,13 +112,13 @@ struct RankDenseArgs {
 // atomic ORs -- ~5 % of the rows -- and k_ap evaluates it afterwards) instead of LDS: the block is then its counter
 // columns alone, (b + 2) KB, and two to four blocks share a CU where a 62 KB bitmap (R = 500k) leaves room for one.
 struct RankDenseLds { int cnt, tot, misc, bm, total; };              // byte offsets
-__host__ __device__ inline RankDenseLds rank_dense_layout(int NB, i64 RW, bool gbm) {     // NB: counter rows (RankDenseArgs::nrows)
+__host__ __device__ inline RankDenseLds rank_dense_layout(int NR, i64 RW, bool gbm) {     // NR: counter rows in all (DENSE: b + 1; SLICES: nrows + 1, the pad row)
     RankDenseLds l;
-    l.cnt = 0;                                   // [NB + 1][256] u32: thread tid's counter of distance d at d * 256 + tid; row NB: pad rows (the AP epilogue's scratch afterwards)
-    int cb = (NB + 1) * RD_THREADS * 4;
+    l.cnt = 0;                                   // [NR][256] u32: thread tid's counter of distance d at d * 256 + tid (the AP epilogue's scratch afterwards)
+    int cb = NR * RD_THREADS * 4;
     if (cb < AP_LDS_BYTES + 8) cb = (AP_LDS_BYTES + 8 + 15) & ~15;
-    l.tot = l.cnt + cb;                          // [NB] u32: totals, then bucket starts
-    l.misc = l.tot + ((NB * 4 + 15) & ~15);      // [16] u32
+    l.tot = l.cnt + cb;                          // [NR] u32: totals, then bucket starts
+    l.misc = l.tot + ((NR * 4 + 15) & ~15);      // [16] u32
     l.bm = l.misc + 64;                          // [2 RW + 1] u32 (the last word takes the ORs of rows beyond the cut)
     l.total = l.bm + (gbm ? 0 : (((int)(2 * RW) + 1) * 4 + 15) & ~15);
     return l;
@@ -139,14 +139,19 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NB = a.nrows;                          // distances with a counter row; row NB takes the pad bytes
     const int bmw = (int)(2 * a.RW);
-    const RankDenseLds L = rank_dense_layout(NB, a.RW, GBM);
+    // The pad bytes' row.  SLICES: one past the distances.  DENSE: the LAST distance's own row, b -- pad rows have the highest
+    // indices, so inside that bucket they rank behind every real row and beyond N >= R: never members, and the cut is found as
+    // without them (one KB less of LDS: C1 gets four blocks per CU instead of three -- 1000 queries in one round).
+    const int padrow = SLICES ? NB : NB - 1;
+    const int NR = padrow + 1 > NB ? padrow + 1 : NB;
+    const RankDenseLds L = rank_dense_layout(NR, a.RW, GBM);
     u32* cnt = (u32*)(dlds + L.cnt);
     u32* tot = (u32*)(dlds + L.tot);
     u32* misc = (u32*)(dlds + L.misc);
     u32* bm = (u32*)(dlds + L.bm);
     u32* __restrict__ grow = mbits32 + (i64)q * 2 * a.RW;
 
-    for (int i = tid; i < (NB + 1) * nthr; i += nthr) cnt[i] = 0u;
+    for (int i = tid; i < NR * nthr; i += nthr) cnt[i] = 0u;
     if (!GBM) for (int i = tid; i <= bmw; i += nthr) bm[i] = 0u;
     if (tid < NB) tot[tid] = 0u;
 
@@ -181,9 +186,9 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
         pstride = nthr;
         drow = (const uint4*)(a.D + (i64)blockIdx.x * a.Npad) + tid;
     }
-    const u32 padw = (u32)NB * 0x01010101u;
+    const u32 padw = (u32)padrow * 0x01010101u;
     // (SLICES: a record beyond the counter rows cannot come from a bet that holds -- it would index past the columns: clamp it onto the pad row)
-    auto rowof = [&](const u32 d) -> u32 { return SLICES ? (d < (u32)NB ? d : (u32)NB) : d; };
+    auto rowof = [&](const u32 d) -> u32 { return SLICES ? (d < (u32)NB ? d : (u32)padrow) : d; };
     // piece p of the thread's range, pad bytes in place
     auto piece = [&](const i64 p) -> uint4 {
         uint4 v = drow[(p < P ? p : 0) * pstride];
@@ -273,7 +278,7 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
     if (t < 0) return;
     // counters -> global ranks: start of the bucket + the rows of earlier threads at that distance; the columns of
     // distances beyond the cut (and of the pad rows) start at 2^31: whatever such a row draws is no rank below R
-    for (int d = wave; d <= NB; d += NWAV) {
+    for (int d = wave; d < NR; d += NWAV) {
         if (d <= t) {
             u32 carry = tot[d];
 #pragma unroll

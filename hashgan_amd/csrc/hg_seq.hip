@@ -292,7 +292,7 @@ static bool rank_dense_fits(const hg_ctx* c, int64_t R) {
 static void launch_dense_bytes(hg_ctx* c, u8* D, i64 Npad, int q0, int nq) {
     const int qper = 64;
     const dim3 grid((unsigned)(Npad / 1024), (unsigned)((nq + qper - 1) / qper));
-    const u32 padbyte = (u32)(c->b + 1);               // = NB: the distance of the rows past N
+    const u32 padbyte = (u32)c->b;                     // the distance of the rows past N (k_rank_dense: padrow)
 #define HG_DENSE_BYTES(NW_, LW_)                                                                                                      \
     hipLaunchKernelGGL((k_dense_bytes<NW_, LW_>), grid, dim3(256), 0, c->stream, c->qc.as<u32>(), c->qlab.as<u64>(), c->db.as<u32>(), \
                        c->dblab.as<u64>(), D, c->N, Npad, q0, nq, qper, padbyte)
@@ -542,9 +542,9 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
     // (the bet's cut never exceeds b/2 + 1 -- enqueue_optimistic's sampled pass stops there --, so b/2 + 2 counter rows cover its records)
     const int sl_rows = (!c->exact_mx && g.NB / 2 + 2 < g.NB) ? g.NB / 2 + 2 : g.NB;
     if (!counted && !c->rec_il && c->optimistic && c->opt_rank_slices > 0 && mode == 0 && c->rec8 && !c->want_lists && g.S <= RD_THREADS && g.NB <= 127 &&
-        g.R >= c->opt_rank_slices && rank_dense_layout(sl_rows, c->RW, false).total <= 160 * 1024) {
+        g.R >= c->opt_rank_slices && rank_dense_layout(sl_rows + 1, c->RW, false).total <= 160 * 1024) {
         // long lists of a bet (beyond k_rank_lean's LDS): k_rank_dense's two passes over the query's record slices, thread = part of a slice
-        const int total = rank_dense_layout(sl_rows, c->RW, false).total;
+        const int total = rank_dense_layout(sl_rows + 1, c->RW, false).total;
         const bool fuse = c->fuse_ap && c->opt_fuse_ap && 160 * 1024 / total >= 2;
         bool use_recip = false;
         if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
