@@ -183,6 +183,7 @@ struct hg_ctx {
     i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
     i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
     i64 opt_rank_cnt = 1;      // ... and ranks them with the per-thread counting sort (k_rank_cnt) where it applies
+    i64 opt_segments_for_lean = 1;   // "segments_for_lean": make_geometry keeps the segment count within k_rank_lean's 256 when that still fills the GPU
     i64 opt_rank_lean = 1;     // "rank_lean": ... in its lean form (k_rank_lean) for one-byte records without lists, <= 256 slices, <= 1024 pieces per query
     i64 real_grouped = 0;      // stat: the last real-valued ranking ordered its record lists group by group (k_real_group_*)
     i64 opt_real_groups = 1;   // "real_groups": record lists beyond the LDS are split by score range and ordered group by group in LDS (0: the four radix passes)
