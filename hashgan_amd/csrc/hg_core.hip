@@ -781,6 +781,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "rank_dense")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "rank_dense must be 0 or 1 (2 is accepted and means 1)");
         c->opt_rank_dense = value;
+    } else if (!strcmp(key, "inline_leftovers")) {
+        c->opt_inline_leftovers = value != 0;
     } else if (!strcmp(key, "segments_for_lean")) {
         c->opt_segments_for_lean = value != 0;
     } else if (!strcmp(key, "rank_slices")) {

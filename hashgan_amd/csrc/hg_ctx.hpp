@@ -195,6 +195,9 @@ struct hg_ctx {
     i64 opt_rank_direct_lds = 80;    // "rank_direct_lds": KB of LDS a k_rank_direct block may take (80: two blocks per CU -- C1 0.25 ms vs 0.31 with 160 and one)
     i64 opt_rank_direct = 1;   // "rank_direct": R = N on one shard in one counting-sort kernel, k_rank_direct, when its LDS fits (2: also N/8 < R < N)
     i64 opt_rank_dense = 1;    // "rank_dense": N/8 < R <= N on one shard through the byte matrix (k_dense_bytes + k_rank_dense, hg_rank_dense.hpp; codes of <= 126 bits, <= 128 classes); 0: off
+    bool leftovers_expected = false;   // the last fused step on this context left queries to the general kernel
+    bool leftovers_inline = false;     // ... and this step ranked its own within the stream (launch_rank_slices with the flags)
+    i64 opt_inline_leftovers = 1;      // "inline_leftovers"
     i64 opt_rank_slices = 7000;    // "rank_slices": a bet's one-byte records with R >= this are ranked by k_rank_dense<slices>; 0: off (k_rank_cnt's tiles).
                                    // Q = 10k, N = 1M: R = 5000 0.274 ms against k_rank_lean's 0.139 (fixed costs of the counter columns); R = 8000 0.318 / 0.372; R = 50 000 1.38 / 3.83
     i64 opt_rank_dense_gbm = -1;   // "rank_dense_gbm": k_rank_dense's bitmap in global memory (1) or LDS (0, where it fits); -1: by the blocks per CU

@@ -104,6 +104,7 @@ struct RankDenseArgs {
     const u32* fail;            // [Qpad]: a slice of the query overflowed (the bet is lost for it)
     u32 cap;
     i64 crow;
+    const u32* only;            // SLICES, optional [Q]: rank only the flagged queries (what k_rank_lean declined)
     int nrows;                  // counter rows (distances 0 .. nrows - 1; row `nrows`: pad bytes).  DENSE: b + 1.  SLICES: the bet's cut never exceeds
                                 // b/2 + 1 (the sampled pass stops there; a thinner sample takes everything, overflows and is flagged): b/2 + 2 rows
 };
@@ -134,6 +135,7 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
     extern __shared__ __attribute__((aligned(16))) u8 dlds[];
     constexpr int nthr = RD_THREADS, NWAV = RD_THREADS / 64;
     const int q = a.q0 + blockIdx.x;
+    if (SLICES && a.only && !a.only[q]) return;          // (block-uniform) not one of the flagged queries
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -351,7 +351,7 @@ static int launch_rank_dense(hg_ctx* c) {
         HG_TRY(c->check_launch("k_dense_bytes"));
         RankDenseArgs da{c->dbytes.as<u8>(), Npad, (int)q0, c->err.as<int>(), c->qbad.as<u32>(), c->RW,
                          fused ? c->shapes.as<ApShape>() : nullptr, fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>(),
-                         nullptr, nullptr, nullptr, 0u, 0, g.NB};
+                         nullptr, nullptr, nullptr, 0u, 0, nullptr, g.NB};
         c->t_begin(KI_RANK_FUSED);
 #define HG_RANK_DENSE(LISTS_, GBM_)                                                                                                              \
     do {                                                                                                                                         \
@@ -367,6 +367,50 @@ static int launch_rank_dense(hg_ctx* c) {
     }
     c->last_rank = 7;
     c->ap_fused = fused;
+    return HG_OK;
+}
+
+// k_rank_dense<slices> (hg_rank_dense.hpp) over the bet's one-byte records: the whole launch (long lists), or only the queries
+// flagged in `only` (what k_rank_lean declined -- then always with the AP from the epilogue: a handful of blocks)
+static int slices_rows(const hg_ctx* c) {
+    // the bet's cut never exceeds b/2 + 1 -- enqueue_optimistic's sampled pass stops there --, so b/2 + 2 counter rows cover its records
+    return (!c->exact_mx && c->geo.NB / 2 + 2 < c->geo.NB) ? c->geo.NB / 2 + 2 : c->geo.NB;
+}
+static bool rank_slices_fits(const hg_ctx* c) {
+    return c->optimistic && c->rec8 && !c->rec_il && !c->want_lists && c->geo.S <= RD_THREADS && slices_rows(c) <= 126 &&
+           rank_dense_layout(slices_rows(c) + 1, c->RW, false).total <= 160 * 1024;
+}
+static int launch_rank_slices(hg_ctx* c, const u32* only) {
+    const Geo& g = c->geo;
+    const int sl_rows = slices_rows(c);
+    const int total = rank_dense_layout(sl_rows + 1, c->RW, false).total;
+    const bool fuse = c->fuse_ap && c->opt_fuse_ap && (only || 160 * 1024 / total >= 2);
+    bool use_recip = false;
+    if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
+    const bool fused = fuse && use_recip;
+    if (only && !fused) return fail(HG_ERR_STATE, "launch_rank_slices: the leftover form needs the AP tables");
+    RankDenseArgs da{nullptr, 0, 0, c->err.as<int>(), c->qbad.as<u32>(), c->RW,
+                     fused ? c->shapes.as<ApShape>() : nullptr, fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>(),
+                     c->cand.as<u8>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, only, sl_rows};
+    HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_dense<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, total));
+    c->t_begin(only ? KI_RANK_FUSED : KI_RANK_LDS);
+    hipLaunchKernelGGL((k_rank_dense<false, false, true>), dim3(g.Q), dim3(RD_THREADS), (size_t)total, c->stream, da, c->out_idx.as<u32>(),
+                       c->out_dist.as<u8>(), c->mbits.as<u32>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_rank_dense<slices>"));
+    if (!only) { c->last_rank = 8; c->ap_fused = fused; }
+    return HG_OK;
+}
+
+// The last fused step on this context had queries its rank kernel declined (one of C5's 10 000 spans more distances than
+// k_rank_lean places): rank the flagged ones right behind it, in the same stream -- a launch of mostly returning blocks --
+// instead of a second host round trip (k_rank_fused + k_ap + three downloads: 0.08 ms of C5's 1.27).
+static int rank_leftovers_inline(hg_ctx* c, int mode, bool use_recip) {
+    c->leftovers_inline = false;
+    if (c->leftovers_expected && mode == 0 && c->opt_inline_leftovers && use_recip && rank_slices_fits(c)) {
+        HG_TRY(launch_rank_slices(c, c->bigq.as<u32>()));
+        c->leftovers_inline = true;
+    }
     return HG_OK;
 }
 
@@ -543,33 +587,18 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
             c->t_end();
             HG_TRY(c->check_launch("k_rank_lean"));
             c->last_rank = 6;
-            if (fuse) { c->ap_fused = true; return HG_OK; }
+            if (fuse) {
+                c->ap_fused = true;
+                HG_TRY(rank_leftovers_inline(c, mode, use_recip));
+                return HG_OK;
+            }
             only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
             counted = true;
         }
     }
-    // (the bet's cut never exceeds b/2 + 1 -- enqueue_optimistic's sampled pass stops there --, so b/2 + 2 counter rows cover its records)
-    const int sl_rows = (!c->exact_mx && g.NB / 2 + 2 < g.NB) ? g.NB / 2 + 2 : g.NB;
-    if (!counted && !c->rec_il && c->optimistic && c->opt_rank_slices > 0 && mode == 0 && c->rec8 && !c->want_lists && g.S <= RD_THREADS && g.NB <= 127 &&
-        g.R >= c->opt_rank_slices && rank_dense_layout(sl_rows + 1, c->RW, false).total <= 160 * 1024) {
+    if (!counted && mode == 0 && g.R >= c->opt_rank_slices && c->opt_rank_slices > 0 && rank_slices_fits(c)) {
         // long lists of a bet (beyond k_rank_lean's LDS): k_rank_dense's two passes over the query's record slices, thread = part of a slice
-        const int total = rank_dense_layout(sl_rows + 1, c->RW, false).total;
-        const bool fuse = c->fuse_ap && c->opt_fuse_ap && 160 * 1024 / total >= 2;
-        bool use_recip = false;
-        if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
-        const bool fused = fuse && use_recip;
-        RankDenseArgs da{nullptr, 0, 0, c->err.as<int>(), c->qbad.as<u32>(), c->RW,
-                         fused ? c->shapes.as<ApShape>() : nullptr, fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>(),
-                         c->cand.as<u8>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, sl_rows};
-        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_dense<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, total));
-        c->t_begin(KI_RANK_LDS);
-        hipLaunchKernelGGL((k_rank_dense<false, false, true>), dim3(g.Q), dim3(RD_THREADS), (size_t)total, c->stream, da, c->out_idx.as<u32>(),
-                           c->out_dist.as<u8>(), c->mbits.as<u32>(), g);
-        c->t_end();
-        HG_TRY(c->check_launch("k_rank_dense<slices>"));
-        c->last_rank = 8;
-        c->ap_fused = fused;
-        return HG_OK;
+        return launch_rank_slices(c, nullptr);
     }
     if (!counted && !c->rec_il && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
         // per-thread counting sort (k_rank_cnt): byte counters for every distance + a tile of the records, <= 64 KiB per
@@ -614,7 +643,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
             c->t_end();
             HG_TRY(c->check_launch("k_rank_cnt"));
             c->last_rank = 3;
-            if (fuse) { c->ap_fused = true; return HG_OK; }
+            if (fuse) { c->ap_fused = true; if (c->rec8) HG_TRY(rank_leftovers_inline(c, mode, use_recip)); return HG_OK; }
             only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
             counted = true;
         }
@@ -1426,8 +1455,10 @@ static int capture_step(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
 static int finish_leftovers(hg_ctx* c, int* flag) {
     if (!c->ap_fused) return HG_OK;
     const u32 nleft = ((const u32*)c->pin)[1];
+    if ((nleft != 0) != c->leftovers_expected) { c->leftovers_expected = nleft != 0; c->cfg_epoch++; }
     if (!nleft) return HG_OK;
     c->opt_leftover += nleft;
+    if (c->leftovers_inline) { c->leftovers_inline = false; return HG_OK; }     // k_rank_dense<slices> ranked them within the step
     const size_t Q = (size_t)c->geo.Q;
     int nbits = 1;
     while ((1 << nbits) < c->geo.NB) ++nbits;

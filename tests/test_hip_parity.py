@@ -1008,6 +1008,19 @@ def test_fused_step_hands_wide_lists_to_the_general_kernel(ctx):
         assert ctx.get_stat("last_optimistic") == 1 and ctx.get_stat("optimistic_fallbacks") == f0
         assert ctx.get_stat("ap_fused") == 0 and ctx.get_stat("rank_leftovers") - l0 >= 2      # (the leftover pass clears ap_fused)
         assert np.array_equal(ap[probe], ap_ref, equal_nan=True)
+        # the next step expects leftovers and ranks them within its stream (k_rank_dense<slices> on the flagged queries): no second
+        # round trip, the epilogue's APs stay in force, the same numbers
+        ctx.set_option("max_segments", 200)               # (192 queries ask for more segments than that kernel's 256 slices)
+        l1 = ctx.get_stat("rank_leftovers")
+        ap1, rel1 = ctx.map(R)
+        assert ctx.get_stat("ap_fused") == 1 and ctx.get_stat("rank_leftovers") - l1 >= 2
+        assert np.array_equal(ap1, ap, equal_nan=True) and np.array_equal(rel1, rel)
+        ctx.set_option("inline_leftovers", 0)
+        ap1, rel1 = ctx.map(R)
+        assert ctx.get_stat("ap_fused") == 0
+        assert np.array_equal(ap1, ap, equal_nan=True) and np.array_equal(rel1, rel)
+        ctx.set_option("inline_leftovers", 1)
+        ctx.set_option("max_segments", 2048)
         ctx.set_option("fuse_ap", 0)
         ap2, rel2 = ctx.map(R)
         assert np.array_equal(ap2, ap, equal_nan=True) and np.array_equal(rel2, rel)
