@@ -499,6 +499,44 @@ def class_sorted(spec, packed, steps=10):
         ctx.close()
 
 
+def large_r(spec, packed, steps=3):
+    """The timed workload's database and queries at LARGE R (not a BASELINE configuration; lib/metric.py:14,19 with MAP_R of the
+    order of the database): R = N/20 -- the bet with long lists, ranked slice by slice (k_rank_dense<slices>) -- and R = N/2 --
+    the byte matrix (k_dense_bytes + k_rank_dense).  Parity: against the engine's older sequences (k_rank_cnt's tiles; k_hist +
+    k_select + k_rank_fused on 8-byte records) on a sample of the queries."""
+    from hashgan_amd import _native
+    qw, ql, dw, dl = packed
+    N, Q = dw.shape[0], qw.shape[0]
+    out = {}
+    ctx = _native.Context(0)
+    try:
+        ctx.set_database(dw, dl, spec["b"], spec["C"])
+        for name, R in (("r_n_over_20", N // 20), ("r_n_over_2", N // 2)):
+            ctx.set_queries(qw, ql)
+            ctx.map(R)
+            ctx.map(R)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                a, r = ctx.map(R)
+            dt = (time.perf_counter() - t0) / steps
+            leg = {"R": R, "ms_per_step": dt * 1e3, "queries_per_sec": Q / dt, "bet": bool(ctx.get_stat("last_optimistic")),
+                   "rank_kernel": RANK_VARIANTS.get(ctx.get_stat("rank_variant"))}
+            k = min(48, Q)
+            ctx.set_option("rank_dense", 0)
+            ctx.set_option("rank_slices", 0)
+            ctx.set_queries(qw[:k], ql[:k])
+            a2, _ = ctx.map(R)
+            leg["equal_to_older_sequence"] = {"queries": k, "rank_kernel": RANK_VARIANTS.get(ctx.get_stat("rank_variant")),
+                                              "equal": bool(np.array_equal(a[:k], a2, equal_nan=True))}
+            ctx.set_option("rank_dense", 1)
+            ctx.set_option("rank_slices", 7000)
+            out[name] = leg
+            ctx.trim()
+        return out
+    finally:
+        ctx.close()
+
+
 def query_split_leg(args, spec, rank, world, local_rank, dry_dir, comm, qw, ql):
     """The same workload decomposed the other way (hashgan_amd.sharded.evaluate_query_split): the WHOLE database on every
     GPU, the queries split, no data-path collective -- timed like the main leg (barrier, K steps, barrier, max over ranks)
@@ -608,6 +646,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive MAPs(...) timing")
     ap.add_argument("--no-sorted", action="store_true", help="skip the class-sorted database timing")
+    ap.add_argument("--no-large-r", action="store_true", help="skip the large-R legs (R = N/20, R = N/2 on the timed workload's arrays)")
     ap.add_argument("--no-real", action="store_true", help="skip the real-valued (tanh features) call timing")
     ap.add_argument("--no-c4-ref", action="store_true", help="skip the one-GPU C4 point of the scaling curve")
     ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C5 legs (the other BASELINE.json configurations)")
@@ -785,6 +824,8 @@ def main():
             side("class_sorted_database", lambda: class_sorted(spec, packed))
         if not args.no_real:
             side("real_valued", lambda: real_valued(spec))
+        if not args.no_large_r and wl == "c2":
+            side("large_r", lambda: large_r(spec, packed))
         if not args.no_configs:
             copts = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt]
             out["configs"] = {}

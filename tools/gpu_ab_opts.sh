@@ -3,7 +3,7 @@
 # one line each: ms per step (mean of 3 runs), parity, step accounting, per-kernel averages when timed
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-B="python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-c4-ref --no-configs"
+B="python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-large-r --no-c4-ref --no-configs"
 for spec in "$@"; do
   IFS='|' read -r label lib args <<< "$spec"
   for i in 1 2 3; do
