@@ -470,7 +470,7 @@ static LeanPlan rank_lean_plan(const hg_ctx* c, int mode) {
 // (called by launch_select once rec8, cap and crow are set): the records may interleave iff k_rank_lean will read them
 static bool records_may_interleave(const hg_ctx* c) {
     if (!c->opt_interleave || !c->rec8) return false;
-    return !rank_wave_plan(c, 0).ok && !rank_wave_plan(c, 3).ok && rank_lean_plan(c, 0).ok;
+    return rank_lean_plan(c, 0).ok;                    // (k_rank_lean is tried first; its plan does not depend on the mode)
 }
 
 // leftovers_only: the second half of a fused step -- k_rank_cnt has run (with its AP epilogue) and flagged in bigq the queries
@@ -540,7 +540,10 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
     c->ap_fused = false;
     if (!leftovers_only) c->last_rank = 1;                // k_rank_fused unless one of the LDS-resident kernels takes the lists
     if (leftovers_only) { only = c->bigq.as<u32>(); counted = true; }
-    if (!counted && !c->rec_il) {
+    const LeanPlan lp = rank_lean_plan(c, mode);
+    if (!counted && !c->rec_il && !lp.ok) {
+        // (k_rank_lean first wherever it applies: round 4's kernel beats this one on short lists too -- Q = 10k, N = 1M, R = 100: 0.066 ms
+        // with the AP against 0.092 + k_ap 0.017; a G = 8 shard of C4: 0.049 against 0.115)
         // one wavefront per query (k_rank_wave): no block barriers, 5 KB + the records of LDS per query in flight
         // ... which pays for SHORT lists only (a sharded rank's share of R, a small R): a wavefront walks its query's records
         // with 64 lanes where k_rank_cnt has 256, and at C2's 6500 records (16 KB of LDS per query, 10 in flight per CU) it
@@ -567,7 +570,6 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
     }
     if (!counted) {
         // the lean counting sort (k_rank_lean): the whole record row in one coalesced read, piecewise compaction, chunks in registers
-        const LeanPlan lp = rank_lean_plan(c, mode);
         const int nbc = lp.nbc, psp = lp.psp;
         const i64 rb = lp.rb;
         const int* cut = nbc ? (c->exact_mx ? c->t.as<int>() : c->tguess.as<int>()) : nullptr;

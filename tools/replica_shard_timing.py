@@ -27,14 +27,27 @@ class ReplicaComm:
             self.ctx.memcpy_dtod(base + r * buf.nbytes, buf.ptr, buf.nbytes)
         return sharded.DevBuf(base, buf.nbytes * self.world)
 
+    def all_to_all(self, buf):
+        """[world] equal blocks, block r for rank r -> [world] blocks, block r FROM rank r: every peer is a replica of this rank,
+        so each of them sends what this rank would send to itself -- block `rank` of its own buffer."""
+        slot = self._slot
+        self._slot = (slot + 1) % 4
+        per = buf.nbytes // self.world
+        base = self.ctx.scratch(slot, buf.nbytes)
+        for r in range(self.world):
+            self.ctx.memcpy_dtod(base + r * per, buf.ptr + self.rank * per, per)
+        return sharded.DevBuf(base, buf.nbytes)
+
     def barrier(self):
         self.ctx.synchronize()
 
 
-def one(G, steps=10):
+def one(G, steps=10, opts=()):
     rows = N // G
     ctx = _native.Context(0)
     try:
+        for k_, v_ in opts:
+            ctx.set_option(k_, v_)
         ctx.set_database(synth.random_code_words(seed, rows, b), synth.onehot_label_words(seed * 3 + 1, rows, C), b, C, idx_base=0, n_total=N)
         ctx.set_queries(synth.random_code_words(seed + 7, Q, b), synth.onehot_label_words(seed * 3 + 2, Q, C))
         comm = ReplicaComm(ctx, G)
@@ -53,12 +66,14 @@ def one(G, steps=10):
         ctx.synchronize()
         k = {n: round(v[0] / max(v[1], 1), 4) for n, v in ctx.timing_read().items()}
         ctx.timing_enable(False)
-        print("G=%d  shard rows %d  step %.3f ms   kernels (ms per launch, timed separately): %s   [bets %d, lost %d]"
-              % (G, rows, dt * 1e3, k, ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks")), flush=True)
+        print("G=%d  shard rows %d  step %.3f ms   kernels (ms per launch, timed separately): %s   [bets %d, lost %d, rank variant %d, segments %d]"
+              % (G, rows, dt * 1e3, k, ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks"), ctx.get_stat("rank_variant"), ctx.get_stat("segments")), flush=True)
     finally:
         ctx.close()
 
 
 if __name__ == "__main__":
-    for G in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]):
-        one(G)
+    opts = [(a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[1:] if "=" in a]
+    for G in ([int(x) for x in sys.argv[1:] if "=" not in x] or [1, 2, 4, 8]):
+        one(G, opts=opts)
+    print("# (exchanges routed by query owner: hg_alltoall stands in as G device copies of this rank's own block)")
