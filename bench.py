@@ -474,20 +474,32 @@ def class_sorted(spec, packed, steps=10):
     order = np.argsort(key, kind="stable")
     dws, dls = np.ascontiguousarray(dw[order]), np.ascontiguousarray(dl[order])
     R = spec["R"]
+    firsts = []
+    for _ in range(2):                     # the first call on a NEW context, twice (a box's one-off stall -- 123 ms once -- is not the library's)
+        ctx = _native.Context(0)
+        try:
+            ctx.set_database(dws, dls, spec["b"], spec["C"])
+            ctx.set_queries(qw, ql)
+            t0 = time.perf_counter()
+            ctx.map(R)
+            firsts.append(time.perf_counter() - t0)
+        finally:
+            ctx.close()
     ctx = _native.Context(0)
     try:
         ctx.set_database(dws, dls, spec["b"], spec["C"])
         ctx.set_queries(qw, ql)
         t0 = time.perf_counter()
         a, r = ctx.map(R)
-        first = time.perf_counter() - t0
+        firsts.append(time.perf_counter() - t0)
+        first = min(firsts)
         ctx.map(R)
         t0 = time.perf_counter()
         for _ in range(steps):
             a, r = ctx.map(R)
         dt = (time.perf_counter() - t0) / steps
         out = {"workload": "the timed workload, database rows stably sorted by label", "ms_per_step": dt * 1e3, "first_call_ms": first * 1e3,
-               "queries_per_sec": spec["Q"] / dt, "bet_held": bool(ctx.get_stat("last_optimistic")), "cap_boost": ctx.get_stat("cap_boost"),
+               "first_call_ms_each_new_context": [round(x * 1e3, 3) for x in firsts], "queries_per_sec": spec["Q"] / dt, "bet_held": bool(ctx.get_stat("last_optimistic")), "cap_boost": ctx.get_stat("cap_boost"),
                "lost_bets": ctx.get_stat("optimistic_rebets"), "exact_fallbacks": ctx.get_stat("optimistic_fallbacks"), "map": float(metric.mean_over_hits(a, r))}
         k = min(256, qw.shape[0])
         ctx.set_option("optimistic", 0)

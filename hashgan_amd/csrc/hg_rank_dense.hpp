@@ -104,6 +104,8 @@ struct RankDenseArgs {
     const u32* fail;            // [Qpad]: a slice of the query overflowed (the bet is lost for it)
     u32 cap;
     i64 crow;
+    i64 rw_part;                // DENSE, 0 or the 64-bit bitmap words of ONE of gridDim.y blocks per query: block y ranks everything but keeps
+                                // (in LDS) and writes only the ranks [y * 64 rw_part, (y + 1) * 64 rw_part) -- an R-bit bitmap beyond one block's LDS
     const u32* only;            // SLICES, optional [Q]: rank only the flagged queries (what k_rank_lean declined)
     int nrows;                  // counter rows (distances 0 .. nrows - 1; row `nrows`: pad bytes).  DENSE: b + 1.  SLICES: the bet's cut never exceeds
                                 // b/2 + 1 (the sampled pass stops there; a thinner sample takes everything, overflows and is flagged): b/2 + 2 rows
@@ -146,7 +148,9 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
     // without them (one KB less of LDS: C1 gets four blocks per CU instead of three -- 1000 queries in one round).
     const int padrow = SLICES ? NB : NB - 1;
     const int NR = padrow + 1 > NB ? padrow + 1 : NB;
-    const RankDenseLds L = rank_dense_layout(NR, a.RW, GBM);
+    const i64 RWl = a.rw_part ? a.rw_part : a.RW;      // bitmap words this block holds
+    const u32 rk_lo = a.rw_part ? (u32)(blockIdx.y * a.rw_part * 64) : 0u;
+    const RankDenseLds L = rank_dense_layout(NR, RWl, GBM);
     u32* cnt = (u32*)(dlds + L.cnt);
     u32* tot = (u32*)(dlds + L.tot);
     u32* misc = (u32*)(dlds + L.misc);
@@ -154,7 +158,8 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
     u32* __restrict__ grow = mbits32 + (i64)q * 2 * a.RW;
 
     for (int i = tid; i < NR * nthr; i += nthr) cnt[i] = 0u;
-    if (!GBM) for (int i = tid; i <= bmw; i += nthr) bm[i] = 0u;
+    const int bml = (int)(2 * RWl);                    // its words
+    if (!GBM) for (int i = tid; i <= bml; i += nthr) bm[i] = 0u;
     if (tid < NB) tot[tid] = 0u;
 
     // DENSE: thread tid owns rows [tid Lr, (tid + 1) Lr), Lr = 16 P: piece p of its range is the uint4 at p * 256 + tid of the query's row of D.
@@ -306,6 +311,8 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
     //      that match leave their bit ----
     {
         const u32 R = (u32)g.R;
+        const u32 rk_hi = a.rw_part ? (rk_lo + (u32)(a.rw_part * 64) < R ? rk_lo + (u32)(a.rw_part * 64) : (rk_lo < R ? R : rk_lo)) : R;
+        const u32 span = rk_hi - rk_lo;                  // this block's ranks: [rk_lo, rk_lo + span)
         u32* __restrict__ oi = out_idx + (i64)q * g.R;
         u8* __restrict__ od = out_dist + (i64)q * g.R;
         const u32 row0 = g.idx_base + (u32)((i64)tid * P * 16);
@@ -329,15 +336,15 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const u32 w = w4[e >> 2];
-                        const u32 ps = pos[e];
-                        const bool hit = (w & (0x80u << (8 * (e & 3)))) != 0u && ps < R;
+                        const u32 ps = pos[e] - rk_lo;                 // (wraps for ranks below the block's window: not < span)
+                        const bool hit = (w & (0x80u << (8 * (e & 3)))) != 0u && ps < span;
                         if (hit) {
                             if (GBM) atomicOr(&grow[ps >> 5], 1u << (ps & 31));
                             else atomicOr(&bm[ps >> 5], 1u << (ps & 31));
                         }
-                        if (LISTS && ps < R) {
-                            oi[ps] = row0 + (u32)((p0 + k) * 16 + e);
-                            od[ps] = (u8)((w >> (8 * (e & 3))) & 0x7Fu);
+                        if (LISTS && ps < span) {
+                            oi[ps + rk_lo] = row0 + (u32)((p0 + k) * 16 + e);
+                            od[ps + rk_lo] = (u8)((w >> (8 * (e & 3))) & 0x7Fu);
                         }
                     }
                 }
@@ -348,8 +355,9 @@ static __global__ __launch_bounds__(RD_THREADS) void k_rank_dense(const RankDens
     }
     if (GBM) return;
     __syncthreads();
-    for (int w = tid; w < bmw; w += nthr) grow[w] = bm[w];
-    if (a.ap_shapes) {
+    for (int w = tid; w < bml; w += nthr)
+        if ((int)(rk_lo >> 5) + w < bmw) grow[(rk_lo >> 5) + w] = bm[w];
+    if (a.ap_shapes && !a.rw_part) {
         __syncthreads();                                 // (the counters -- the AP's scratch from here on -- are no longer read)
         const u64* bm64 = (const u64*)bm;
         ap_eval2<nthr>([&](const i64 w) { return bm64[w]; }, a.RW, g.R, a.ap_shapes, a.ap_recip, ap_lds_at(dlds + L.cnt), tid, a.ap + q, a.rel + q);

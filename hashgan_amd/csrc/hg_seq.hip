@@ -331,15 +331,25 @@ static int launch_rank_dense(hg_ctx* c) {
     const int lds_cu = 160 * 1024;
     const int tot_lds = rank_dense_layout(g.NB, c->RW, false).total, tot_gbm = rank_dense_layout(g.NB, c->RW, true).total;
     const int blocks_lds = (c->RW * 8 + 4096 < lds_cu && tot_lds <= lds_cu) ? lds_cu / tot_lds : 0;
-    const bool gbm = c->opt_rank_dense_gbm >= 0 ? c->opt_rank_dense_gbm != 0 || blocks_lds == 0 : (blocks_lds == 0 || (blocks_lds < 2 && g.R * 4 < c->N));
-    const int total = gbm ? tot_gbm : tot_lds;
+    // A bitmap beyond one block's LDS with R >= N/4: K blocks per query, each ranks everything and keeps its K-th of the ranks in LDS
+    // (R = N = 1M: two blocks per query, 2 x 10 ms, against 37 ms of atomic ORs on a bitmap in global memory)
+    i64 rw_part = 0;
+    int kparts = 1;
+    if (blocks_lds == 0 && g.R * 4 >= c->N && c->opt_rank_dense_gbm != 1) {
+        const i64 room = lds_cu - tot_gbm - 4096;
+        kparts = (int)((c->RW * 8 + room - 1) / room);
+        if (kparts >= 2 && kparts <= 8) rw_part = (c->RW + kparts - 1) / kparts; else kparts = 1;
+    }
+    const bool gbm = rw_part ? false
+                   : c->opt_rank_dense_gbm >= 0 ? c->opt_rank_dense_gbm != 0 || blocks_lds == 0 : (blocks_lds == 0 || (blocks_lds < 2 && g.R * 4 < c->N));
+    const int total = gbm ? tot_gbm : rw_part ? rank_dense_layout(g.NB, rw_part, false).total : tot_lds;
     const i64 Npad = rank_dense_pieces(c->N) * RD_THREADS * 16;
     i64 qchunk = (c->opt_dense_budget_mb << 20) / Npad;
     if (qchunk < 1) qchunk = 1;
     if (qchunk > g.Q) qchunk = g.Q;
     HG_TRY(c->dbytes.reserve((size_t)qchunk * Npad));
     bool use_recip = false;
-    const bool fuse = !gbm && blocks_lds >= 2 && c->fuse_ap && c->opt_fuse_ap && !c->want_lists;
+    const bool fuse = !gbm && !rw_part && blocks_lds >= 2 && c->fuse_ap && c->opt_fuse_ap && !c->want_lists;
     if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
     const bool fused = fuse && use_recip;
     if (gbm) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
@@ -351,12 +361,12 @@ static int launch_rank_dense(hg_ctx* c) {
         HG_TRY(c->check_launch("k_dense_bytes"));
         RankDenseArgs da{c->dbytes.as<u8>(), Npad, (int)q0, c->err.as<int>(), c->qbad.as<u32>(), c->RW,
                          fused ? c->shapes.as<ApShape>() : nullptr, fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>(),
-                         nullptr, nullptr, nullptr, 0u, 0, nullptr, g.NB};
+                         nullptr, nullptr, nullptr, 0u, 0, rw_part, nullptr, g.NB};
         c->t_begin(KI_RANK_FUSED);
 #define HG_RANK_DENSE(LISTS_, GBM_)                                                                                                              \
     do {                                                                                                                                         \
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_dense<LISTS_, GBM_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, total)); \
-        hipLaunchKernelGGL((k_rank_dense<LISTS_, GBM_, false>), dim3(nq), dim3(RD_THREADS), (size_t)total, c->stream, da, c->out_idx.as<u32>(),  \
+        hipLaunchKernelGGL((k_rank_dense<LISTS_, GBM_, false>), dim3(nq, kparts), dim3(RD_THREADS), (size_t)total, c->stream, da, c->out_idx.as<u32>(),  \
                            c->out_dist.as<u8>(), c->mbits.as<u32>(), g);                                                                         \
     } while (0)
         if (c->want_lists) { if (gbm) HG_RANK_DENSE(true, true); else HG_RANK_DENSE(true, false); }
@@ -391,7 +401,7 @@ static int launch_rank_slices(hg_ctx* c, const u32* only) {
     if (only && !fused) return fail(HG_ERR_STATE, "launch_rank_slices: the leftover form needs the AP tables");
     RankDenseArgs da{nullptr, 0, 0, c->err.as<int>(), c->qbad.as<u32>(), c->RW,
                      fused ? c->shapes.as<ApShape>() : nullptr, fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>(),
-                     c->cand.as<u8>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, only, sl_rows};
+                     c->cand.as<u8>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow, 0, only, sl_rows};
     HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_dense<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, total));
     c->t_begin(only ? KI_RANK_FUSED : KI_RANK_LDS);
     hipLaunchKernelGGL((k_rank_dense<false, false, true>), dim3(g.Q), dim3(RD_THREADS), (size_t)total, c->stream, da, c->out_idx.as<u32>(),

@@ -854,7 +854,8 @@ def test_one_lane_bursts_while_its_neighbours_stay_sparse(b):
 
 
 @pytest.mark.parametrize("Q,N,b,R,C", [(40, 200000, 64, 100000, 10), (25, 70001, 33, 70001, 70), (60, 30000, 100, 9000, 3),
-                                       (33, 150000, 16, 30001, 128), (70, 9000, 64, 8999, 5)])
+                                       (33, 150000, 16, 30001, 128), (70, 9000, 64, 8999, 5),
+                                       (30, 300000, 126, 300000, 7), (24, 900000, 64, 800000, 10)])     # (bitmaps beyond one block's LDS: two blocks per query)
 def test_dense_regime_ranks_the_rows_directly(Q, N, b, R, C):
     """R > N / 8 on one shard (up to the reference's own R = N, lib/metric.py:14,19 with MAP_R = DB_SIZE): k_rank_direct
     ranks a query's rows straight from the packed tables -- several tiles of rows, a bitmap of R bits in LDS, ties by
