@@ -440,8 +440,8 @@ def config_leg(name, opts, steps=20, untimed=25, packed=None):
             roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": t * 1e3, "algorithmic_bytes": ab, "achieved": ab / t / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / t / 1e9 / HBM_PEAK_GBS,
                     "note": "two streams over the query's row of the byte matrix (2 * Q * N bytes; at this size it is cache "
-                            "resident) + R match bits; what bounds the kernel is the rate of LDS atomics (two per row on the "
-                            "thread's own counter column, ~4 lanes per clock and CU measured), not this stream"}
+                            "resident) + R match bits; what bounds the kernel is the latency of its chain "
+                            "of LDS atomics (two per row on the thread's own counter column) at one to four wavefronts per SIMD, not this stream"}
         else:
             ab = (Q + N) * (NW * 4 + LW * 8) + Q * R
             roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": t * 1e3, "algorithmic_bytes": ab, "achieved": ab / t / 1e9,

@@ -1,10 +1,12 @@
 #!/bin/bash
 # usage: tools/gpu_pmc.sh <tag> [bench args...] : SQ counter passes + kernel trace of bench.py (no cpu baseline)
+#        HG_PMC_CMD="python tools/shape_sweep.py Q N b R" tools/gpu_pmc.sh <tag> : the same passes over another command (relative to the repo root)
 TAG=${1:-pmc}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-large-r --no-c4-ref --no-configs --kernel-timing none $*"
+B0="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-large-r --no-c4-ref --no-configs --kernel-timing none $*"
+if [ -n "$HG_PMC_CMD" ]; then B=$(echo "$HG_PMC_CMD" | sed "s#python tools/#python $GRAFT_REPO_ROOT/tools/#"); else B=$B0; fi
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS" \
