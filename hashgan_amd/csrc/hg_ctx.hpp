@@ -132,6 +132,12 @@ struct DevBuf {
         if (p != o.p) ++g_alloc_epoch;
         p = o.p; cap = o.cap; borrowed = true;
     }
+    // `bytes` at `off` inside another buffer (which must outlive the view)
+    void view(const DevBuf& o, size_t off, size_t bytes) {
+        drop();
+        if (p != (char*)o.p + off) ++g_alloc_epoch;
+        p = (char*)o.p + off; cap = bytes; borrowed = true;
+    }
     void release() { drop(); if (p) ++g_alloc_epoch; p = nullptr; cap = 0; borrowed = false; }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -272,6 +278,8 @@ struct hg_ctx {
     DevBuf obuf[2];            // owner-routed exchanges: [0] the blocks this rank sends (hg_pack_*_by_owner), [1] its answers as an owner (hg_guess_owned)
     bool ranked_local = false; // mbits holds this shard's bitmap in LOCAL rank order (hg_select_ranked)
     DevBuf cand, out_idx, out_dist, mbits, shapes, ap_recip, ap, rel, stage_in, badcnt, qbad, flist, hwq, bigq;
+    DevBuf outblk;             // [verdict 16 B][ap Q x 8][rel Q x 4]: err, ap and rel are views of it (ensure_out_block), so a call's results come home in ONE copy
+    i64 outblk_q = -1;         // the Q those views were cut for
     DevBuf dbytes;             // the byte matrix D[q][Npad] of the dense regime (k_dense_bytes)
     DevBuf dbf, qf, samp, thr, sortA, sortB, scores, gtab;   // real-valued path
     DevBuf dbfx;               // float features of the database in MFMA A-fragment order (k_real_select_mx), built on first use
@@ -431,6 +439,7 @@ int do_match(hg_ctx* c);                         // k_match through the ranked i
 int ensure_ap_tables(hg_ctx* c, bool* use_recip);   // summation trees + reciprocals for the current R, c->ap / c->rel sized
 int do_ap_range(hg_ctx* c, i64 q0, i64 nq, const u32* only = nullptr);      // k_ap on queries [q0, q0 + nq) (only: device flags [Q], just the flagged ones)
 inline int do_ap(hg_ctx* c) { return do_ap_range(c, 0, c->geo.Q); }
+int ensure_out_block(hg_ctx* c);                   // err / ap / rel as views of one block (before anything of the call is enqueued)
 int read_plan_flag(hg_ctx* c, int* flag);        // *err back to the host (synchronises)
 int launch_min_topr(hg_ctx* c, const u32* idx_all, const u8* dist_all, i64 n, int G);
 // hg_seq.hip

@@ -1416,7 +1416,12 @@ static int stage_ap_download(hg_ctx* c) {
     const size_t Q = (size_t)c->geo.Q;
     HG_TRY(ensure_pin(c, Q * 12 + 16));
     char* pb = (char*)c->pin;                  // [flag: 16 B][ap Q x 8][rel Q x 4]
-    HG_HIP(hipMemcpyAsync(pb, c->err.p, 4, hipMemcpyDeviceToHost, c->stream));
+    const char* base = (const char*)c->outblk.p;
+    if (base && c->outblk_q == (i64)Q && c->err.p == base && c->ap.p == base + 16 && c->rel.p == base + 16 + Q * 8) {
+        HG_HIP(hipMemcpyAsync(pb, base, 16 + Q * 12, hipMemcpyDeviceToHost, c->stream));     // the three are views of one block (ensure_out_block)
+        return HG_OK;
+    }
+    HG_HIP(hipMemcpyAsync(pb, c->err.p, 8, hipMemcpyDeviceToHost, c->stream));
     HG_HIP(hipMemcpyAsync(pb + 16, c->ap.p, Q * 8, hipMemcpyDeviceToHost, c->stream));
     HG_HIP(hipMemcpyAsync(pb + 16 + Q * 8, c->rel.p, Q * 4, hipMemcpyDeviceToHost, c->stream));
     return HG_OK;
@@ -1430,11 +1435,7 @@ static int enqueue_bet_with_ap(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     HG_TRY(rc);
     if (c->ap_fused) { c->ap_staged = false; c->stage |= ST_AP; }     // k_rank_cnt's epilogue left the APs (leftovers: run_oneshot)
     else HG_TRY(do_ap(c));
-    const size_t Q = (size_t)c->geo.Q;
-    char* pb = (char*)c->pin;                  // [flag, leftover count: 16 B][ap Q x 8][rel Q x 4]
-    HG_HIP(hipMemcpyAsync(pb, c->err.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HG_HIP(hipMemcpyAsync(pb + 16, c->ap.p, Q * 8, hipMemcpyDeviceToHost, c->stream));
-    HG_HIP(hipMemcpyAsync(pb + 16 + Q * 8, c->rel.p, Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HG_TRY(stage_ap_download(c));              // [flag, leftover count: 16 B][ap Q x 8][rel Q x 4]
     c->t_step_end();
     return HG_OK;
 }
@@ -1504,6 +1505,7 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
     if (R < 1 || R > c->n_total)
         return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->n_total);
     c->want_lists = lists;
+    if (with_ap && !c->is_sub) HG_TRY(ensure_out_block(c));
     const bool bet = optimistic_eligible(c, R, &stride, &need_cnt);
     int flag = 0;
     if (bet) {
