@@ -23,6 +23,9 @@
 
 namespace hg {
 
+#ifndef HG_RL_INFLIGHT
+#define HG_RL_INFLIGHT 4
+#endif
 constexpr int RL_NPT = 4;                       // 16-byte pieces of the record row a thread fetches
 constexpr int RL_MAX_PIECES = 256 * RL_NPT;
 
@@ -281,19 +284,20 @@ void k_rank_lean(const u8* __restrict__ cand8, const RankLdsArgs a, u32* __restr
         for (int k = 0; k < RL_NPT; ++k) {
             if (k < PPT && p0 + k < n16) {
                 const u32 w[4] = {ch[k].x, ch[k].y, ch[k].z, ch[k].w};
+                constexpr int GR = HG_RL_INFLIGHT;                // returning adds in flight per thread (4, 8 or 16: one to four dwords of the piece)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    u32 r[4];
+                for (int i0 = 0; i0 < 16; i0 += GR) {
+                    u32 r[GR];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int d = (int)((w[i] >> (8 * j)) & 0x7Fu);
+                    for (int e = 0; e < GR; ++e) {
+                        const int d = (int)((w[(i0 + e) >> 2] >> (8 * ((i0 + e) & 3))) & 0x7Fu);
                         const int kk = d > t ? RC_MAXB : d - dmin;
-                        r[j] = atomicAdd((u32*)(obase + kk * 512), one);
+                        r[e] = atomicAdd((u32*)(obase + kk * 512), one);
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const u32 pos = (r[j] >> sh) & 0xFFFFu;
-                        if (((w[i] >> (8 * j + 7)) & 1u) && pos < wantu) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
+                    for (int e = 0; e < GR; ++e) {
+                        const u32 pos = (r[e] >> sh) & 0xFFFFu;
+                        if (((w[(i0 + e) >> 2] >> (8 * ((i0 + e) & 3) + 7)) & 1u) && pos < wantu) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
                     }
                 }
             }
