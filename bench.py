@@ -54,6 +54,9 @@ WORKLOADS = {
     "c3": dict(Q=2100, N=190000, b=48, R=5000, C=81, kind="multihot", seed=0xC3, flip=0.20, golden="c3_nus_q64"),
     "c1": dict(Q=1000, N=54000, b=32, R=54000, C=10, kind="cifar", seed=0xC1, flip=0.25, golden="c1_cifar_full"),
     "c4": dict(Q=10000, N=10000000, b=64, R=5000, C=10, kind="iid", seed=0xC4, golden="c4_n10m_q8"),
+    # BASELINE.json configs[1] as literally written ("synthetic random codes"): the timed shape on i.i.d. Bernoulli(1/2) bits
+    # (SURVEY.md 8d); the reference's golden covers its first 64 queries.
+    "c2_iid": dict(Q=10000, N=1000000, b=64, R=5000, C=10, kind="iid", seed=0x2C2, golden="c2_iid_q64"),
 }
 
 
@@ -134,16 +137,21 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def traffic_from_profiles(kernel):
+def traffic_from_profiles(kernel, workload=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass (profiles/latest_traffic.json, written by
     tools/pmc_traffic.py from FETCH_SIZE / WRITE_SIZE passes of this same command) -- quoted only if that pass measured
-    the device code this run executes (same source fingerprint); else None plus the reason."""
+    the device code this run executes (same source fingerprint); else None plus the reason.  workload: one of the other
+    configurations' passes (`_workloads` in the file: C5's, collected with `--workload c5`); None: the headline step's."""
     path = os.path.join(ROOT, "profiles", "latest_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
     except (OSError, ValueError):
         return None, "no PMC pass committed"
+    if workload:
+        d = d.get("_workloads", {}).get(workload)
+        if not d:
+            return None, "no PMC pass of workload %s committed" % workload
     sha = d.get("_kernel_sources_sha")
     if sha != kernel_sources_sha():
         return None, "profiles/latest_traffic.json was measured on other kernel sources (%s); rerun tools/pmc_traffic.py" % sha
@@ -266,6 +274,7 @@ def h2d_inclusive(spec, packed, reps=10):
     host_bytes = db.output.nbytes + db.label.nbytes + q.output.nbytes + q.label.nbytes
     return {"call": "MAPs(R).get_maps_by_feature(database, query) from host float32 features + int64 labels",
             "calls_timed": reps, "ms_per_call": full * 1e3, "median_ms_per_call": float(np.median(each)) * 1e3, "min_ms_per_call": min(each) * 1e3,
+            "ms_each_call": [round(x * 1e3, 3) for x in each],
             "queries_per_sec": Q / full, "host_array_bytes": host_bytes,
             "bytes_over_pcie": int(dw.nbytes + dl.nbytes + qw.nbytes + ql.nbytes),
             "with_resident_database": {"call": "MAPs.set_database(database) once, then get_maps_by_feature(None, query)",
@@ -402,6 +411,7 @@ def config_leg(name, opts, steps=20, untimed=25, packed=None):
             each.append(time.perf_counter() - t1)
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        kept = ctx.get_stat("records_kept")                # (a download of the slice counts, outside the timed region)
         ctx.set_option("timing_every", 1)
         ctx.timing_enable(2)                               # every kernel between HIP events: a pass of its own (the events cost time)
         for _ in range(4):
@@ -450,15 +460,29 @@ def config_leg(name, opts, steps=20, untimed=25, packed=None):
         roof["valu_equiv_frac"] = {"definition": "pairs * 4 * ceil(b/64) lane-ops / (t * 78.6e12)  (SURVEY.md 8d)",
                                    "kernel": pairs * 4 * W / t / (VALU_NOMINAL_FP32_TLANEOPS * 1e12),
                                    "step": pairs * 4 * W / dt / (VALU_NOMINAL_FP32_TLANEOPS * 1e12)}
+        if name in ("c5",):                                # HBM bytes per launch of the leg's dominant kernel, from ITS committed PMC passes
+            traffic, traffic_note = traffic_from_profiles(slot, name)
+            roof["traffic"], roof["traffic_source"] = traffic, traffic_note
         g = cases.load_golden(spec["golden"])
         k = g["ap"].shape[0]
-        return {"workload": "%s: Q=%d N=%d b=%d R=%d C=%d, %s codes" % (name.upper(), Q, N, b, R, C, spec["kind"]),
-                "steps": steps, "untimed_steps": untimed, "ms_per_step": dt * 1e3, "ms_per_step_min": min(each) * 1e3,
-                "ms_per_step_median": float(np.median(each)) * 1e3, "queries_per_sec": Q / dt, "pairs_per_sec": pairs / dt,
-                "map": float(m), "parity_vs_reference_golden": bool(np.array_equal(a[:k], g["ap"][:Q], equal_nan=True)), "golden_queries": int(min(k, Q)),
-                "bet": bool(ctx.get_stat("last_optimistic")), "optimistic_fallbacks": ctx.get_stat("optimistic_fallbacks"),
-                "dominant_kernel": dom, "roofline": roof, "kernels": kern,
-                "gpu_span_ms_with_events": round(span[0] / max(span[1], 1), 5) if span else None}
+        out = {"workload": "%s: Q=%d N=%d b=%d R=%d C=%d, %s codes" % (name.upper(), Q, N, b, R, C, spec["kind"]),
+               "steps": steps, "untimed_steps": untimed, "ms_per_step": dt * 1e3, "ms_per_step_min": min(each) * 1e3,
+               "ms_per_step_median": float(np.median(each)) * 1e3, "queries_per_sec": Q / dt, "pairs_per_sec": pairs / dt,
+               "map": float(m), "parity_vs_reference_golden": bool(np.array_equal(a[:k], g["ap"][:Q], equal_nan=True)), "golden_queries": int(min(k, Q)),
+               "bet": bool(ctx.get_stat("last_optimistic")), "optimistic_fallbacks": ctx.get_stat("optimistic_fallbacks"),
+               "dominant_kernel": dom, "roofline": roof, "kernels": kern}
+        if kept >= 0:
+            out["records_kept_over_R"] = round(kept / float(Q * R), 4)
+        span_ms = span[0] / max(span[1], 1) if span else None
+        if span_ms is not None and span_ms > dt * 1e3:
+            # a step this short is a chain of launches: bracketing every kernel with HIP events costs more than the gaps it would
+            # measure (the bracketed span exceeds the un-bracketed step), so no span is reported -- the per-kernel times above are
+            # the bracketed pass's, the step time is the un-bracketed loop's; profiles/ holds the rocprofv3 trace of the same step
+            out["gpu_span_ms_with_events"] = None
+            out["event_bracketing"] = "span dropped: %.3f ms bracketed > %.3f ms un-bracketed step" % (span_ms, dt * 1e3)
+        else:
+            out["gpu_span_ms_with_events"] = round(span_ms, 5) if span_ms is not None else None
+        return out
     finally:
         ctx.close()
 
@@ -661,7 +685,7 @@ def main():
     ap.add_argument("--no-large-r", action="store_true", help="skip the large-R legs (R = N/20, R = N/2 on the timed workload's arrays)")
     ap.add_argument("--no-real", action="store_true", help="skip the real-valued (tanh features) call timing")
     ap.add_argument("--no-c4-ref", action="store_true", help="skip the one-GPU C4 point of the scaling curve")
-    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C5 legs (the other BASELINE.json configurations)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C2-iid / C1 / C3 / C5 legs (the timed shape on i.i.d. codes; the other BASELINE.json configurations)")
     ap.add_argument("--no-query-split", action="store_true", help="sharded runs: skip the replicated-database / split-queries leg")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (hg_set_option), repeatable")
     ap.add_argument("--timing-every", type=int, default=4,
@@ -791,6 +815,9 @@ def main():
         "optimistic_runs": ctx.get_stat("optimistic_runs"), "optimistic_fallbacks": ctx.get_stat("optimistic_fallbacks"),
         "pairs_per_sec": Q * N / per_step,
     }
+    kept = ctx.get_stat("records_kept")              # the last step's slice counts, downloaded now (outside the timed region)
+    if kept >= 0:
+        out["records_kept_over_R"] = round(kept / float(Q * R), 4)      # what the guess's safety margin costs the select's drain (1.0 = no surplus)
     if sharded_leg or wl == "c4":
         out["scaling"] = "strong"                            # the fixed N = 10M database over the GPUs (a one-GPU C2 line scales nothing)
     if qsplit is not None:
@@ -841,7 +868,7 @@ def main():
         if not args.no_configs:
             copts = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt]
             out["configs"] = {}
-            for nm in ("c1", "c3", "c5"):
+            for nm in ("c2_iid", "c1", "c3", "c5"):
                 if nm == wl:
                     continue
                 try:

@@ -132,8 +132,9 @@ int hg_allgather(hg_ctx* c, int slot, const void* dev_src, int64_t nbytes, void*
     DevBuf& out = c->gathered[slot];
     HG_TRY(out.reserve((size_t)nbytes * c->comm_world));
     c->t_begin(KI_COMM);
-    HG_NCCL(g_rccl.AllGather(dev_src, out.p, (size_t)nbytes, ncclUint8, c->comm, c->stream));
-    c->t_end();
+    const ncclResult_t rg = g_rccl.AllGather(dev_src, out.p, (size_t)nbytes, ncclUint8, c->comm, c->stream);
+    c->t_end();                                        // (before a failure is reported: the timing slots stay balanced)
+    if (rg != ncclSuccess) return fail(HG_ERR_HIP, "hg_allgather: ncclAllGather: %s", g_rccl.GetErrorString(rg));
     *dev_gathered = out.p;
     return c->stage_end();
 }
@@ -149,13 +150,24 @@ int hg_alltoall(hg_ctx* c, int slot, const void* dev_src, int64_t nbytes_per_pee
     DevBuf& out = c->gathered[slot];
     HG_TRY(out.reserve((size_t)nbytes_per_peer * c->comm_world));
     c->t_begin(KI_COMM);
-    HG_NCCL(g_rccl.GroupStart());
-    for (int r = 0; r < c->comm_world; ++r) {
-        HG_NCCL(g_rccl.Send((const char*)dev_src + (size_t)r * nbytes_per_peer, (size_t)nbytes_per_peer, ncclUint8, r, c->comm, c->stream));
-        HG_NCCL(g_rccl.Recv(out.as<char>() + (size_t)r * nbytes_per_peer, (size_t)nbytes_per_peer, ncclUint8, r, c->comm, c->stream));
+    // Whatever fails inside the group, the group is closed and the timing slot ended before the first failure is reported:
+    // a communicator left inside an open group (or an unbalanced t_begin) would make every later collective on this
+    // stream undefined.
+    ncclResult_t first = g_rccl.GroupStart();
+    const char* where = "ncclGroupStart";
+    if (first == ncclSuccess) {
+        for (int r = 0; r < c->comm_world && first == ncclSuccess; ++r) {
+            first = g_rccl.Send((const char*)dev_src + (size_t)r * nbytes_per_peer, (size_t)nbytes_per_peer, ncclUint8, r, c->comm, c->stream);
+            where = "ncclSend";
+            if (first != ncclSuccess) break;
+            first = g_rccl.Recv(out.as<char>() + (size_t)r * nbytes_per_peer, (size_t)nbytes_per_peer, ncclUint8, r, c->comm, c->stream);
+            where = "ncclRecv";
+        }
+        const ncclResult_t ended = g_rccl.GroupEnd();
+        if (first == ncclSuccess && ended != ncclSuccess) { first = ended; where = "ncclGroupEnd"; }
     }
-    HG_NCCL(g_rccl.GroupEnd());
     c->t_end();
+    if (first != ncclSuccess) return fail(HG_ERR_HIP, "hg_alltoall: %s: %s", where, g_rccl.GetErrorString(first));
     *dev_out = out.p;
     return c->stage_end();
 }
@@ -171,9 +183,10 @@ int hg_allgather_topr(hg_ctx* c) {
     HG_TRY(c->gath_idx.reserve((size_t)n * 4 * G));       // own landing zones: hg_allgather's slots may hold live data
     HG_TRY(c->gath_dist.reserve((size_t)n * G));
     c->t_begin(KI_COMM);
-    HG_NCCL(g_rccl.AllGather(c->out_idx.p, c->gath_idx.p, (size_t)n * 4, ncclUint8, c->comm, c->stream));
-    HG_NCCL(g_rccl.AllGather(c->out_dist.p, c->gath_dist.p, (size_t)n, ncclUint8, c->comm, c->stream));
+    ncclResult_t rt = g_rccl.AllGather(c->out_idx.p, c->gath_idx.p, (size_t)n * 4, ncclUint8, c->comm, c->stream);
+    if (rt == ncclSuccess) rt = g_rccl.AllGather(c->out_dist.p, c->gath_dist.p, (size_t)n, ncclUint8, c->comm, c->stream);
     c->t_end();
+    if (rt != ncclSuccess) return fail(HG_ERR_HIP, "hg_allgather_topr: ncclAllGather: %s", g_rccl.GetErrorString(rt));
     HG_TRY(launch_min_topr(c, c->gath_idx.as<u32>(), c->gath_dist.as<u8>(), n, G));
     return c->stage_end();
 }

@@ -950,6 +950,21 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "segment_rows")) *value = c->geo.L;
     else if (!strcmp(key, "slice_capacity")) *value = c->cap;
     else if (!strcmp(key, "record_row")) *value = c->crow;
+    else if (!strcmp(key, "records_kept")) {
+        // records the last bet's select pass left in the slices, over all live queries (a download of the slice counts: a
+        // measurement read after the step, never part of one) -- kept / (Q R) is what the guess's margin costs
+        const Geo& g = c->geo;
+        *value = -1;
+        if (c->optimistic && c->sl_cnt.p && c->sl_cnt.cap >= (size_t)g.S * g.Qpad * 4) {
+            HG_TRY(c->use());
+            HG_TRY(c->sync());
+            std::vector<u32> h((size_t)g.S * g.Qpad);
+            HG_HIP(hipMemcpy(h.data(), c->sl_cnt.p, h.size() * 4, hipMemcpyDeviceToHost));
+            i64 total = 0;
+            for (int s = 0; s < g.S; ++s) for (int q = 0; q < g.Q; ++q) total += h[(size_t)s * g.Qpad + q];
+            *value = total;
+        }
+    }
     else return fail(HG_ERR_ARG, "hg_get_stat: unknown key '%s'", key);
     return HG_OK;
 }

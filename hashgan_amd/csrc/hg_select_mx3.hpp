@@ -21,7 +21,7 @@
 // so the query image qx (+1 / -1 for a clear / set bit) is shared with the other matrix-core kernels.
 //
 // Drain (one-byte compact records only: hg_mx_drain.hpp explains rings and slices).  Per supertile and query tile every
-// lane with a hit appends ONE 12-byte entry {A | lane | tile | supertile | buffer, B | slice position & 15, C} to the
+// lane with a hit appends ONE 12-byte entry {A | query tag | lane-half | supertile | buffer, B | slice position & 15, C} to the
 // wavefront's queue (ring buffer in LDS, slot = rank among the pushing lanes).  The emit works the queue off in batches
 // of exactly 64 entries -- every lane busy -- and entries that do not fill a batch WAIT for the next window: the packed
 // codes and labels the emit needs are triple-buffered, so an entry may be emitted one window late, and the
@@ -51,6 +51,12 @@ constexpr int M3_QCAP = 128;               // queue entries per wavefront (ring 
 constexpr int M3_RING = 16;                // records per slice ring
 #ifndef HG_M3_WPB
 #define HG_M3_WPB 8
+#endif
+#ifndef HG_M3_Q12
+#define HG_M3_Q12 1                        // queue entries of 12 bytes at ONE address (0: round 4's two arrays, 8 + 4 bytes -- select 0.627 vs 0.615 ms at C2)
+#endif
+#ifndef HG_M3_ILV
+#define HG_M3_ILV 8                        // tile 1's MFMAs carry that many of tile 0's harvest ops between them (0: round 4's order, all six MFMAs first -- 0.634 vs 0.626 ms)
 #endif
 constexpr int M3_WPB = HG_M3_WPB;          // wavefronts per block: they share the staged window (4: 40 KB of LDS, four blocks per CU; 8: two)
 
@@ -86,12 +92,31 @@ template <int SH> __device__ __forceinline__ u32 m3_lshl_or_t(const u32 x, const
     return d;
 }
 #define m3_lshl_or(x, sh, y) m3_lshl_or_t<sh>(x, y)
+// v_ffbl_b32: index of the lowest set bit, ~0 for 0
+__device__ __forceinline__ u32 m3_ffbl(const u32 x) {
+    u32 d;
+    asm("v_ffbl_b32 %0, %1" : "=v"(d) : "v"(x));
+    return d;
+}
+// (x & K) | y in one op
+__device__ __forceinline__ u32 m3_and_or(const u32 x, const u32 k, const u32 y) {
+    u32 d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "n"(k), "v"(y));
+    return d;
+}
+// x * 0x421 for x < 2^22 (the C word's six hit bits -> contiguous): the full-rate 24-bit multiply (the compiler turns __umul24 by a
+// constant back into the quarter-rate v_mul_lo_u32)
+__device__ __forceinline__ u32 m3_mul24_421(const u32 x) {
+    u32 d;
+    asm("v_mul_u32_u24 %0, 0x421, %1" : "=v"(d) : "v"(x));
+    return d;
+}
 
 struct Mx3Lds {                // byte offsets inside the block's dynamic LDS
     int a, abuf;               // A fragments: 2 buffers of abuf bytes
     int cl, clbuf, labels;     // packed codes + labels of a window's rows (both halves): 3 buffers of clbuf bytes; labels inside a buffer
     int qcodes, qlabels;       // the block's query tables
-    int qab, qc;               // per-wave queues: [QCAP] u64 {A, B} and [QCAP] u32 {C}
+    int qab, qc;               // per-wave queues: [QCAP] entries of 12 bytes {A, B, C} at qab (HG_M3_Q12); else [QCAP] u64 {A, B} at qab and [QCAP] u32 {C} at qc
     int rings;                 // per-wave slice rings
     int total;
 };
@@ -106,7 +131,7 @@ __host__ __device__ inline Mx3Lds mx3_lds_layout(int NW, int LW) {
     l.qcodes = l.cl + 3 * l.clbuf;
     l.qlabels = l.qcodes + M3_WPB * 64 * NW * 4;
     l.qab = l.qlabels + M3_WPB * 64 * LW * 8;
-    l.qc = l.qab + M3_WPB * M3_QCAP * 8;
+    l.qc = l.qab + M3_WPB * M3_QCAP * 8;        // (12-byte entries: one array of M3_WPB * M3_QCAP * 12 bytes from qab on; qc unused)
     l.rings = l.qc + M3_WPB * M3_QCAP * 4;
     l.total = l.rings + M3_WPB * 64 * M3_QT * M3_RING;
     return l;
@@ -120,6 +145,8 @@ struct Mx3Drain {
     Mx3Lds L;
     u64* qab;                            // this wavefront's queue
     u32* qc;
+    u32 ring_base;                       // LDS address of the wavefront's first ring
+    u32 q12_base;                        // ... as 12-byte entries (HG_M3_Q12): byte offset of the wavefront's first entry (opaque: keeps ONE address per entry)
     u8* rings;                           // this wavefront's rings: slice (t, lane) at (t * 64 + lane) * M3_RING
     int wave, lane;
     u32 cap;                             // slice capacity (records), a multiple of 16
@@ -137,7 +164,10 @@ struct Mx3Drain {
         lds = lds_; L = L_; wave = wave_; lane = lane_; cap = cap_; crow = crow_; probe = probe_;
         qab = (u64*)(lds + L.qab) + wave * M3_QCAP;
         qc = (u32*)(lds + L.qc) + wave * M3_QCAP;
+        q12_base = (u32)(L.qab + wave * (M3_QCAP * 12));
+        asm volatile("" : "+s"(q12_base));
         rings = lds + L.rings + wave * (64 * QT * M3_RING);
+        ring_base = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)rings;
         const int h = lane >> 5, j = lane & 31;
         // Interleaved record rows (SelArgs::il): the 32 queries of a tile share a region of 32 * crow bytes in which piece p16
         // of slice s of query j sits at ((s * cap/16 + p16) * 32 + j) * 16 -- the lanes of a half-wavefront that flush the same
@@ -155,6 +185,8 @@ struct Mx3Drain {
 #pragma unroll
         for (int t = 0; t < QT; ++t) cnt[t] = prev[t] = flushed[t] = 0;
     }
+    // ring of slice (t, lane): half * 64 + t * 32 + query-in-tile -- the low six bits are the tag a queue entry carries
+    __device__ __forceinline__ int ring_index(const int t) const { return (lane >> 5) * 64 + t * 32 + (lane & 31); }
     __device__ __forceinline__ u8* slice(const int t) const { return tb0 + (i64)t * 32 * crow + lane_off; }
     // byte offset of record p inside the lane's slice: whole 16-byte pieces are `ilk` pieces apart
     __device__ __forceinline__ u32 rec_off(const u32 p) const {
@@ -175,7 +207,7 @@ struct Mx3Drain {
             for (int t = 0; t < QT; ++t) {
                 const u32 f = flushed[t];
                 if (limit[t] - f >= 8u) {
-                    const u8* ring = rings + (t * 64 + lane) * M3_RING;
+                    const u8* ring = rings + ring_index(t) * M3_RING;
                     u8* tb = tb0 + (i64)t * 32 * crow;                // wave-uniform base; the lane's part fits 32 bits
                     *(u64*)(tb + (lane_off + rec_off(min(f, cap - 8u)))) = *(const u64*)(ring + (f & 8u));
                     flushed[t] = f + 8u;
@@ -191,38 +223,47 @@ struct Mx3Drain {
         wave_lds_sync();
         if ((u32)lane < n && !(kProbes && (probe & 8))) {
             const u32 i = (qhead + (u32)lane) & (M3_QCAP - 1);
+#if HG_M3_Q12
+            const u32* e = (const u32*)(lds + (q12_base + i * 12u));
+            const u32 a = e[0], b = e[1], c = e[2];
+#else
             const u64 ab = qab[i];
             const u32 c = qc[i];
             const u32 a = (u32)ab, b = (u32)(ab >> 32);
-            const u32 src = a & 63u, t = (a >> 27) & 1u, st = (a >> 28) & 3u, sel = a >> 30;
+#endif
+            // entry: a = {query tag t * 32 + j : 6 | A : 21 | lane-half : 1 | supertile : 2 | buffer : 2}, b = {0 : 6 | B : 21 | position : 5}
+            const u32 x = a & 63u, h = (a >> 27) & 1u, st = (a >> 28) & 3u, sel = a >> 30;
             u32 pos = b >> 27;                                        // slice position & 15 of the entry's first hit
-            // flat hit mask of the supertile: bit P <-> row P
-            const u32 a21 = (a >> 6) & 0x1FFFFFu, b21 = (b >> 6) & 0x1FFFFFu, c6 = ((c * 0x421u) >> 16) & 0x3Fu;
-            u32 xlo = a21 | (b21 << 21), xhi = (b21 >> 11) | (c6 << 10);
-            const int ql = wave * 64 + (int)t * 32 + (int)(src & 31u);    // the entry's query, block-local
+            // flat hit mask of the supertile: bit P <-> row P.  b holds B at bits 6..26 and the position above them, nothing below:
+            // b << 15 IS B's rows 0..10 at bits 21..31; the C word's six bits become contiguous through one 24-bit multiply
+            u32 xlo = m3_lshl_or(b, 15, __builtin_amdgcn_ubfe(a, 6, 21));
+            u32 xhi = ((m3_mul24_421(c) >> 6) & 0xFC00u) | __builtin_amdgcn_ubfe(b, 17, 10);
+            const u32 ql = (u32)wave * 64u + x;                       // the entry's query, block-local
             u32 qcw[NW];
             u64 qlw[LW];
 #pragma unroll
             for (int k = 0; k < NW; ++k) qcw[k] = ((const u32*)(lds + L.qcodes + ql * CB))[k];
 #pragma unroll
             for (int k = 0; k < LW; ++k) qlw[k] = ((const u64*)(lds + L.qlabels + ql * LB))[k];
-            u8* ring = rings + (t * 64 + src) * M3_RING;
-            const u8* clb = lds + L.cl + sel * L.clbuf;
-            const u32 row0 = (src >> 5) * M3_WROWS + st * M3_ROWS;
+            const u32 ring = ring_base + (h * 64u + x) * M3_RING;     // LDS address (the block's dynamic LDS starts at 0), a multiple of 16
+            // LDS byte offsets of the code / label words of the supertile's row 0 (buffer sel, lane-half h, supertile st)
+            const u32 row0 = h * M3_WROWS + st * M3_ROWS;
+            const u32 code0 = (u32)L.cl + sel * (u32)L.clbuf + row0 * CB;
+            const u32 lab0 = (u32)L.cl + sel * (u32)L.clbuf + (u32)L.labels + row0 * LB;
             while (xlo | xhi) {
-                const u32 P = xlo ? (u32)__builtin_ctz(xlo) : 32u + (u32)__builtin_ctz(xhi);       // lowest set bit = earliest row
+                const u32 P = min(m3_ffbl(xlo), m3_ffbl(xhi) | 32u);  // lowest set bit = earliest row (v_ffbl of 0 is ~0)
                 const u32 lo1 = xlo - 1u;
                 xhi &= xhi - (xlo == 0u ? 1u : 0u);
                 xlo &= lo1;
-                const u32* rp = (const u32*)(clb + (row0 + P) * CB);
+                const u32* rp = (const u32*)(lds + (code0 + P * CB));
                 u32 d = 0;
 #pragma unroll
                 for (int k = 0; k < NW; ++k) d += __builtin_popcount(qcw[k] ^ rp[k]);
-                const u64* lp = (const u64*)(clb + L.labels + (row0 + P) * LB);
+                const u64* lp = (const u64*)(lds + (lab0 + P * LB));
                 u64 any = 0;
 #pragma unroll
                 for (int k = 0; k < LW; ++k) any |= lp[k] & qlw[k];
-                if (!(kProbes && (probe & 4))) ring[pos & (M3_RING - 1)] = make_rec8(d, any != 0);
+                if (!(kProbes && (probe & 4))) *(u8 __attribute__((address_space(3)))*)(uintptr_t)m3_and_or(pos, M3_RING - 1, ring) = make_rec8(d, any != 0);
                 ++pos;
             }
         }
@@ -239,8 +280,8 @@ struct Mx3Drain {
     // (its ring's leftovers first, so the slice stays in index order; every record also passes through the ring, whose
     // last partial piece is then what a later flush expects)
     __device__ __forceinline__ void direct_walk(const int t, const u32 wa, const u32 wb, const u32 wc, const int st, const u32 sel) {
-        const u8* ring_r = rings + (t * 64 + lane) * M3_RING;
-        u8* ring = rings + (t * 64 + lane) * M3_RING;
+        const u8* ring_r = rings + ring_index(t) * M3_RING;
+        u8* ring = rings + ring_index(t) * M3_RING;
         u8* out = slice(t);
         for (u32 p = flushed[t]; p < cnt[t]; ++p) if (p < cap) out[rec_off(p)] = ring_r[p & (M3_RING - 1)];
         const u32 a21 = (wa >> 6) & 0x1FFFFFu, b21 = (wb >> 6) & 0x1FFFFFu, c6 = ((wc * 0x421u) >> 16) & 0x3Fu;
@@ -300,13 +341,25 @@ struct Mx3Drain {
     __device__ __forceinline__ void push(u32 (&w)[QT][3], const int st, const u32 sel) {
         u32 any[QT], want[QT];
         u64 bal[QT];
-        bool over = false;
+        {
+            bool over = false;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                want[t] = cnt[t] + (u32)__builtin_popcount(w[t][0]) + (u32)__builtin_popcount(w[t][1]) + (u32)__builtin_popcount(w[t][2]);
+                over |= want[t] - flushed[t] > (u32)M3_RING;
+            }
+            if (__builtin_expect(__any(over) != 0, 0)) {              // rare: afterwards every ring takes what is left of the words
+                make_room(w, st, sel);
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    want[t] = cnt[t] + (u32)__builtin_popcount(w[t][0]) + (u32)__builtin_popcount(w[t][1]) + (u32)__builtin_popcount(w[t][2]);
+            }
+        }
+        // (the hit flags and ballots have ONE definition, behind the rare branch: no second compare for the stores' exec mask)
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             any[t] = w[t][0] | w[t][1] | w[t][2];
             bal[t] = __ballot(any[t] != 0u);
-            want[t] = cnt[t] + (u32)__builtin_popcount(w[t][0]) + (u32)__builtin_popcount(w[t][1]) + (u32)__builtin_popcount(w[t][2]);
-            over |= want[t] - flushed[t] > (u32)M3_RING;
         }
         u32 nz = 0;
 #pragma unroll
@@ -315,25 +368,21 @@ struct Mx3Drain {
             while (qfill >= 64u) emit_batch(64u);                     // a dense supertile (up to 128 entries) needs it empty
             if (qfill + nz > (u32)M3_QCAP) emit_batch(qfill);
         }
-        if (__builtin_expect(__any(over) != 0, 0)) {
-            make_room(w, st, sel);
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                any[t] = w[t][0] | w[t][1] | w[t][2];
-                bal[t] = __ballot(any[t] != 0u);
-                want[t] = cnt[t] + (u32)__builtin_popcount(w[t][0]) + (u32)__builtin_popcount(w[t][1]) + (u32)__builtin_popcount(w[t][2]);
-            }
-        }
         const u32 desc = ((u32)st << 28) | (sel << 30);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const u64 b = bal[t];
             const u32 slot = (qhead + qfill + __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u))) & (M3_QCAP - 1);
-            if (any[t] != 0u) {
-                const u32 ea = w[t][0] | (u32)lane | ((u32)t << 27) | desc;
+            if (__builtin_amdgcn_inverse_ballot_w64(b)) {             // (the ballot IS the exec mask: no second compare)
+                const u32 ea = w[t][0] | ((u32)(lane & 31) | ((u32)t << 5) | ((u32)(lane >> 5) << 27)) | desc;
                 const u32 eb = w[t][1] | (cnt[t] << 27);
+#if HG_M3_Q12
+                u32* e = (u32*)(lds + (q12_base + slot * 12u));
+                e[0] = ea; e[1] = eb; e[2] = w[t][2];
+#else
                 qab[slot] = ((u64)eb << 32) | ea;
                 qc[slot] = w[t][2];
+#endif
             }
             cnt[t] = want[t];
             qfill += (u32)__builtin_popcountll(b);
@@ -360,7 +409,7 @@ struct Mx3Drain {
         for (int t = 0; t < QT; ++t) {
             const u32 f = flushed[t];
             if (cnt[t] > f) {
-                const u8* ring = rings + (t * 64 + lane) * M3_RING;
+                const u8* ring = rings + ring_index(t) * M3_RING;
                 *(u64*)(slice(t) + rec_off(min(f, cap - 8u))) = *(const u64*)(ring + (f & 8u));
             }
         }
@@ -526,6 +575,30 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
             f32x16 acc[QT];
 #pragma unroll
             for (int t = 0; t < QT; ++t) acc[t] = cv[t];
+            u32 w[QT][3];
+#if HG_M3_ILV
+            // tile by tile: tile 1's three MFMAs are issued with tile 0's harvest between them (the matrix pipe works on one
+            // tile while the vector ALU harvests the other; sched_group_barrier: 0x8 = MFMA, 0x2 = VALU)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const i32x8 B = {bq[t].x, bq[t].y, bq[t].z, bq[t].w, 0, 0, 0, 0};
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const i32x8 A = {af[f].x, af[f].y, af[f].z, af[f].w, 0, 0, 0, 0};
+                    acc[t] = f == 0 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[t], 4, 4, 0, scale_a, 0, scale_b)
+                           : f == 1 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[t], 4, 4, 1, scale_a, 0, scale_b)
+                                    : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[t], 4, 4, 2, scale_a, 0, scale_b);
+                }
+            }
+            harvest(acc[0], 0, w[0]);
+            harvest(acc[1], 1, w[1]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, HG_M3_ILV, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, HG_M3_ILV, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);
+#else
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
                 const i32x8 A = {af[f].x, af[f].y, af[f].z, af[f].w, 0, 0, 0, 0};
@@ -537,9 +610,9 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
                                     : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[t], 4, 4, 2, scale_a, 0, scale_b);
                 }
             }
-            u32 w[QT][3];
 #pragma unroll
             for (int t = 0; t < QT; ++t) harvest(acc[t], t, w[t]);
+#endif
             // rows past the end of the lane's segment (ragged last window, unpaired last segment) never count
             const i64 base_row = win * M3_WROWS + st * M3_ROWS;
             if (minlen - base_row < M3_ROWS) {

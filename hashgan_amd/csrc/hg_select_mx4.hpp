@@ -95,7 +95,8 @@ struct Mx4Drain {
     u8* lds;
     Mx4Lds L;
     u64* qab;                            // this wavefront's queue
-    u8* rings;                           // this wavefront's rings: slice (t, lane) at (t * 64 + lane) * M4_RING
+    u8* rings;                           // this wavefront's rings: slice (t, lane) at ring_index(t) * M4_RING
+    u32 ring_base;                       // ... as an LDS address
     int wave, lane;
     u32 cap;                             // slice capacity (records), a multiple of 16
     u8* tb0;                             // the wavefront's first slice (t = 0, lane 0); tile t adds t * 32 * crow
@@ -111,6 +112,7 @@ struct Mx4Drain {
         lds = lds_; L = L_; wave = wave_; lane = lane_; cap = cap_; crow = crow_;
         qab = (u64*)(lds + L.queue) + wave * M4_QCAP;
         rings = lds + L.rings + wave * (64 * QT * M4_RING);
+        ring_base = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)rings;
         const int h = lane >> 5, j = lane & 31;
         // Interleaved record rows (SelArgs::il): the 32 queries of a tile share a region of 32 * crow bytes in which piece p16
         // of slice s of query j sits at ((s * cap/16 + p16) * 32 + j) * 16 -- the lanes of a half-wavefront that flush the same
@@ -128,6 +130,8 @@ struct Mx4Drain {
 #pragma unroll
         for (int t = 0; t < QT; ++t) cnt[t] = prev[t] = flushed[t] = 0;
     }
+    // ring of slice (t, lane): half * 64 + t * 32 + query-in-tile -- the low six bits are the tag a queue entry carries
+    __device__ __forceinline__ int ring_index(const int t) const { return (lane >> 5) * 64 + t * 32 + (lane & 31); }
     __device__ __forceinline__ u8* slice(const int t) const { return tb0 + (i64)t * 32 * crow + lane_off; }
     // byte offset of record p inside the lane's slice: whole 16-byte pieces are `ilk` pieces apart
     __device__ __forceinline__ u32 rec_off(const u32 p) const {
@@ -151,7 +155,7 @@ struct Mx4Drain {
             for (int t = 0; t < QT; ++t) {
                 const u32 f = flushed[t];
                 if (limit[t] - f >= 8u) {
-                    const u8* ring = rings + (t * 64 + lane) * M4_RING;
+                    const u8* ring = rings + ring_index(t) * M4_RING;
                     u8* tb = tb0 + (i64)t * 32 * crow;                // wave-uniform base; the lane's part fits 32 bits
                     *(u64*)(tb + (lane_off + rec_off(min(f, cap - 8u)))) = *(const u64*)(ring + (f & 8u));
                     flushed[t] = f + 8u;
@@ -169,31 +173,34 @@ struct Mx4Drain {
             const u32 i = (qhead + (u32)lane) & (M4_QCAP - 1);
             const u64 ab = qab[i];
             const u32 a = (u32)ab, b = (u32)(ab >> 32);
-            const u32 src = a & 63u, t = (a >> 27) & 1u, st = (a >> 28) & 3u, sel = a >> 30;
+            // entry: a = {query tag t * 32 + j : 6 | 0 | A : 16 | 0 : 4 | lane-half : 1 | supertile : 2 | buffer : 2}, b = {.. B : 16 .. | position : 5}
+            const u32 qx = a & 63u, h = (a >> 27) & 1u, st = (a >> 28) & 3u, sel = a >> 30;
             u32 pos = b >> 27;                                        // slice position & 15 of the entry's first hit
             u32 x = flat(a, b);
-            const int ql = wave * 64 + (int)t * 32 + (int)(src & 31u);    // the entry's query, block-local
+            const u32 ql = (u32)wave * 64u + qx;                      // the entry's query, block-local
             u32 qcw[NW];
             u64 qlw[LW];
 #pragma unroll
             for (int k = 0; k < NW; ++k) qcw[k] = ((const u32*)(lds + L.qcodes + ql * CB))[k];
 #pragma unroll
             for (int k = 0; k < LW; ++k) qlw[k] = ((const u64*)(lds + L.qlabels + ql * LB))[k];
-            u8* ring = rings + (t * 64 + src) * M4_RING;
-            const u8* clb = lds + L.cl + sel * L.clbuf;
-            const u32 row0 = (src >> 5) * WROWS + st * M4_ROWS;
+            const u32 ring = ring_base + (h * 64u + qx) * M4_RING;    // LDS address (the block's dynamic LDS starts at 0), a multiple of 16
+            // LDS byte offsets of the code / label words of the supertile's row 0 (buffer sel, lane-half h, supertile st)
+            const u32 row0 = h * WROWS + st * M4_ROWS;
+            const u32 code0 = (u32)L.cl + sel * (u32)L.clbuf + row0 * CB;
+            const u32 lab0 = (u32)L.cl + sel * (u32)L.clbuf + (u32)L.labels + row0 * LB;
             while (x) {
                 const u32 P = (u32)__builtin_ctz(x);                  // lowest set bit = earliest row
                 x &= x - 1u;
-                const u32* rp = (const u32*)(clb + (row0 + P) * CB);
+                const u32* rp = (const u32*)(lds + (code0 + P * CB));
                 u32 d = 0;
 #pragma unroll
                 for (int k = 0; k < NW; ++k) d += __builtin_popcount(qcw[k] ^ rp[k]);
-                const u64* lp = (const u64*)(clb + L.labels + (row0 + P) * LB);
+                const u64* lp = (const u64*)(lds + (lab0 + P * LB));
                 u64 any = 0;
 #pragma unroll
                 for (int k = 0; k < LW; ++k) any |= lp[k] & qlw[k];
-                ring[pos & (M4_RING - 1)] = make_rec8(d, any != 0);
+                *(u8 __attribute__((address_space(3)))*)(uintptr_t)m3_and_or(pos, M4_RING - 1, ring) = make_rec8(d, any != 0);
                 ++pos;
             }
         }
@@ -210,8 +217,8 @@ struct Mx4Drain {
     // (its ring's leftovers first, so the slice stays in index order; every record also passes through the ring, whose
     // last partial piece is then what a later flush expects)
     __device__ __forceinline__ void direct_walk(const int t, const u32 wa, const u32 wb, const int st, const u32 sel) {
-        const u8* ring_r = rings + (t * 64 + lane) * M4_RING;
-        u8* ring = rings + (t * 64 + lane) * M4_RING;
+        const u8* ring_r = rings + ring_index(t) * M4_RING;
+        u8* ring = rings + ring_index(t) * M4_RING;
         u8* out = slice(t);
         for (u32 p = flushed[t]; p < cnt[t]; ++p) if (p < cap) out[rec_off(p)] = ring_r[p & (M4_RING - 1)];
         u32 x = flat(wa, wb);
@@ -269,13 +276,24 @@ struct Mx4Drain {
     __device__ __forceinline__ void push(u32 (&w)[QT][2], const int st, const u32 sel) {
         u32 any[QT], want[QT];
         u64 bal[QT];
-        bool over = false;
+        {
+            bool over = false;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                want[t] = cnt[t] + (u32)__builtin_popcount(w[t][0]) + (u32)__builtin_popcount(w[t][1]);
+                over |= want[t] - flushed[t] > (u32)M4_RING;
+            }
+            if (__builtin_expect(__any(over) != 0, 0)) {              // rare: afterwards every ring takes what is left of the words
+                make_room(w, st, sel);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) want[t] = cnt[t] + (u32)__builtin_popcount(w[t][0]) + (u32)__builtin_popcount(w[t][1]);
+            }
+        }
+        // (the hit flags and ballots have ONE definition, behind the rare branch: no second compare for the stores' exec mask)
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             any[t] = w[t][0] | w[t][1];
             bal[t] = __ballot(any[t] != 0u);
-            want[t] = cnt[t] + (u32)__builtin_popcount(w[t][0]) + (u32)__builtin_popcount(w[t][1]);
-            over |= want[t] - flushed[t] > (u32)M4_RING;
         }
         u32 nz = 0;
 #pragma unroll
@@ -284,22 +302,14 @@ struct Mx4Drain {
             while (qfill >= 64u) emit_batch(64u);                     // a dense supertile (up to 128 entries) needs it empty
             if (qfill + nz > (u32)M4_QCAP) emit_batch(qfill);
         }
-        if (__builtin_expect(__any(over) != 0, 0)) {
-            make_room(w, st, sel);
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                any[t] = w[t][0] | w[t][1];
-                bal[t] = __ballot(any[t] != 0u);
-                want[t] = cnt[t] + (u32)__builtin_popcount(w[t][0]) + (u32)__builtin_popcount(w[t][1]);
-            }
-        }
         const u32 desc = ((u32)st << 28) | (sel << 30);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const u64 b = bal[t];
             const u32 slot = (qhead + qfill + __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u))) & (M4_QCAP - 1);
-            if (any[t] != 0u) {
-                const u32 ea = w[t][0] | (u32)lane | ((u32)t << 27) | desc;       // hit bits 7..22; lane in 0..5; tile, supertile, buffer above
+            if (__builtin_amdgcn_inverse_ballot_w64(b)) {             // (the ballot IS the exec mask: no second compare)
+                // hit bits 7..22; the query tag t * 32 + j in 0..5; lane-half, supertile, buffer above
+                const u32 ea = w[t][0] | ((u32)(lane & 31) | ((u32)t << 5) | ((u32)(lane >> 5) << 27)) | desc;
                 const u32 eb = w[t][1] | (cnt[t] << 27);
                 qab[slot] = ((u64)eb << 32) | ea;
             }
@@ -328,7 +338,7 @@ struct Mx4Drain {
         for (int t = 0; t < QT; ++t) {
             const u32 f = flushed[t];
             if (cnt[t] > f) {
-                const u8* ring = rings + (t * 64 + lane) * M4_RING;
+                const u8* ring = rings + ring_index(t) * M4_RING;
                 *(u64*)(slice(t) + rec_off(min(f, cap - 8u))) = *(const u64*)(ring + (f & 8u));
             }
         }

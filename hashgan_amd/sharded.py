@@ -52,6 +52,7 @@ class RcclComm:
         if self.world < 1:
             raise RuntimeError("the context has no communicator: call init_rccl(ctx) first")
         self._slot = 0
+        self.routed_verified = None    # evaluate_shard: has the owner-routed (hg_alltoall) form matched the all-gather form here?
 
     def all_gather(self, buf):
         slot = self._slot
@@ -376,10 +377,36 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
     engine: HipShardEngine (or any object with the same five methods -- the CPU
     tests drive this very function with a NumPy engine over gloo).
     route_by_owner: the bet's exchanges as all-to-alls by query owner when engine and communicator can (else, or with
-    False, the all-gather form: same results).
+    False, the all-gather form: same results).  Over a real RCCL communicator with more than one rank the routed form has
+    to EARN that default: the first call on a communicator runs the all-gather form (ncclAllGather only), then the routed
+    form (grouped ncclSend / ncclRecv), compares the two per-query results bit for bit, and the ranks agree (one
+    all-reduce) whether anyone saw an error or a difference -- only then do later calls route by owner
+    (`comm.routed_verified`; HG_ROUTE_BY_OWNER=0 / 1 skips the check and forces the form).
     Returns (ap [Q] float64 with nan for skipped queries, rel [Q] int64) -- and
     (idx, dist) of the merged global top-R when gather_topr is set.
     """
+    if (route_by_owner and bet and not gather_topr and isinstance(comm, RcclComm) and comm.world > 1
+            and hasattr(engine, "merge_ap_owned")):
+        forced = os.environ.get("HG_ROUTE_BY_OWNER")
+        if forced in ("0", "1"):
+            route_by_owner = forced == "1"
+        elif comm.routed_verified is None:
+            ref = _evaluate_shard(engine, comm, R, False, always_gather, bet, False)
+            bad = 0.0
+            try:
+                got = _evaluate_shard(engine, comm, R, False, always_gather, bet, True)
+                if not (np.array_equal(got[0], ref[0], equal_nan=True) and np.array_equal(got[1], ref[1])):
+                    bad = 1.0
+            except Exception:      # noqa: BLE001 -- an hg_alltoall failure on this rank: every rank must learn of it
+                bad = 2.0
+            comm.routed_verified = comm.allreduce_max(bad) == 0.0
+            return ref
+        else:
+            route_by_owner = comm.routed_verified
+    return _evaluate_shard(engine, comm, R, gather_topr, always_gather, bet, route_by_owner)
+
+
+def _evaluate_shard(engine, comm, R, gather_topr, always_gather, bet, route_by_owner):
     multi = comm.world > 1 or always_gather          # always_gather: exercise the collectives even with one rank
     gather = (lambda t: comm.all_gather(t)) if multi else (lambda t: None)
     bits = None

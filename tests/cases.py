@@ -19,6 +19,8 @@ CASES = {
     "c3_nus_q64":      dict(Q=2100, q_take=64, N=190000, b=48, R=5000, C=81, kind="multihot", seed=0xC3, flip=0.20),
     "c4_n10m_q8":      dict(Q=10000, q_take=8, N=10000000, b=64, R=5000, C=10, kind="iid", seed=0xC4),
     "c5_b128_q32":     dict(Q=10000, q_take=32, N=1000000, b=128, R=5000, C=10, kind="planted", seed=0xC5, flip=0.35),
+    # BASELINE.json configs[1] as literally written: "synthetic random codes" -- C2's shape on i.i.d. Bernoulli(1/2) bits (bench.py's c2_iid leg)
+    "c2_iid_q64":      dict(Q=10000, q_take=64, N=1000000, b=64, R=5000, C=10, kind="iid", seed=0x2C2),
     # --- edge cases ----------------------------------------------------------
     "e_r_eq_n":        dict(Q=70, N=3000, b=32, R=3000, C=10, kind="planted", seed=0xE1, flip=0.25),
     "e_r_1":           dict(Q=70, N=3000, b=32, R=1, C=10, kind="planted", seed=0xE2, flip=0.25),

@@ -10,7 +10,7 @@ from hashgan_amd import _native, metric
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["c2_q64", "c3_nus_q64", "c5_b128_q32", "c4_n10m_q8"])
+@pytest.mark.parametrize("name", ["c2_q64", "c2_iid_q64", "c3_nus_q64", "c5_b128_q32", "c4_n10m_q8"])
 def test_full_size_properties(name):
     spec = dict(cases.CASES[name])
     spec.pop("q_take")

@@ -16,7 +16,7 @@ from hashgan_amd import _native, metric
 pytestmark = pytest.mark.gpu
 
 STAGED = cases.SMALL + ["e_big_r", "c3_nus_q64"]
-BIG = ["c2_q64", "c5_b128_q32", "c4_n10m_q8"]
+BIG = ["c2_q64", "c2_iid_q64", "c5_b128_q32", "c4_n10m_q8"]
 
 
 @pytest.fixture(scope="module")

@@ -7,7 +7,7 @@ import pytest
 from tests import cases
 from oracle import hamming_map as O
 
-FAST = cases.SMALL + ["c3_nus_q64", "e_big_r", "c2_q64", "c5_b128_q32"]
+FAST = cases.SMALL + ["c3_nus_q64", "e_big_r", "c2_q64", "c2_iid_q64", "c5_b128_q32"]
 
 
 def _check(name, case_cache, q_limit=None):

@@ -21,8 +21,8 @@ for i in (1, 2, 3):
     except Exception as e:
         print(label, "ERR", e, open("%s/%s_%d.err" % (out, label, i)).read()[-800:])
 if last:
-    print("%-14s %s mean %.4f parity %s fallbacks %s span %s kernels %s" % (label, ["%.4f" % m for m in ms], sum(ms) / len(ms),
-          last.get("parity_vs_reference_golden"), last.get("optimistic_fallbacks"), last.get("step_accounting", {}).get("gpu_span_ms"),
+    print("%-14s %s mean %.4f parity %s fallbacks %s kept/R %s span %s kernels %s" % (label, ["%.4f" % m for m in ms], sum(ms) / len(ms),
+          last.get("parity_vs_reference_golden"), last.get("optimistic_fallbacks"), last.get("records_kept_over_R"), last.get("step_accounting", {}).get("gpu_span_ms"),
           {k: round(v["avg_ms"], 4) for k, v in last.get("kernels", {}).items()}))
 PY
 done

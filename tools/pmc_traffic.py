@@ -2,7 +2,9 @@
 """Turn two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass) into HBM bytes
 per launch per kernel -> profiles/latest_traffic.json (read by bench.py's roofline.traffic).
 
-usage: pmc_traffic.py fetch_results.db write_results.db out.json
+usage: pmc_traffic.py fetch_results.db write_results.db out.json [workload [base.json]]
+       with a workload name (c5): the passes were run with `--workload c5`; the result is merged under "_workloads"/<name> of
+       base.json (default profiles/latest_traffic.json), whose own entries (the headline step's) stay as they are
 
 Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE come in KiB; on gfx950
 FETCH_SIZE reports HALF the bytes of wide (16 B per lane) coalesced streaming reads.  The matrix-core
@@ -49,9 +51,21 @@ def main():
                   "hbm_bytes_per_launch": (fx * f + w) * 1024.0, "launches_sampled": fetch.get(k, (0, 0))[1]}
     from bench import kernel_sources_sha
     out["_kernel_sources_sha"] = kernel_sources_sha()
-    out["_collected"] = time.strftime("%Y-%m-%d") + ", rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 10 --warmup 3` on MI355X"
-    with open(sys.argv[3], "w") as fh:
-        json.dump(out, fh, indent=1)
+    wl = sys.argv[4] if len(sys.argv) > 4 else None
+    out["_collected"] = time.strftime("%Y-%m-%d") + ", rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 10 --warmup 3%s` on MI355X" % (" --workload " + wl if wl else "")
+    if wl:
+        base = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "latest_traffic.json")
+        try:
+            with open(base) as fh:
+                whole = json.load(fh)
+        except (OSError, ValueError):
+            whole = {}
+        whole.setdefault("_workloads", {})[wl] = out
+        with open(sys.argv[3], "w") as fh:
+            json.dump(whole, fh, indent=1)
+    else:
+        with open(sys.argv[3], "w") as fh:
+            json.dump(out, fh, indent=1)
     for k, v in out.items():
         if k.startswith("_"):
             continue
