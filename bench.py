@@ -155,7 +155,7 @@ def traffic_from_profiles(kernel, workload=None):
     sha = d.get("_kernel_sources_sha")
     if sha != kernel_sources_sha():
         return None, "profiles/latest_traffic.json was measured on other kernel sources (%s); rerun tools/pmc_traffic.py" % sha
-    # the timing slot "k_select_mx" covers the kernel variants k_select_mx / k_select_mx2 / k_select_mx3: take the one the pass saw most
+    # the timing slot "k_select_mx" covers the kernel variants k_select_mx / k_select_mx3 / k_select_mx4: take the one the pass saw most
     cands = [k for k in d if k.startswith(kernel) and isinstance(d[k], dict)]
     if not cands:
         return None, "the PMC pass holds no %s* kernel" % kernel
@@ -163,13 +163,13 @@ def traffic_from_profiles(kernel, workload=None):
     return d[best].get("hbm_bytes_per_launch"), "rocprofv3 PMC pass of these sources (%s), kernel %s" % (d.get("_collected", "?"), best)
 
 
-SELECT_VARIANTS = {1: "k_select", 2: "k_select_dense", 3: "k_select_mx", 4: "k_select_mx2", 5: "k_select_mx3", 6: "k_select_mx4"}
-RANK_VARIANTS = {1: "k_rank_fused", 2: "k_rank_lds", 3: "k_rank_cnt", 4: "k_rank_wave", 5: "k_rank_direct", 6: "k_rank_lean", 7: "k_rank_dense", 8: "k_rank_dense<slices>"}
+SELECT_VARIANTS = {1: "k_select", 2: "k_select_dense", 3: "k_select_mx", 5: "k_select_mx3", 6: "k_select_mx4"}
+RANK_VARIANTS = {1: "k_rank_fused", 3: "k_rank_cnt", 6: "k_rank_lean", 7: "k_rank_dense", 8: "k_rank_dense<slices>"}
 
 
 def kernel_names(ctx, spec):
     """The kernels behind the timing slots of the last step, by the names a rocprofv3 trace shows (the slots `k_select_mx`,
-    `k_rank_lds`, `k_hist` each cover several kernels; the library reports which one it launched)."""
+    `k_rank_cnt`, `k_hist` each cover several kernels; the library reports which one it launched)."""
     NW, LW = (spec["b"] + 31) // 32, (spec["C"] + 63) // 64
     sel = SELECT_VARIANTS.get(ctx.get_stat("select_variant"))
     rank = RANK_VARIANTS.get(ctx.get_stat("rank_variant"))
@@ -178,8 +178,6 @@ def kernel_names(ctx, spec):
         names["k_select_mx"] = "k_select_mx3<%d,%d>" % (2 if NW == 2 else 1, LW)
     elif sel == "k_select_mx4":
         names["k_select_mx"] = "k_select_mx4<%d,%d>" % (NW, LW)
-    elif sel == "k_select_mx2":
-        names["k_select_mx"] = "k_select_mx2<%d,%d,compact>" % (NW, LW)
     elif sel == "k_select_mx":
         names["k_select_mx"] = "k_select_mx<%d,%d,%d,compact>" % (NW, LW if LW <= 2 else 0, 2 if NW <= 4 else 1)
     elif sel:
@@ -187,7 +185,7 @@ def kernel_names(ctx, spec):
     if rank == "k_rank_dense":
         names["k_select"] = "k_dense_bytes<%d,%d>" % (NW, LW)
     if rank:
-        names["k_rank_lds" if rank in ("k_rank_lds", "k_rank_cnt", "k_rank_wave", "k_rank_lean", "k_rank_dense<slices>") else "k_rank_fused"] = rank
+        names["k_rank_cnt" if rank in ("k_rank_cnt", "k_rank_lean", "k_rank_dense<slices>") else "k_rank_fused"] = rank
     names["k_hist"] = "k_hist_i8<%d>" % NW if NW <= 4 else "k_hist_mx<%d>" % NW
     names["k_guess"] = "k_guess_direct"
     return names
@@ -435,14 +433,6 @@ def config_leg(name, opts, steps=20, untimed=25, packed=None):
                     "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t / 1e12 / MFMA_FP4_PEAK_TFLOPS,
                     "note": "fp4 MFMA inner product, 2 flops per code bit (K = %d) and pair; the kernel's other per-pair cost is the "
                             "vector-ALU harvest of the accumulators (does not overlap the MFMAs on gfx950)" % (64 * W)}
-        elif dom == "k_rank_direct":
-            # R = N: no pair pass at all -- one block per query streams every row's code and label words (the whole table is
-            # L2-resident: N * (4 NW + 8 LW) bytes) and counting-sorts the N one-byte {match, dist} keys in LDS
-            ab = Q * N * (4 * NW + 8 * LW) + Q * ((R + 63) // 64) * 8
-            roof = {"bound": "l2", "kernel": dom, "avg_launch_ms": t * 1e3, "algorithmic_bytes": ab, "achieved": ab / t / 1e9,
-                    "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": ab / t / 1e9 / L2_PEAK_GBS,
-                    "note": "every query's block reads all N rows from L2 (Q * N * %d B) and writes R match bits; what bounds the "
-                            "kernel is the LDS counting sort's chain of dependent phases per tile of rows, not this stream" % (4 * NW + 8 * LW)}
         elif dom == "k_rank_dense":
             # N/8 < R <= N: k_dense_bytes wrote one byte {match, dist} per pair; one block per query streams its N bytes twice
             # (count, then place) and writes R match bits -- each row costs two LDS atomics on its thread's counter column
@@ -838,7 +828,7 @@ def main():
             busy = span[0] / max(span[1], 1)
             out["step_accounting"] = {"gpu_span_ms": round(busy, 5), "host_and_launch_ms": round(per_step * 1e3 - busy, 5),
                                       "kernels_timed_ms": round(sum(v["avg_ms"] * v["launches"] for v in per_kernel.values()) / max(span[1], 1), 5),
-                                      "graph_replays": ctx.get_stat("graph_replays"), "graph_captures": ctx.get_stat("graph_captures")}
+                                      "graph_replays": ctx.get_stat("graph_replays")}
     if dry_dir:
         out["dry_run_not_a_measurement"] = "ranks share GPU 0 and exchange through files (HG_BENCH_FILECOMM)"
     if sharded_leg:

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "hg_set_stream": [_p, _p],
     "hg_set_option": [_p, C.c_char_p, _i64],
     "hg_get_stat": [_p, C.c_char_p, C.POINTER(_i64)],
+    "hg_get_census": [_p, C.c_int, C.POINTER(_i64)],
     "hg_trim": [_p],
     "hg_timing_enable": [_p, C.c_int],
     "hg_timing_reset": [_p],
@@ -443,6 +444,12 @@ class Context:
         v = _i64()
         check(self._lib.hg_get_stat(self._h, key.encode(), C.byref(v)))
         return v.value
+
+    def census(self, queries):
+        """(entries outside {-1,0,+1}, zeros, minus ones, floats resident on the device) of the float table hg_set_*_f32 was handed."""
+        out = (_i64 * 4)()
+        check(self._lib.hg_get_census(self._h, 1 if queries else 0, out))
+        return out[0], out[1], out[2], bool(out[3])
 
     def timing_enable(self, on=True):
         """on: False/0 off, True/2 every kernel, 1 only the select pass over the pairs (k_select, k_select_mx*) and the step's span."""

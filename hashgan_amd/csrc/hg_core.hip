@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* const kKernelNames[KI_COUNT] = {"k_hist", "k_hist_reduce", "k_plan", "k_seg_counts", "k_seg_layout", "k_guess",
                                             "k_select", "k_rank_hist", "k_order", "k_rank_fused", "k_match", "k_ap", "k_merge", "k_pack",
-                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish", "k_select_mx", "k_rank_lds", "rccl_allgather", "step_gpu_span", "k_real_rescore"};
+                                            "k_real_sample", "k_real_guess", "k_real_select", "k_radix_pass", "k_real_finish", "k_select_mx", "k_rank_cnt", "rccl_allgather", "step_gpu_span", "k_real_rescore"};
 // Flatten NumPy's pairwise-summation tree for a chunk of n elements (n <= 8192):
 // numpy/_core/src/umath/loops_utils.h.src, pairwise_sum: n <= 128 is a leaf,
 // otherwise split at n/2 rounded down to a multiple of 8.
@@ -171,7 +171,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part, &c->dbytes, &c->outblk};
+                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part, &c->dbytes, &c->outblk};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -226,7 +226,6 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     HG_TRY(c->sync());
     c->stage = ST_DB;   // queries must be (re)set after the database: b, C may have changed
     c->dbx_valid = false;
-    c->dbx2_valid = false;
     c->dbx3_valid = false;
     c->dbx4_valid = false;
     c->dbx8_valid = false;
@@ -295,7 +294,7 @@ static int stage_floats(hg_ctx* c, const float* x, i64 n, int b, int bpad, DevBu
             const i64 r1 = r0 + rows_per < n ? r0 + rows_per : n;
             if (used[slot]) HG_HIP(hipEventSynchronize(c->fstage_ev[slot]));
             float* st = (float*)((char*)c->fstage + (size_t)slot * CH);
-            host_copy_rows(x, r0, r1, b, bpad, st, (int)c->opt_pack_threads, which_pool);
+            host_copy_rows(x, r0, r1, b, bpad, st, 0, which_pool);
             HG_HIP(hipMemcpyAsync((char*)feats.p + (size_t)r0 * bpad * 4, st, (size_t)(r1 - r0) * bpad * 4, hipMemcpyHostToDevice, stream));
             HG_HIP(hipEventRecord(c->fstage_ev[slot], stream));
             used[slot] = true;
@@ -369,7 +368,7 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
     }
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{stager};
     try {
-        host_pack_ship(x, lab, n, b, C, hc, hl, &cs, (int)c->opt_pack_threads,
+        host_pack_ship(x, lab, n, b, C, hc, hl, &cs, 0,
                        +[](void* f, long long rows) { (*static_cast<decltype(ship)*>(f))(rows); }, &ship);
     } catch (const std::exception& e) {               // no exception crosses the C ABI (thread creation can fail)
         return fail(HG_ERR_NOMEM, "host-side packing failed: %s", e.what());
@@ -428,7 +427,6 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     if (!c->dbf_resident) c->bpad = 0;
     c->stage = ST_DB;
     c->dbx_valid = false;
-    c->dbx2_valid = false;
     c->dbx3_valid = false;
     c->dbx4_valid = false;
     c->dbx8_valid = false;
@@ -459,7 +457,6 @@ int hg_set_queries_f32(hg_ctx* c, const float* host_x, const int64_t* host_label
     }
     c->stage = ST_DB | ST_Q;
     c->qx_valid = false;
-    c->qx2_valid = false;
     c->cfg_epoch++;
     return HG_OK;
 }
@@ -486,7 +483,6 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     HG_TRY(c->sync());
     c->stage = ST_DB | ST_Q;
     c->qx_valid = false;
-    c->qx2_valid = false;
     c->qf_resident = false;                            // packed input: no float table
     c->cfg_epoch++;
     return HG_OK;
@@ -737,6 +733,7 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     c->cfg_epoch++;                                    // whatever changes: a captured step is rebuilt
     if (!strcmp(key, "step_graph")) { c->opt_graph = value != 0; return HG_OK; }
     if (!strcmp(key, "stage_sync")) { c->stage_sync = value != 0; return HG_OK; }
+    if (!strcmp(key, "defer_verdict")) { c->defer_verdict = value != 0; return HG_OK; }
     if (!strcmp(key, "target_units")) {
         if (value < 1) return fail(HG_ERR_ARG, "target_units must be >= 1");
         c->target_units = value;
@@ -757,51 +754,26 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_sigma = value;
     } else if (!strcmp(key, "staged_lists")) {
         c->staged_lists = value != 0;
-    } else if (!strcmp(key, "real_queries_per_lane")) {
-        if (value != 1 && value != 2) return fail(HG_ERR_ARG, "real_queries_per_lane must be 1 or 2");
-        c->opt_real_qpl = value;
-    } else if (!strcmp(key, "rank_waves")) {
-        if (value != 0 && value != 4 && value != 16) return fail(HG_ERR_ARG, "rank_waves must be 0, 4 or 16");
-        c->opt_rank_waves = value;
     } else if (!strcmp(key, "all_rows_shortcut")) {
         c->opt_all_rows = value != 0;
-    } else if (!strcmp(key, "sample_ratio")) {
-        if (value < 1 || value > 64) return fail(HG_ERR_ARG, "sample_ratio must be 1..64");
-        c->opt_sample_ratio = value;
-    } else if (!strcmp(key, "defer_verdict")) {
-        c->defer_verdict = value != 0;
-    } else if (!strcmp(key, "rank_wave")) {
-        if (value < 0 || value > 400) return fail(HG_ERR_ARG, "rank_wave must be 0 (off) or the LDS record capacity in tenths of R, <= 400");
-        c->opt_rank_wave = value;
     } else if (!strcmp(key, "timing_every")) {
         if (value < 1 || value > 1024) return fail(HG_ERR_ARG, "timing_every must be 1..1024");
         c->opt_timing_every = value;
     } else if (!strcmp(key, "cap_boost")) {
         if (value < 1 || value > 4096) return fail(HG_ERR_ARG, "cap_boost must be 1..4096");
+        // a caller that WIDENS the slices is retrying a lost sharded bet within the same call (sharded.evaluate_shard): that attempt
+        // does not count towards hg_bet_eligible's "two calls in a row lost their bets"
+        if (value > c->cap_boost && c->shard_bet_fail > 0) c->shard_bet_fail--;
         c->cap_boost = value;
-    } else if (!strcmp(key, "forgive_lost_bet")) {
-        // the caller retries the lost sharded bet within the same call (sharded.evaluate_shard widens the slices): that
-        // attempt does not count towards hg_bet_eligible's "two calls in a row"
-        if (value && c->shard_bet_fail > 0) c->shard_bet_fail--;
     } else if (!strcmp(key, "crowd_probe")) {
         c->opt_crowd_probe = value != 0;
     } else if (!strcmp(key, "fuse_ap")) {
         c->opt_fuse_ap = value != 0;
-    } else if (!strcmp(key, "rank_direct_lds")) {
-        if (value < 32 || value > 160) return fail(HG_ERR_ARG, "rank_direct_lds must be 32..160 (KB)");
-        c->opt_rank_direct_lds = value;
-    } else if (!strcmp(key, "rank_direct")) {
-        if (value < 0 || value > 2) return fail(HG_ERR_ARG, "rank_direct must be 0, 1 (R = N) or 2 (also N/8 < R < N)");
-        c->opt_rank_direct = value;
-    } else if (!strcmp(key, "interleave_records")) {
-        c->opt_interleave = value != 0;
     } else if (!strcmp(key, "rank_dense")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "rank_dense must be 0 or 1 (2 is accepted and means 1)");
         c->opt_rank_dense = value;
     } else if (!strcmp(key, "inline_leftovers")) {
         c->opt_inline_leftovers = value != 0;
-    } else if (!strcmp(key, "segments_for_lean")) {
-        c->opt_segments_for_lean = value != 0;
     } else if (!strcmp(key, "rank_slices")) {
         if (value < 0) return fail(HG_ERR_ARG, "rank_slices must be >= 0 (the smallest R it takes; 0: off)");
         c->opt_rank_slices = value;
@@ -811,48 +783,34 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "dense_budget_mb")) {
         if (value < 1) return fail(HG_ERR_ARG, "dense_budget_mb must be >= 1");
         c->opt_dense_budget_mb = value;
-    } else if (!strcmp(key, "rank_wave_max")) {
-        if (value < 0 || value > 16128) return fail(HG_ERR_ARG, "rank_wave_max must be 0..16128 (a lane's chunk must fit its byte counters)");
-        c->opt_rank_wave_max = value;
     } else if (!strcmp(key, "select_packed")) {
         c->opt_select_packed = value;
     } else if (!strcmp(key, "rank_lds")) {
-        c->opt_rank_lds = value != 0;
-    } else if (!strcmp(key, "rank_cnt")) {
-        c->opt_rank_cnt = value != 0;
-    } else if (!strcmp(key, "rank_lean")) {
-        c->opt_rank_lean = value != 0;
+        // the bet's rank stage with a query's records resident in LDS: 2 = k_rank_lean where it applies, else k_rank_cnt (default);
+        // 1 = k_rank_cnt only; 0 = neither: k_rank_fused walks the records in global memory
+        if (value < 0 || value > 2) return fail(HG_ERR_ARG, "rank_lds must be 0, 1 or 2");
+        c->opt_rank_cnt = value >= 1;
+        c->opt_rank_lean = value >= 2;
     } else if (!strcmp(key, "host_pack")) {
         c->opt_host_pack = value != 0;
     } else if (!strcmp(key, "keep_floats")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "keep_floats must be 0, 1 or 2");
         c->opt_keep_floats = value;
-    } else if (!strcmp(key, "pack_threads")) {
-        if (value < 0 || value > 1024) return fail(HG_ERR_ARG, "pack_threads must be 0..1024");
-        c->opt_pack_threads = value;
     } else if (!strcmp(key, "compact_records")) {
         c->opt_compact = value != 0;
     } else if (!strcmp(key, "second_bet")) {
         c->opt_second_bet = value != 0;
-    } else if (!strcmp(key, "lds_pad")) {
-        if (value < 0 || value > 24 * 1024) return fail(HG_ERR_ARG, "lds_pad must be 0..24576");
-        c->opt_lds_pad = value;
     } else if (!strcmp(key, "hist_mfma")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "hist_mfma must be 0, 1 or 2");
         c->opt_hist_mfma = value;
     } else if (!strcmp(key, "ap_recip")) {
         c->opt_ap_recip = value != 0;
-    } else if (!strcmp(key, "exact_mfma")) {
-        c->opt_exact_mfma = value != 0;
     } else if (!strcmp(key, "select_mfma")) {
         c->opt_select_mfma = value != 0;
-    } else if (!strcmp(key, "probe_select")) {
-        if (value && !kProbes)
-            return fail(HG_ERR_ARG, "probe_select: this is the production build -- the probes live in libhashgan_amd_probe.so "
-                                    "(python -m hashgan_amd.build --probes, HG_LIBRARY=<path>)");
+#if HG_PROBES
+    } else if (!strcmp(key, "probe_select")) {         // (libhashgan_amd_probe.so only: python -m hashgan_amd.build --probes)
         c->opt_probe = value;
-    } else if (!strcmp(key, "select_qt")) {
-        (void)value;                                   // retired (round 1 experiment): the tile count follows the code length
+#endif
     } else if (!strcmp(key, "real_mfma")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "real_mfma must be 0, 1 or 2");
         c->opt_real_mfma = value;
@@ -860,12 +818,6 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_real_groups = value != 0;
     } else if (!strcmp(key, "real_sort_lds")) {
         c->opt_real_sort_lds = value != 0;
-    } else if (!strcmp(key, "real_sample_hits")) {
-        if (value < 16 || value > 4096) return fail(HG_ERR_ARG, "real_sample_hits must be 16..4096");
-        c->opt_real_sample_hits = value;
-    } else if (!strcmp(key, "real_segment_bytes")) {
-        if (value < 4096) return fail(HG_ERR_ARG, "real_segment_bytes must be >= 4096");
-        c->opt_real_seg_bytes = value;
     } else if (!strcmp(key, "cand_budget_x10")) {
         if (value < 11 || value > 1000) return fail(HG_ERR_ARG, "cand_budget_x10 must be 11..1000");
         c->cand_budget_x10 = value;
@@ -883,7 +835,7 @@ int hg_trim(hg_ctx* c) {
     HG_TRY(c->sync());
     DevBuf* work[] = {&c->hist, &c->seglt, &c->segtie, &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->cand, &c->out_idx,
                       &c->out_dist, &c->stage_in, &c->hwq, &c->samp, &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->bigq, &c->mbits2,
-                      &c->dbx, &c->qx, &c->dbx2, &c->qx2, &c->dbfx, &c->dbfb, &c->sampx, &c->dbytes};   // the images are rebuilt on demand
+                      &c->dbx, &c->qx, &c->dbfx, &c->dbfb, &c->sampx, &c->dbytes};   // the images are rebuilt on demand
     for (auto* d : work) d->release();
     c->dbfx_valid = false;
     c->dbfb_valid = false;
@@ -891,7 +843,7 @@ int hg_trim(hg_ctx* c) {
     for (auto& d : c->scratch) d.release();
     c->gath_idx.release(); c->gath_dist.release();
     c->obuf[0].release(); c->obuf[1].release();
-    c->dbx_valid = c->qx_valid = c->dbx2_valid = c->qx2_valid = false;
+    c->dbx_valid = c->qx_valid = false;
     c->dbx8.release(); c->dbx8_valid = false;
     c->dbx3.release(); c->dbx3_valid = false;
     c->dbx4.release(); c->dbx4_valid = false;
@@ -911,22 +863,21 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "rank_leftovers")) *value = c->opt_leftover;
     else if (!strcmp(key, "select_variant")) *value = c->last_select;
     else if (!strcmp(key, "rank_variant")) *value = c->last_rank;
-    else if (!strcmp(key, "records_interleaved")) *value = c->rec_il ? 1 : 0;
     else if (!strcmp(key, "ap_fused")) *value = c->ap_fused ? 1 : 0;
     else if (!strcmp(key, "cap_boost")) *value = c->cap_boost;
     else if (!strcmp(key, "crowding_x100")) *value = c->crowd_x100;
     else if (!strcmp(key, "real_cap_boost")) *value = c->real_cap_boost;
-    else if (!strcmp(key, "real_grouped")) *value = c->real_grouped;
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
     else if (!strcmp(key, "real_attempts")) *value = c->real_attempts;
-    else if (!strcmp(key, "real_filtered")) *value = c->real_filtered ? 1 : 0;
-    else if (!strcmp(key, "real_lds_ranked")) *value = c->real_lds_ranked;
+    // how the last real-valued ranking ran: bit 0 = bf16 filter + exact rescoring, bit 1 = ranked by the LDS-resident kernel,
+    // bit 2 = record lists beyond the LDS ordered group by group (k_real_group_*)
+    else if (!strcmp(key, "real_path")) *value = (c->real_filtered ? 1 : 0) | (c->real_lds_ranked ? 2 : 0) | (c->real_grouped ? 4 : 0);
     else if (!strcmp(key, "device_bytes")) {
         DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
                          &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err,
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
-                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->dbx2, &c->qx2, &c->mbits2,
+                         &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->mbits2,
                          &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
@@ -935,21 +886,8 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
 #ifdef HG_RANK_PROFILE
     else if (!strcmp(key, "dbg_hwq_ptr")) *value = (int64_t)(uintptr_t)c->hwq.p;
 #endif
-    else if (!strcmp(key, "db_nonbinary")) *value = c->census_db[0];
-    else if (!strcmp(key, "db_zeros")) *value = c->census_db[1];
-    else if (!strcmp(key, "db_minus_ones")) *value = c->census_db[2];
-    else if (!strcmp(key, "q_nonbinary")) *value = c->census_q[0];
-    else if (!strcmp(key, "q_zeros")) *value = c->census_q[1];
-    else if (!strcmp(key, "q_minus_ones")) *value = c->census_q[2];
-    else if (!strcmp(key, "probe_build")) *value = kProbes ? 1 : 0;
-    else if (!strcmp(key, "db_floats")) *value = c->dbf_resident ? 1 : 0;
-    else if (!strcmp(key, "q_floats")) *value = c->qf_resident ? 1 : 0;
     else if (!strcmp(key, "graph_replays")) *value = c->graph_replays;
-    else if (!strcmp(key, "graph_captures")) *value = c->graph_captures;
     else if (!strcmp(key, "segments")) *value = c->geo.S;
-    else if (!strcmp(key, "segment_rows")) *value = c->geo.L;
-    else if (!strcmp(key, "slice_capacity")) *value = c->cap;
-    else if (!strcmp(key, "record_row")) *value = c->crow;
     else if (!strcmp(key, "records_kept")) {
         // records the last bet's select pass left in the slices, over all live queries (a download of the slice counts: a
         // measurement read after the step, never part of one) -- kept / (Q R) is what the guess's margin costs
@@ -966,6 +904,17 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
         }
     }
     else return fail(HG_ERR_ARG, "hg_get_stat: unknown key '%s'", key);
+    return HG_OK;
+}
+
+// What hg_set_database_f32 / hg_set_queries_f32 saw in the float table they were handed: entries outside {-1, 0, +1}, zeros, minus
+// ones, and whether the floats are resident on the device -- from which the caller tells +-1 codes (Hamming ranking), {0,1} bits
+// and real-valued features (inner-product ranking) apart.
+int hg_get_census(hg_ctx* c, int queries, int64_t out[4]) {
+    if (!c || !out) return fail(HG_ERR_ARG, "hg_get_census: null argument");
+    const i64* cs = queries ? c->census_q : c->census_db;
+    out[0] = cs[0]; out[1] = cs[1]; out[2] = cs[2];
+    out[3] = (queries ? c->qf_resident : c->dbf_resident) ? 1 : 0;
     return HG_OK;
 }
 

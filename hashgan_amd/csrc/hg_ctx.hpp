@@ -4,7 +4,7 @@
 //   hg_core.hip        context, tables (hg_set_*), options / statistics / timing, label match, AP, downloads
 //   hg_seq.hip         the Hamming sequences: geometry, histogram -> plan -> select -> rank, staged (sharded) and one-shot forms
 //   hg_pairs_valu.hip  launchers of the vector-ALU pair passes (k_hist, k_select, k_select_dense)
-//   hg_pairs_mx.hip    launchers of the matrix-core pair passes (k_select_mx2 / mx3, k_hist_mx, k_hist_i8) and their images
+//   hg_pairs_mx.hip    launchers of the matrix-core pair passes (k_select_mx3 / mx4, k_hist_mx, k_hist_i8) and their images
 //   hg_pairs_mx1.hip   launcher of k_select_mx (every code length: the longest compile)
 //   hg_real.hip        real-valued (float32 inner product) ranking
 //   hg_comm.hip        RCCL collectives (library dlopen'ed on first use)
@@ -178,18 +178,12 @@ struct hg_ctx {
                                // about once in 3 million -- it is then rerun alone; 6 -> 5 keeps ~4 % fewer surplus records)
     i64 staged_lists = 1;      // staged hg_select materialises the idx/dist lists
     i64 cand_budget_x10 = 40;  // optimistic record budget per query, in tenths of R
-    i64 opt_real_seg_bytes = 512 * 1024;   // real-valued path: bytes of feature rows per segment
-    i64 opt_real_qpl = 1;      // real-valued path: queries per lane (1 or 2)
-    i64 opt_rank_waves = 0;    // k_rank_fused wavefronts per query: 0 = by list length, else 4 or 16
     i64 opt_select_mfma = 1;   // optimistic select: 1 = matrix-core kernel (k_select_mx), 0 = vector-ALU k_select
     i64 opt_probe = 0;         // measurement probes of the matrix-core select kernels (SelArgs::probe)
-    i64 opt_select_packed = 3; // codes of <= 64 bits, several distances per MFMA accumulator: 1 = k_select_mx2 (two) for <= 32 bits,
-                               // 2 = k_select_mx2 up to 64 bits, 3 = k_select_mx3 (three, batched drain) for compact records, else like 1
-    i64 opt_sample_ratio = 2;  // the sampled pass works on segments this many times longer than the select pass's
+    i64 opt_select_packed = 3; // several distances per MFMA accumulator: 3 = k_select_mx3 (<= 64 bits, three) / k_select_mx4 (65..128 bits, two) with
+                               // the batched drain, for one-byte records; anything else = k_select_mx (one distance per accumulator)
     i64 opt_all_rows = 1;      // R = N: skip histogram and plan (every row is a member)
-    i64 opt_rank_lds = 1;      // the bet's rank stage keeps a query's records in LDS when they fit (k_rank_lds)
-    i64 opt_rank_cnt = 1;      // ... and ranks them with the per-thread counting sort (k_rank_cnt) where it applies
-    i64 opt_segments_for_lean = 1;   // "segments_for_lean": make_geometry keeps the segment count within k_rank_lean's 256 when that still fills the GPU
+    i64 opt_rank_cnt = 1;      // the bet's rank stage keeps a query's records in LDS and ranks them with the per-thread counting sort (k_rank_cnt / k_rank_lean) where it applies
     i64 opt_rank_lean = 1;     // "rank_lean": ... in its lean form (k_rank_lean) for one-byte records without lists, <= 256 slices, <= 1024 pieces per query
     i64 real_grouped = 0;      // stat: the last real-valued ranking ordered its record lists group by group (k_real_group_*)
     i64 opt_real_groups = 1;   // "real_groups": record lists beyond the LDS are split by score range and ordered group by group in LDS (0: the four radix passes)
@@ -198,8 +192,6 @@ struct hg_ctx {
     i64 crowd_x100 = 0;        // stat "crowding_x100": that measure, x 100 (~200: rows in random order; ~100 x classes: stored class by class)
     i64 opt_crowd_probe = 1;   // "crowd_probe"
     i64 cap_boost = 1;         // slice capacity multiplier a lost bet escalated to on this database (run_oneshot); 1 after every load
-    i64 opt_rank_direct_lds = 80;    // "rank_direct_lds": KB of LDS a k_rank_direct block may take (80: two blocks per CU -- C1 0.25 ms vs 0.31 with 160 and one)
-    i64 opt_rank_direct = 1;   // "rank_direct": R = N on one shard in one counting-sort kernel, k_rank_direct, when its LDS fits (2: also N/8 < R < N)
     i64 opt_rank_dense = 1;    // "rank_dense": N/8 < R <= N on one shard through the byte matrix (k_dense_bytes + k_rank_dense, hg_rank_dense.hpp; codes of <= 126 bits, <= 128 classes); 0: off
     bool leftovers_expected = false;   // the last fused step on this context left queries to the general kernel
     bool leftovers_inline = false;     // ... and this step ranked its own within the stream (launch_rank_slices with the flags)
@@ -209,11 +201,6 @@ struct hg_ctx {
     i64 opt_rank_dense_gbm = -1;   // "rank_dense_gbm": k_rank_dense's bitmap in global memory (1) or LDS (0, where it fits); -1: by the blocks per CU
     i64 opt_dense_budget_mb = 16384;   // "dense_budget_mb": the byte matrix D holds at most this much (queries are chunked)
     bool dense_rank = false;   // run state of enqueue_all_rows: rank through the byte matrix
-    i64 opt_rank_wave = 40;    // "rank_wave": one wavefront per query (k_rank_wave) for SHORT lists of one-byte records; the value is the
-                               // record capacity of a query's LDS share in tenths of the shard's share of R (+ 256; lists beyond it
-                               // go to k_rank_fused); 0 = off
-    i64 opt_rank_wave_max = 4608;   // "rank_wave_max": ... used when that capacity is at most this many records (<= 16128)
-    i64 opt_select_qt = 2;     // k_select_mx query tiles per wavefront (2: 4 wavefronts per SIMD, 4: 2)
 
     // run state
     bool optimistic = false;   // records come from a guessed threshold (fixed-capacity slices)
@@ -222,8 +209,8 @@ struct hg_ctx {
     u32 cap = 0;               // optimistic slice capacity
     i64 crow = 0;              // record-row stride
     i64 opt_runs = 0, opt_fallbacks = 0, opt_requeried = 0;
-    int last_select = 0;       // stat "select_variant": 1 k_select, 2 k_select_dense, 3 k_select_mx, 4 k_select_mx2, 5 k_select_mx3, 6 k_select_mx4
-    int last_rank = 0;         // stat "rank_variant": 1 k_rank_fused, 2 k_rank_lds, 3 k_rank_cnt, 4 k_rank_wave, 5 k_rank_direct, 6 k_rank_lean, 7 k_rank_dense, 8 k_rank_dense<slices>
+    int last_select = 0;       // stat "select_variant": 1 k_select, 2 k_select_dense, 3 k_select_mx, 5 k_select_mx3, 6 k_select_mx4
+    int last_rank = 0;         // stat "rank_variant": 1 k_rank_fused, 3 k_rank_cnt, 6 k_rank_lean, 7 k_rank_dense, 8 k_rank_dense<slices>
     i64 opt_leftover = 0;      // stat "rank_leftovers": queries of fused steps that k_rank_cnt left to the general rank kernel
     int opt_consecutive_fail = 0;   // one-shot bets lost in a row (this context only)
     int shard_bet_fail = 0;         // sharded bets lost in a row: identical on every rank by construction
@@ -234,8 +221,6 @@ struct hg_ctx {
     DevBuf db, dblab, qc, qlab;
     DevBuf dbx, qx;            // fp4 images of db / qc in MFMA fragment order for k_select_mx (built on first use)
     bool dbx_valid = false, qx_valid = false;
-    DevBuf dbx2, qx2;          // the same for k_select_mx2 (two rows per accumulator, codes of <= 64 bits)
-    bool dbx2_valid = false, qx2_valid = false;
     DevBuf dbx8;               // i8 image of the database codes in A-fragment order (k_hist_i8), built on first use
     bool dbx8_valid = false;
     DevBuf dbx3;               // fp4 image for k_select_mx3 (48-row supertiles, three rows per accumulator), built on first use
@@ -246,16 +231,10 @@ struct hg_ctx {
     i64 opt_hist_mfma = 2;     // "hist_mfma": histograms (sampled pass; full pass of the one-shot exact sequence) on the matrix cores -- 2: the integer instruction delivers the counter address (k_hist_i8, codes of <= 128 bits), 1: fp4 distances (k_hist_mx), 0: vector ALU
     bool hist_pairs = false;   // the last FULL histogram pass ran per segment pair (k_hist_mx)
     bool exact_mx = false;     // the matrix-core select runs with the EXACT threshold (hg_hist + k_plan) instead of a guess
-    i64 opt_exact_mfma = 1;    // "exact_mfma": the one-shot exact sequence selects on the matrix cores when R << N
     bool rec8 = false;         // the record rows hold one-byte compact records (matrix-core select, no lists wanted)
     i64 opt_compact = 1;       // "compact_records": allow them
-    bool rec_il = false;       // ... with the 16-byte pieces of 32 queries' slices interleaved (rec8_at): k_select_mx3 / mx4 -> k_rank_lean
-    i64 opt_interleave = 0;    // "interleave_records": allow that.  Off: measured at C2 (profiles/r04_interleaved_records.txt) the select's HBM traffic
-                               // falls 440 -> 368 MB and k_rank_lean's 164 -> 91 MB per launch, but the step gets 1 % slower (0.926 -> 0.936 ms) -- the L2
-                               // does not merge 8-byte stores that arrive tens of microseconds apart in either layout (33 bytes written per store)
     i64 opt_second_bet = 1;    // "second_bet": a lost one-shot bet is retried once with a wider margin before the exact sequence
     i64 opt_rebets = 0;
-    i64 opt_lds_pad = 0;       // "lds_pad": extra dynamic LDS per block of the matrix-core select (occupancy experiments)
     bool err_zeroed = false;   // the guess kernel of a one-shot bet already cleared err
     // AP from the rank kernel's epilogue (k_rank_cnt: the bitmap is still in LDS) -- one launch less per step, and the general
     // rank kernel for the queries k_rank_cnt declines is launched only when the step's download says there are any
@@ -287,7 +266,6 @@ struct hg_ctx {
     DevBuf sampx;              // float features of the sampled rows in MFMA A-fragment order (k_real_sample_mx), rebuilt per call
     DevBuf dbfb, thr2, xmax2;  // filter + rescore path (hg_real_bf.hpp): bf16 image of the database, lowered cuts, max row norm^2
     bool dbfb_valid = false;
-    i64 opt_real_sample_hits = 64;   // "real_sample_hits": the real-valued bet samples so that this many of a query's top R rows are in the sample
     i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit
     bool real_no_cut = false;     // the current real_attempt takes every row (thr = -inf)
     bool real_filtered = false;   // the last real_select left unscored candidates that k_real_rescore completed
@@ -299,7 +277,6 @@ struct hg_ctx {
     // hand-over of float32 / int64 arrays: packed on the host by a thread pool before the upload (hg_host_pack.hpp)
     i64 opt_host_pack = 1;     // "host_pack": 0 = upload the raw arrays and pack on the GPU (k_pack_*)
     i64 opt_keep_floats = 2;   // "keep_floats": database float table on the GPU -- 0 never, 1 always, 2 only if it is not a +-1 code
-    i64 opt_pack_threads = 0;  // "pack_threads": 0 = from the hardware (up to 96)
     hipStream_t stream2 = nullptr;   // the float table's uploads while the packing pool works (pack_on_host)
     hipEvent_t stream2_ev = nullptr;
     void* fstage = nullptr;    // 4 x 16 MB of pinned staging for float tables on their way to the GPU (pack_on_host)
@@ -327,7 +304,7 @@ struct hg_ctx {
         i64 R = -1, seen_R = -1;
         int timing = -1, seen_timing = -1;
         // host-side state the captured enqueue functions leave behind
-        unsigned stage = 0; bool optimistic = false, lists_valid = false, ap_fused = false, rec8 = false, rec_il = false; u32 cap = 0; i64 crow = 0, RW = 0; Geo geo{};
+        unsigned stage = 0; bool optimistic = false, lists_valid = false, ap_fused = false, rec8 = false; u32 cap = 0; i64 crow = 0, RW = 0; Geo geo{};
         std::vector<Pending> evs;          // event-record nodes inside the graph (kernel timing)
     } sg;
     i64 opt_graph = 0;         // "step_graph": 1 = hg_map captures and replays its step (see run_oneshot); off by default
@@ -454,7 +431,6 @@ int launch_select_dense(hg_ctx* c, int lw);      // k_select_dense<NW, LW>
 int ensure_mx_images(hg_ctx* c, bool need_db);  // fp4 images of database / query codes, built on first use
 int launch_hist_mx(hg_ctx* c);                   // k_hist_i8 / k_hist_mx
 int launch_select_mx(hg_ctx* c, int lw);         // k_select_mx<NW, LW, QT, COMPACT>
-int launch_select_mx2(hg_ctx* c, int lw);        // k_select_mx2 (codes of <= 64 bits)
 int launch_select_mx3(hg_ctx* c, int lw);        // k_select_mx3 (codes of <= 64 bits, one-byte records)
 int launch_select_mx4(hg_ctx* c, int lw);        // k_select_mx4 (codes of 65..128 bits, one-byte records)
 // hg_comm.hip

@@ -481,15 +481,7 @@ struct SelArgs {
     const int* sstar;      // optimistic mode: [Qpad] last segment that still collects dist == T (k_guess)
     int probe;             // measurement probes of the matrix-core kernels (option "probe_select"): 2 no drain,
                            // 4 no record stores, 8 no emit -- each breaks the bet on purpose (exact rerun follows)
-    int il;                // one-byte records with the 16-byte pieces of 32 queries' slices interleaved (k_select_mx3 / mx4 -> k_rank_lean; rec8_at)
 };
-
-// Byte offset of one-byte record i of slice s of query q in the record rows.  Plain: q * crow + s * cap + i.  Interleaved (il):
-// the tile of 32 queries q / 32 owns 32 * crow bytes; 16-byte piece p16 of slice s of query j = q % 32 at ((s * cap/16 + p16) * 32 + j) * 16.
-__host__ __device__ __forceinline__ i64 rec8_at(const i64 q, const i64 s, const u32 i, const u32 cap, const i64 crow, const int il) {
-    if (!il) return q * crow + s * cap + i;
-    return (q >> 5) * 32 * crow + ((s * (cap >> 4) + (i >> 4)) * 32 + (q & 31)) * 16 + (i & 15u);
-}
 
 constexpr int sel_batch_rows(int nw) {          // rows per scalar-load batch: <= 64 SGPRs of code words, <= 32 rows
     int r = 64 / nw, p = 1;
@@ -842,7 +834,7 @@ struct RankArgs {
     int want_lists;
     int bits_lds;
     i64 RW;
-    const u32* only;       // optional [Q]: handle only the flagged queries (the rest were ranked by k_rank_lds)
+    const u32* only;       // optional [Q]: handle only the flagged queries (the rest were ranked by k_rank_cnt / k_rank_lean)
     // direct mode (R = N on one shard): there are no records -- "record" i of a query is row i of the shard,
     // its distance and match bit are computed from the codes and labels on the fly, in both passes
     int direct;
@@ -851,7 +843,6 @@ struct RankArgs {
     const u64* dblab;      // [N][LW]
     const u32* qc;         // [Q][NW]
     const u64* qlab;       // [Q][LW]
-    int il;                // one-byte records interleaved (rec8_at)
 };
 
 template <int NWAV>   // wavefronts per query: 4, or 16 for long lists
@@ -937,7 +928,7 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
             return make_rec(g.idx_base + (u32)n, d, any != 0);
         }
         if (a.rec8) {
-            const u32 m = ((const u8*)cand)[rec8_at(q, w.s, (u32)i, a.cap, a.crow, a.il)];
+            const u32 m = ((const u8*)cand)[(i64)q * a.crow + (i64)w.s * a.cap + i];
             return (u64)((m & 0x7Fu) | ((m >> 7) << 8)) << 32;
         }
         return row[(i64)w.s * a.cap + i];
@@ -1109,7 +1100,7 @@ __global__ __launch_bounds__(NWAV * 64) void k_rank_fused(const u64* __restrict_
 
 // ----------------------------------------------------------------------------
 // K4m  merge of per-shard rankings (sharded bet, AP only).  Every shard has ranked its own records
-// (k_rank_lds / k_rank_fused mode 3): a match bitmap in LOCAL rank order -- distance ascending, index
+// (k_rank_cnt / k_rank_lean / k_rank_fused mode 3): a match bitmap in LOCAL rank order -- distance ascending, index
 // ascending -- and its per-distance record counts.  Shards own contiguous index ranges, so the global order
 // is: for each distance d, shard 0's bucket d, then shard 1's, ...  One wavefront per query (lane r <->
 // shard r) derives the global cut from the gathered counts exactly like k_plan and stitches the global

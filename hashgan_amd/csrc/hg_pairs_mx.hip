@@ -1,9 +1,8 @@
-// libhashgan_amd.so -- launchers of the matrix-core pair passes and of the images they read: k_select_mx / mx2 / mx3
+// libhashgan_amd.so -- launchers of the matrix-core pair passes and of the images they read: k_select_mx3 / mx4
 // (optimistic record pass), k_hist_mx / k_hist_i8 (histograms).
 #include "hg_ctx.hpp"
 #include "hg_mx_drain.hpp"
 #include "hg_select_mx.hpp"
-#include "hg_select_mx2.hpp"
 #include "hg_select_mx3.hpp"
 #include "hg_select_mx4.hpp"
 #include "hg_hist_mx.hpp"
@@ -70,55 +69,6 @@ template <int NW> int launch_hist_mx_t(hg_ctx* c) {
     return c->check_launch("k_hist_mx");
 }
 
-// codes of <= 64 bits: two rows per accumulator (k_select_mx2); blocks = (pair of segments) x (256 queries)
-template <int NW, int LW, bool COMPACT> int launch_select_mx2_c(hg_ctx* c);
-template <int NW, int LW> int launch_select_mx2_t(hg_ctx* c) {
-    return c->rec8 ? launch_select_mx2_c<NW, LW, true>(c) : launch_select_mx2_c<NW, LW, false>(c);
-}
-template <int NW, int LW, bool COMPACT> int launch_select_mx2_c(hg_ctx* c) {
-    if (!c->dbx2_valid) {
-        const i64 n32 = (c->N + 31) / 32 * 32;
-        HG_TRY(c->dbx2.reserve((size_t)(n32 > 0 ? n32 : 32) * NW * 16));
-        const i64 items = n32 * NW;
-        c->t_begin(KI_PACK);
-        if (items) hipLaunchKernelGGL(k_expand_db2, dim3(grid_for(items)), dim3(256), 0, c->stream, c->db.as<u32>(),
-                                      c->dbx2.as<uint4>(), (i64)c->N, n32, NW);
-        c->t_end();
-        HG_TRY(c->check_launch("k_expand_db2"));
-        c->dbx2_valid = true;
-    }
-    Geo g = c->geo;
-    const int nSP = (g.S + 1) / 2;
-    const int nQB = (g.Q + 255) / 256;
-    if (!c->qx2_valid) {
-        const i64 qpad = (i64)nQB * 256;
-        HG_TRY(c->qx2.reserve((size_t)qpad * NW * 32));
-        const i64 items = qpad * NW;
-        c->t_begin(KI_PACK);
-        hipLaunchKernelGGL(k_expand_queries2, dim3(grid_for(items)), dim3(256), 0, c->stream, c->qc.as<u32>(), c->qx2.as<uint4>(),
-                           (i64)c->Q, qpad, NW);
-        c->t_end();
-        HG_TRY(c->check_launch("k_expand_queries2"));
-        c->qx2_valid = true;
-    }
-    g.nQT = nQB;
-    g.nUnits = (i64)nSP * nQB;
-    g.wpb = WPB;
-    g.nBlk = (int)g.nUnits;
-    const Mx2Lds L = mx2_lds_layout(NW, LW, COMPACT);
-    if (L.total > 64 * 1024)
-        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx2<NW, LW, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   L.total));
-    SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
-              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
-    c->t_begin(KI_SELECT_MX);
-    hipLaunchKernelGGL((k_select_mx2<NW, LW, COMPACT>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total, c->stream, c->qc.as<u32>(),
-                       c->qlab.as<u64>(), c->qx2.as<u8>(), c->db.as<u32>(), c->dbx2.as<u8>(), c->dblab.as<u64>(), a,
-                       c->cand.as<u64>(), g);
-    c->t_end();
-    return c->check_launch("k_select_mx2");
-}
-
 // codes of 33..64 bits, compact records: three rows per accumulator and the batched drain (k_select_mx3);
 // blocks = (pair of segments) x (256 queries); the query image is k_select_mx's
 template <int NW, int LW> int launch_select_mx3_t(hg_ctx* c) {
@@ -145,9 +95,9 @@ template <int NW, int LW> int launch_select_mx3_t(hg_ctx* c) {
     if (L.total > 64 * 1024)
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx3<NW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
     SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
-              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe, c->rec_il ? 1 : 0};
+              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
     c->t_begin(KI_SELECT_MX);
-    hipLaunchKernelGGL((k_select_mx3<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(64 * M3_WPB), (size_t)L.total + (size_t)c->opt_lds_pad, c->stream, c->qc.as<u32>(),
+    hipLaunchKernelGGL((k_select_mx3<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(64 * M3_WPB), (size_t)L.total, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx3.as<u8>(), c->dblab.as<u64>(), a,
                        c->cand.as<u8>(), g);
     c->t_end();
@@ -205,21 +155,6 @@ int launch_hist_mx(hg_ctx* c) {
     HG_DISPATCH_NW(launch_hist_mx_t, c)
 }
 
-int launch_select_mx2(hg_ctx* c, int lw) {           // codes of <= 64 bits
-    if (c->NW == 1) {
-        switch (lw) {
-            case 1: return launch_select_mx2_t<1, 1>(c);
-            case 2: return launch_select_mx2_t<1, 2>(c);
-            default: return launch_select_mx2_t<1, 0>(c);
-        }
-    }
-    if (c->NW != 2) return fail(HG_ERR_ARG, "k_select_mx2 takes codes of <= 64 bits");
-    switch (lw) {
-        case 1: return launch_select_mx2_t<2, 1>(c);
-        case 2: return launch_select_mx2_t<2, 2>(c);
-        default: return launch_select_mx2_t<2, 0>(c);
-    }
-}
 
 namespace {
 // codes of 65..128 bits, compact records: two rows per accumulator and the batched drain (k_select_mx4);
@@ -247,9 +182,9 @@ template <int NW, int LW> int launch_select_mx4_t(hg_ctx* c) {
     if (L.total > 64 * 1024)
         HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mx4<NW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
     SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
-              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), 0, c->rec_il ? 1 : 0};
+              c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), 0};
     c->t_begin(KI_SELECT_MX);
-    hipLaunchKernelGGL((k_select_mx4<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(64 * M4_WPB), (size_t)L.total + (size_t)c->opt_lds_pad, c->stream, c->qc.as<u32>(),
+    hipLaunchKernelGGL((k_select_mx4<NW, LW>), dim3(padded_grid(g.nBlk)), dim3(64 * M4_WPB), (size_t)L.total, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx4.as<u8>(), c->dblab.as<u64>(), a,
                        c->cand.as<u8>(), g);
     c->t_end();

@@ -30,7 +30,7 @@ template <int NW, int LW, int QT, bool COMPACT> int launch_select_mx_q(hg_ctx* c
     SelArgs a{c->exact_mx ? c->t.as<int>() : c->tguess.as<int>(), c->sl_start.as<u32>(), c->sl_tie.as<u32>(), c->sl_cnt.as<u32>(),
               c->failq.as<u32>(), c->cap, c->crow, 1, c->sstar.as<int>(), (int)c->opt_probe};
     c->t_begin(KI_SELECT_MX);
-    hipLaunchKernelGGL((k_select_mx<NW, LW, QT, COMPACT>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total + (size_t)c->opt_lds_pad, c->stream, c->qc.as<u32>(),
+    hipLaunchKernelGGL((k_select_mx<NW, LW, QT, COMPACT>), dim3(padded_grid(g.nBlk)), dim3(256), (size_t)L.total, c->stream, c->qc.as<u32>(),
                        c->qlab.as<u64>(), c->qx.as<u8>(), c->db.as<u32>(), c->dbx.as<u8>(), c->dblab.as<u64>(), a,
                        c->cand.as<u64>(), g);
     c->t_end();

@@ -1,7 +1,7 @@
 // hashgan_amd -- verify + plan + order of the bet as a per-thread counting sort (metric.py:14 and the [0:R] cut at
 // :19, for one query per block, records resident in LDS).
 //
-// k_rank_lds places 64 records per wavefront step with a bit-sliced ballot match (which lanes hold the same
+// Round 1's k_rank_lds placed 64 records per wavefront step with a bit-sliced ballot match (which lanes hold the same
 // distance?) -- ~70 vector + ~50 scalar instructions per step, 8.5 k scalar instructions per query
 // (profiles/r02_compact_pmc_summary.txt).  A ranked list only spans about ten distinct distances, so the classic
 // counting sort is far cheaper: every thread owns a CONTIGUOUS chunk of the query's records (index order is the
@@ -18,9 +18,46 @@
 // Modes 0 (single shard, fused) and 3 (local ranking for hg_merge_ranked) of k_rank_fused.
 #pragma once
 #include "hg_kernels.hpp"
-#include "hg_rank_lds.hpp"
 
 namespace hg {
+
+// Arguments of the LDS-resident rank kernels of the bet (k_rank_cnt, k_rank_lean)
+struct RankLdsArgs {
+    const u32* sl_cnt;     // [S][Qpad]
+    const u32* fail;       // [Qpad]
+    int* err;
+    u32* qbad;             // [Q]
+    u32* big;              // [Q] out: 1 = not handled here (too many records for the LDS)
+    u32 cap;
+    i64 crow;
+    int want_lists;
+    int rec8;              // records are one byte {match:1 | dist:7} (compact select, no lists) instead of 8-byte {idx, dist, match}
+    i64 RW;
+    int lds_recs;          // record capacity of the LDS arrays
+    // several shards (k_rank_fused's modes): 0 fused; 1 histogram phase only (per-wave histograms -> hwq,
+    // shard totals -> hown); 2 placement with the plan computed from the gathered histograms
+    int mode;
+    u32* hwq;              // [Q][NWAV][NB]
+    u32* hown;             // [NB][Qpad] (+ tail)
+    const int* xt;
+    const u32* xcnt_lt;
+    const u32* xquota;
+    const u32* xtie_before;
+    const u32* xposbase;   // [NB][Qpad]
+    int nbc;               // k_rank_cnt: distances that have counters (0: all up to 127); a record beyond them sends the query to k_rank_fused
+    // k_rank_cnt, mode 0: the AP of every query it ranks comes out of its epilogue (the bitmap is still in LDS) -- metric.py:20-23
+    const ApShape* ap_shapes;   // null: no AP here (k_ap runs later)
+    const double* ap_recip;     // [R + 1] or null
+    double* ap;                 // [Q]
+    u32* rel;                   // [Q]
+    u32* nleft;                 // count of queries left to the general kernel (big[q] = 1): the host launches it only if > 0
+    // k_rank_cnt: the nbc counters cover the distances [max(0, cut[q] - nbc + 1), cut[q]] -- every record of a bet is within
+    // its query's cut (the guess, or the exact threshold), and a list that reaches further down than the 16 (32) distances
+    // this kernel places leaves it anyway (null: the counters cover [0, nbc))
+    const int* cut;
+    int spec_pieces;       // k_rank_lean: 16-byte pieces of every slice fetched before the slice counts are known
+};
+
 
 inline __host__ __device__ int rank_cnt_maxb(int NB) { return NB <= 65 ? 16 : 32; }    // distances a ranked list may span on this path
 

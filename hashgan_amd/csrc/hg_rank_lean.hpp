@@ -103,15 +103,14 @@ void k_rank_lean(const u8* __restrict__ cand8, const RankLdsArgs a, u32* __restr
     const int PSP = a.spec_pieces;                                // pieces per slice fetched up front (<= PPS, S * PSP <= RL_MAX_PIECES)
     const int TP = S * PSP;
     const u32 inv = (65536u + (u32)PSP - 1u) / (u32)PSP;          // p / PSP = (p * inv) >> 16 for p < 1024, PSP <= 64
-    // piece ps of slice s is row16[(s * PPS + ps) * ilk]: in interleaved rows the tile's 32 queries take turns (rec8_at)
-    const u32 ilk = a.il ? 32u : 1u;
-    const uint4* __restrict__ row16 = a.il ? (const uint4*)(cand8 + (i64)(q >> 5) * 32 * a.crow) + (q & 31) : (const uint4*)(cand8 + (i64)q * a.crow);
+    // piece ps of slice s is row16[s * PPS + ps]
+    const uint4* __restrict__ row16 = (const uint4*)(cand8 + (i64)q * a.crow);
     uint4 spec[RL_NPT];
 #pragma unroll
     for (int k = 0; k < RL_NPT; ++k) {
         const u32 p = (u32)(tid + nthr * k);
         const u32 s = (p * inv) >> 16, ps = p - s * (u32)PSP;
-        spec[k] = p < (u32)TP ? row16[(s * (u32)PPS + ps) * ilk] : uint4{0u, 0u, 0u, 0u};
+        spec[k] = p < (u32)TP ? row16[s * (u32)PPS + ps] : uint4{0u, 0u, 0u, 0u};
     }
     for (int i = tid * 16; i < L.pref; i += nthr * 16) *(uint4*)(rlds + i) = uint4{0u, 0u, 0u, 0u};      // counters, ranks, totals, misc, bitmap
 
@@ -174,7 +173,7 @@ void k_rank_lean(const u8* __restrict__ cand8, const RankLdsArgs a, u32* __restr
     }
     if (pc > (u32)PSP) {                              // rare: a slice longer than what was fetched up front -- its own thread finishes it
         const u32 first = wbase + incl - pc;
-        for (u32 ps = (u32)PSP; ps < pc; ++ps) put_piece(row16[((u32)tid * (u32)PPS + ps) * ilk], (int)c_s - (int)(16u * ps), first + ps);
+        for (u32 ps = (u32)PSP; ps < pc; ++ps) put_piece(row16[(u32)tid * (u32)PPS + ps], (int)c_s - (int)(16u * ps), first + ps);
     }
     __syncthreads();
     HG_TKL();                                         // 1: compaction

@@ -5,6 +5,9 @@
 #include "hg_real_mx.hpp"
 #include "hg_real_bf.hpp"
 
+constexpr i64 REAL_SAMPLE_HITS = 64;          // the real-valued bet samples so that this many of a query's top R rows are in the sample (tools/real_sample_sweep.py: 32 .. 256 measured)
+constexpr i64 REAL_SEG_BYTES = 512 * 1024;    // bytes of feature rows per segment of the real-valued pair passes
+
 namespace {
 template <int BP> int real_launch_sample(hg_ctx* c, i64 M, i64 stride) {
     const Geo& g = c->geo;
@@ -30,7 +33,6 @@ template <int BP, int QPL> int real_launch_select_q(hg_ctx* c) {
 }
 template <int BP> int real_launch_select(hg_ctx* c) {
     // queries per lane (see k_real_select): two while their features fit the register file comfortably
-    if (BP <= 32 && c->opt_real_qpl == 2) return real_launch_select_q<BP, (BP <= 32 ? 2 : 1)>(c);
     return real_launch_select_q<BP, 1>(c);
 }
 // real-valued select on the matrix cores: blocks = (pair of segments) x (256 queries)
@@ -239,7 +241,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     {   // Float rows are 4*bpad bytes (32x a 64-bit code): keep a segment's rows within ~512 KB so the few
         // segments an XCD works on at a time stay in its 4 MiB L2 while all query tiles pass over them.
         Geo& gg = c->geo;
-        i64 L = (i64)c->opt_real_seg_bytes / ((i64)c->bpad * 4);
+        i64 L = (i64)REAL_SEG_BYTES / ((i64)c->bpad * 4);
         L = L / 16 * 16;
         if (L < 64) L = 64;
         if (gg.L > L) {
@@ -258,7 +260,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     if (bet) {
         // sample so that about 64 of a query's top R rows are in it; guess the cut `sigma` deviations deep
-        i64 stride = (i64)((double)R / (double)c->opt_real_sample_hits);
+        i64 stride = (i64)((double)R / (double)REAL_SAMPLE_HITS);
         if (stride < 1) stride = 1;
         const i64 M = (c->N + stride - 1) / stride;
         const double fr = (double)R * (double)M / (double)c->N;

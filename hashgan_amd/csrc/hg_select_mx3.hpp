@@ -52,9 +52,6 @@ constexpr int M3_RING = 16;                // records per slice ring
 #ifndef HG_M3_WPB
 #define HG_M3_WPB 8
 #endif
-#ifndef HG_M3_Q12
-#define HG_M3_Q12 1                        // queue entries of 12 bytes at ONE address (0: round 4's two arrays, 8 + 4 bytes -- select 0.627 vs 0.615 ms at C2)
-#endif
 #ifndef HG_M3_ILV
 #define HG_M3_ILV 8                        // tile 1's MFMAs carry that many of tile 0's harvest ops between them (0: round 4's order, all six MFMAs first -- 0.634 vs 0.626 ms)
 #endif
@@ -116,7 +113,7 @@ struct Mx3Lds {                // byte offsets inside the block's dynamic LDS
     int a, abuf;               // A fragments: 2 buffers of abuf bytes
     int cl, clbuf, labels;     // packed codes + labels of a window's rows (both halves): 3 buffers of clbuf bytes; labels inside a buffer
     int qcodes, qlabels;       // the block's query tables
-    int qab, qc;               // per-wave queues: [QCAP] entries of 12 bytes {A, B, C} at qab (HG_M3_Q12); else [QCAP] u64 {A, B} at qab and [QCAP] u32 {C} at qc
+    int queue;                 // per-wave queues: [QCAP] entries of 12 bytes {A, B, C} (ONE address per entry; round 4 kept {A, B} and {C} in two arrays: 0.627 vs 0.615 ms)
     int rings;                 // per-wave slice rings
     int total;
 };
@@ -130,9 +127,8 @@ __host__ __device__ inline Mx3Lds mx3_lds_layout(int NW, int LW) {
     l.clbuf = (l.labels + 2 * M3_WROWS * LW * 8 + 15) & ~15;
     l.qcodes = l.cl + 3 * l.clbuf;
     l.qlabels = l.qcodes + M3_WPB * 64 * NW * 4;
-    l.qab = l.qlabels + M3_WPB * 64 * LW * 8;
-    l.qc = l.qab + M3_WPB * M3_QCAP * 8;        // (12-byte entries: one array of M3_WPB * M3_QCAP * 12 bytes from qab on; qc unused)
-    l.rings = l.qc + M3_WPB * M3_QCAP * 4;
+    l.queue = l.qlabels + M3_WPB * 64 * LW * 8;
+    l.rings = l.queue + M3_WPB * M3_QCAP * 12;
     l.total = l.rings + M3_WPB * 64 * M3_QT * M3_RING;
     return l;
 }
@@ -143,44 +139,29 @@ struct Mx3Drain {
     static constexpr int M3_WS = m3_ws(LW), M3_WROWS = M3_WS * M3_ROWS;
     u8* lds;
     Mx3Lds L;
-    u64* qab;                            // this wavefront's queue
-    u32* qc;
     u32 ring_base;                       // LDS address of the wavefront's first ring
-    u32 q12_base;                        // ... as 12-byte entries (HG_M3_Q12): byte offset of the wavefront's first entry (opaque: keeps ONE address per entry)
+    u32 q12_base;                        // this wavefront's queue: LDS address of its first 12-byte entry (kept opaque: ONE address per entry)
     u8* rings;                           // this wavefront's rings: slice (t, lane) at (t * 64 + lane) * M3_RING
     int wave, lane;
     u32 cap;                             // slice capacity (records), a multiple of 16
     u8* tb0;                             // the wavefront's first slice (t = 0, lane 0); tile t adds t * 32 * crow
     i64 crow;
     u32 lane_off;                        // byte offset of the lane's slices relative to that (the launcher keeps 64 * crow below 2^31)
-    u32 ilk;                             // 1: a slice is `cap` contiguous bytes; 32: its 16-byte pieces interleave with the tile's other 31 queries' (rec_off)
     u32 cnt[QT];                         // records of slice (t, lane) pushed so far (may exceed cap: the surplus is dropped at the flush)
     u32 prev[QT];                        // ... pushed before the current window: those are in the rings for sure
     u32 flushed[QT];                     // ... written to global memory (a multiple of 8)
     u32 qhead, qfill, old;               // queue: first entry, entries, entries pushed before the current window (wave-uniform)
     int probe;
 
-    __device__ __forceinline__ void init(u8* lds_, const Mx3Lds& L_, int wave_, int lane_, int qb, int sp, u32 cap_, i64 crow_, u8* cand8, int probe_, int il) {
+    __device__ __forceinline__ void init(u8* lds_, const Mx3Lds& L_, int wave_, int lane_, int qb, int sp, u32 cap_, i64 crow_, u8* cand8, int probe_) {
         lds = lds_; L = L_; wave = wave_; lane = lane_; cap = cap_; crow = crow_; probe = probe_;
-        qab = (u64*)(lds + L.qab) + wave * M3_QCAP;
-        qc = (u32*)(lds + L.qc) + wave * M3_QCAP;
-        q12_base = (u32)(L.qab + wave * (M3_QCAP * 12));
+        q12_base = (u32)(L.queue + wave * (M3_QCAP * 12));
         asm volatile("" : "+s"(q12_base));
         rings = lds + L.rings + wave * (64 * QT * M3_RING);
         ring_base = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)rings;
         const int h = lane >> 5, j = lane & 31;
-        // Interleaved record rows (SelArgs::il): the 32 queries of a tile share a region of 32 * crow bytes in which piece p16
-        // of slice s of query j sits at ((s * cap/16 + p16) * 32 + j) * 16 -- the lanes of a half-wavefront that flush the same
-        // piece of their slices write side by side, and the L2 sees whole lines instead of 8 bytes of a 128-byte line per slice
-        // (4.8x write amplification at C2, profiles/r03_pmc_traffic.json).
-        ilk = il ? 32u : 1u;
-        if (il) {
-            lane_off = (u32)(2 * sp + h) * cap * 32u + (u32)j * 16u;
-            tb0 = cand8 + (i64)(qb * M3_WPB + wave) * 64 * crow;
-        } else {
-            lane_off = (u32)j * (u32)crow + (u32)h * cap;
-            tb0 = cand8 + (i64)(qb * M3_WPB + wave) * 64 * crow + (i64)(2 * sp) * cap;
-        }
+        lane_off = (u32)j * (u32)crow + (u32)h * cap;
+        tb0 = cand8 + (i64)(qb * M3_WPB + wave) * 64 * crow + (i64)(2 * sp) * cap;
         qhead = qfill = old = 0;
 #pragma unroll
         for (int t = 0; t < QT; ++t) cnt[t] = prev[t] = flushed[t] = 0;
@@ -188,11 +169,6 @@ struct Mx3Drain {
     // ring of slice (t, lane): half * 64 + t * 32 + query-in-tile -- the low six bits are the tag a queue entry carries
     __device__ __forceinline__ int ring_index(const int t) const { return (lane >> 5) * 64 + t * 32 + (lane & 31); }
     __device__ __forceinline__ u8* slice(const int t) const { return tb0 + (i64)t * 32 * crow + lane_off; }
-    // byte offset of record p inside the lane's slice: whole 16-byte pieces are `ilk` pieces apart
-    __device__ __forceinline__ u32 rec_off(const u32 p) const {
-        if (__builtin_expect(ilk == 1u, 1)) return p;              // (wave-uniform: plain rows pay nothing for the other layout)
-        return (p & ~15u) * 32u + (p & 15u);
-    }
 
     // ---- owner side: completed 8-record pieces below limit[t] leave the ring with one aligned 8-byte store each ----
     // (a slice that is already full keeps advancing: its surplus pieces land on its last piece -- the query is flagged
@@ -209,7 +185,7 @@ struct Mx3Drain {
                 if (limit[t] - f >= 8u) {
                     const u8* ring = rings + ring_index(t) * M3_RING;
                     u8* tb = tb0 + (i64)t * 32 * crow;                // wave-uniform base; the lane's part fits 32 bits
-                    *(u64*)(tb + (lane_off + rec_off(min(f, cap - 8u)))) = *(const u64*)(ring + (f & 8u));
+                    *(u64*)(tb + (lane_off + min(f, cap - 8u))) = *(const u64*)(ring + (f & 8u));
                     flushed[t] = f + 8u;
                     need |= limit[t] - f >= 16u;
                 }
@@ -223,14 +199,8 @@ struct Mx3Drain {
         wave_lds_sync();
         if ((u32)lane < n && !(kProbes && (probe & 8))) {
             const u32 i = (qhead + (u32)lane) & (M3_QCAP - 1);
-#if HG_M3_Q12
             const u32* e = (const u32*)(lds + (q12_base + i * 12u));
             const u32 a = e[0], b = e[1], c = e[2];
-#else
-            const u64 ab = qab[i];
-            const u32 c = qc[i];
-            const u32 a = (u32)ab, b = (u32)(ab >> 32);
-#endif
             // entry: a = {query tag t * 32 + j : 6 | A : 21 | lane-half : 1 | supertile : 2 | buffer : 2}, b = {0 : 6 | B : 21 | position : 5}
             const u32 x = a & 63u, h = (a >> 27) & 1u, st = (a >> 28) & 3u, sel = a >> 30;
             u32 pos = b >> 27;                                        // slice position & 15 of the entry's first hit
@@ -283,7 +253,7 @@ struct Mx3Drain {
         const u8* ring_r = rings + ring_index(t) * M3_RING;
         u8* ring = rings + ring_index(t) * M3_RING;
         u8* out = slice(t);
-        for (u32 p = flushed[t]; p < cnt[t]; ++p) if (p < cap) out[rec_off(p)] = ring_r[p & (M3_RING - 1)];
+        for (u32 p = flushed[t]; p < cnt[t]; ++p) if (p < cap) out[p] = ring_r[p & (M3_RING - 1)];
         const u32 a21 = (wa >> 6) & 0x1FFFFFu, b21 = (wb >> 6) & 0x1FFFFFu, c6 = ((wc * 0x421u) >> 16) & 0x3Fu;
         u64 x = (u64)a21 | ((u64)b21 << 21) | ((u64)c6 << 42);
         const int ql = wave * 64 + t * 32 + (lane & 31);
@@ -308,7 +278,7 @@ struct Mx3Drain {
 #pragma unroll
             for (int k = 0; k < LW; ++k) any |= lp[k] & qlw[k];
             const u8 rec = make_rec8(d, any != 0);
-            if (pos < cap) out[rec_off(pos)] = rec;
+            if (pos < cap) out[pos] = rec;
             ring[pos & (M3_RING - 1)] = rec;
             ++pos;
         }
@@ -376,13 +346,8 @@ struct Mx3Drain {
             if (__builtin_amdgcn_inverse_ballot_w64(b)) {             // (the ballot IS the exec mask: no second compare)
                 const u32 ea = w[t][0] | ((u32)(lane & 31) | ((u32)t << 5) | ((u32)(lane >> 5) << 27)) | desc;
                 const u32 eb = w[t][1] | (cnt[t] << 27);
-#if HG_M3_Q12
                 u32* e = (u32*)(lds + (q12_base + slot * 12u));
                 e[0] = ea; e[1] = eb; e[2] = w[t][2];
-#else
-                qab[slot] = ((u64)eb << 32) | ea;
-                qc[slot] = w[t][2];
-#endif
             }
             cnt[t] = want[t];
             qfill += (u32)__builtin_popcountll(b);
@@ -410,7 +375,7 @@ struct Mx3Drain {
             const u32 f = flushed[t];
             if (cnt[t] > f) {
                 const u8* ring = rings + ring_index(t) * M3_RING;
-                *(u64*)(slice(t) + rec_off(min(f, cap - 8u))) = *(const u64*)(ring + (f & 8u));
+                *(u64*)(slice(t) + min(f, cap - 8u)) = *(const u64*)(ring + (f & 8u));
             }
         }
     }
@@ -470,7 +435,7 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
     u32 K[QT][3];
     bool far[QT];
     Mx3Drain<NW, LW> dr;
-    dr.init(mxlds, L, wave, lane, qb, sp, a.cap, a.crow, cand8, a.probe, a.il);
+    dr.init(mxlds, L, wave, lane, qb, sp, a.cap, a.crow, cand8, a.probe);
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = q0w + t * 32 + j;
@@ -535,8 +500,13 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
                 // rows past the table: anything (masked); the last chunk may overhang the table by < 16 B (allocation slack, see k_select_mx)
                 u8* dst = scl + (is_lab ? L.labels : 0) + hh * M3_WROWS * rowb + piece * 1024;
                 if (piece * 1024 + (int)lane16 < M3_WROWS * rowb) {
-                    if (off + 1024 <= lim) HG_GLDS16(tab + off + lane16, dst);
-                    else HG_GLDS16(tab + (off + lane16 < lim ? off + lane16 : 0), dst);
+                    // (the lane's offset is made opaque here: hoisted out of the window loop, `table + lane offset` is a 64-bit value per
+                    // table that lives across the whole kernel -- and, spilled, comes back behind an s_waitcnt vmcnt(0) that also
+                    // waits for the A fragments just requested: 0.609 -> 0.644 ms when a refactoring made the allocator choose it)
+                    u32 l16 = lane16;
+                    asm volatile("" : "+v"(l16));
+                    if (off + 1024 <= lim) HG_GLDS16(tab + off + l16, dst);
+                    else HG_GLDS16(tab + (off + l16 < lim ? off + l16 : 0), dst);
                 }
             }
         }
@@ -569,6 +539,8 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
         const u8* sa = mxlds + L.a + abuf * L.abuf;
 #pragma unroll
         for (int st = 0; st < M3_WS; ++st) {
+            // (requesting supertile st + 1's fragments while st's hits are pushed changes nothing -- 0.6092 vs 0.6090 ms: four
+            // wavefronts per SIMD hide the LDS latency; round 5)
             i32x4 af[3];
 #pragma unroll
             for (int f = 0; f < 3; ++f) af[f] = *(const i32x4*)(sa + ((st * 3 + f) * 64 + lane) * 16);

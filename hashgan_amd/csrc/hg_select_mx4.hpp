@@ -102,30 +102,19 @@ struct Mx4Drain {
     u8* tb0;                             // the wavefront's first slice (t = 0, lane 0); tile t adds t * 32 * crow
     i64 crow;
     u32 lane_off;                        // byte offset of the lane's slices relative to that (the launcher keeps 64 * crow below 2^31)
-    u32 ilk;                             // 1: a slice is `cap` contiguous bytes; 32: its 16-byte pieces interleave with the tile's other 31 queries' (rec_off)
     u32 cnt[QT];                         // records of slice (t, lane) pushed so far (may exceed cap: the surplus is dropped at the flush)
     u32 prev[QT];                        // ... pushed before the current window: those are in the rings for sure
     u32 flushed[QT];                     // ... written to global memory (a multiple of 8)
     u32 qhead, qfill, old;               // queue: first entry, entries, entries pushed before the current window (wave-uniform)
 
-    __device__ __forceinline__ void init(u8* lds_, const Mx4Lds& L_, int wave_, int lane_, int qb, int sp, u32 cap_, i64 crow_, u8* cand8, int il) {
+    __device__ __forceinline__ void init(u8* lds_, const Mx4Lds& L_, int wave_, int lane_, int qb, int sp, u32 cap_, i64 crow_, u8* cand8) {
         lds = lds_; L = L_; wave = wave_; lane = lane_; cap = cap_; crow = crow_;
         qab = (u64*)(lds + L.queue) + wave * M4_QCAP;
         rings = lds + L.rings + wave * (64 * QT * M4_RING);
         ring_base = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)rings;
         const int h = lane >> 5, j = lane & 31;
-        // Interleaved record rows (SelArgs::il): the 32 queries of a tile share a region of 32 * crow bytes in which piece p16
-        // of slice s of query j sits at ((s * cap/16 + p16) * 32 + j) * 16 -- the lanes of a half-wavefront that flush the same
-        // piece of their slices write side by side, and the L2 sees whole lines instead of 8 bytes of a 128-byte line per slice
-        // (4.8x write amplification at C2, profiles/r03_pmc_traffic.json).
-        ilk = il ? 32u : 1u;
-        if (il) {
-            lane_off = (u32)(2 * sp + h) * cap * 32u + (u32)j * 16u;
-            tb0 = cand8 + (i64)(qb * M4_WPB + wave) * 64 * crow;
-        } else {
-            lane_off = (u32)j * (u32)crow + (u32)h * cap;
-            tb0 = cand8 + (i64)(qb * M4_WPB + wave) * 64 * crow + (i64)(2 * sp) * cap;
-        }
+        lane_off = (u32)j * (u32)crow + (u32)h * cap;
+        tb0 = cand8 + (i64)(qb * M4_WPB + wave) * 64 * crow + (i64)(2 * sp) * cap;
         qhead = qfill = old = 0;
 #pragma unroll
         for (int t = 0; t < QT; ++t) cnt[t] = prev[t] = flushed[t] = 0;
@@ -133,11 +122,6 @@ struct Mx4Drain {
     // ring of slice (t, lane): half * 64 + t * 32 + query-in-tile -- the low six bits are the tag a queue entry carries
     __device__ __forceinline__ int ring_index(const int t) const { return (lane >> 5) * 64 + t * 32 + (lane & 31); }
     __device__ __forceinline__ u8* slice(const int t) const { return tb0 + (i64)t * 32 * crow + lane_off; }
-    // byte offset of record p inside the lane's slice: whole 16-byte pieces are `ilk` pieces apart
-    __device__ __forceinline__ u32 rec_off(const u32 p) const {
-        if (__builtin_expect(ilk == 1u, 1)) return p;              // (wave-uniform: plain rows pay nothing for the other layout)
-        return (p & ~15u) * 32u + (p & 15u);
-    }
     static __device__ __forceinline__ u32 flat(const u32 a, const u32 b) {       // {A, B} -> hit mask of the supertile, bit P <-> row P
         return ((a >> 7) & 0xFFFFu) | (((b >> 7) & 0xFFFFu) << 16);
     }
@@ -157,7 +141,7 @@ struct Mx4Drain {
                 if (limit[t] - f >= 8u) {
                     const u8* ring = rings + ring_index(t) * M4_RING;
                     u8* tb = tb0 + (i64)t * 32 * crow;                // wave-uniform base; the lane's part fits 32 bits
-                    *(u64*)(tb + (lane_off + rec_off(min(f, cap - 8u)))) = *(const u64*)(ring + (f & 8u));
+                    *(u64*)(tb + (lane_off + min(f, cap - 8u))) = *(const u64*)(ring + (f & 8u));
                     flushed[t] = f + 8u;
                     need |= limit[t] - f >= 16u;
                 }
@@ -220,7 +204,7 @@ struct Mx4Drain {
         const u8* ring_r = rings + ring_index(t) * M4_RING;
         u8* ring = rings + ring_index(t) * M4_RING;
         u8* out = slice(t);
-        for (u32 p = flushed[t]; p < cnt[t]; ++p) if (p < cap) out[rec_off(p)] = ring_r[p & (M4_RING - 1)];
+        for (u32 p = flushed[t]; p < cnt[t]; ++p) if (p < cap) out[p] = ring_r[p & (M4_RING - 1)];
         u32 x = flat(wa, wb);
         const int ql = wave * 64 + t * 32 + (lane & 31);
         u32 qcw[NW];
@@ -244,7 +228,7 @@ struct Mx4Drain {
 #pragma unroll
             for (int k = 0; k < LW; ++k) any |= lp[k] & qlw[k];
             const u8 rec = make_rec8(d, any != 0);
-            if (pos < cap) out[rec_off(pos)] = rec;
+            if (pos < cap) out[pos] = rec;
             ring[pos & (M4_RING - 1)] = rec;
             ++pos;
         }
@@ -339,7 +323,7 @@ struct Mx4Drain {
             const u32 f = flushed[t];
             if (cnt[t] > f) {
                 const u8* ring = rings + ring_index(t) * M4_RING;
-                *(u64*)(slice(t) + rec_off(min(f, cap - 8u))) = *(const u64*)(ring + (f & 8u));
+                *(u64*)(slice(t) + min(f, cap - 8u)) = *(const u64*)(ring + (f & 8u));
             }
         }
     }
@@ -403,7 +387,7 @@ void k_select_mx4(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
     u32 alive[QT];                                         // all ones / zero: a dead lane (query beyond Q, cut outside 0..127) harvests nothing
     bool far[QT];
     Mx4Drain<NW, LW> dr;
-    dr.init(mxlds, L, wave, lane, qb, sp, a.cap, a.crow, cand8, a.il);
+    dr.init(mxlds, L, wave, lane, qb, sp, a.cap, a.crow, cand8);
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = q0w + t * 32 + j;
@@ -474,8 +458,10 @@ void k_select_mx4(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
                 // rows past the table: anything (masked); the last chunk may overhang the table by < 16 B (allocation slack, see k_select_mx)
                 u8* dst = scl + (is_lab ? L.labels : 0) + hh * WROWS * rowb + piece * 1024;
                 if (piece * 1024 + (int)lane16 < WROWS * rowb) {
-                    if (off + 1024 <= lim) HG_GLDS16(tab + off + lane16, dst);
-                    else HG_GLDS16(tab + (off + lane16 < lim ? off + lane16 : 0), dst);
+                    u32 l16 = lane16;                                // (opaque: see k_select_mx3's staging -- no hoisted 64-bit `table + lane offset` to spill)
+                    asm volatile("" : "+v"(l16));
+                    if (off + 1024 <= lim) HG_GLDS16(tab + off + l16, dst);
+                    else HG_GLDS16(tab + (off + l16 < lim ? off + l16 : 0), dst);
                 }
             }
         }

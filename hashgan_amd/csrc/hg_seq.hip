@@ -6,14 +6,13 @@
 #include "hg_select_mx3.hpp"
 #include "hg_select_mx4.hpp"
 #include "hg_hist_mx.hpp"
-#include "hg_rank_lds.hpp"
 #include "hg_rank_cnt.hpp"
-#include "hg_rank_wave.hpp"
 #include "hg_rank_lean.hpp"
-#include "hg_rank_direct.hpp"
 #include "hg_rank_dense.hpp"
 
 // Segment geometry of the pair passes: ~target_units wavefront-sized units.
+constexpr i64 SAMPLE_RATIO = 2;      // the sampled pass works on segments this many times longer than the select pass's (= per segment pair)
+
 void make_geometry(hg_ctx* c) {
     Geo& g = c->geo;
     g.Q = (int)c->Q;
@@ -29,7 +28,7 @@ void make_geometry(hg_ctx* c) {
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     i64 L = (c->N + S - 1) / S;
-    const i64 lq = (c->opt_select_packed >= 3 && c->NW <= 2) ? 96 : 32;   // k_select_mx2 walks segments in 32-row tiles, k_select_mx3 in 48-row supertiles
+    const i64 lq = (c->opt_select_packed >= 3 && c->NW <= 2) ? 96 : 32;   // k_select_mx walks segments in 32-row tiles, k_select_mx3 in 48-row supertiles
     L = (L + lq - 1) / lq * lq;
     if (L < lq) L = lq;
     S = (c->N + L - 1) / L;
@@ -47,7 +46,7 @@ void make_geometry(hg_ctx* c) {
         // k_rank_lean takes at most 256 slices per query.  A target beyond that (few queries: C3's 2100 ask for 496 segments)
         // is cut to the whole rounds that 256 segments fill, when that is at least one: C3 396 -> 198 segments, one round of
         // blocks instead of two, k_rank_lean instead of k_rank_cnt: 0.277 -> 0.200 ms per step
-        if (mx3 && c->opt_rank_lean && c->opt_segments_for_lean && S > 256 && 128 * nQB >= slots) {
+        if (mx3 && c->opt_rank_lean && S > 256 && 128 * nQB >= slots) {
             k = 128 * nQB / slots;
             L = (c->N + 255) / 256;
             L = (L + lq - 1) / lq * lq;
@@ -76,7 +75,7 @@ void make_geometry(hg_ctx* c) {
 Geo hist_geometry(const hg_ctx* c) {
     Geo g = c->geo;
     if (g.hist_stride > 1 || c->hist_pairs) {
-        const i64 L = g.L * (c->hist_pairs ? 2 : c->opt_sample_ratio);
+        const i64 L = g.L * (c->hist_pairs ? 2 : SAMPLE_RATIO);
         g.L = L;
         g.S = (int)((g.N + L - 1) / L);
         g.nUnits = (i64)g.S * g.nQT;
@@ -94,9 +93,8 @@ bool hist_mx_applies(const hg_ctx* c, int stride, bool pairs_ok) {
         const bool pack16 = 2 * tiles_per_half * 16 < 65536;
         if ((size_t)WPB * (pack16 ? 1 : 2) * g.NB * 32 * 4 > 160u * 1024u) return false;
     }
-    return stride > 1 ? c->opt_sample_ratio == 2 : pairs_ok;
+    return stride > 1 ? SAMPLE_RATIO == 2 : pairs_ok;
 }
-static bool records_may_interleave(const hg_ctx* c);
 
 // The record pass of the current sequence: which kernel takes it (the launchers live in hg_pairs_valu.hip / hg_pairs_mx.hip).
 int launch_select(hg_ctx* c) {
@@ -105,18 +103,12 @@ int launch_select(hg_ctx* c) {
     // one-byte records (no index): only the matrix-core kernels of the bet produce them, and only when nobody wants the lists
     const bool mx = c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS);
     c->rec8 = mx && c->opt_compact && !c->want_lists && c->LW <= 2 && c->cap % 16 == 0 && c->crow * 64 < (1ll << 31);
-    c->rec_il = false;
     if (!c->optimistic && c->R * 4 >= c->n_total) { c->last_select = 2; return launch_select_dense(c, lw); }   // dense regime: most pairs are selected
     // three rows per accumulator + batched drain: codes of <= 64 bits, one-byte records (<= 128 classes).  (For <= 32 bits the
-    // second k-half of every MFMA is empty, and it still beats k_select_mx2's two rows per accumulator: 0.69 vs 0.85 ms at b = 32.)
-    if (NW <= 2 && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 5; c->rec_il = records_may_interleave(c); return launch_select_mx3(c, lw); }
+    // second k-half of every MFMA is empty, and it still beat round 2's two-rows-per-accumulator kernel: 0.69 vs 0.85 ms at b = 32.)
+    if (NW <= 2 && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M3_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 5; return launch_select_mx3(c, lw); }
     // codes of 65..128 bits: two rows per accumulator (8-bit fields) and the same drain
-    if ((NW == 3 || NW == 4) && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M4_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 6; c->rec_il = records_may_interleave(c); return launch_select_mx4(c, lw); }
-    // two rows per accumulator: wins for one-word codes (half the MFMAs: 0.92 vs 1.02 ms at b = 32); for 33-64 bits
-    // its cheaper harvest (0.36 vs 0.44 ms) is eaten by the wider queue entries (select_packed = 2 forces it)
-    if (mx && c->geo.L % 32 == 0 &&
-        (((c->opt_select_packed == 1 || c->opt_select_packed >= 3) && NW == 1) || (c->opt_select_packed == 2 && NW <= 2)))
-        { c->last_select = 4; return launch_select_mx2(c, lw); }
+    if ((NW == 3 || NW == 4) && c->opt_select_packed == 3 && c->rec8 && c->geo.L % M4_ROWS == 0 && (lw == 1 || lw == 2)) { c->last_select = 6; return launch_select_mx4(c, lw); }
     if (mx) { c->last_select = 3; return launch_select_mx(c, lw); }
     c->last_select = 1;
     return launch_select_valu(c, lw, c->optimistic);
@@ -142,14 +134,14 @@ template <int NW> i64 sampled_rows_t(Geo g, int stride, int ratio) {
 i64 sampled_rows(hg_ctx* c, int stride) {
     if (hist_mx_applies(c, stride, false)) return hist_mx_sampled_rows(c->geo, stride);
     switch (c->NW) {
-        case 1: return sampled_rows_t<1>(c->geo, stride, (int)c->opt_sample_ratio);
-        case 2: return sampled_rows_t<2>(c->geo, stride, (int)c->opt_sample_ratio);
-        case 3: return sampled_rows_t<3>(c->geo, stride, (int)c->opt_sample_ratio);
-        case 4: return sampled_rows_t<4>(c->geo, stride, (int)c->opt_sample_ratio);
-        case 5: return sampled_rows_t<5>(c->geo, stride, (int)c->opt_sample_ratio);
-        case 6: return sampled_rows_t<6>(c->geo, stride, (int)c->opt_sample_ratio);
-        case 7: return sampled_rows_t<7>(c->geo, stride, (int)c->opt_sample_ratio);
-        default: return sampled_rows_t<8>(c->geo, stride, (int)c->opt_sample_ratio);
+        case 1: return sampled_rows_t<1>(c->geo, stride, (int)SAMPLE_RATIO);
+        case 2: return sampled_rows_t<2>(c->geo, stride, (int)SAMPLE_RATIO);
+        case 3: return sampled_rows_t<3>(c->geo, stride, (int)SAMPLE_RATIO);
+        case 4: return sampled_rows_t<4>(c->geo, stride, (int)SAMPLE_RATIO);
+        case 5: return sampled_rows_t<5>(c->geo, stride, (int)SAMPLE_RATIO);
+        case 6: return sampled_rows_t<6>(c->geo, stride, (int)SAMPLE_RATIO);
+        case 7: return sampled_rows_t<7>(c->geo, stride, (int)SAMPLE_RATIO);
+        default: return sampled_rows_t<8>(c->geo, stride, (int)SAMPLE_RATIO);
     }
 }
 
@@ -280,18 +272,6 @@ int hg_plan(hg_ctx* c, int64_t R, const uint32_t* dev_hist_all, int G, int rank)
 
 // k_rank_fused in one of its modes: 0 = histogram + plan + placement in one launch (single shard),
 // 1 = histogram phase (several shards, before the exchange), 2 = placement phase (after k_plan).
-// the dense regime in one kernel (k_rank_direct): fits when a block's LDS holds the counters, the R-bit bitmap and a tile of rows
-static i64 rank_direct_tile(const hg_ctx* c, int64_t R) {
-    if (!c->opt_rank_direct || c->LW > 2 || c->NW > 8 || c->b > 127) return 0;
-    const i64 RW = (R + 63) / 64;
-    const i64 fixed = rank_direct_layout(c->b + 1, RW, 0).total;
-    i64 tile = (c->opt_rank_direct_lds * 1024 - fixed) & ~(i64)15;
-    if (tile > 252 * 256) tile = 252 * 256;             // a thread's chunk must fit its byte counters
-    const i64 n8 = (c->N + 7) / 8 * 8;
-    if (tile > n8) tile = n8;
-    return tile >= 8192 || tile >= n8 ? tile : 0;
-}
-
 // the dense regime through the byte matrix (hg_rank_dense.hpp): the counter columns always fit a block's LDS for codes of <= 126 bits
 static bool rank_dense_fits(const hg_ctx* c, int64_t R) {
     (void)R;
@@ -387,7 +367,7 @@ static int slices_rows(const hg_ctx* c) {
     return (!c->exact_mx && c->geo.NB / 2 + 2 < c->geo.NB) ? c->geo.NB / 2 + 2 : c->geo.NB;
 }
 static bool rank_slices_fits(const hg_ctx* c) {
-    return c->optimistic && c->rec8 && !c->rec_il && !c->want_lists && c->geo.S <= RD_THREADS && slices_rows(c) <= 126 &&
+    return c->optimistic && c->rec8 && !c->want_lists && c->geo.S <= RD_THREADS && slices_rows(c) <= 126 &&
            rank_dense_layout(slices_rows(c) + 1, c->RW, false).total <= 160 * 1024;
 }
 static int launch_rank_slices(hg_ctx* c, const u32* only) {
@@ -427,32 +407,11 @@ static int rank_leftovers_inline(hg_ctx* c, int mode, bool use_recip) {
 // Which LDS-resident rank kernel a bet's one-byte records will meet -- decided from what is known BEFORE the select runs (R, the
 // slices' capacity, the segment count, options), because the select writes the interleaved record layout (SelArgs::il) only for
 // the kernel that reads it, k_rank_lean (k_rank_fused, the general kernel behind every path, reads both layouts).
-struct WavePlan { bool ok; i64 r2; int nbc, wpb; size_t lds; };
-static WavePlan rank_wave_plan(const hg_ctx* c, int mode) {
-    const Geo& g = c->geo;
-    WavePlan w{false, 0, 0, 1, 0};
-    if (!(c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_wave > 0 && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
-          g.S <= RW_SMAX)) return w;
-    const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
-    i64 r2 = (i64)(0.1 * (double)c->opt_rank_wave * (double)c->R * share) + 256;
-    if (r2 < 1024) r2 = 1024;
-    r2 = (r2 + 63) / 64 * 64;
-    if (r2 > (i64)c->opt_rank_wave_max) r2 = 0;                 // long lists: k_rank_cnt / k_rank_lean
-    w.nbc = (mode == 0 && !c->exact_mx && c->G == 1) ? g.NB / 2 + 2 : 0;
-    const RankWaveLds L = rank_wave_layout(g.NB, c->RW, g.S, (int)r2, w.nbc);
-    // wavefronts per block: the split that wastes the least of a CU's 160 KB
-    const int fit1 = (int)(160 * 1024 / L.per_wave), fit2 = 2 * (int)(160 * 1024 / (2 * L.per_wave));
-    w.wpb = fit2 >= fit1 ? 2 : 1;
-    w.r2 = r2;
-    w.lds = (size_t)w.wpb * L.per_wave;
-    w.ok = r2 > 0 && fit1 >= 4;
-    return w;
-}
 struct LeanPlan { bool ok; int nbc, psp; i64 rb; };
 static LeanPlan rank_lean_plan(const hg_ctx* c, int mode) {
     const Geo& g = c->geo;
     LeanPlan l{false, 0, 1, 0};
-    if (!(c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && c->opt_rank_lean && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
+    if (!(c->optimistic && c->opt_rank_cnt && c->opt_rank_lean && (mode == 0 || mode == 3) && c->rec8 && !c->want_lists &&
           g.S <= 256 && (c->cap & 15u) == 0 && c->cap <= 1024 && g.R <= 60000)) return l;
     const int nbc = rank_cnt_maxb(g.NB) + 2 < g.NB ? rank_cnt_maxb(g.NB) + 2 : 0;
     const int nbc_eff = nbc ? nbc : (g.NB < 128 ? g.NB : 128);
@@ -477,60 +436,13 @@ static LeanPlan rank_lean_plan(const hg_ctx* c, int mode) {
     l.ok = nbc_eff <= 63 && L.total <= 64 * 1024 && rb >= 16 && (rb >= least || rb == all);
     return l;
 }
-// (called by launch_select once rec8, cap and crow are set): the records may interleave iff k_rank_lean will read them
-static bool records_may_interleave(const hg_ctx* c) {
-    if (!c->opt_interleave || !c->rec8) return false;
-    return rank_lean_plan(c, 0).ok;                    // (k_rank_lean is tried first; its plan does not depend on the mode)
-}
-
 // leftovers_only: the second half of a fused step -- k_rank_cnt has run (with its AP epilogue) and flagged in bigq the queries
 // it declined; rank just those with the general kernel
 static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = false) {
     const Geo& g = c->geo;
     if (c->dense_rank && mode == 0) return launch_rank_dense(c);
-    if (c->direct_rank && mode == 0) {
-        const i64 tile = rank_direct_tile(c, g.R);
-        if (tile > 0) {
-            HG_TRY(c->err.reserve(16));
-            HG_TRY(c->qbad.reserve((size_t)g.Qpad * 4));
-            const RankDirectLds L = rank_direct_layout(g.NB, c->RW, (int)tile);
-            if (L.total > 64 * 1024)
-                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_direct), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-            // hg_map: the AP comes out of the kernel's epilogue (one launch less, the bitmap never re-read)
-            bool use_recip = false;
-            const bool fuse = c->fuse_ap && c->opt_fuse_ap && !c->want_lists && L.bm % 8 == 0;
-            if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
-            const bool fused = fuse && use_recip;
-            RankDirectArgs da{c->qc.as<u32>(), c->qlab.as<u64>(), c->db.as<u32>(), c->dblab.as<u64>(), c->err.as<int>(), c->qbad.as<u32>(),
-                              c->RW, (int)tile, c->want_lists ? 1 : 0, fused ? c->shapes.as<ApShape>() : nullptr,
-                              fused ? c->ap_recip.as<double>() : nullptr, c->ap.as<double>(), c->rel.as<u32>()};
-            c->t_begin(KI_RANK_FUSED);
-            hipLaunchKernelGGL(k_rank_direct, dim3(g.Q), dim3(256), (size_t)L.total, c->stream, da, c->out_idx.as<u32>(), c->out_dist.as<u8>(),
-                               c->mbits.as<u32>(), g);
-            c->t_end();
-            c->last_rank = 5;
-            c->ap_fused = fused;
-            return c->check_launch("k_rank_direct");
-        }
-    }
-    int nwav = c->opt_rank_waves ? (int)c->opt_rank_waves
-                                 : ((c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4);   // records per query ~ 3R / R
-    // k_rank_lds: the query's records resident in LDS -- room for ~2.5 R per query (the bet keeps 1.3-2 R),
-    // at most 64 KiB per block; queries with more are left to k_rank_fused (flagged in bigq)
-    bool use_lds = false;
-    i64 recs = 0;
-    const size_t fixed = ((size_t)5 * g.NB + 8 + 4 + 8 + 2 * (size_t)c->RW + (size_t)g.S + 2) * 4;
-    const size_t per_rec = c->want_lists ? 6 : 2;
-    if (c->optimistic && c->opt_rank_lds) {
-        const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);    // this shard's part of the list
-        recs = (i64)(2.5 * (double)c->R * share) + 2048;   // small R: the guess's safety margin is relatively larger (R = 100 keeps ~4 R)
-        const i64 fit = fixed < 64 * 1024 ? (i64)((64 * 1024 - fixed) / per_rec) : 0;
-        if (recs > fit) recs = fit;
-        recs = recs / 64 * 64;
-        use_lds = (double)recs >= 2.0 * (double)c->R * share && recs >= 64;
-        if (use_lds) nwav = 4;                        // the two kernels share hwq's [Q][4][NB] layout
-    }
-    if (leftovers_only && !c->opt_rank_waves && c->R >= 1024) nwav = 16;   // a handful of blocks (mode 0: no hwq): what counts is one block's latency
+    int nwav = (c->optimistic ? 3 * c->R : c->R) >= 16384 ? 16 : 4;   // k_rank_fused's wavefronts per query, by the records per query (~ 3R / R)
+    if (leftovers_only && c->R >= 1024) nwav = 16;   // a handful of blocks (mode 0: no hwq): what counts is one block's latency
     const size_t fixed_words = (size_t)(nwav + 1) * g.NB + 8;
     const int bits_lds = (fixed_words + 2 * (size_t)c->RW) * 4 <= 64 * 1024;
     if (mode != 1 && !bits_lds && !leftovers_only) HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
@@ -551,33 +463,6 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
     if (!leftovers_only) c->last_rank = 1;                // k_rank_fused unless one of the LDS-resident kernels takes the lists
     if (leftovers_only) { only = c->bigq.as<u32>(); counted = true; }
     const LeanPlan lp = rank_lean_plan(c, mode);
-    if (!counted && !c->rec_il && !lp.ok) {
-        // (k_rank_lean first wherever it applies: round 4's kernel beats this one on short lists too -- Q = 10k, N = 1M, R = 100: 0.066 ms
-        // with the AP against 0.092 + k_ap 0.017; a G = 8 shard of C4: 0.049 against 0.115)
-        // one wavefront per query (k_rank_wave): no block barriers, 5 KB + the records of LDS per query in flight
-        // ... which pays for SHORT lists only (a sharded rank's share of R, a small R): a wavefront walks its query's records
-        // with 64 lanes where k_rank_cnt has 256, and at C2's 6500 records (16 KB of LDS per query, 10 in flight per CU) it
-        // is slower, 0.23 vs 0.19 ms; at 800 records (7 KB, 22 in flight) it wins, 0.105 vs 0.134 ms.
-        const WavePlan wp = rank_wave_plan(c, mode);
-        const i64 r2 = wp.r2;
-        const int nbc = wp.nbc, wpb = wp.wpb;
-        if (wp.ok) {
-            HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
-            RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
-                           c->cap, c->crow, 0, 1, c->RW, (int)r2, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
-                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc};
-            const size_t lds = wp.lds;
-            if (lds > 64 * 1024)
-                HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            c->t_begin(KI_RANK_LDS);
-            hipLaunchKernelGGL(k_rank_wave, dim3(grid_for(g.Q, wpb)), dim3(64 * wpb), lds, c->stream, c->cand.as<u8>(), la, c->mbits.as<u32>(), g);
-            c->t_end();
-            HG_TRY(c->check_launch("k_rank_wave"));
-            c->last_rank = 4;
-            only = c->bigq.as<u32>();                // k_rank_fused below ranks what this path declined
-            counted = true;
-        }
-    }
     if (!counted) {
         // the lean counting sort (k_rank_lean): the whole record row in one coalesced read, piecewise compaction, chunks in registers
         const int nbc = lp.nbc, psp = lp.psp;
@@ -593,7 +478,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
                            c->cap, c->crow, 0, 1, c->RW, (int)rb, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
                            c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), nbc,
                            fuse ? c->shapes.as<ApShape>() : nullptr, fuse && use_recip ? c->ap_recip.as<double>() : nullptr,
-                           c->ap.as<double>(), c->rel.as<u32>(), fuse ? c->err.as<u32>() + 1 : nullptr, cut, psp, c->rec_il ? 1 : 0};
+                           c->ap.as<double>(), c->rel.as<u32>(), fuse ? c->err.as<u32>() + 1 : nullptr, cut, psp};
             c->t_begin(KI_RANK_LDS);
             hipLaunchKernelGGL(k_rank_lean, dim3(padded_grid(g.Q)), dim3(256), (size_t)L.total, c->stream, c->cand.as<u8>(), la, c->mbits.as<u32>(), g);
             c->t_end();
@@ -612,7 +497,7 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
         // long lists of a bet (beyond k_rank_lean's LDS): k_rank_dense's two passes over the query's record slices, thread = part of a slice
         return launch_rank_slices(c, nullptr);
     }
-    if (!counted && !c->rec_il && c->optimistic && c->opt_rank_lds && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
+    if (!counted && c->optimistic && c->opt_rank_cnt && (mode == 0 || mode == 3)) {
         // per-thread counting sort (k_rank_cnt): byte counters for every distance + a tile of the records, <= 64 KiB per
         // block; lists longer than a tile are ranked tile by tile
         const double share = (double)c->N / (double)(c->n_total > 0 ? c->n_total : 1);
@@ -660,28 +545,11 @@ static int launch_rank(hg_ctx* c, int mode, int nbits, bool leftovers_only = fal
             counted = true;
         }
     }
-    if (use_lds && !counted) {
-        {
-            HG_TRY(c->bigq.reserve((size_t)g.Qpad * 4));
-            if (mode != 0) HG_TRY(c->hwq.reserve((size_t)g.Q * nwav * g.NB * 4));
-            RankLdsArgs la{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(), c->bigq.as<u32>(),
-                           c->cap, c->crow, c->want_lists ? 1 : 0, c->rec8 ? 1 : 0, c->RW, (int)recs, mode, c->hwq.as<u32>(), c->hown.as<u32>(),
-                           c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(), c->tie_before.as<u32>(), c->posbase.as<u32>(), 0};
-            const size_t lb = fixed + (size_t)recs * per_rec;
-            c->t_begin(KI_RANK_LDS);
-            hipLaunchKernelGGL(k_rank_lds<4>, dim3(g.Q), dim3(256), lb, c->stream, c->cand.as<u64>(), la, c->out_idx.as<u32>(),
-                               c->out_dist.as<u8>(), c->mbits.as<u32>(), nbits, g);
-            c->t_end();
-            HG_TRY(c->check_launch("k_rank_lds"));
-            c->last_rank = 2;
-            only = c->bigq.as<u32>();                // k_rank_fused below only ranks what did not fit
-        }
-    }
     RankArgs ra{c->sl_cnt.as<u32>(), c->tot.as<u32>(), c->failq.as<u32>(), c->err.as<int>(), c->qbad.as<u32>(),
                 mode, c->hwq.as<u32>(), c->hown.as<u32>(), c->t.as<int>(), c->cnt_lt.as<u32>(), c->quota.as<u32>(),
                 c->tie_before.as<u32>(), c->posbase.as<u32>(),
                 c->optimistic ? c->cap : 256u, c->crow, c->optimistic ? 0 : 1, c->want_lists ? 1 : 0, bits_lds, c->RW, only,
-                c->direct_rank ? 1 : 0, c->rec8 ? 1 : 0, c->db.as<u32>(), c->dblab.as<u64>(), c->qc.as<u32>(), c->qlab.as<u64>(), c->rec_il ? 1 : 0};
+                c->direct_rank ? 1 : 0, c->rec8 ? 1 : 0, c->db.as<u32>(), c->dblab.as<u64>(), c->qc.as<u32>(), c->qlab.as<u64>()};
     const size_t lds_bytes = (fixed_words + (bits_lds ? 2 * (size_t)c->RW : 0)) * 4;
     c->t_begin(mode == 1 ? KI_CAND_HIST : KI_RANK_FUSED);
     if (nwav == 16)
@@ -1232,19 +1100,13 @@ static int enqueue_all_rows(hg_ctx* c, int64_t R) {
 }
 
 static int enqueue_exact(hg_ctx* c, int64_t R) {
-    // N/8 < R <= N through the byte matrix (k_dense_bytes + k_rank_dense: R = N/2 of N = 1M 68.8 -> 16.3 ms, C1 0.35 -> 0.19 ms);
-    // "rank_direct" = 2 keeps the round-3 kernel for that regime
-    if (R * 8 > c->N && c->opt_all_rows && c->opt_rank_direct != 2 && rank_dense_fits(c, R)) {
+    // N/8 < R <= N through the byte matrix (k_dense_bytes + k_rank_dense: R = N/2 of N = 1M 68.8 -> 16.3 ms, C1 0.35 -> 0.19 ms)
+    if (R * 8 > c->N && c->opt_all_rows && rank_dense_fits(c, R)) {
         c->dense_rank = true;
         return enqueue_all_rows(c, R);
     }
     if (c->N == c->n_total && R == c->N && c->opt_all_rows && c->LW <= 2 && c->NW <= 8)
-        return enqueue_all_rows(c, R);                 // one-shot calls are single-shard
-    // (k_rank_direct ranks ANY R from the rows themselves, but with one block per query it re-reads the whole database per
-    // query and runs one wavefront per SIMD: measured against k_hist + k_select + k_rank_fused it loses for N/8 < R < N --
-    // 15.7 vs 12.3 ms at N = 200k, R = 100k; 82 vs 70 ms at N = 1M, R = 500k -- so only "rank_direct" = 2 routes that regime to it)
-    if (c->opt_rank_direct == 2 && c->N == c->n_total && R * 8 > c->N && c->opt_all_rows && !c->is_sub && rank_direct_tile(c, R) > 0)
-        return enqueue_all_rows(c, R);
+        return enqueue_all_rows(c, R);                 // one-shot calls are single-shard; codes / label sets the byte matrix does not take: k_rank_fused walks the rows
     HG_TRY(do_hist(c, 1));
     HG_TRY(do_plan(c, R, nullptr, 1, 0));
     return do_select(c);
@@ -1255,7 +1117,7 @@ static int enqueue_exact(hg_ctx* c, int64_t R) {
 // fixed-capacity slices -> the bet's rank stage, which cuts the ties at the quota.  Nothing is guessed, so the only way
 // this can fail is a slice overflowing its capacity (clustered rows): *err then, and the caller runs enqueue_exact.
 static bool exact_mx_applies(const hg_ctx* c, int64_t R) {
-    return c->opt_exact_mfma && c->opt_select_mfma && c->N == c->n_total && R * 8 <= c->N && c->N >= 65536 && !c->is_sub;
+    return c->opt_select_mfma && c->N == c->n_total && R * 8 <= c->N && c->N >= 65536 && !c->is_sub;
 }
 static int enqueue_exact_mx(hg_ctx* c, int64_t R) {
     HG_TRY(do_hist(c, 1, true, true));                 // per segment pair on the matrix cores where that applies
@@ -1468,7 +1330,7 @@ static int capture_step(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     sg.graph = gr; sg.exec = ex;
     sg.epoch = g_alloc_epoch; sg.cfg = c->cfg_epoch; sg.R = R; sg.timing = c->timing;
     sg.stage = c->stage; sg.optimistic = c->optimistic; sg.lists_valid = c->lists_valid; sg.cap = c->cap; sg.crow = c->crow;
-    sg.RW = c->RW; sg.geo = c->geo; sg.ap_fused = c->ap_fused; sg.rec8 = c->rec8; sg.rec_il = c->rec_il;
+    sg.RW = c->RW; sg.geo = c->geo; sg.ap_fused = c->ap_fused; sg.rec8 = c->rec8;
     c->graph_captures++;
     return HG_OK;
 }
@@ -1529,7 +1391,7 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
                     // what the captured enqueue functions leave behind on the host side
                     HG_TRY(set_R(c, R, 1, 0));
                     c->geo = sg.geo; c->RW = sg.RW; c->stage = sg.stage; c->optimistic = sg.optimistic; c->lists_valid = sg.lists_valid;
-                    c->cap = sg.cap; c->crow = sg.crow; c->err_zeroed = false; c->ap_fused = sg.ap_fused; c->rec8 = sg.rec8; c->rec_il = sg.rec_il;
+                    c->cap = sg.cap; c->crow = sg.crow; c->err_zeroed = false; c->ap_fused = sg.ap_fused; c->rec8 = sg.rec8;
                     c->graph_replays++;
                     launched = true;
                 }
@@ -1634,7 +1496,7 @@ static int run_oneshot(hg_ctx* c, int64_t R, bool lists, bool with_ap) {
     c->fuse_ap = false;
     HG_TRY(rce);
     if (with_ap) {
-        if (c->ap_fused) { c->ap_staged = false; c->stage |= ST_AP; }     // k_rank_direct's epilogue left the APs
+        if (c->ap_fused) { c->ap_staged = false; c->stage |= ST_AP; }     // a rank kernel's epilogue left the APs
         else HG_TRY(do_ap(c));
     }
     c->ap_fused = false;                               // (no leftovers on this path: nothing for finish_leftovers)

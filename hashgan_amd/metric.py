@@ -152,8 +152,7 @@ def _check_shapes(q_codes, db_codes, q_labels, db_labels, R):
 def _kind(ctx, which):
     """What hg_set_*_f32 found in a float table: 'ones' (every entry +1: reads as either spelling), 'pm1' (every
     entry +-1), 'bits' (every entry 0/1), 'ternary' (-1/0/+1 mixed) or 'real'."""
-    p = "q_" if which else "db_"
-    other, zeros, neg = ctx.get_stat(p + "nonbinary"), ctx.get_stat(p + "zeros"), ctx.get_stat(p + "minus_ones")
+    other, zeros, neg, _ = ctx.census(which)
     if other:
         return "real"
     if not zeros:
@@ -199,7 +198,7 @@ def _rank(eng, q_codes, q_labels, R, mode):
                          "features to MAPs.get_maps_by_feature, which ranks them by inner product like metric.py:13" % (qk, dk))
     if q_codes.shape[1] > 255:                        # (the loaders take up to 255 columns)
         raise ValueError("inner-product ranking supports up to 255 features (have %d)" % q_codes.shape[1])
-    if not eng.ctx.get_stat("db_floats"):             # a +-1 database whose floats stayed on the host: bring them over now
+    if not eng.ctx.census(0)[3]:             # a +-1 database whose floats stayed on the host: bring them over now
         src = eng.db_src
         _load_database(eng, src[0], src[1], floats=1)
         eng.ctx.set_queries_f32(q_codes, q_labels)

@@ -286,10 +286,9 @@ class HipShardEngine:
         if boost >= 64:
             self.ctx.set_option("cap_boost", 1)
             return False
+        # (raising "cap_boost" also tells the library that the lost attempt is retried within the same call: it does not count
+        # towards "two calls in a row lost their bets" -- hg_bet_eligible -- only the attempt a call gives up on does)
         self.ctx.set_option("cap_boost", boost * 8)
-        # the lost attempt is retried within the same call: it does not count towards "two calls in a row lost their bets"
-        # (hg_bet_eligible) -- only the attempt a call gives up on does
-        self.ctx.set_option("forgive_lost_bet", 1)
         return True
 
     def ranked_merge_ok(self, world):

@@ -76,7 +76,7 @@ int hg_set_queries(hg_ctx* ctx, const uint64_t* host_codes, const uint64_t* host
  * database is not a +-1 code, 1 always, 0 never; the queries' floats follow the database's.
  * *bad_codes counts feature entries outside {-1, 0, +1}, *bad_labels label entries outside
  * {0, 1}: the caller decides what non-binary features mean (the Python mirror ranks them by inner product
- * like metric.py:13-14 unless binarize=True); hg_get_stat has the finer census (zeros, minus ones). */
+ * like metric.py:13-14 unless binarize=True); hg_get_census has the finer census (zeros, minus ones). */
 int hg_set_database_f32(hg_ctx* ctx, const float* host_features, const int64_t* host_labels, int64_t N, int b, int C,
                         int64_t idx_base, int64_t n_total, int64_t* bad_codes, int64_t* bad_labels);
 int hg_set_queries_f32(hg_ctx* ctx, const float* host_features, const int64_t* host_labels, int64_t Q,
@@ -253,55 +253,42 @@ int hg_synchronize(hg_ctx* ctx);
 int hg_set_stream(hg_ctx* ctx, void* hip_stream);
 
 /* ---- tuning and measurement -------------------------------------------------- */
-/* key: "stage_sync" (see hg_set_stream), "target_units" (wavefront-sized units the pair passes are split into),
- * "min_segment" (rows), "max_segments", "optimistic" (0/1: one-shot calls may bet on a sampled
- * threshold -- verified on device, exact fallback), "sample_stride" (0 = auto),
- * "guess_sigma", "staged_lists" (0/1: hg_select materialises idx/dist lists),
- * "cand_budget_x10" (record budget of the bet per query, tenths of R), "rank_waves" (0 = auto, 4, 16),
- * "select_mfma" (1: the bet's select pass runs on the matrix cores -- fp4 MFMA distance tiles,
- * k_select_mx; 0: vector-ALU xor+popcount k_select; same records either way), "probe_select" (probe build only --
- * python -m hashgan_amd.build --probes: bits 2/4/8 switch parts of the matrix-core kernels' drain off; the bet
- * then fails and the exact sequence runs, so results stay right; the production library refuses the key),
- * "rank_direct" (1, default: R = N on one shard is ranked straight from the packed tables by one counting-sort kernel,
- * k_rank_direct, when its LDS fits; 2: also N/8 < R < N; 0: k_rank_fused's direct mode), "rank_direct_lds" (80: KB of LDS per block),
- * "rank_wave" (40, default: the bet's rank stage runs one wavefront per query, k_rank_wave, when a query's list of one-byte
- * records is short -- capacity value/10 x the shard's share of R + 256 records of LDS per query, used when that is at most
- * "rank_wave_max" = 4608 records: a sharded rank, a small R; 0 = always the block-per-query k_rank_cnt),
- * "select_packed" (several rows per MFMA accumulator: 3, default = k_select_mx3 (three rows through per-row MX scales,
- * batched drain) for codes of <= 64 bits with one-byte records, k_select_mx2 (two rows) for <= 32 bits otherwise; 1 =
- * k_select_mx2 for <= 32 bits only, 2 = k_select_mx2 up to 64 bits, 0 = never), "rank_lds" (0/1), "rank_cnt" (0/1:
- * the bet's rank stage as a per-thread counting sort, k_rank_cnt),
- * "host_pack", "keep_floats", "pack_threads" (hg_set_*_f32, see there), "second_bet" (1, default: a one-shot bet that too many queries lost is retried once with twice the margin and record
- * budget before the exact two-pass sequence runs; if that loses too the slices are widened -- "cap_boost" x8, then x64, kept for
- * the next calls on this database: hits crowded into few segments, e.g. rows stored class by class),
- * "cap_boost" (1..4096: multiplier on the slices' record budget; every database load sets it back to 1; the sharded
- * sequence raises it on all ranks alike after a lost bet, sharded.HipShardEngine.widen_slices), "compact_records" (1, default: when no ranked lists are wanted the matrix-core select writes one-byte records
- * {match, dist} through per-slice LDS rings instead of 8-byte {idx, dist, match} records),
- * "hist_mfma" (histogram passes -- the sampled pass of the bet, the full pass of the one-shot exact sequence: 2, default:
- * the integer matrix instruction delivers the counter addresses, k_hist_i8, codes of <= 128 bits; 1: fp4 distances,
- * k_hist_mx; 0: vector ALU), "exact_mfma" (1, default: the one-shot exact sequence selects on the matrix cores when
- * R << N), "ap_recip" (1, default: the AP kernel replaces its division by three multiply-adds against a table of
- * correctly rounded reciprocals of the ranks -- the same bits; 0: divide), "lds_pad" (extra LDS per block of the
- * matrix-core select: occupancy experiments),
- * "real_mfma" (real-valued select pass -- 2, default: bfloat16 matrix-core filter with a rigorous margin, then the exact
- * float32 chain for the rows it keeps; 1: every pair exactly on the float32 matrix-core instruction; 0: vector ALU; same
- * lists either way), "real_sort_lds" (1, default: after the filter a query's records are ranked by one LDS-resident
- * kernel when they fit; 0: always the global-memory radix passes), "real_groups" (1, default: without a cut -- every row a
- * record, R = N -- the rows are split by score range into LDS-sized groups and ordered group by group; the exact float32
- * pair pass then stands in for filter + rescore; 0: the radix passes),
- * "real_queries_per_lane", "real_segment_bytes" (real-valued path), "step_graph" (0, default: always enqueue kernel
- * by kernel; 1: hg_map captures its one-shot sequence into a hipGraph the second time it sees the same problem and
- * replays it afterwards). */
+/* Engine options (33 keys; DESIGN.md section 9 lists every key with its default and the test that sets it):
+ *   geometry      "target_units" (16384: wavefront-sized units the pair passes are split into), "min_segment" (256 rows), "max_segments" (2048)
+ *   the bet       "optimistic" (1: one-shot calls bet on a sampled threshold -- verified on the device, exact fallback), "sample_stride" (0 = auto: every
+ *                 24th tile of 16 rows), "guess_sigma" (5: margin of the guess in standard deviations of the sampled count), "cand_budget_x10" (40: record
+ *                 budget per query in tenths of R), "second_bet" (1: a lost bet is retried once with twice the margin before the exact sequence),
+ *                 "cap_boost" (1..4096: multiplier of the slices' capacity; every database load sets it back to 1, lost bets raise it; raising it also
+ *                 forgives the sharded bet just lost), "crowd_probe" (1: the first bet on a database measures how its near rows crowd and widens the slices)
+ *   kernels       "select_mfma" (1: the pair passes of bet and exact sequence on the matrix cores; 0: vector-ALU xor + popcount -- same records),
+ *                 "select_packed" (3: k_select_mx3 / k_select_mx4, several distances per accumulator, one-byte records; else k_select_mx),
+ *                 "compact_records" (1: one-byte records {match, dist} when no ranked lists are wanted), "hist_mfma" (2: k_hist_i8; 1: k_hist_mx; 0: k_hist),
+ *                 "rank_lds" (2: k_rank_lean where it applies, else k_rank_cnt; 1: k_rank_cnt; 0: k_rank_fused only), "rank_slices" (7000: smallest R whose
+ *                 bet is ranked by k_rank_dense<slices>; 0: off), "rank_dense" (1: N/8 < R <= N through the byte matrix), "rank_dense_gbm" (-1: auto; 1 / 0:
+ *                 its bitmap in global memory / LDS), "dense_budget_mb" (16384), "all_rows_shortcut" (1: R = N needs no histogram and no plan),
+ *                 "fuse_ap" (1: the AP leaves from the rank kernel's epilogue), "inline_leftovers" (1: queries the rank kernel declined are ranked within
+ *                 the next step's stream), "ap_recip" (1: the AP's division as three multiply-adds against correctly rounded reciprocals -- the same bits)
+ *   staging       "stage_sync" (1; 0: staged calls and collectives only enqueue, see hg_set_stream), "defer_verdict" (0; 1: hg_rank does not wait for the
+ *                 bet's verdict), "staged_lists" (1: the staged hg_select materialises the idx / dist lists), "step_graph" (0; 1: hg_map replays its
+ *                 sequence as a hipGraph), "timing_every" (1: kernel timing brackets every n-th step)
+ *   loading       "host_pack" (1: hg_set_*_f32 pack on the host's cores before the upload), "keep_floats" (hg_set_*_f32: 0 never / 1 always / 2 = only
+ *                 if not a +-1 code: keep the float table on the device)
+ *   real-valued   "real_mfma" (2: bf16 matrix-core filter + exact float32 rescoring; 1: every pair on the float32 matrix-core instruction; 0: vector
+ *                 ALU), "real_sort_lds" (1: ranked by the LDS-resident kernel when the records fit), "real_groups" (1: lists beyond the LDS ordered group by group)
+ *   ("probe_select" exists only in the measurement build, python -m hashgan_amd.build --probes) */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
-/* key: "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly), "optimistic_requeried"
- * (single queries rerun exactly after losing their bet), "optimistic_rebets" (second and widened bets), "cap_boost", "real_cap_boost" (the same for hg_map_real), "real_grouped" (the last real-valued ranking ordered lists beyond the LDS group by group), "last_optimistic", "device_bytes", "segments",
- * "segment_rows", "slice_capacity", "record_row"; census of the float tables loaded by hg_set_*_f32 --
- * "db_nonbinary" / "q_nonbinary" (entries outside {-1,0,+1}), "db_zeros" / "q_zeros", "db_minus_ones" /
- * "q_minus_ones" -- from which the caller tells +-1 codes, {0,1} bits and real-valued features apart;
- * "db_floats" / "q_floats" (the float tables are on the GPU), "probe_build", "graph_captures", "graph_replays";
- * of the last real-valued ranking: "real_attempts" (1 = the first sampled cut held), "real_filtered" (filter + rescore
- * ran), "real_lds_ranked" (the LDS-resident rank kernel produced the lists). */
+/* Counters and facts about the last call (18 keys): "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly),
+ * "optimistic_requeried" (single queries rerun exactly after losing their bet), "optimistic_rebets" (second and widened bets), "last_optimistic",
+ * "rank_leftovers" (queries the LDS-resident rank kernel left to the general one), "select_variant" (1 k_select, 2 k_select_dense, 3 k_select_mx,
+ * 5 k_select_mx3, 6 k_select_mx4), "rank_variant" (1 k_rank_fused, 3 k_rank_cnt, 6 k_rank_lean, 7 k_rank_dense, 8 k_rank_dense<slices>), "ap_fused",
+ * "cap_boost", "crowding_x100", "segments", "records_kept" (records the last bet's select left in the slices: a download, not part of a step),
+ * "device_bytes", "graph_replays"; real-valued path: "real_attempts", "real_cap_boost", "real_path" (bit 0 filter + rescoring, bit 1 ranked in LDS,
+ * bit 2 lists ordered group by group). */
 int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
+/* What hg_set_database_f32 (queries = 0) / hg_set_queries_f32 (queries = 1) found in the float table: out[0] entries outside
+ * {-1, 0, +1}, out[1] zeros, out[2] minus ones, out[3] = 1 if the float table is resident on the device -- from which the caller
+ * tells +-1 codes (ranked by Hamming distance), {0,1} bits and real-valued features (ranked by inner product, metric.py:13) apart. */
+int hg_get_census(hg_ctx* ctx, int queries, int64_t out[4]);
 /* Work buffers only grow; hg_trim frees everything except the resident code/label/feature tables
  * (stat "device_bytes" reports what the context holds). */
 int hg_trim(hg_ctx* ctx);

@@ -270,7 +270,7 @@ def test_bursts_of_hits_take_the_direct_route():
             if compact:
                 assert ctx.get_stat("select_variant") == 6
         assert np.array_equal(res[0], res[1], equal_nan=True)
-        # and with short codes (k_select_mx2's harvest feeding the same drain)
+        # and with short codes (the second k-half of every MFMA empty)
         c32 = dict(c, qbits=qb[:, :32].copy(), dbbits=db[:, :32].copy(), b=32)
         _load(ctx, c32)
         res = []
@@ -336,8 +336,8 @@ def test_device_pack_matches_host_pack(ctx):
                 lab = (rng.random((n, C)) < 0.2).astype(np.int64)
                 bad = ctx.set_database_f32(x, lab)
                 assert bad == (0, 0)
-                assert ctx.get_stat("db_zeros") == 0 and ctx.get_stat("db_minus_ones") == int((x == -1).sum())
-                assert ctx.get_stat("db_floats") == (0 if host_pack else 1)          # a +-1 code: its floats stay on the host
+                assert ctx.census(0)[1] == 0 and ctx.census(0)[2] == int((x == -1).sum())
+                assert ctx.census(0)[3] == (False if host_pack else True)          # a +-1 code: its floats stay on the host
                 codes, labels = ctx.get_packed(0)
                 ref = metric.pack_codes(x).view(np.uint32).reshape(n, -1)[:, :(b + 31) // 32]
                 assert np.array_equal(codes, ref), (b, C, host_pack)
@@ -345,8 +345,8 @@ def test_device_pack_matches_host_pack(ctx):
                 x01 = (x > 0).astype(np.float32)                       # {0,1} spelling packs to the same words
                 assert ctx.set_database_f32(x01, lab) == (0, 0)
                 assert np.array_equal(ctx.get_packed(0)[0], ref)
-                assert ctx.get_stat("db_zeros") == int((x01 == 0).sum()) and ctx.get_stat("db_minus_ones") == 0
-                assert ctx.get_stat("db_floats") == 1                                # not a +-1 code: np.dot would not rank it by Hamming distance
+                assert ctx.census(0)[1] == int((x01 == 0).sum()) and ctx.census(0)[2] == 0
+                assert ctx.census(0)[3] is True                                # not a +-1 code: np.dot would not rank it by Hamming distance
             x = rng.standard_normal((50, 16)).astype(np.float32)
             x[3, 3] = np.nan
             lab = np.zeros((50, 3), np.int64); lab[7, 1] = 2
@@ -359,7 +359,7 @@ def test_device_pack_matches_host_pack(ctx):
             codes, labels = ctx.get_packed(0)
             assert np.array_equal(codes, metric.pack_codes(x).view(np.uint32).reshape(n, -1)[:, :2])
             assert np.array_equal(labels, metric.pack_labels(lab))
-            assert ctx.get_stat("db_zeros") == int((x == 0).sum()) and ctx.get_stat("db_minus_ones") == int((x == -1).sum())
+            assert ctx.census(0)[1] == int((x == 0).sum()) and ctx.census(0)[2] == int((x == -1).sum())
     finally:
         ctx.set_option("host_pack", 1)
 
@@ -382,9 +382,9 @@ def test_pm1_database_meets_real_valued_queries():
     m = MAPs(R)
     db = types.SimpleNamespace(output=dbf, label=dl)
     assert m.get_maps_by_feature(db, types.SimpleNamespace(output=np.where(qf > 0, 1.0, -1.0).astype(np.float32), label=ql)) is not None
-    assert m._eng.ctx.get_stat("db_floats") == 0                     # +-1 on both sides: Hamming, no float table
+    assert m._eng.ctx.census(0)[3] is False                     # +-1 on both sides: Hamming, no float table
     assert m.get_maps_by_feature(db, types.SimpleNamespace(output=qf, label=ql)) == m_ref
-    assert m._eng.ctx.get_stat("db_floats") == 1
+    assert m._eng.ctx.census(0)[3] is True
     m.close()
 
 
@@ -857,8 +857,8 @@ def test_one_lane_bursts_while_its_neighbours_stay_sparse(b):
                                        (33, 150000, 16, 30001, 128), (70, 9000, 64, 8999, 5),
                                        (30, 300000, 126, 300000, 7), (24, 900000, 64, 800000, 10)])     # (bitmaps beyond one block's LDS: two blocks per query)
 def test_dense_regime_ranks_the_rows_directly(Q, N, b, R, C):
-    """R > N / 8 on one shard (up to the reference's own R = N, lib/metric.py:14,19 with MAP_R = DB_SIZE): k_rank_direct
-    ranks a query's rows straight from the packed tables -- several tiles of rows, a bitmap of R bits in LDS, ties by
+    """R > N / 8 on one shard (up to the reference's own R = N, lib/metric.py:14,19 with MAP_R = DB_SIZE): the byte matrix
+    (k_dense_bytes + k_rank_dense) ranks every row of every query -- counter columns per thread, a bitmap of R bits, ties by
     index.  AP, ranked indices and distances equal the oracle; no bet is placed, no histogram pass runs."""
     rng = np.random.default_rng(N + R)
     proto = (rng.random((C, b)) < 0.5).astype(np.uint8)
@@ -872,17 +872,10 @@ def test_dense_regime_ranks_the_rows_directly(Q, N, b, R, C):
         _, ap_ref, imatch_ref, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
     ctx = _native.Context(0)
     try:
-        ctx.set_option("rank_direct", 2)                  # R = N takes the kernel by default; N/8 < R < N on request
         _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
-        ap, rel = ctx.map(R)
-        assert np.array_equal(ap, ap_ref, equal_nan=True)
-        assert ctx.get_stat("optimistic_runs") == 0
-        ctx.topr(R)
-        idx, dist = ctx.get_topr()
-        assert np.array_equal(idx.astype(np.int64), idx_ref) and np.array_equal(dist.astype(np.int64), dist_ref)
-        ctx.set_option("rank_direct", 1)                  # the default: N/8 < R <= N through the byte matrix (k_dense_bytes + k_rank_dense)
-        ap3, _ = ctx.map(R)
+        ap3, _ = ctx.map(R)                               # the default: N/8 < R <= N through the byte matrix (k_dense_bytes + k_rank_dense)
         assert np.array_equal(ap3, ap_ref, equal_nan=True)
+        assert ctx.get_stat("optimistic_runs") == 0
         assert ctx.get_stat("rank_variant") == 7
         ctx.topr(R)
         idx, dist = ctx.get_topr()
@@ -899,42 +892,14 @@ def test_dense_regime_ranks_the_rows_directly(Q, N, b, R, C):
             idx, dist = ctx.get_topr()
             assert np.array_equal(idx.astype(np.int64), idx_ref) and np.array_equal(dist.astype(np.int64), dist_ref)
         ctx.set_option("rank_dense_gbm", -1)
-        ctx.set_option("rank_dense", 0)
-        ctx.set_option("rank_direct", 0)                  # the older sequences give the same
+        ctx.set_option("rank_dense", 0)                   # the older sequences give the same (R = N: k_rank_fused walks the rows itself)
         ap2, _ = ctx.map(R)
         assert np.array_equal(ap2, ap_ref, equal_nan=True)
         assert ctx.get_stat("rank_variant") != 7
-    finally:
-        ctx.close()
-
-
-@pytest.mark.parametrize("Q,N,b,R,C", [(4200, 200000, 64, 1500, 10), (4130, 150000, 100, 2000, 100), (5000, 131072, 48, 1200, 81)])
-def test_interleaved_record_rows_match_plain(Q, N, b, R, C):
-    """The bet's one-byte records reach k_rank_lean through record rows in which the 16-byte pieces of 32 queries' slices
-    interleave (rec8_at: whole cache lines leave the select instead of 8 bytes per slice).  Same APs as
-    with plain rows, and as the oracle's -- bet and the ranked lists' path (which keeps plain 8-byte records) alike."""
-    rng = np.random.default_rng(Q + N)
-    proto = (rng.random((C, b)) < 0.5).astype(np.uint8)
-    lab_db, lab_q = rng.integers(0, C, N), rng.integers(0, C, Q)
-    db = proto[lab_db] ^ (rng.random((N, b)) < 0.35).astype(np.uint8)
-    qb = proto[lab_q] ^ (rng.random((Q, b)) < 0.35).astype(np.uint8)
-    dl = np.eye(C, dtype=np.int8)[lab_db]
-    ql = np.eye(C, dtype=np.int8)[lab_q]
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        _, ap_ref, *_ = O.map_from_codes(qb, db, ql, dl, R)
-    ctx = _native.Context(0)
-    try:
-        ctx.set_option("interleave_records", 1)           # (off by default: traffic falls, the step does not get faster)
-        _load(ctx, dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, b=b))
-        ap, rel = ctx.map(R)
-        assert ctx.get_stat("last_optimistic") == 1 and ctx.get_stat("rank_variant") == 6
-        assert ctx.get_stat("records_interleaved") == 1
-        assert np.array_equal(ap, ap_ref, equal_nan=True)
-        ctx.set_option("interleave_records", 0)
+        ctx.set_option("all_rows_shortcut", 0)            # ... and histogram -> plan -> select -> rank
         ap2, _ = ctx.map(R)
-        assert ctx.get_stat("records_interleaved") == 0 and ctx.get_stat("rank_variant") == 6
         assert np.array_equal(ap2, ap_ref, equal_nan=True)
+        assert ctx.get_stat("rank_variant") != 7
     finally:
         ctx.close()
 
@@ -982,7 +947,7 @@ def test_fused_step_hands_wide_lists_to_the_general_kernel(ctx):
     the leftovers, ranked by k_rank_fused and evaluated by k_ap afterwards; all APs equal the oracle's, with the fused
     epilogue on and off."""
     from hashgan_amd import synth
-    Q, N, b, R, C = 192, 100000, 64, 2000, 10              # (lists too long for k_rank_wave, which takes the short ones)
+    Q, N, b, R, C = 192, 100000, 64, 2000, 10              # (long lists)
     dl, _ = synth.onehot_labels(71, N, C)
     ql, _ = synth.onehot_labels(72, Q, C)
     db = synth.random_bits(73, N, b)

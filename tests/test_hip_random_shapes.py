@@ -81,7 +81,7 @@ def test_random_bet_shapes():
                 _, ap_ref, _, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
             ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
             ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
-            for mfma, packed in ((1, 1), (1, 2), (0, 1)):       # k_select_mx / k_select_mx2 by default rule, mx2 forced, vector ALU
+            for mfma, packed in ((1, 3), (1, 1), (0, 1)):       # k_select_mx3 / mx4 (one-byte records) by the default rule, k_select_mx forced, vector ALU
                 ctx.set_option("select_mfma", mfma)
                 ctx.set_option("select_packed", packed)
                 r0 = ctx.get_stat("optimistic_runs")
@@ -98,7 +98,7 @@ def test_random_bet_shapes():
 
 def test_mx_select_segment_shapes():
     """k_select_mx geometry corners: an unpaired last segment (odd segment count), a ragged last window,
-    segments shorter than one 128-row window, and both query-tile variants."""
+    segments shorter than one window, under both matrix-core select kernels."""
     rng = np.random.default_rng(11)
     ctx = _native.Context(0)
     try:
@@ -114,13 +114,12 @@ def test_mx_select_segment_shapes():
                 _, ap_ref, _, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
             ctx.set_option("target_units", units)
             ctx.set_option("min_segment", minseg)
-            ctx.set_option("select_qt", qt)
-            ctx.set_option("select_packed", 2 if qt == 2 else 0)     # both matrix-core kernels see these geometries
+            ctx.set_option("select_packed", 3 if qt == 2 else 0)     # k_select_mx3 and k_select_mx both see these geometries
             ctx.set_option("optimistic", 1)
             ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
             ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
             ap, rel = ctx.map(R)
-            key = (N, units, minseg, qt, ctx.get_stat("segments"), ctx.get_stat("segment_rows"))
+            key = (N, units, minseg, qt, ctx.get_stat("segments"))
             assert ctx.get_stat("last_optimistic") == 1, key
             assert np.array_equal(ap, ap_ref, equal_nan=True), key
             ctx.topr(R)
@@ -162,7 +161,7 @@ def test_fuzz_bet_shapes():
                 _, ap_ref, _, idx_ref, dist_ref = O.map_from_codes(qb, db, ql, dl, R)
             ctx.set_database(metric.pack_codes(db), metric.pack_labels(dl), b, C)
             ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
-            for mfma, packed in ((1, 1), (1, 2), (0, 1)):
+            for mfma, packed in ((1, 3), (1, 1), (0, 1)):
                 ctx.set_option("select_mfma", mfma)
                 ctx.set_option("select_packed", packed)
                 ctx.set_option("optimistic", 1)

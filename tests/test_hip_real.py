@@ -67,7 +67,7 @@ def test_generic_float_features_match_oracle_bit_for_bit(Q, N, b, R, C, ctx):
 def test_every_row_ranked_group_by_group(kind):
     """R = N (the reference's CIFAR-10 setting) on real-valued features: every row is a record, far more than the LDS holds.
     Continuous scores are split by score range into LDS-sized groups and ordered group by group (k_real_group_split /
-    k_real_group_sort, stat real_grouped); scores on a coarse grid pile up in the buckets and take the radix passes.  The
+    k_real_group_sort, stat real_path bit 2); scores on a coarse grid pile up in the buckets and take the radix passes.  The
     oracle's lists and APs either way, bit for bit."""
     rng = np.random.default_rng(31)
     Q, N, b, C = 6, 30000, 32, 10
@@ -86,13 +86,13 @@ def test_every_row_ranked_group_by_group(kind):
         c.set_database_f32(dbf, dl)
         c.set_queries_f32(qf, ql)
         idx, score = c.topr_real(R)
-        assert c.get_stat("real_grouped") == (1 if kind == "tanh" else 0)
+        assert ((c.get_stat("real_path") >> 2) & 1) == (1 if kind == "tanh" else 0)
         assert np.array_equal(idx, idx_ref) and np.array_equal(score.view(np.uint32), score_ref.view(np.uint32))
         ap, rel = c.map_real(R)
         assert np.array_equal(ap, ap_ref, equal_nan=True)
         c.set_option("real_groups", 0)                               # the radix passes: the same lists
         idx2, _ = c.topr_real(R)
-        assert c.get_stat("real_grouped") == 0 and np.array_equal(idx2, idx_ref)
+        assert ((c.get_stat("real_path") >> 2) & 1) == 0 and np.array_equal(idx2, idx_ref)
     finally:
         c.close()
 
@@ -118,7 +118,7 @@ def test_features_that_follow_the_labels_in_a_class_sorted_database():
         c.set_queries_f32(qf, eye[qcls])
         ap, rel = c.map_real(R)
         assert np.array_equal(ap, ap_ref, equal_nan=True)
-        assert c.get_stat("real_attempts") >= 3 and c.get_stat("real_cap_boost") > 1 and c.get_stat("real_filtered") == 1
+        assert c.get_stat("real_attempts") >= 3 and c.get_stat("real_cap_boost") > 1 and (c.get_stat("real_path") & 1) == 1
         idx, score = c.topr_real(R)
         assert c.get_stat("real_attempts") == 1                      # the widened slices are remembered
         assert np.array_equal(idx, idx_ref) and np.array_equal(score.view(np.uint32), score_ref.view(np.uint32))
@@ -242,9 +242,9 @@ def test_filter_and_rescore_equals_the_exact_passes(kind, Q, N, b, R, ctx):
             assert np.array_equal(idx, idx_ref), (kind, mode, lds)
             if kind != "bits":          # (a cut inside a tie group of thousands overflows the slices: deeper attempts, same lists)
                 assert ctx.get_stat("real_attempts") == 1, (kind, mode, lds)
-            assert ctx.get_stat("real_filtered") == (1 if mode == 2 else 0)
+            assert (ctx.get_stat("real_path") & 1) == (1 if mode == 2 else 0)
             if ctx.get_stat("real_attempts") == 1 and kind != "bits":   # (tie groups can exceed the LDS: the global passes take over)
-                assert ctx.get_stat("real_lds_ranked") == (1 if mode == 2 and lds and R <= 6144 else 0)
+                assert ((ctx.get_stat("real_path") >> 1) & 1) == (1 if mode == 2 and lds and R <= 6144 else 0)
             ap, rel = ctx.map_real(R)
             assert np.array_equal(ap, ap_ref, equal_nan=True), (kind, mode, lds)
     finally:

@@ -33,9 +33,9 @@ def one(seed):
         ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
         out = {}
         if "-v" in sys.argv: print("  b=%d N=%d Q=%d R=%d C=%d planted=%s" % (b, N, Q, R, C, planted), flush=True)
-        for name, opts in (("bet", {}), ("bet_again", {}), ("bet8", {"compact_records": 0}), ("exact", {"optimistic": 0}), ("exact_valu", {"optimistic": 0, "hist_mfma": 0, "exact_mfma": 0})):
-            for k in ("compact_records", "optimistic", "hist_mfma", "exact_mfma"):
-                ctx.set_option(k, {"compact_records": 1, "optimistic": 1, "hist_mfma": 2, "exact_mfma": 1}[k])
+        for name, opts in (("bet", {}), ("bet_again", {}), ("bet8", {"compact_records": 0}), ("exact", {"optimistic": 0}), ("exact_valu", {"optimistic": 0, "hist_mfma": 0, "select_mfma": 0})):
+            for k in ("compact_records", "optimistic", "hist_mfma", "select_mfma"):
+                ctx.set_option(k, {"compact_records": 1, "optimistic": 1, "hist_mfma": 2, "select_mfma": 1}[k])
             for k, v in opts.items(): ctx.set_option(k, v)
             if "-v" in sys.argv: print("   ", name, flush=True)
             out[name] = ctx.map(R)

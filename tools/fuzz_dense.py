@@ -8,7 +8,7 @@ import numpy as np
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from hashgan_amd import _native, synth, metric
 
-NEW = {"rank_dense": 1, "rank_slices": 7000, "inline_leftovers": 1, "rank_dense_gbm": -1, "dense_budget_mb": 16384, "interleave_records": 0, "optimistic": 1}
+NEW = {"rank_dense": 1, "rank_slices": 7000, "inline_leftovers": 1, "rank_dense_gbm": -1, "dense_budget_mb": 16384, "optimistic": 1}
 
 def one(seed):
     rng = np.random.default_rng(seed)
@@ -35,7 +35,7 @@ def one(seed):
         ctx.set_queries(metric.pack_codes(qb), metric.pack_labels(ql))
         out, how = {}, {}
         variants = [("new", {}), ("new_again", {}), ("gbm", {"rank_dense_gbm": 1}), ("lds_chunks", {"rank_dense_gbm": 0, "dense_budget_mb": 64}),
-                    ("interleaved", {"interleave_records": 1}), ("no_inline", {"inline_leftovers": 0}),
+                    ("no_inline", {"inline_leftovers": 0}),
                     ("old", {"rank_dense": 0, "rank_slices": 0, "inline_leftovers": 0}), ("old_exact", {"rank_dense": 0, "rank_slices": 0, "optimistic": 0})]
         for name, opts in variants:
             for k, v in NEW.items(): ctx.set_option(k, v)

@@ -6,13 +6,13 @@ import numpy as np
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from hashgan_amd import _native, synth, metric
 
-OPTS = {"select_mfma": [0, 1], "compact_records": [0, 1], "rank_lds": [0, 1], "rank_cnt": [0, 1], "select_packed": [0, 1, 2],
-        "hist_mfma": [0, 1, 2], "exact_mfma": [0, 1], "second_bet": [0, 1], "guess_sigma": [0, 1, 2, 5], "max_segments": [7, 64, 2048],
-        "target_units": [64, 4096, 16384], "sample_stride": [0, 3, 24, 200], "optimistic": [1, 1, 1, 0], "rank_waves": [0, 4, 16], "cand_budget_x10": [11, 15, 40], "all_rows_shortcut": [0, 1], "sample_ratio": [1, 4, 64],
+OPTS = {"select_mfma": [0, 1], "compact_records": [0, 1], "rank_lds": [0, 1, 2], "select_packed": [0, 3],
+        "hist_mfma": [0, 1, 2], "second_bet": [0, 1], "guess_sigma": [0, 1, 2, 5], "max_segments": [7, 64, 2048],
+        "target_units": [64, 4096, 16384], "sample_stride": [0, 3, 24, 200], "optimistic": [1, 1, 1, 0], "cand_budget_x10": [11, 15, 40], "all_rows_shortcut": [0, 1],
         "staged_lists": [0, 1], "min_segment": [16, 4096, 65536], "step_graph": [0, 1], "ap_recip": [0, 1]}
-DEFAULT = {"select_mfma": 1, "compact_records": 1, "rank_lds": 1, "rank_cnt": 1, "select_packed": 1, "hist_mfma": 2, "exact_mfma": 1,
-           "second_bet": 1, "guess_sigma": 5, "max_segments": 2048, "target_units": 16384, "sample_stride": 0, "optimistic": 1, "rank_waves": 0, "cand_budget_x10": 40, "all_rows_shortcut": 1,
-           "sample_ratio": 2, "staged_lists": 1, "min_segment": 256, "step_graph": 0, "ap_recip": 1}
+DEFAULT = {"select_mfma": 1, "compact_records": 1, "rank_lds": 2, "select_packed": 3, "hist_mfma": 2,
+           "second_bet": 1, "guess_sigma": 5, "max_segments": 2048, "target_units": 16384, "sample_stride": 0, "optimistic": 1, "cand_budget_x10": 40, "all_rows_shortcut": 1,
+           "staged_lists": 1, "min_segment": 256, "step_graph": 0, "ap_recip": 1}
 
 def one(seed):
     rng = np.random.default_rng(seed)
@@ -37,7 +37,7 @@ def one(seed):
             ap2, rel2 = ctx.map(R)                    # and once more: state left behind by the list call
             return ap, rel, idx, dist, ap2, rel2
         if "-v" in sys.argv: print("  b=%d N=%d Q=%d R=%d C=%d" % (b, N, Q, R, C), flush=True)
-        ref = run({"optimistic": 0, "hist_mfma": 0, "exact_mfma": 0, "select_mfma": 0, "ap_recip": 0})
+        ref = run({"optimistic": 0, "hist_mfma": 0, "select_mfma": 0, "ap_recip": 0})
         for trial in range(4):
             opts = {k: int(rng.choice(v)) for k, v in OPTS.items() if rng.random() < 0.5}
             if "-v" in sys.argv: print("   trial", trial, opts, flush=True)

@@ -9,7 +9,7 @@ from hashgan_amd import _native, metric, MAPs, MAP
 def exact_map(qbits, dbits, ql, dl, R):
     ctx = _native.Context(0)
     try:
-        for k, v in (("optimistic", 0), ("hist_mfma", 0), ("exact_mfma", 0), ("select_mfma", 0)): ctx.set_option(k, v)
+        for k, v in (("optimistic", 0), ("hist_mfma", 0), ("select_mfma", 0)): ctx.set_option(k, v)
         ctx.set_database(metric.pack_codes(dbits), metric.pack_labels(dl), dbits.shape[1], dl.shape[1])
         ctx.set_queries(metric.pack_codes(qbits), metric.pack_labels(ql))
         ap, rel = ctx.map(R)

@@ -18,4 +18,4 @@ done
 cd $GRAFT_REPO_ROOT
 for f in $(find $OUT -name "*.db" | sort); do python tools/prof_summary.py $f; done > $OUT/summary.txt 2>&1
 python tools/pmc_traffic.py $(find $OUT/pmc3 -name "*.db" | head -1) $(find $OUT/pmc4 -name "*.db" | head -1) $OUT/traffic.json > $OUT/traffic.txt 2>&1
-grep -E "k_select_mx|k_rank_lds|== " $OUT/summary.txt | head -80
+grep -E "k_select_mx|k_rank_|== " $OUT/summary.txt | head -80

@@ -24,5 +24,5 @@ for opts in variants:
     tm = ctx.timing_read()
     if ref is None: ref = ap.copy()
     print("%-28s %.2f ms per call  equal_to_first=%s attempts=%d lds_ranked=%d | %s" % (opts, dt * 1e3, bool(np.array_equal(ap, ref, equal_nan=True)),
-          ctx.get_stat("real_attempts"), ctx.get_stat("real_lds_ranked"), {k: round(v[0] / max(v[1], 1), 3) for k, v in tm.items() if v[1]}), flush=True)
+          ctx.get_stat("real_attempts"), (ctx.get_stat("real_path") >> 1) & 1, {k: round(v[0] / max(v[1], 1), 3) for k, v in tm.items() if v[1]}), flush=True)
     ctx.close()

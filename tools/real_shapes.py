@@ -31,7 +31,7 @@ def run(name, Q, N, b, R, C, multi=False, steps=5):
         tm = ctx.timing_read(); ctx.timing_enable(0)
         kern = " ".join("%s=%.3f" % (k.replace("k_", ""), v[0] / 2) for k, v in sorted(tm.items(), key=lambda kv: -kv[1][0]) if k != "step_gpu_span" and v[0] / 2 >= 0.01)
         print("%-22s Q=%-6d N=%-8d b=%-3d R=%-6d %8.3f ms/call  attempts %d filtered %d lds_ranked %d  mAP %.4f | %s" % (name, Q, N, b, R, dt * 1e3,
-              ctx.get_stat("real_attempts"), ctx.get_stat("real_filtered"), ctx.get_stat("real_lds_ranked"), metric.mean_over_hits(a, r), kern), flush=True)
+              ctx.get_stat("real_attempts"), ctx.get_stat("real_path") & 1, (ctx.get_stat("real_path") >> 1) & 1, metric.mean_over_hits(a, r), kern), flush=True)
     finally:
         ctx.close()
 

@@ -18,8 +18,8 @@ def run(tag, qf, ql, df, dl, R, steps=4):
         t = time.perf_counter()
         for _ in range(steps): ctx.map_real(R)
         dt = (time.perf_counter() - t) / steps
-        print("%-8s %8.3f ms/call  attempts first call %d, later %d  lds_ranked=%d boost=%d cap=%d  mAP=%.6f" % (tag, dt * 1e3, att0, ctx.get_stat("real_attempts"),
-              ctx.get_stat("real_lds_ranked"), ctx.get_stat("real_cap_boost"), ctx.get_stat("slice_capacity"), metric.mean_over_hits(a0, r0)), flush=True)
+        print("%-8s %8.3f ms/call  attempts first call %d, later %d  lds_ranked=%d boost=%d  mAP=%.6f" % (tag, dt * 1e3, att0, ctx.get_stat("real_attempts"),
+              (ctx.get_stat("real_path") >> 1) & 1, ctx.get_stat("real_cap_boost"), metric.mean_over_hits(a0, r0)), flush=True)
         return a0
     finally:
         ctx.close()
