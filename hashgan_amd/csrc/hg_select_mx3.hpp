@@ -52,6 +52,9 @@ constexpr int M3_RING = 16;                // records per slice ring
 #ifndef HG_M3_WPB
 #define HG_M3_WPB 8
 #endif
+#ifndef HG_M3_FLUSH
+#define HG_M3_FLUSH 4                      // the owners flush their rings every this many supertiles (a multiple of the window)
+#endif
 #ifndef HG_M3_ILV
 #define HG_M3_ILV 8                        // tile 1's MFMAs carry that many of tile 0's harvest ops between them (0: round 4's order, all six MFMAs first -- 0.634 vs 0.626 ms)
 #endif
@@ -600,7 +603,7 @@ void k_select_mx3(const u32* __restrict__ qc, const u64* __restrict__ qlab, cons
             __builtin_amdgcn_sched_barrier(0);
         }
         // the owners flush every fourth supertile (192 rows: ~1.2 records per slice at C2; every second one cost 4 % more)
-        if (!(kProbes && (a.probe & 2))) dr.end_window(((win + 1) * M3_WS) % 4 == 0);
+        if (!(kProbes && (a.probe & 2))) dr.end_window(((win + 1) * M3_WS) % HG_M3_FLUSH == 0);
         clsel = clnext;
     }
     dr.finish();
