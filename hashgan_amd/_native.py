@@ -87,6 +87,7 @@ _SIGNATURES = {
     "hg_set_option": [_p, C.c_char_p, _i64],
     "hg_get_stat": [_p, C.c_char_p, C.POINTER(_i64)],
     "hg_get_census": [_p, C.c_int, C.POINTER(_i64)],
+    "hg_shard_step": [_p, _i64, C.c_int, _p, _p, C.POINTER(C.c_int)],
     "hg_trim": [_p],
     "hg_timing_enable": [_p, C.c_int],
     "hg_timing_reset": [_p],
@@ -399,6 +400,16 @@ class Context:
         out = _p()
         check(self._lib.hg_alltoall(self._h, int(slot), _p(dev_ptr), int(nbytes_per_peer), C.byref(out)))
         return out.value
+
+    def shard_step(self, R, replica_world=0):
+        """One rank's whole step of the database-sharded bet in one call (hg_shard_step) -> (ap [Q] float64, rel [Q] int64, lost):
+        lost False / True, or None when nothing was enqueued (the bet is not eligible: use the staged sequences)."""
+        ap = np.empty(self.Q, dtype=np.float64)
+        rel = np.empty(self.Q, dtype=np.int64)
+        lost = C.c_int()
+        check(self._lib.hg_shard_step(self._h, int(R), int(replica_world), _ptr(ap), _ptr(rel), C.byref(lost)))
+        self.R = int(R)
+        return ap, rel, (None if lost.value < 0 else bool(lost.value))
 
     def allgather_topr(self):
         check(self._lib.hg_allgather_topr(self._h))

@@ -172,6 +172,72 @@ int hg_alltoall(hg_ctx* c, int slot, const void* dev_src, int64_t nbytes_per_pee
     return c->stage_end();
 }
 
+// ---- one rank's whole step of the database-sharded bet in ONE call -------------------------------------------------------------
+// sampled histogram -> [all-to-all by query owner] -> the owners guess -> [all-to-all back] -> select + rank the shard's own records ->
+// [all-to-all by query owner] -> merge + AP of this rank's queries -> [all-gather of 16 bytes per query] -> one download.
+// Everything is enqueued back to back on the context's stream (kernels and RCCL alike): no host round trip before the final download,
+// no Python between the stages -- sharded.evaluate_shard's twelve stage calls cost a rank ~0.1 ms of a 1 ms step at G = 8.
+// The exchange: the context's RCCL communicator; without one, `replica_world` >= 1 stands in for it with device-to-device copies of
+// this rank's own blocks (every peer a replica of this rank: tools/replica_shard_timing.py times what ONE rank of a G-GPU run
+// executes; with replica_world = 1 the result is the one-GPU result, which the tests check).
+namespace {
+int shard_alltoall(hg_ctx* c, bool replica, int world, int rank, int slot, const void* src, int64_t per, void** out) {
+    if (!replica) return hg_alltoall(c, slot, src, per, out);
+    DevBuf& o = c->gathered[slot];
+    HG_TRY(o.reserve((size_t)per * world));
+    c->t_begin(KI_COMM);
+    for (int r = 0; r < world; ++r)        // what replica r would send here = what this rank sends to itself
+        HG_HIP(hipMemcpyAsync(o.as<char>() + (size_t)r * per, (const char*)src + (size_t)rank * per, (size_t)per, hipMemcpyDeviceToDevice, c->stream));
+    c->t_end();
+    *out = o.p;
+    return HG_OK;
+}
+int shard_allgather(hg_ctx* c, bool replica, int world, int slot, const void* src, int64_t nbytes, void** out) {
+    if (!replica) return hg_allgather(c, slot, src, nbytes, out);
+    DevBuf& o = c->gathered[slot];
+    HG_TRY(o.reserve((size_t)nbytes * world));
+    c->t_begin(KI_COMM);
+    for (int r = 0; r < world; ++r)
+        HG_HIP(hipMemcpyAsync(o.as<char>() + (size_t)r * nbytes, src, (size_t)nbytes, hipMemcpyDeviceToDevice, c->stream));
+    c->t_end();
+    *out = o.p;
+    return HG_OK;
+}
+int shard_step_enqueue(hg_ctx* c, int64_t R, bool replica, int world, int rank, double* host_ap, int64_t* host_rel, int* bet_lost) {
+    void *p = nullptr, *recv = nullptr;
+    int64_t n = 0;
+    HG_TRY(hg_sample_hist(c, R));
+    HG_TRY(hg_pack_sample_by_owner(c, world, &p, &n));
+    HG_TRY(shard_alltoall(c, replica, world, rank, 0, p, n, &recv));
+    HG_TRY(hg_guess_owned(c, R, recv, world, rank, &p, &n));
+    HG_TRY(shard_alltoall(c, replica, world, rank, 1, p, n, &recv));
+    HG_TRY(hg_guess_finish(c, R, recv, world, rank));
+    HG_TRY(hg_select_ranked(c));
+    HG_TRY(hg_pack_ranked_by_owner(c, world, &p, &n));
+    HG_TRY(shard_alltoall(c, replica, world, rank, 2, p, n, &recv));
+    HG_TRY(hg_merge_ap_owned(c, recv, world, rank, &p, &n));
+    HG_TRY(shard_allgather(c, replica, world, 3, p, n, &recv));
+    const int64_t width = make_owners(c->geo.Q, world).width;
+    return hg_unpack_parts(c, recv, world, width, host_ap, host_rel, bet_lost);      // the step's one synchronisation
+}
+}  // namespace
+
+int hg_shard_step(hg_ctx* c, int64_t R, int replica_world, double* host_ap, int64_t* host_rel, int* bet_lost) {
+    if (!c || !host_ap || !host_rel || !bet_lost) return fail(HG_ERR_ARG, "hg_shard_step: null argument");
+    const bool replica = !c->comm;
+    if (replica && replica_world < 1) return fail(HG_ERR_STATE, "hg_shard_step: no communicator (hg_comm_init), and no replica world given");
+    const int world = replica ? replica_world : c->comm_world, rank = replica ? 0 : c->comm_rank;
+    int eligible = 0;
+    HG_TRY(hg_bet_eligible(c, R, world, &eligible));
+    // (hg_merge_ranked's limits: lane r <-> shard r, the four queries of a block keep their [G][b + 1] record counts in LDS)
+    if (!eligible || world > 64 || (size_t)4 * world * (c->b + 1) * 4 > 160u * 1024u) { *bet_lost = -1; return HG_OK; }   // nothing enqueued: the staged sequences apply
+    const bool sync0 = c->stage_sync;
+    c->stage_sync = false;                             // the stages only enqueue; hg_unpack_parts waits once
+    const int rc = shard_step_enqueue(c, R, replica, world, rank, host_ap, host_rel, bet_lost);
+    c->stage_sync = sync0;
+    return rc;
+}
+
 // The north star's exchange: every shard's ranked (dist, idx) lists all-gathered and merged (exactly one shard owns a
 // slot, the others hold HG_IDX_NONE / 0xFF there).  hg_get_topr then returns the global lists on every rank.
 int hg_allgather_topr(hg_ctx* c) {

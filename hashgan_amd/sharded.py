@@ -350,6 +350,10 @@ class HipShardEngine:
     def merge_ap_owned(self, received, world, rank):
         return DevBuf(*self.ctx.merge_ap_owned(received.ptr, world, rank))
 
+    def shard_step(self, R):
+        """The owner-routed bet as one library call over the context's own communicator -> (ap, rel, lost | None): hg_shard_step."""
+        return self.ctx.shard_step(R)
+
     def verdict(self):
         """True if a deferred bet (rank_candidates returned None) turned out lost."""
         return self.ctx.bet_verdict()
@@ -370,7 +374,7 @@ class HipShardEngine:
 
 
 # ------------------------------------------------------------------ orchestration
-def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=True, route_by_owner=True):
+def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=True, route_by_owner=True, one_call=True):
     """Run one rank's part of the sharded evaluation.
 
     engine: HipShardEngine (or any object with the same five methods -- the CPU
@@ -381,6 +385,8 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
     form (grouped ncclSend / ncclRecv), compares the two per-query results bit for bit, and the ranks agree (one
     all-reduce) whether anyone saw an error or a difference -- only then do later calls route by owner
     (`comm.routed_verified`; HG_ROUTE_BY_OWNER=0 / 1 skips the check and forces the form).
+    one_call: over an RcclComm the routed bet runs as ONE library call (hg_shard_step: every stage and exchange enqueued back to back);
+    False keeps the same stages driven from here, call by call -- the form the tests hold the one-call form against.
     Returns (ap [Q] float64 with nan for skipped queries, rel [Q] int64) -- and
     (idx, dist) of the merged global top-R when gather_topr is set.
     """
@@ -390,10 +396,10 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
         if forced in ("0", "1"):
             route_by_owner = forced == "1"
         elif comm.routed_verified is None:
-            ref = _evaluate_shard(engine, comm, R, False, always_gather, bet, False)
+            ref = _evaluate_shard(engine, comm, R, False, always_gather, bet, False, one_call)
             bad = 0.0
             try:
-                got = _evaluate_shard(engine, comm, R, False, always_gather, bet, True)
+                got = _evaluate_shard(engine, comm, R, False, always_gather, bet, True, one_call)
                 if not (np.array_equal(got[0], ref[0], equal_nan=True) and np.array_equal(got[1], ref[1])):
                     bad = 1.0
             except Exception:      # noqa: BLE001 -- an hg_alltoall failure on this rank: every rank must learn of it
@@ -402,10 +408,10 @@ def evaluate_shard(engine, comm, R, gather_topr=False, always_gather=False, bet=
             return ref
         else:
             route_by_owner = comm.routed_verified
-    return _evaluate_shard(engine, comm, R, gather_topr, always_gather, bet, route_by_owner)
+    return _evaluate_shard(engine, comm, R, gather_topr, always_gather, bet, route_by_owner, one_call)
 
 
-def _evaluate_shard(engine, comm, R, gather_topr, always_gather, bet, route_by_owner):
+def _evaluate_shard(engine, comm, R, gather_topr, always_gather, bet, route_by_owner, one_call=True):
     multi = comm.world > 1 or always_gather          # always_gather: exercise the collectives even with one rank
     gather = (lambda t: comm.all_gather(t)) if multi else (lambda t: None)
     bits = None
@@ -415,6 +421,15 @@ def _evaluate_shard(engine, comm, R, gather_topr, always_gather, bet, route_by_o
         # global bitmap is stitched from the gathered local ones (hg_merge_ranked)
         routed = route_by_owner and multi and hasattr(engine, "merge_ap_owned") and hasattr(comm, "all_to_all")
         while True:
+            if routed and one_call and isinstance(comm, RcclComm) and hasattr(engine, "shard_step"):
+                # the same owner-routed sequence as ONE library call: every stage and every RCCL exchange enqueued back to back
+                # on the context's stream, one synchronisation at the final download (hg_shard_step)
+                ap, rel, lost = engine.shard_step(R)
+                if lost is False:
+                    return ap, rel
+                if lost is None or not (hasattr(engine, "widen_slices") and engine.widen_slices()):
+                    break
+                continue
             if routed:
                 # every table goes only to the owner of its queries (all-to-all): the sampled histograms to the rank that
                 # guesses for them, its answers back, the record counts + local bitmaps to the rank that stitches and

@@ -230,6 +230,16 @@ int hg_allgather(hg_ctx* ctx, int slot, const void* dev_src, int64_t nbytes, voi
  *                       = what rank r sent here (a context buffer, slot 0..3 shared with hg_allgather).  The exchange of
  *                       the owner-routed sequence below. */
 int hg_alltoall(hg_ctx* ctx, int slot, const void* dev_src, int64_t nbytes_per_peer, void** dev_out);
+/* One rank's WHOLE step of the database-sharded bet (AP only, exchanges routed by query owner), enqueued back to back on the
+ * context's stream with a single synchronisation at its final download -- the sequence hg_sample_hist -> hg_pack_sample_by_owner ->
+ * hg_alltoall -> hg_guess_owned -> hg_alltoall -> hg_guess_finish -> hg_select_ranked -> hg_pack_ranked_by_owner -> hg_alltoall ->
+ * hg_merge_ap_owned -> hg_allgather -> hg_unpack_parts in one call.  host_ap / host_rel: [Q] of ALL queries, identical on every rank.
+ * *bet_lost: 0 the bet held; 1 lost on some shard (the same on every rank: widen the slices -- "cap_boost" -- and call again, or run
+ * the staged exact sequence); -1 nothing was enqueued (hg_bet_eligible says no, or more shards than hg_merge_ranked takes).
+ * The exchange is the context's communicator (hg_comm_init).  Without one, replica_world >= 1 makes every peer a replica of this
+ * rank (device-to-device copies of its own blocks): what ONE rank of a replica_world-GPU run executes, for timing on one GPU;
+ * replica_world = 1 is the one-GPU result. */
+int hg_shard_step(hg_ctx* ctx, int64_t R, int replica_world, double* host_ap, int64_t* host_rel, int* bet_lost);
 int hg_allgather_topr(hg_ctx* ctx);
 int hg_allreduce_max_f64(hg_ctx* ctx, double* host_inout);
 int hg_barrier(hg_ctx* ctx);

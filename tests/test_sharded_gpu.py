@@ -141,7 +141,7 @@ def test_virtual_shards_wide_labels_take_the_bet():
             assert all(st == (1, 0) for st in _run_virtual.last_stats), _run_virtual.last_stats
 
 
-def _one_rank_rccl(c, gather_topr, async_stages):
+def _one_rank_rccl(c, gather_topr, async_stages, one_call=True):
     ctx = _native.Context(0)
     try:
         ctx.set_database(metric.pack_codes(c["dbbits"]), metric.pack_labels(c["dblab"]), c["b"], c["dblab"].shape[1])
@@ -149,7 +149,7 @@ def _one_rank_rccl(c, gather_topr, async_stages):
         comm = sharded.init_rccl(ctx, rank=0, world=1)
         assert (comm.rank, comm.world) == (0, 1)
         eng = sharded.HipShardEngine(ctx, want_lists=gather_topr, async_stages=async_stages)
-        out = sharded.evaluate_shard(eng, comm, c["R"], gather_topr=gather_topr, always_gather=True)
+        out = sharded.evaluate_shard(eng, comm, c["R"], gather_topr=gather_topr, always_gather=True, one_call=one_call)
         stats = (ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks"))
         ctx.comm_destroy()
         return out, stats
@@ -163,15 +163,43 @@ def test_one_rank_native_rccl_matches_golden(name, case_cache):
     hg_allgather_topr) -- one rank, because a box has one GPU; no torch in the process."""
     c = case_cache(name)
     g = cases.load_golden(name)
-    for async_stages in (False, True):
-        (ap, rel), stats = _one_rank_rccl(c, False, async_stages)
-        assert np.array_equal(ap, g["ap"], equal_nan=True), (name, async_stages)
+    for async_stages, one_call in ((False, True), (True, True), (True, False), (False, False)):
+        # one_call: the owner-routed bet as ONE library call (hg_shard_step); else the same stages driven from Python, call by call
+        (ap, rel), stats = _one_rank_rccl(c, False, async_stages, one_call)
+        assert np.array_equal(ap, g["ap"], equal_nan=True), (name, async_stages, one_call)
         if name == "c2_q64":
             assert stats == (1, 0), stats                  # the merged-ranking bet ran, over real collectives
     (ap, rel, (idx, dist)), _ = _one_rank_rccl(c, True, False)
     assert np.array_equal(ap, g["ap"], equal_nan=True)
     if "idx" in g:
         assert np.array_equal(idx, g["idx"])
+
+
+@pytest.mark.parametrize("name", ["c2_q64", "c3_nus_q64", "c5_b128_q32", "e_ragged"])
+def test_shard_step_with_a_replica_world_of_one_is_the_one_gpu_result(name, case_cache):
+    """hg_shard_step without a communicator: replica_world = 1 (this rank its own only peer -- the exchanges are device copies
+    inside the library) is the whole sequence of the sharded bet on one GPU: equal to the reference's golden.  A shape the bet does
+    not take reports None and enqueues nothing; replica worlds > 1 are a timing aid (tools/replica_shard_timing.py), the step
+    must still complete on them."""
+    c = case_cache(name)
+    g = cases.load_golden(name)
+    ctx = _native.Context(0)
+    try:
+        ctx.set_database(metric.pack_codes(c["dbbits"]), metric.pack_labels(c["dblab"]), c["b"], c["dblab"].shape[1])
+        ctx.set_queries(metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"]))
+        ap, rel, lost = ctx.shard_step(c["R"], replica_world=1)
+        if name == "e_ragged":                             # N = 10 007: no bet on a database this small
+            assert lost is None
+        else:
+            assert lost is False and np.array_equal(ap, g["ap"], equal_nan=True)
+            ap2, rel2, lost2 = ctx.shard_step(c["R"], replica_world=1)     # and again: state left behind
+            assert lost2 is False and np.array_equal(ap2, ap, equal_nan=True) and np.array_equal(rel2, rel)
+            _, _, lost4 = ctx.shard_step(c["R"], replica_world=4)          # (peers that are copies of this rank: not the database's mAP)
+            assert lost4 in (False, True, None)
+            a3, r3 = ctx.map(c["R"])                                       # the context still serves the one-shot call
+            assert np.array_equal(a3, g["ap"], equal_nan=True)
+    finally:
+        ctx.close()
 
 
 def test_sharded_product_path_is_torch_free():

@@ -5,7 +5,7 @@ stream stand in for the wire).  i.i.d. shards are statistically alike, so G copi
 bitmaps cost the merge stages what the true gathered tables would -- the mAP is NOT the database's, the stage times are.
 Prints wall time per step (one stream, no host waits between stages) and the per-kernel times.
 
-    python tools/replica_shard_timing.py [G ...]
+    python tools/replica_shard_timing.py [G ...]      (each G through hg_shard_step; then G = 8 once more stage by stage from Python)
 """
 import sys, time
 import numpy as np
@@ -42,7 +42,7 @@ class ReplicaComm:
         self.ctx.synchronize()
 
 
-def one(G, steps=10, opts=()):
+def one(G, steps=10, opts=(), one_call=True):
     rows = N // G
     ctx = _native.Context(0)
     try:
@@ -52,22 +52,29 @@ def one(G, steps=10, opts=()):
         ctx.set_queries(synth.random_code_words(seed + 7, Q, b), synth.onehot_label_words(seed * 3 + 2, Q, C))
         comm = ReplicaComm(ctx, G)
         eng = sharded.HipShardEngine(ctx, want_lists=False, async_stages=True)
+        if one_call:                                  # hg_shard_step: the whole step one library call, the replica exchange inside the library
+            def step():
+                ap, rel, lost = ctx.shard_step(R, replica_world=G)
+                assert lost is False, lost
+        else:                                         # the same stages driven from Python (sharded.evaluate_shard), ReplicaComm's copies
+            def step():
+                sharded.evaluate_shard(eng, comm, R, always_gather=True)
         for _ in range(3):
-            sharded.evaluate_shard(eng, comm, R, always_gather=True)
+            step()
         ctx.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            ap, rel = sharded.evaluate_shard(eng, comm, R, always_gather=True)
+            step()
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / steps
         ctx.timing_enable(2); ctx.timing_reset()
         for _ in range(3):
-            sharded.evaluate_shard(eng, comm, R, always_gather=True)
+            step()
         ctx.synchronize()
         k = {n: round(v[0] / max(v[1], 1), 4) for n, v in ctx.timing_read().items()}
         ctx.timing_enable(False)
-        print("G=%d  shard rows %d  step %.3f ms   kernels (ms per launch, timed separately): %s   [bets %d, lost %d, rank variant %d, segments %d]"
-              % (G, rows, dt * 1e3, k, ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks"), ctx.get_stat("rank_variant"), ctx.get_stat("segments")), flush=True)
+        print("%s G=%d  shard rows %d  step %.3f ms   kernels (ms per launch, timed separately): %s   [bets %d, lost %d, rank variant %d, segments %d]"
+              % ("hg_shard_step" if one_call else "staged (Python)", G, rows, dt * 1e3, k, ctx.get_stat("optimistic_runs"), ctx.get_stat("optimistic_fallbacks"), ctx.get_stat("rank_variant"), ctx.get_stat("segments")), flush=True)
     finally:
         ctx.close()
 
@@ -75,5 +82,6 @@ def one(G, steps=10, opts=()):
 if __name__ == "__main__":
     opts = [(a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[1:] if "=" in a]
     for G in ([int(x) for x in sys.argv[1:] if "=" not in x] or [1, 2, 4, 8]):
-        one(G, opts=opts)
+        one(G, opts=opts, one_call=True)
+    one(8, opts=opts, one_call=False)
     print("# (exchanges routed by query owner: hg_alltoall stands in as G device copies of this rank's own block)")
