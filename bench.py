@@ -771,6 +771,36 @@ def main():
         dt = comm.allreduce_max(dt)                     # the slowest rank's clock
     timing = ctx.timing_read()
     ctx.timing_enable(False)
+    exchange = None
+    if sharded_leg:
+        # what crosses the wire per step and rank (the owner-routed form: three all-to-alls and one small all-gather), and how long the
+        # exchanges take on the stream (HIP events around every kernel and collective: a short pass of its own, after the timed region)
+        NBp, HC, width, RWw = b + 1, min((b + 1) // 2 + 2, b + 1), -(-Q // world), -(-R // 64)
+        cw = (NBp * width + 1) & ~1
+        by = {"alltoall_sampled_histograms": world * (4 + HC * width) * 4, "alltoall_guess_answers": world * width * 16,
+              "alltoall_record_counts_and_local_bitmaps": world * (cw + 64 + 2 * width * RWw) * 4, "allgather_ap_parts": world * (width + 1) * 16}
+        exchange = {"form": "owner-routed (hg_shard_step: every stage and exchange one enqueue)" if getattr(comm, "routed_verified", None) or (world == 1 and not dry_dir)
+                            else "all-gather of whole tables (the owner-routed form was not verified on this communicator, or no RCCL)",
+                    "rccl_ranks": world, "routed_verified_against_allgather": getattr(comm, "routed_verified", None),
+                    "ingress_bytes_per_rank_and_step": by, "ingress_bytes_total": int(sum(by.values()))}
+        try:
+            if dry_dir:
+                raise RuntimeError("dry run through files: nothing to time")
+            ctx.set_option("timing_every", 1)
+            ctx.timing_enable(2)
+            step()
+            ctx.timing_reset()
+            for _ in range(3):
+                step()
+            fence()
+            tx = ctx.timing_read()
+            ctx.timing_enable(False)
+            if "rccl_allgather" in tx:
+                exchange["exchanges_ms_per_step"] = round(tx["rccl_allgather"][0] / 3.0, 5)
+                exchange["exchange_calls_per_step"] = tx["rccl_allgather"][1] / 3.0
+            exchange["kernels_ms_per_launch_with_events"] = {k_: round(v_[0] / max(v_[1], 1), 5) for k_, v_ in tx.items()}
+        except Exception as e:      # noqa: BLE001 -- a side measurement must never cost the main line
+            exchange["timing_error"] = "%s: %s" % (type(e).__name__, e)
     qsplit = None
     if sharded_leg and not args.no_query_split:
         try:
@@ -810,6 +840,8 @@ def main():
         out["records_kept_over_R"] = round(kept / float(Q * R), 4)      # what the guess's safety margin costs the select's drain (1.0 = no surplus)
     if sharded_leg or wl == "c4":
         out["scaling"] = "strong"                            # the fixed N = 10M database over the GPUs (a one-GPU C2 line scales nothing)
+    if exchange is not None:
+        out["exchange"] = exchange
     if qsplit is not None:
         out["query_split"] = qsplit
     if sharded_leg:
