@@ -870,8 +870,8 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
     else if (!strcmp(key, "real_attempts")) *value = c->real_attempts;
     // how the last real-valued ranking ran: bit 0 = bf16 filter + exact rescoring, bit 1 = ranked by the LDS-resident kernel,
-    // bit 2 = record lists beyond the LDS ordered group by group (k_real_group_*)
-    else if (!strcmp(key, "real_path")) *value = (c->real_filtered ? 1 : 0) | (c->real_lds_ranked ? 2 : 0) | (c->real_grouped ? 4 : 0);
+    // bit 2 = record lists beyond the LDS ordered group by group (k_real_group_*), bit 3 = the filter ran in IEEE half (else bfloat16)
+    else if (!strcmp(key, "real_path")) *value = (c->real_filtered ? 1 : 0) | (c->real_lds_ranked ? 2 : 0) | (c->real_grouped ? 4 : 0) | (c->real_filtered && c->dbfb_half ? 8 : 0);
     else if (!strcmp(key, "device_bytes")) {
         DevBuf* all[] = {&c->db, &c->dblab, &c->qc, &c->qlab, &c->hist, &c->hown, &c->posbase, &c->seglt, &c->segtie,
                          &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err,

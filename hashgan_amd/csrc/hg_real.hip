@@ -71,9 +71,19 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
         HG_TRY(c->xmax2.reserve(4));
         HG_HIP(hipMemsetAsync(c->xmax2.p, 0, 4, c->stream));
         c->t_begin(KI_PACK);
-        hipLaunchKernelGGL(k_expand_dbf_bf16, dim3(grid_for(n16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
-                           c->dbfb.as<uint4>(), (i64)c->N, n16, KP);
         hipLaunchKernelGGL(k_row_norm_max, dim3(grid_for(c->N)), dim3(256), 0, c->stream, c->dbf.as<float>(), (i64)c->N, KP, c->xmax2.as<u32>());
+        // Which 16-bit format the filter's image takes -- once per database, one 4-byte download: IEEE half (three more significant
+        // bits: a margin an eighth of bfloat16's) when no feature can overflow it (every |x_k| <= the row's norm < 2^15), else bfloat16
+        float xm = 0.0f;
+        HG_HIP(hipMemcpyAsync(&xm, c->xmax2.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HG_TRY(c->sync());
+        // (... and when the rows are not tiny either: half's error has an absolute floor -- subnormals, flushed or not -- that outgrows
+        // the relative term once norms fall below ~0.1; bfloat16 has float32's exponents and no such floor)
+        c->dbfb_half = c->opt_real_mfma == 2 && xm >= 1.0f && xm < 1073741824.0f;         // 1 <= largest row norm^2 < 2^30 (inf and the NaN marker fail the test)
+        if (c->dbfb_half) hipLaunchKernelGGL(k_expand_dbf_bf16<true>, dim3(grid_for(n16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
+                                             c->dbfb.as<uint4>(), (i64)c->N, n16, KP);
+        else hipLaunchKernelGGL(k_expand_dbf_bf16<false>, dim3(grid_for(n16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
+                                c->dbfb.as<uint4>(), (i64)c->N, n16, KP);
         c->t_end();
         HG_TRY(c->check_launch("k_expand_dbf_bf16"));
         c->dbfb_valid = true;
@@ -82,7 +92,7 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     HG_TRY(c->thr2.reserve((size_t)g.Qpad * 4));
     c->t_begin(KI_REAL_GUESS);
     hipLaunchKernelGGL(k_real_thr2, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, c->qf.as<float>(), c->thr.as<float>(),
-                       c->xmax2.as<u32>(), c->thr2.as<float>(), g.Q, KP);
+                       c->xmax2.as<u32>(), c->thr2.as<float>(), g.Q, KP, c->dbfb_half ? 1.0 / 1024.0 : 1.0 / 256.0, c->dbfb_half ? 1.0 / 16384.0 : 0.0);
     c->t_end();
     HG_TRY(c->check_launch("k_real_thr2"));
     const int nSP = (g.S + 1) / 2;
@@ -94,10 +104,15 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     gs.nBlk = (int)gs.nUnits;
     RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
     c->t_begin(KI_REAL_SELECT);
-    if (real_bf_lds_bytes(KP) > 64 * 1024)
-        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_select_bf<KP, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, real_bf_lds_bytes(KP)));
-    hipLaunchKernelGGL((k_real_select_bf<KP, QT>), dim3(padded_grid(gs.nBlk)), dim3(256), real_bf_lds_bytes(KP), c->stream,
-                       c->qf.as<float>(), c->dbfb.as<u8>(), c->thr2.as<float>(), a, c->cand.as<u64>(), gs);
+#define HG_FILTER(HALF_)                                                                                                                     \
+    do {                                                                                                                                     \
+        if (real_bf_lds_bytes(KP) > 64 * 1024)                                                                                               \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_select_bf<KP, QT, HALF_>), hipFuncAttributeMaxDynamicSharedMemorySize, real_bf_lds_bytes(KP))); \
+        hipLaunchKernelGGL((k_real_select_bf<KP, QT, HALF_>), dim3(padded_grid(gs.nBlk)), dim3(256), real_bf_lds_bytes(KP), c->stream,       \
+                           c->qf.as<float>(), c->dbfb.as<u8>(), c->thr2.as<float>(), a, c->cand.as<u64>(), gs);                              \
+    } while (0)
+    if (c->dbfb_half) HG_FILTER(true); else HG_FILTER(false);
+#undef HG_FILTER
     c->t_end();
     HG_TRY(c->check_launch("k_real_select_bf"));
     // slices per wavefront of the rescoring pass: about one round of 64 kept rows (the filter keeps ~2 R per query)

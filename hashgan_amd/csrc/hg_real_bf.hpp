@@ -23,6 +23,7 @@
 #include "hg_kernels.hpp"
 #include "hg_real_kernels.hpp"
 #include "hg_select_mx.hpp"
+#include <type_traits>
 
 namespace hg {
 
@@ -30,15 +31,28 @@ typedef unsigned short u16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ u32 pack_bf16x2(float lo, float hi) {      // v_cvt_pk_bf16_f32 (round to nearest even)
     const f2 v = {lo, hi};
     const bf16x2 r = __builtin_convertvector(v, bf16x2);
     return *(const u32*)&r;
 }
+__device__ __forceinline__ u32 pack_f16x2(float lo, float hi) {       // two v_cvt_f16_f32 (round to nearest even; beyond 65504: inf -- the callers keep such tables out)
+    const f2 v = {lo, hi};
+    const f16x2 r = __builtin_convertvector(v, f16x2);
+    return *(const u32*)&r;
+}
+// HALF: the filter's 16-bit format is IEEE half (11 significant bits: the margin shrinks eightfold against bfloat16's 8) -- taken when
+// every feature of the database is below 2^15 in magnitude (the host checks the largest row norm once per database; a query with a
+// feature beyond that keeps every row, decided in the kernel); else bfloat16, whose range is float32's.
+template <bool HALF> __device__ __forceinline__ u32 pack_h2(float lo, float hi) { return HALF ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
 
 // Database image in A-fragment order of v_mfma_f32_32x32x16_bf16: groups of 16 rows; chunk (group G, MFMA m, k-half
 // hh, row r) = 16 bytes at (((G * (KP/16) + m) * 2 + hh) * 16 + r) * 16 holding bf16 features 16 m + 8 hh .. + 7 of
 // row 16 G + r.
+template <bool HALF>
 static __global__ __launch_bounds__(256) void k_expand_dbf_bf16(const float* __restrict__ dbf, uint4* __restrict__ img, i64 N, i64 n16, int KP) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     const int per_row = KP / 8;
@@ -49,8 +63,8 @@ static __global__ __launch_bounds__(256) void k_expand_dbf_bf16(const float* __r
     if (row < N) {
         const float4* f = (const float4*)(dbf + row * KP + 16 * m + 8 * hh);
         const float4 a = f[0], b = f[1];
-        v.x = pack_bf16x2(a.x, a.y); v.y = pack_bf16x2(a.z, a.w);
-        v.z = pack_bf16x2(b.x, b.y); v.w = pack_bf16x2(b.z, b.w);
+        v.x = pack_h2<HALF>(a.x, a.y); v.y = pack_h2<HALF>(a.z, a.w);
+        v.z = pack_h2<HALF>(b.x, b.y); v.w = pack_h2<HALF>(b.z, b.w);
     }
     img[(((row >> 4) * (KP / 16) + m) * 2 + hh) * 16 + (row & 15)] = v;
 }
@@ -71,8 +85,12 @@ static __global__ __launch_bounds__(256) void k_row_norm_max(const float* __rest
 }
 
 // thr2[q] = thr[q] - eps[q], rounded down (see the header).  One thread per query, double arithmetic.
+// u: relative error of one conversion under either rounding (2^-8 bfloat16, 2^-10 half); eta: its absolute floor (half: 2^-14 --
+// a subnormal half, or one the matrix pipe flushes to zero, is off by at most the smallest normal; bfloat16 has float32's exponents: 0):
+//   |q^ x^ - q x| <= |q^| |x^ - x| + |x| |q^ - q|,  |x^ - x| <= u |x| + eta   =>
+//   |approx - chain| <= (2u + u^2) sum |q x| + eta (1 + u) (|q|_1 + |x|_1) + K eta^2 + (K + 2) 2^-21 sum |q^ x^|
 static __global__ __launch_bounds__(256) void k_real_thr2(const float* __restrict__ qf, const float* __restrict__ thr, const u32* __restrict__ xmax2,
-                                                   float* __restrict__ thr2, int Q, int KP) {
+                                                   float* __restrict__ thr2, int Q, int KP, const double u, const double eta) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= Q) return;
     const float t = thr[q];
@@ -80,19 +98,22 @@ static __global__ __launch_bounds__(256) void k_real_thr2(const float* __restric
     double qq = 0.0;
     for (int k = 0; k < KP; ++k) { const double v = (double)qf[(i64)q * KP + k]; qq += v * v; }
     const double xx = (double)__uint_as_float(*xmax2) * 1.0001;       // the float32 sum of squares, inflated
-    const double u = 1.0 / 256.0;
     const double c = 2.0 * u + u * u + (double)(KP + 2) * 4.76837158203125e-07;   // 2^-21
-    const double eps = 1.0001 * c * sqrt(qq * xx) + (double)(KP + 2) * 4.76837158203125e-07 * fabs((double)t) + 1e-30;
+    const double eps = 1.0001 * c * sqrt(qq * xx) + (double)(KP + 2) * 4.76837158203125e-07 * fabs((double)t)
+                     + 1.01 * eta * sqrt((double)KP) * (sqrt(qq) + sqrt(xx)) + (double)KP * eta * eta + 1e-30;
     const double want = (double)t - eps;
     float r = (float)want;
     if ((double)r > want) r = __uint_as_float(r > 0.0f ? __float_as_uint(r) - 1u : (r < 0.0f ? __float_as_uint(r) + 1u : 0x80000001u));
     thr2[q] = r;
 }
 
+__device__ __forceinline__ f32x16 real_filter_mfma(const bf16x8 a, const bf16x8 b, const f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 real_filter_mfma(const f16x8 a, const f16x8 b, const f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
 constexpr int RB_WT = 4;                                     // row tiles per staged window
 constexpr int real_bf_lds_bytes(int KP) { return 2 * RB_WT * (KP / 16) * 1024; }
 
-template <int KP, int QT>          // QT query tiles (of 32) per wavefront: 2 up to 128 features, 1 beyond (B fragments live in registers)
+template <int KP, int QT, bool HALF>          // QT query tiles (of 32) per wavefront: 2 up to 128 features, 1 beyond (B fragments live in registers)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KP <= 64 ? 4 : 2, KP <= 64 ? 4 : 2)))
 void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, const float* __restrict__ thr2, const RealSelArgs a,
                       u64* __restrict__ cand, const Geo g) {
@@ -118,7 +139,8 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
 
     // ---- queries: B fragments (-bf16 of features 16 m + 8 h .. + 7 of query j), cut, slice cursors ----
     const int q0w = (qb * WPB + wave) * WQ;
-    bf16x8 bq[QT][NM];
+    typedef typename std::conditional<HALF, f16x8, bf16x8>::type hx8;
+    hx8 bq[QT][NM];
     float cut[QT];
     u32 cnt[QT], room[QT], dropped[QT];
     u64* wp[QT];
@@ -126,18 +148,33 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
     for (int t = 0; t < QT; ++t) {
         const int q = q0w + t * 32 + j;
         const bool live = q < g.Q && seg_ok;
+        float big = 0.0f;                                            // HALF: the largest magnitude among the lane's share of the query's features
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             u32 w[4] = {0u, 0u, 0u, 0u};
             if (q < g.Q) {
                 const float4* f = (const float4*)(qf + (i64)q * KP + 16 * m + 8 * h);
                 const float4 x = f[0], y = f[1];
-                w[0] = pack_bf16x2(-x.x, -x.y); w[1] = pack_bf16x2(-x.z, -x.w);
-                w[2] = pack_bf16x2(-y.x, -y.y); w[3] = pack_bf16x2(-y.z, -y.w);
+                w[0] = pack_h2<HALF>(-x.x, -x.y); w[1] = pack_h2<HALF>(-x.z, -x.w);
+                w[2] = pack_h2<HALF>(-y.x, -y.y); w[3] = pack_h2<HALF>(-y.z, -y.w);
+                if (HALF) big = fmaxf(big, fmaxf(fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))),
+                                                 fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)))));
             }
-            bq[t][m] = *(const bf16x8*)w;
+            bq[t][m] = *(const hx8*)w;
         }
         cut[t] = live ? thr2[q] : __uint_as_float(0x7F800000u);      // +inf: nothing qualifies
+        if (HALF) {
+            // a query feature half cannot hold (|q_k| >= 2^15, or NaN): no bound holds for this query -- B = 0 and C = -inf keep every
+            // row of it (a superset, like everything this kernel keeps); both lane-halves of the column must agree
+            const bool mine = !(big < 32768.0f);
+            const bool theirs = __shfl_xor((int)mine, 32) != 0;     // (every lane asks, before any `||` can skip it)
+            const bool wild = mine || theirs;
+            if (wild) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) { const u32 z[4] = {0u, 0u, 0u, 0u}; bq[t][m] = *(const hx8*)z; }
+                if (live) cut[t] = __uint_as_float(0xFF800000u);
+            }
+        }
         cnt[t] = 0; room[t] = live ? a.cap : 0u; dropped[t] = 0;
         wp[t] = cand + (i64)(q < g.Q ? q : 0) * a.crow + (i64)(seg_ok ? s : 0) * a.cap;
     }
@@ -177,9 +214,9 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
             for (int half = 0; half < 2; ++half) {
                 const i64 left = mylen - (T + half) * 16;    // valid rows of this lane in the tile (tiles past the end: none)
                 const u32 keep = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : (1u << (int)left) - 1u);
-                bf16x8 av[NM];
+                hx8 av[NM];
 #pragma unroll
-                for (int m = 0; m < NM; ++m) av[m] = *(const bf16x8*)(st + (((Tw + half) * NM + m) * 64 + lane) * 16);
+                for (int m = 0; m < NM; ++m) av[m] = *(const hx8*)(st + (((Tw + half) * NM + m) * 64 + lane) * 16);
                 // harvest: bit r <-> row 16 (T + half) + r of the lane's segment may qualify (thr2 - approx < 0)
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
@@ -187,7 +224,7 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = cut[t];
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bq[t][m], acc, 0, 0, 0);
+                    for (int m = 0; m < NM; ++m) acc = real_filter_mfma(av[m], bq[t][m], acc);
                     u32 mm = 0;
 #pragma unroll
                     for (int r = 15; r >= 0; --r) mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(acc[r]), 31);
@@ -266,16 +303,34 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
     for (int x = 0; x < SG; ++x) kept[x] = 0;
     const u64 below = (1ull << lane) - 1ull;
     const int pr = lane >> 3, pp = lane & 7;                 // staging role: row 8 e + pr of the round, 16-byte piece pp
+    // record i of the group's concatenated slices -> (slice k, offset): the row number of the NEXT round is requested before this
+    // round's gathers, so a round is two dependent memory round trips (gathers, write-back) instead of three
+    auto locate = [&](const u32 i, int& k, u32& off) {
+        k = 0;
+#pragma unroll
+        for (int x = 1; x < SG; ++x) k += i >= pre[x] ? 1 : 0;
+        off = i;
+#pragma unroll
+        for (int x = 1; x < SG; ++x) off = k == x ? i - pre[x] : off;
+    };
+    u32 idx_next = g.idx_base;
+    {
+        int k0; u32 off0;
+        locate((u32)lane, k0, off0);
+        if ((u32)lane < total) idx_next = (u32)rows[(i64)k0 * cap + off0];
+    }
     for (u32 base = 0; base < total; base += 64) {
         const u32 i = base + lane;
         const bool valid = i < total;
-        int k = 0;
-#pragma unroll
-        for (int x = 1; x < SG; ++x) k += i >= pre[x] ? 1 : 0;
-        u32 off = i;
-#pragma unroll
-        for (int x = 1; x < SG; ++x) off = k == x ? i - pre[x] : off;
-        const u32 idx = valid ? (u32)rows[(i64)k * cap + off] : g.idx_base;     // idle lanes: any valid row
+        int k; u32 off;
+        locate(i, k, off);
+        const u32 idx = idx_next;                                               // (idle lanes: any valid row)
+        idx_next = g.idx_base;
+        if (i + 64 < total) {                                                   // (this round's write-back lands at or before slot `off` of ITS slices:
+            int kn; u32 offn;                                                   //  a record never moves to the right, so the next round's slots are still intact)
+            locate(i + 64, kn, offn);
+            idx_next = (u32)rows[(i64)kn * cap + offn];
+        }
         const u32 local = idx - g.idx_base;
         u32 ridx[8];
 #pragma unroll

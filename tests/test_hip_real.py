@@ -209,6 +209,17 @@ def _adversarial(kind, rng, Q, N, b):
         return d, q
     if kind == "bits":          # {0,1} features: integer scores, ties by the thousand, the cut falls inside a tie group
         return (rng.random((N, b)) < 0.5).astype(np.float64), (rng.random((Q, b)) < 0.5).astype(np.float64)
+    if kind == "tiny":          # magnitudes around and below half's smallest normal (6.1e-5): half's absolute error floor would swamp the margin -- bfloat16 for this database
+        d = rng.standard_normal((N, b)) * 10.0 ** rng.uniform(-7, -3, (N, 1))
+        q = rng.standard_normal((Q, b)) * 10.0 ** rng.uniform(-6, -2, (Q, 1))
+        return d, q
+    if kind == "huge":          # database features beyond half's range: the filter must take bfloat16 for this database
+        d = rng.standard_normal((N, b)) * 10.0 ** rng.integers(0, 7, (N, 1))
+        return d, rng.standard_normal((Q, b))
+    if kind == "wildq":         # an ordinary database, but every third query has a feature half cannot hold: it keeps every row (the slices overflow: deeper attempts)
+        q = np.tanh(rng.standard_normal((Q, b)))
+        q[::3, 5] = 1.0e5
+        return np.tanh(rng.standard_normal((N, b))), q
     if kind == "dups":          # a few distinct rows repeated all over the database
         base = np.tanh(rng.standard_normal((37, b)))
         return base[rng.integers(0, 37, N)], np.tanh(rng.standard_normal((Q, b)))
@@ -216,7 +227,8 @@ def _adversarial(kind, rng, Q, N, b):
 
 
 @pytest.mark.parametrize("kind,Q,N,b,R", [("tanh", 70, 80000, 64, 3000), ("wide", 40, 70000, 48, 2000), ("bits", 33, 90000, 32, 5000),
-                                          ("dups", 20, 66000, 16, 1500), ("tanh", 12, 131072, 128, 6000)])
+                                          ("dups", 20, 66000, 16, 1500), ("tanh", 12, 131072, 128, 6000),
+                                          ("tiny", 50, 80000, 64, 3000), ("huge", 30, 70000, 64, 2000), ("wildq", 30, 70000, 32, 1000)])
 def test_filter_and_rescore_equals_the_exact_passes(kind, Q, N, b, R, ctx):
     """The sampled bet at sizes where it applies (N >= 65536, R <= N / 8): the bfloat16 filter + exact rescoring
     (hg_real_bf.hpp, real_mfma = 2), the float32 matrix-core pass (1) and the vector-ALU pass (0) must all deliver
@@ -240,10 +252,12 @@ def test_filter_and_rescore_equals_the_exact_passes(kind, Q, N, b, R, ctx):
             idx, score = ctx.topr_real(R)
             assert np.array_equal(score.view(np.uint32), score_ref.view(np.uint32)), (kind, mode, lds)
             assert np.array_equal(idx, idx_ref), (kind, mode, lds)
-            if kind != "bits":          # (a cut inside a tie group of thousands overflows the slices: deeper attempts, same lists)
+            if kind not in ("bits", "wildq"):   # (a cut inside a tie group of thousands overflows the slices: deeper attempts, same lists)
                 assert ctx.get_stat("real_attempts") == 1, (kind, mode, lds)
             assert (ctx.get_stat("real_path") & 1) == (1 if mode == 2 else 0)
-            if ctx.get_stat("real_attempts") == 1 and kind != "bits":   # (tie groups can exceed the LDS: the global passes take over)
+            if mode == 2:               # the filter's format: IEEE half unless a database feature could overflow it
+                assert ((ctx.get_stat("real_path") >> 3) & 1) == (0 if kind in ("huge", "tiny") else 1), kind
+            if ctx.get_stat("real_attempts") == 1 and kind not in ("bits", "wildq"):   # (tie groups can exceed the LDS: the global passes take over)
                 assert ((ctx.get_stat("real_path") >> 1) & 1) == (1 if mode == 2 and lds and R <= 6144 else 0)
             ap, rel = ctx.map_real(R)
             assert np.array_equal(ap, ap_ref, equal_nan=True), (kind, mode, lds)
