@@ -270,9 +270,12 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
 // Rescore: wavefront = (group of SG consecutive slices, query); lane = one kept row.  The query's features are
 // wave-uniform (scalar loads); consecutive wavefronts take consecutive queries of the SAME segment group, whose rows
 // (SG x real_segment_bytes) stay in the L2 while all queries pass.  The 64 rows of a round are fetched COALESCED, 32
-// features at a time -- 8 lanes per row, 8 rows per load instruction, whole cache lines -- and turned through LDS (rows
-// padded to 144 bytes) so that every lane then walks its own row in feature order: one float32 fma chain, k ascending.
-constexpr int RS_ROWB = 144;                                 // bytes per staged row: 32 floats + 16 (bank spread)
+// features at a time -- 8 lanes per row, 8 rows per load instruction, whole cache lines -- and turned through LDS so that
+// every lane then walks its own row in feature order: one float32 fma chain, k ascending.  Rows lie 128 bytes apart in
+// LDS, unpadded (8 KB per wavefront: five blocks per compute unit instead of the four that 144-byte rows allowed); the
+// 16-byte piece p of row r sits in slot p ^ ((r >> 1) & 7), so the 16 lanes of a ds_read_b128 group (16 rows, one p)
+// hit 16 different bank quads, and a row's 8 pieces written by 8 consecutive lanes fill its 128 bytes in some order.
+constexpr int RS_ROWB = 128;                                 // bytes per staged row: 32 floats
 constexpr int rescore_lds_bytes() { return WPB * 64 * RS_ROWB; }
 
 template <int KPT, int SG>          // KPT: the (padded) feature count, 0 = taken at run time (kp_rt; beyond 128 features)
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
     for (int x = 0; x < SG; ++x) kept[x] = 0;
     const u64 below = (1ull << lane) - 1ull;
     const int pr = lane >> 3, pp = lane & 7;                 // staging role: row 8 e + pr of the round, 16-byte piece pp
+    const int rsw = (lane >> 1) & 7;                         // reading role: row `lane`, piece p from slot p ^ rsw
     // record i of the group's concatenated slices -> (slice k, offset): the row number of the NEXT round is requested before this
     // round's gathers, so a round is two dependent memory round trips (gathers, write-back) instead of three
     auto locate = [&](const u32 i, int& k, u32& off) {
@@ -350,11 +354,11 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
                 const int cu = c0 + 32 * u;
                 if (cu < KP) {                                // (wave-uniform)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) *(float4*)(st + (8 * e + pr) * RS_ROWB + pp * 16) = gl[u][e];
+                    for (int e = 0; e < 8; ++e) *(float4*)(st + (8 * e + pr) * RS_ROWB + ((pp ^ (pr >> 1) ^ (4 * (e & 1))) * 16)) = gl[u][e];
                     wave_lds_sync();
                     float4 v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = *(const float4*)(st + lane * RS_ROWB + e * 16);
+                    for (int e = 0; e < 8; ++e) v[e] = *(const float4*)(st + lane * RS_ROWB + ((e ^ rsw) * 16));
                     wave_lds_sync();
                     // KP is a multiple of 16: a piece is whole or half -- no per-feature guards, so the query's scalar loads batch
                     const float* __restrict__ qc = qrow + cu;
