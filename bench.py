@@ -678,6 +678,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the C2-iid / C1 / C3 / C5 legs (the timed shape on i.i.d. codes; the other BASELINE.json configurations)")
     ap.add_argument("--no-query-split", action="store_true", help="sharded runs: skip the replicated-database / split-queries leg")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (hg_set_option), repeatable")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one GPU: every timed step is a synchronous hg_map (default: hg_map_begin / hg_map_end with two steps in flight -- "
+                         "every step still delivers its verdict, APs and hit counts to the host inside the timed region)")
     ap.add_argument("--timing-every", type=int, default=4,
                     help="pair-passes timing brackets the select pass on every n-th step of the timed region (its events cost a "
                          "step ~0.025 ms: tools/gpu_event_cost.sh); the average is over those launches")
@@ -743,6 +746,7 @@ def main():
 
         def fence():
             ctx.synchronize()                           # hipStreamSynchronize (every one-shot call also ends synchronised)
+    pipelined = not sharded_leg and not args.no_pipeline
 
     # Untimed steps first: the W the caller asked for, and at least SETTLE_STEPS in all -- a GPU that has idled (the inputs
     # were generated on the host for seconds) needs ~20 ms of load before its clocks are back up (the first steps run 5-20 %
@@ -761,16 +765,39 @@ def main():
     fence()
     each = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        t1 = time.perf_counter()
-        m, a = step()                                   # (ends synchronised: the AP vector is on the host)
-        each.append(time.perf_counter() - t1)
+    if pipelined:
+        # hg_map in two halves, two steps in flight: step i + 1 is enqueued before step i's results are waited for, so the GPU goes
+        # from one step straight into the next; every step's verdict is checked and its APs are on the host when its map_end returns
+        ctx.map_begin(R)
+        for i in range(args.steps):
+            t1 = time.perf_counter()
+            if i + 1 < args.steps:
+                ctx.map_begin(R)
+            a, r = ctx.map_end()
+            m = metric.mean_over_hits(a, r)
+            each.append(time.perf_counter() - t1)
+    else:
+        for _ in range(args.steps):
+            t1 = time.perf_counter()
+            m, a = step()                               # (ends synchronised: the AP vector is on the host)
+            each.append(time.perf_counter() - t1)
     fence()
     dt = time.perf_counter() - t0
     if sharded_leg:
         dt = comm.allreduce_max(dt)                     # the slowest rank's clock
     timing = ctx.timing_read()
     ctx.timing_enable(False)
+    pipe = None
+    if pipelined:
+        # the same steps one at a time (hg_map: enqueue, wait, copy out, return), for the latency of a single call
+        ns = max(1, min(args.steps, 20))
+        fence()
+        ts = time.perf_counter()
+        for _ in range(ns):
+            step()
+        fence()
+        pipe = {"steps_in_flight": 2, "api": "hg_map_begin / hg_map_end", "sync_ms_per_step": (time.perf_counter() - ts) / ns * 1e3,
+                "sync_steps_timed": ns, "blind_steps": ctx.get_stat("map_async_steps"), "blind_steps_redone": ctx.get_stat("map_async_redone")}
     exchange = None
     if sharded_leg:
         # what crosses the wire per step and rank (the owner-routed form: three all-to-alls and one small all-gather), and how long the
@@ -840,6 +867,8 @@ def main():
         out["records_kept_over_R"] = round(kept / float(Q * R), 4)      # what the guess's safety margin costs the select's drain (1.0 = no surplus)
     if sharded_leg or wl == "c4":
         out["scaling"] = "strong"                            # the fixed N = 10M database over the GPUs (a one-GPU C2 line scales nothing)
+    if pipe is not None:
+        out["pipeline"] = pipe
     if exchange is not None:
         out["exchange"] = exchange
     if qsplit is not None:

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "hg_merge_topr": [_p, _p, _p, C.c_int],
     "hg_topr": [_p, _i64],
     "hg_map": [_p, _i64, _p, _p],
+    "hg_map_begin": [_p, _i64],
+    "hg_map_end": [_p, _p, _p],
     "hg_map_real": [_p, _i64, _p, _p],
     "hg_topr_real": [_p, _i64],
     "hg_get_topr_real": [_p, _p, _p],
@@ -335,6 +337,18 @@ class Context:
         rel = np.empty(self.Q, dtype=np.int64)
         check(self._lib.hg_map(self._h, int(R), _ptr(ap), _ptr(rel)))
         self.R = int(R)
+        return ap, rel
+
+    def map_begin(self, R):
+        """First half of map(): enqueue a step and return (at most two in flight; see hg_map_begin in include/hashgan_amd.h)."""
+        check(self._lib.hg_map_begin(self._h, int(R)))
+        self.R = int(R)
+
+    def map_end(self):
+        """Second half of map(): wait for the oldest step in flight, return its (ap, rel)."""
+        ap = np.empty(self.Q, dtype=np.float64)
+        rel = np.empty(self.Q, dtype=np.int64)
+        check(self._lib.hg_map_end(self._h, _ptr(ap), _ptr(rel)))
         return ap, rel
 
     # -- real-valued features ---------------------------------------------------

@@ -180,6 +180,7 @@ int hg_destroy(hg_ctx* c) {
     comm_release(c);
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
     if (c->pin) (void)hipHostFree(c->pin);
+    for (auto& m : c->mslot) { if (m.pin) (void)hipHostFree(m.pin); if (m.ev) (void)hipEventDestroy(m.ev); m.pin = nullptr; m.ev = nullptr; }
     if (c->hpk) (void)hipHostFree(c->hpk);
     if (c->fstage) (void)hipHostFree(c->fstage);
     if (c->stream2_ev) (void)hipEventDestroy(c->stream2_ev);
@@ -887,6 +888,8 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "dbg_hwq_ptr")) *value = (int64_t)(uintptr_t)c->hwq.p;
 #endif
     else if (!strcmp(key, "graph_replays")) *value = c->graph_replays;
+    else if (!strcmp(key, "map_async_steps")) *value = c->map_async_steps;
+    else if (!strcmp(key, "map_async_redone")) *value = c->map_async_redone;
     else if (!strcmp(key, "segments")) *value = c->geo.S;
     else if (!strcmp(key, "records_kept")) {
         // records the last bet's select pass left in the slices, over all live queries (a download of the slice counts: a

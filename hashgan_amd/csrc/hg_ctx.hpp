@@ -248,6 +248,17 @@ struct hg_ctx {
     // call's single synchronisation instead of three blocking copies into pageable memory afterwards
     void* pin = nullptr;
     size_t pin_cap = 0;
+    // hg_map_begin / hg_map_end: up to two steps in flight, each with its own pinned landing block and event
+    struct MapSlot {
+        void* pin = nullptr; size_t cap = 0; hipEvent_t ev = nullptr;
+        bool async = false;            // enqueued only (else: ran synchronously, results in ap / rel)
+        i64 R = 0, Q = 0;
+        std::vector<double> ap; std::vector<int64_t> rel;
+    } mslot[2];
+    int ms_head = 0, ms_n = 0;
+    unsigned long long map_warm_cfg = 0, map_warm_epoch = 0;   // configuration of the last synchronous hg_map that won its bet outright
+    i64 map_warm_R = -1;
+    i64 map_async_steps = 0, map_async_redone = 0;
     bool ap_staged = false;
     DevBuf hist, hown, posbase, seglt, segtie;
     DevBuf t, tguess, sstar, cnt_lt, quota, tie_before, n_lt, err;

@@ -1274,14 +1274,30 @@ static int rerun_lost_queries(hg_ctx* c, int64_t R, bool lists, bool with_ap, bo
 // buffers are warm), so it can run under stream capture.
 // The verdict word, the APs and the hit counts into pinned memory behind everything enqueued so far (hg_get_ap then copies from there):
 // one synchronisation for the whole call instead of a pageable 4-byte download, a wait, and hg_get_ap's own copies and wait.
-static int stage_ap_download(hg_ctx* c) {
+// The step's results into pinned host memory by a KERNEL (the host block is device-addressable: stores go over the link as posted
+// writes): a hipMemcpyAsync of these ~120 KB runs on a copy engine behind a cross-queue barrier and holds the stream ~20 us -- the
+// gap between one step's last kernel and the next step's first (hg_map_begin) -- where this launch costs a few.
+static __global__ __launch_bounds__(256) void k_copy_out(const uint4* __restrict__ src, uint4* __restrict__ dst, const u32 n16, const u32 tail_dwords) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+    if (i < tail_dwords) ((u32*)(dst + n16))[i] = ((const u32*)(src + n16))[i];
+}
+
+static int stage_ap_download(hg_ctx* c, void* dst = nullptr) {      // dst: a pinned block of its own (hg_map_begin), else the context's
     const size_t Q = (size_t)c->geo.Q;
-    HG_TRY(ensure_pin(c, Q * 12 + 16));
-    char* pb = (char*)c->pin;                  // [flag: 16 B][ap Q x 8][rel Q x 4]
+    if (!dst) HG_TRY(ensure_pin(c, Q * 12 + 16));
+    char* pb = (char*)(dst ? dst : c->pin);    // [flag: 16 B][ap Q x 8][rel Q x 4]
     const char* base = (const char*)c->outblk.p;
     if (base && c->outblk_q == (i64)Q && c->err.p == base && c->ap.p == base + 16 && c->rel.p == base + 16 + Q * 8) {
-        HG_HIP(hipMemcpyAsync(pb, base, 16 + Q * 12, hipMemcpyDeviceToHost, c->stream));     // the three are views of one block (ensure_out_block)
-        return HG_OK;
+        const size_t bytes = 16 + Q * 12;      // the three are views of one block (ensure_out_block)
+        static const bool by_engine = getenv("HG_COPY_ENGINE_DOWNLOAD") != nullptr;       // (A/B: the copy-engine form)
+        if (by_engine || c->capturing) {
+            HG_HIP(hipMemcpyAsync(pb, base, bytes, hipMemcpyDeviceToHost, c->stream));
+            return HG_OK;
+        }
+        const u32 n16 = (u32)(bytes / 16), tail = (u32)((bytes % 16) / 4);
+        hipLaunchKernelGGL(k_copy_out, dim3((n16 + 255) / 256 + (n16 % 256 == 0 && tail ? 1 : 0)), dim3(256), 0, c->stream, (const uint4*)base, (uint4*)pb, n16, tail);
+        return c->check_launch("k_copy_out");
     }
     HG_HIP(hipMemcpyAsync(pb, c->err.p, 8, hipMemcpyDeviceToHost, c->stream));
     HG_HIP(hipMemcpyAsync(pb + 16, c->ap.p, Q * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1289,7 +1305,7 @@ static int stage_ap_download(hg_ctx* c) {
     return HG_OK;
 }
 
-static int enqueue_bet_with_ap(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
+static int enqueue_bet_with_ap(hg_ctx* c, int64_t R, int stride, u32 need_cnt, void* dst = nullptr) {
     c->t_step_begin();
     c->fuse_ap = true;
     const int rc = enqueue_optimistic(c, R, stride, need_cnt);
@@ -1297,7 +1313,7 @@ static int enqueue_bet_with_ap(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     HG_TRY(rc);
     if (c->ap_fused) { c->ap_staged = false; c->stage |= ST_AP; }     // k_rank_cnt's epilogue left the APs (leftovers: run_oneshot)
     else HG_TRY(do_ap(c));
-    HG_TRY(stage_ap_download(c));              // [flag, leftover count: 16 B][ap Q x 8][rel Q x 4]
+    HG_TRY(stage_ap_download(c, dst));         // [flag, leftover count: 16 B][ap Q x 8][rel Q x 4]
     c->t_step_end();
     return HG_OK;
 }
@@ -1522,8 +1538,92 @@ int hg_topr(hg_ctx* c, int64_t R) {
 
 int hg_map(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
     HG_TRY(need(c, ST_DB | ST_Q, "hg_map", "hg_set_database + hg_set_queries"));
+    const i64 fails0 = c->opt_fallbacks + c->opt_requeried + c->opt_rebets, left0 = c->opt_leftover;
     HG_TRY(run_oneshot(c, R, false, true));
-    return hg_get_ap(c, host_ap, host_rel);
+    HG_TRY(hg_get_ap(c, host_ap, host_rel));
+    // what hg_map_begin may enqueue without looking back: this very step, when it just won its bet outright
+    if (c->optimistic && c->opt_fallbacks + c->opt_requeried + c->opt_rebets == fails0 && c->opt_leftover == left0 && !c->is_sub) {
+        c->map_warm_cfg = c->cfg_epoch; c->map_warm_epoch = g_alloc_epoch; c->map_warm_R = R;
+    } else {
+        c->map_warm_R = -1;
+    }
+    return HG_OK;
+}
+
+// hg_map in two halves, for a caller that evaluates batch after batch: hg_map_begin enqueues a step (kernels and the download of
+// its verdict, APs and hit counts into a pinned block of its own) and returns; hg_map_end waits for the OLDEST step in flight and
+// hands its results over.  Two steps may be in flight, so the GPU starts step i + 1 the moment step i ends -- the host's wake-up,
+// its copies and its next enqueue (~40 us per step at C2) no longer sit between them.  A step is only enqueued blind when the
+// last synchronous hg_map with the same tables, options and R won its bet outright; otherwise hg_map_begin runs the whole call
+// itself (and keeps the results for hg_map_end).  A blind step that loses its bet is run again, synchronously, by hg_map_end:
+// results are those of hg_map in every case.
+int hg_map_begin(hg_ctx* c, int64_t R) {
+    HG_TRY(need(c, ST_DB | ST_Q, "hg_map_begin", "hg_set_database + hg_set_queries"));
+    if (c->ms_n == 2) return fail(HG_ERR_STATE, "hg_map_begin: two steps are in flight already (hg_map_end takes the oldest)");
+    hg_ctx::MapSlot& m = c->mslot[(c->ms_head + c->ms_n) & 1];
+    m.R = R; m.Q = c->Q;
+    int stride = 0;
+    u32 need_cnt = 0;
+    bool blind = c->map_warm_R == R && c->map_warm_cfg == c->cfg_epoch && c->map_warm_epoch == g_alloc_epoch && !c->is_sub;
+    if (blind) {
+        c->real_lists = false;
+        c->want_lists = false;
+        HG_TRY(ensure_out_block(c));
+        blind = optimistic_eligible(c, R, &stride, &need_cnt) && c->map_warm_epoch == g_alloc_epoch;
+    }
+    if (blind) {
+        const size_t need_b = (size_t)c->Q * 12 + 16;
+        if (m.cap < need_b) {
+            if (m.pin) (void)hipHostFree(m.pin);
+            m.pin = nullptr; m.cap = 0;
+            HG_HIP(hipHostMalloc(&m.pin, need_b, hipHostMallocDefault));
+            m.cap = need_b;
+        }
+        if (!m.ev) HG_HIP(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
+        c->opt_runs++;
+        HG_TRY(enqueue_bet_with_ap(c, R, stride, need_cnt, m.pin));
+        HG_HIP(hipEventRecord(m.ev, c->stream));
+        c->ap_staged = false;
+        m.async = true;
+        c->map_async_steps++;
+    } else {
+        m.ap.resize((size_t)c->Q); m.rel.resize((size_t)c->Q);
+        HG_TRY(hg_map(c, R, m.ap.data(), m.rel.data()));
+        m.async = false;
+    }
+    ++c->ms_n;
+    return HG_OK;
+}
+
+int hg_map_end(hg_ctx* c, double* host_ap, int64_t* host_rel) {
+    if (!c) return fail(HG_ERR_ARG, "hg_map_end: null context");
+    HG_TRY(c->use());
+    if (!c->ms_n) return fail(HG_ERR_STATE, "hg_map_end: no step in flight (hg_map_begin first)");
+    hg_ctx::MapSlot& m = c->mslot[c->ms_head];
+    c->ms_head ^= 1; --c->ms_n;                           // (taken off the queue whatever happens below)
+    const size_t Q = (size_t)m.Q;
+    if (!m.async) {
+        if (host_ap) memcpy(host_ap, m.ap.data(), Q * 8);
+        if (host_rel) memcpy(host_rel, m.rel.data(), Q * 8);
+        return HG_OK;
+    }
+    HG_HIP(hipEventSynchronize(m.ev));
+    const u32* w = (const u32*)m.pin;                      // [verdict][queries the fused rank kernel declined] ...
+    if (w[0] == 0 && w[1] == 0 && (i64)Q == c->Q) {
+        const char* pb = (const char*)m.pin;
+        if (host_ap) memcpy(host_ap, pb + 16, Q * 8);
+        if (host_rel) {
+            const u32* r = (const u32*)(pb + 16 + Q * 8);
+            for (size_t q = 0; q < Q; ++q) host_rel[q] = r[q];
+        }
+        return HG_OK;
+    }
+    // the bet was lost (or queries were left over): the synchronous call sorts that out -- reruns, deeper bets, wider slices -- on
+    // the same tables; a younger step in flight keeps its own verdict in its own block
+    c->map_async_redone++;
+    c->map_warm_R = -1;
+    if ((i64)Q != c->Q) return fail(HG_ERR_STATE, "hg_map_end: the queries were replaced while a step that lost its bet was in flight");
+    return hg_map(c, m.R, host_ap, host_rel);
 }
 
 }  // extern "C"

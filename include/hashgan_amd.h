@@ -188,6 +188,16 @@ int hg_merge_topr(hg_ctx* ctx, const uint32_t* dev_idx_all, const uint8_t* dev_d
  * match bits; use hg_topr when the ranked lists themselves are wanted. */
 int hg_topr(hg_ctx* ctx, int64_t R);
 int hg_map(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel);
+/* hg_map in two halves, for a caller that evaluates batch after batch (lib/metric.py:4-24 once per batch of queries):
+ * hg_map_begin enqueues a step -- its kernels and the download of verdict, APs and hit counts into a pinned block of its
+ * own -- and returns; hg_map_end waits for the OLDEST step in flight and hands over what hg_map would have returned.  Up to
+ * two steps may be in flight (a third hg_map_begin is HG_ERR_STATE), so the GPU starts one step the moment the previous one
+ * ends.  A step is only enqueued blind when the last synchronous hg_map on the same tables, options and R won its bet
+ * outright; otherwise hg_map_begin runs the whole call itself.  A blind step that loses its bet is run again by hg_map_end.
+ * Replacing the tables between the two halves is allowed only for steps that won (else HG_ERR_STATE).
+ * Stats "map_async_steps" / "map_async_redone". */
+int hg_map_begin(hg_ctx* ctx, int64_t R);
+int hg_map_end(hg_ctx* ctx, double* host_ap, int64_t* host_rel);
 
 /* ---- real-valued features (what main.py feeds when nothing is binarised) ----
  * Ranking by float32 inner product, lib/metric.py:13-14 as written, on the float tables kept by
@@ -287,12 +297,13 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  *                 ALU), "real_sort_lds" (1: ranked by the LDS-resident kernel when the records fit), "real_groups" (1: lists beyond the LDS ordered group by group)
  *   ("probe_select" exists only in the measurement build, python -m hashgan_amd.build --probes) */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
-/* Counters and facts about the last call (18 keys): "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly),
+/* Counters and facts about the last call (20 keys): "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly),
  * "optimistic_requeried" (single queries rerun exactly after losing their bet), "optimistic_rebets" (second and widened bets), "last_optimistic",
  * "rank_leftovers" (queries the LDS-resident rank kernel left to the general one), "select_variant" (1 k_select, 2 k_select_dense, 3 k_select_mx,
  * 5 k_select_mx3, 6 k_select_mx4), "rank_variant" (1 k_rank_fused, 3 k_rank_cnt, 6 k_rank_lean, 7 k_rank_dense, 8 k_rank_dense<slices>), "ap_fused",
  * "cap_boost", "crowding_x100", "segments", "records_kept" (records the last bet's select left in the slices: a download, not part of a step),
- * "device_bytes", "graph_replays"; real-valued path: "real_attempts", "real_cap_boost", "real_path" (bit 0 filter + rescoring, bit 1 ranked in LDS,
+ * "device_bytes", "graph_replays", "map_async_steps" / "map_async_redone" (hg_map_begin: steps enqueued blind / of those, run again by hg_map_end);
+ * real-valued path: "real_attempts", "real_cap_boost", "real_path" (bit 0 filter + rescoring, bit 1 ranked in LDS,
  * bit 2 lists ordered group by group). */
 int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
 /* What hg_set_database_f32 (queries = 0) / hg_set_queries_f32 (queries = 1) found in the float table: out[0] entries outside

@@ -322,6 +322,54 @@ def test_step_graph_replays_equal_eager_steps(case_cache):
         ctx.close()
 
 
+def test_map_in_two_halves_equals_map(case_cache):
+    """hg_map_begin / hg_map_end: the same AP and hit counts as hg_map, bit for bit -- the first begin runs the call itself, the
+    following ones enqueue blind with two steps in flight; a third begin is refused; new queries make the next begin synchronous
+    again; a blind step that loses its bet (slices squeezed by an option between the halves' warm-up and the step) is redone."""
+    c = case_cache("c2_q64")
+    g = cases.load_golden("c2_q64")
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, c)
+        R = c["R"]
+        ap0, rel0 = ctx.map(R)
+        assert np.array_equal(ap0, g["ap"], equal_nan=True)
+        ctx.map_begin(R)
+        ctx.map_begin(R)
+        with pytest.raises(_native.HashganNativeError):
+            ctx.map_begin(R)
+        for k in range(6):
+            ap, rel = ctx.map_end()
+            assert np.array_equal(ap, ap0, equal_nan=True) and np.array_equal(rel, rel0), k
+            ctx.map_begin(R)
+        a1, r1 = ctx.map_end()
+        a2, r2 = ctx.map_end()
+        assert np.array_equal(a1, ap0, equal_nan=True) and np.array_equal(a2, ap0, equal_nan=True) and np.array_equal(r2, rel0)
+        with pytest.raises(_native.HashganNativeError):
+            ctx.map_end()
+        if ctx.get_stat("last_optimistic"):
+            assert ctx.get_stat("map_async_steps") >= 6 and ctx.get_stat("map_async_redone") == 0
+        # other queries: the next begin runs synchronously (nothing is known about their bet), the ones after it blind
+        ctx.set_queries(metric.pack_codes(c["qbits"][::-1].copy()), metric.pack_labels(c["qlab"][::-1].copy()))
+        n0 = ctx.get_stat("map_async_steps")
+        ctx.map_begin(R)
+        assert ctx.get_stat("map_async_steps") == n0
+        ctx.map_begin(R)
+        for _ in range(2):
+            ap, rel = ctx.map_end()
+            assert np.array_equal(ap, g["ap"][::-1], equal_nan=True)
+        # another R in flight next to the first
+        ap_half, rel_half = ctx.map(R // 2)
+        ctx.map_begin(R // 2)
+        ctx.map_begin(R)
+        a, r = ctx.map_end()
+        assert np.array_equal(a, ap_half, equal_nan=True) and np.array_equal(r, rel_half)
+        a, r = ctx.map_end()
+        assert np.array_equal(a, g["ap"][::-1], equal_nan=True)
+    finally:
+        ctx.close()
+
+
 def test_device_pack_matches_host_pack(ctx):
     """The two ways float32 features / int64 labels become packed tables -- a pool of host threads before the upload
     (hg_host_pack.hpp, the default) and k_pack_sign_f32 / k_pack_labels_i64 on the GPU -- against the NumPy packing, bit
