@@ -104,14 +104,17 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     gs.nBlk = (int)gs.nUnits;
     RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
     c->t_begin(KI_REAL_SELECT);
-#define HG_FILTER(HALF_)                                                                                                                     \
+#define HG_FILTER(HALF_, FAR_)                                                                                                               \
     do {                                                                                                                                     \
         if (real_bf_lds_bytes(KP) > 64 * 1024)                                                                                               \
-            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_select_bf<KP, QT, HALF_>), hipFuncAttributeMaxDynamicSharedMemorySize, real_bf_lds_bytes(KP))); \
-        hipLaunchKernelGGL((k_real_select_bf<KP, QT, HALF_>), dim3(padded_grid(gs.nBlk)), dim3(256), real_bf_lds_bytes(KP), c->stream,       \
+            HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_select_bf<KP, QT, HALF_, FAR_>), hipFuncAttributeMaxDynamicSharedMemorySize, real_bf_lds_bytes(KP))); \
+        hipLaunchKernelGGL((k_real_select_bf<KP, QT, HALF_, FAR_>), dim3(padded_grid(gs.nBlk)), dim3(256), real_bf_lds_bytes(KP), c->stream, \
                            c->qf.as<float>(), c->dbfb.as<u8>(), c->thr2.as<float>(), a, c->cand.as<u64>(), gs);                              \
     } while (0)
-    if (c->dbfb_half) HG_FILTER(true); else HG_FILTER(false);
+    // (a wavefront's 64 record rows within 4 GB: 32-bit cursors -- every bet; beyond, e.g. every row a record of a 10M-row database, 64-bit ones)
+    const bool far_rows = (unsigned long long)c->crow * 8ull * 64ull >= (1ull << 32);
+    if (c->dbfb_half) { if (far_rows) HG_FILTER(true, true); else HG_FILTER(true, false); }
+    else { if (far_rows) HG_FILTER(false, true); else HG_FILTER(false, false); }
 #undef HG_FILTER
     c->t_end();
     HG_TRY(c->check_launch("k_real_select_bf"));

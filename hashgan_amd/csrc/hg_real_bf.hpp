@@ -113,8 +113,12 @@ __device__ __forceinline__ f32x16 real_filter_mfma(const f16x8 a, const f16x8 b,
 constexpr int RB_WT = 4;                                     // row tiles per staged window
 constexpr int real_bf_lds_bytes(int KP) { return 2 * RB_WT * (KP / 16) * 1024; }
 
-template <int KP, int QT, bool HALF>          // QT query tiles (of 32) per wavefront: 2 up to 128 features, 1 beyond (B fragments live in registers)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KP <= 64 ? 4 : 2, KP <= 64 ? 4 : 2)))
+template <int KP, int QT, bool HALF, bool FAR>          // QT query tiles (of 32) per wavefront: 2 up to 128 features, 1 beyond (B fragments live in registers);
+                                                        // FAR: a wavefront's 64 record rows span 4 GB or more (every row a record of a huge database): 64-bit cursors
+#ifndef HG_RB_WAVES
+#define HG_RB_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KP <= 64 ? HG_RB_WAVES : 2, KP <= 64 ? HG_RB_WAVES : 2)))
 void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, const float* __restrict__ thr2, const RealSelArgs a,
                       u64* __restrict__ cand, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 blds[];
@@ -142,7 +146,7 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
     typedef typename std::conditional<HALF, f16x8, bf16x8>::type hx8;
     hx8 bq[QT][NM];
     float cut[QT];
-    u32 cnt[QT], room[QT], dropped[QT];
+    u32 cnt[QT], room[QT], dropped[QT], woff[QT], wbeg[QT], wend[QT];
     u64* wp[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -177,7 +181,14 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
         }
         cnt[t] = 0; room[t] = live ? a.cap : 0u; dropped[t] = 0;
         wp[t] = cand + (i64)(q < g.Q ? q : 0) * a.crow + (i64)(seg_ok ? s : 0) * a.cap;
+        // !FAR: the lane's cursor is a 32-bit byte offset from the wavefront's first record row (the store takes a scalar base and a
+        // vector offset: no 64-bit address arithmetic per hit), and a hit beyond the slice's capacity lands on its last slot -- the
+        // query is flagged and redone anyway -- so the hit costs no branch on the room left
+        woff[t] = (u32)((((i64)(t * 32 + j)) * a.crow + (i64)(seg_ok ? s : 0) * a.cap) * 8);
+        wbeg[t] = woff[t];
+        wend[t] = woff[t] + (a.cap - 1u) * 8u;                    // (the slice's last slot)
     }
+    const char* wbase = (const char*)(cand + (i64)q0w * a.crow);
 
     // ---- A fragments: windows of RB_WT tiles staged global -> LDS (k_select_mx's scheme), shared by the four
     // wavefronts of the block -- every wavefront copies a quarter of a window and reads all of it, lane-linear, so a
@@ -212,8 +223,8 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
             for (int t = 0; t < QT; ++t) mask[t] = 0;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const i64 left = mylen - (T + half) * 16;    // valid rows of this lane in the tile (tiles past the end: none)
-                const u32 keep = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : (1u << (int)left) - 1u);
+                const int left = (int)mylen - (int)(T + half) * 16;    // valid rows of this lane in the tile (tiles past the end: none)
+                const u32 keep = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : (1u << left) - 1u);
                 hx8 av[NM];
 #pragma unroll
                 for (int m = 0; m < NM; ++m) av[m] = *(const hx8*)(st + (((Tw + half) * NM + m) * 64 + lane) * 16);
@@ -243,12 +254,18 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
                     if (mask[t] != 0u) {
                         const int r = __builtin_ctz(mask[t]);
                         mask[t] &= mask[t] - 1u;
-                        if (room[t]) {
-                            wp[t][cnt[t]] = (u64)(row0 + (u32)r);
-                            ++cnt[t];
-                            --room[t];
+                        if (FAR) {
+                            if (room[t]) {
+                                wp[t][cnt[t]] = (u64)(row0 + (u32)r);
+                                ++cnt[t];
+                                --room[t];
+                            } else {
+                                ++dropped[t];
+                            }
                         } else {
-                            ++dropped[t];
+                            const u32 at = woff[t] < wend[t] ? woff[t] : wend[t];
+                            *(u64*)(wbase + at) = (u64)(row0 + (u32)r);
+                            woff[t] += 8u;
                         }
                     }
                     any_mask |= mask[t];
@@ -261,6 +278,11 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
         const int q = q0w + t * 32 + j;
         if (seg_ok && q < g.Qpad) {
             const bool live = q < g.Q;
+            if (!FAR) {
+                const u32 hits = (woff[t] - wbeg[t]) >> 3;
+                cnt[t] = hits < a.cap ? hits : a.cap;
+                dropped[t] = hits - cnt[t];
+            }
             a.sl_cnt[(i64)s * g.Qpad + q] = live ? cnt[t] : 0u;
             if (dropped[t] && live) a.fail[q] = 1u;
         }
