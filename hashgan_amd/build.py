@@ -50,8 +50,14 @@ def _deps_of(dfile):
     except OSError:
         return None
     text = text.replace("\\\n", " ")
-    _, _, rhs = text.partition(":")
-    return shlex.split(rhs)
+    lhs, colon, rhs = text.partition(":")
+    if not colon or not lhs.strip().endswith(".o"):       # not (yet) a rule for an object: treat as unreadable
+        return None
+    try:
+        deps = shlex.split(rhs)
+    except ValueError:
+        return None
+    return deps or None
 
 
 def _obj_stale(obj, src):
@@ -93,7 +99,8 @@ def build(force=False, verbose=False, probes=False, extra_flags=(), out=None):
         obj = os.path.join(od, u + ".o")
         if force or _obj_stale(obj, s):
             tmp = obj + ".tmp%d" % os.getpid()             # concurrent builders (pytest-xdist, N ranks) never see half a file
-            jobs.append((u, obj, tmp, [cc] + flags + ["-c", s, "-MD", "-MF", obj[:-2] + ".d", "-MT", obj, "-o", tmp]))
+            # (the dependency file too: written next to the object under a per-process name, moved into place with it)
+            jobs.append((u, obj, tmp, [cc] + flags + ["-c", s, "-MD", "-MF", tmp + ".d", "-MT", obj, "-o", tmp]))
 
     def run(job):
         u, obj, tmp, cmd = job
@@ -101,9 +108,12 @@ def build(force=False, verbose=False, probes=False, extra_flags=(), out=None):
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            if os.path.exists(tmp):
-                os.unlink(tmp)
+            for f in (tmp, tmp + ".d"):
+                if os.path.exists(f):
+                    os.unlink(f)
             return u, r
+        if os.path.exists(tmp + ".d"):
+            os.replace(tmp + ".d", obj[:-2] + ".d")
         os.replace(tmp, obj)
         return u, r
 

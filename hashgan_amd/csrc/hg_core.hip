@@ -888,6 +888,14 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "dbg_hwq_ptr")) *value = (int64_t)(uintptr_t)c->hwq.p;
 #endif
     else if (!strcmp(key, "graph_replays")) *value = c->graph_replays;
+    else if (!strcmp(key, "cut_beyond_planes")) {      // a download: asked for after a lost owner-routed bet only
+        u32 v = 0;
+        if (c->beyond.p) {
+            HG_HIP(hipMemcpyAsync(&v, c->beyond.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HG_TRY(c->sync());
+        }
+        *value = v;
+    }
     else if (!strcmp(key, "map_async_steps")) *value = c->map_async_steps;
     else if (!strcmp(key, "map_async_redone")) *value = c->map_async_redone;
     else if (!strcmp(key, "segments")) *value = c->geo.S;

@@ -219,6 +219,7 @@ struct hg_ctx {
 
     // device state
     DevBuf db, dblab, qc, qlab;
+    DevBuf beyond;             // one word: hg_guess_finish met a query whose cut lies beyond the planes its owner was sent
     DevBuf dbx, qx;            // fp4 images of db / qc in MFMA fragment order for k_select_mx (built on first use)
     bool dbx_valid = false, qx_valid = false;
     DevBuf dbx8;               // i8 image of the database codes in A-fragment order (k_hist_i8), built on first use

@@ -1267,7 +1267,7 @@ static __global__ __launch_bounds__(256) void k_guess_owner(const u32* __restric
 // the shared cut T and this shard's sstar, exactly as k_guess derives them from all-gathered tables.
 static __global__ __launch_bounds__(256) void k_guess_finish(const u32* __restrict__ ans, const Owners w, const u32* __restrict__ hseg,
                                                               const int Sh, const int ratio, int* __restrict__ T, int* __restrict__ sstar,
-                                                              const Geo g) {
+                                                              u32* __restrict__ beyond, const Geo g) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= g.Q) return;
     const int o = owner_of(w, q), i = q - owner_q0(w, o);
@@ -1275,6 +1275,9 @@ static __global__ __launch_bounds__(256) void k_guess_finish(const u32* __restri
     const int t = (int)a4[0];
     const u64 need = a4[2];
     int ss = g.S - 1;                                  // default: collect distance T everywhere
+    // the owner found no cut within the b/2 + 2 planes it was sent: this query takes every row up to the last plane and overflows
+    // whatever the slices' capacity -- the caller reads *beyond (stat "cut_beyond_planes") and goes to the exact sequence at once
+    if (!a4[3]) *beyond = 1u;
     if (a4[3]) {
         u64 have = a4[1];
         if (have >= need) {

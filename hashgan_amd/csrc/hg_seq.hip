@@ -327,7 +327,14 @@ static int launch_rank_dense(hg_ctx* c) {
     i64 qchunk = (c->opt_dense_budget_mb << 20) / Npad;
     if (qchunk < 1) qchunk = 1;
     if (qchunk > g.Q) qchunk = g.Q;
-    HG_TRY(c->dbytes.reserve((size_t)qchunk * Npad));
+    // (the byte matrix is a budget, not a need: when the device cannot give that much, fewer queries per chunk do)
+    for (;;) {
+        const int rc = c->dbytes.reserve((size_t)qchunk * Npad);
+        if (rc == HG_OK) break;
+        if (qchunk == 1) return rc;
+        (void)hipGetLastError();
+        qchunk = (qchunk + 1) / 2;
+    }
     bool use_recip = false;
     const bool fuse = !gbm && !rw_part && blocks_lds >= 2 && c->fuse_ap && c->opt_fuse_ap && !c->want_lists;
     if (fuse) HG_TRY(ensure_ap_tables(c, &use_recip));
@@ -345,7 +352,7 @@ static int launch_rank_dense(hg_ctx* c) {
         c->t_begin(KI_RANK_FUSED);
 #define HG_RANK_DENSE(LISTS_, GBM_)                                                                                                              \
     do {                                                                                                                                         \
-        HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_dense<LISTS_, GBM_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, total)); \
+        if (q0 == 0) HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_dense<LISTS_, GBM_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, total)); \
         hipLaunchKernelGGL((k_rank_dense<LISTS_, GBM_, false>), dim3(nq, kparts), dim3(RD_THREADS), (size_t)total, c->stream, da, c->out_idx.as<u32>(),  \
                            c->out_dist.as<u8>(), c->mbits.as<u32>(), g);                                                                         \
     } while (0)
@@ -648,6 +655,7 @@ int hg_sample_hist(hg_ctx* c, int64_t R) {
     HG_TRY(need(c, ST_DB | ST_Q, "hg_sample_hist", "hg_set_database + hg_set_queries"));
     const int stride = auto_stride(c, R);
     if (stride < 2) return fail(HG_ERR_ARG, "hg_sample_hist: R=%lld is too small to sample for", (long long)R);
+    if (c->beyond.p) HG_HIP(hipMemsetAsync(c->beyond.p, 0, 4, c->stream));      // (a new bet: "cut_beyond_planes" is about this one)
     HG_TRY(do_hist(c, stride));
     return c->stage_end();
 }
@@ -983,10 +991,12 @@ int hg_guess_finish(hg_ctx* c, int64_t R, const void* dev_answers, int G, int ra
     HG_TRY(c->sl_cnt.reserve((size_t)g.S * qb)); HG_TRY(c->tot.reserve(qb)); HG_TRY(c->failq.reserve(qb));
     HG_TRY(c->sstar.reserve(qb));
     HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
+    HG_TRY(c->beyond.reserve(4));
+    HG_HIP(hipMemsetAsync(c->beyond.p, 0, 4, c->stream));
     const Geo gh = hist_geometry(c);                   // the sampled pass ran on coarser segments
     c->t_begin(KI_GUESS);
     hipLaunchKernelGGL(k_guess_finish, dim3(grid_for(g.Q)), dim3(256), 0, c->stream, (const u32*)dev_answers, w, c->hist.as<u32>(), gh.S,
-                       (int)(gh.L / g.L), c->tguess.as<int>(), c->sstar.as<int>(), g);
+                       (int)(gh.L / g.L), c->tguess.as<int>(), c->sstar.as<int>(), c->beyond.as<u32>(), g);
     c->t_end();
     HG_TRY(c->check_launch("k_guess_finish"));
     // (the slices' budget: as hg_guess)

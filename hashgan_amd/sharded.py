@@ -281,8 +281,13 @@ class HipShardEngine:
 
     def widen_slices(self):
         """After a lost bet: eight times the slice capacity (hg_set_option "cap_boost"), twice at most; False -- and the
-        ordinary capacity back -- when that has been tried.  The losses are the same on every rank, so is this."""
+        ordinary capacity back -- when that has been tried, or when wider slices cannot help: the owner-routed guess met a
+        query whose cut lies beyond the planes it exchanges (stat "cut_beyond_planes"; such a query takes every row).  The
+        losses are the same on every rank, so is this."""
         boost = self.ctx.get_stat("cap_boost")
+        if self.ctx.get_stat("cut_beyond_planes"):
+            self.ctx.set_option("cap_boost", 1)
+            return False
         if boost >= 64:
             self.ctx.set_option("cap_boost", 1)
             return False

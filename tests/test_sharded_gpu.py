@@ -118,6 +118,28 @@ def test_virtual_shards_lost_bet_is_consistent():
         assert bo == [8, 8], bo                              # the escalation ran in lockstep and its second bet held
 
 
+def test_virtual_shards_cut_beyond_the_exchanged_planes_goes_exact_at_once():
+    """Every row far from every query (distance ~0.8 b): the owner-routed guess finds no cut within the b/2 + 2 planes it is
+    sent, the bet takes every row and overflows -- wider slices cannot help, so the ranks must NOT escalate cap_boost (stat
+    "cut_beyond_planes") but run the exact sequence, alike, with the reference's result."""
+    from hashgan_amd import synth
+    from oracle import hamming_map as O
+    Q, N, b, R, C = 64, 131072, 32, 2000, 10
+    rng = np.random.default_rng(91)
+    dl, _ = synth.onehot_labels(92, N, C)
+    ql, _ = synth.onehot_labels(93, Q, C)
+    db = (rng.random((N, b)) < 0.9).astype(np.int8)          # mostly ones
+    qb = (rng.random((Q, b)) < 0.1).astype(np.int8)          # mostly zeros
+    c = dict(qbits=qb, dbbits=db, qlab=ql, dblab=dl, R=R, b=b)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ap_ref, *_ = O.map_from_codes(qb[:16], db, ql[:16], dl, R)
+    res = _run_virtual(c, 2, gather_topr=False)
+    for r in range(2):
+        assert np.array_equal(res[r][0][:16], ap_ref, equal_nan=True)
+    assert _run_virtual.last_boosts == [1, 1], _run_virtual.last_boosts      # nobody widened its slices
+
+
 def test_virtual_shards_wide_labels_take_the_bet():
     """More than 128 classes: the record pass cannot carry the match bit, so the merged-ranking bet builds its local
     bitmaps with k_match through the local ranked lists (this path once produced all-zero bitmaps -> mAP nan)."""
