@@ -226,7 +226,7 @@ def kernel_rooflines(timing, spec, rows, step_s, rec_bytes=1, names=None):
                 "avg_launch_ms": out[dom]["avg_ms"], "algorithmic_flops": flops,
                 "note": "fp4 MFMA inner product over K=%d code bits per pair (2 flops per bit), against the dense fp4 peak; the "
                         "kernel's other per-pair cost is the harvest of the accumulator signs on the vector ALU, which on gfx950 "
-                        "does not overlap the MFMAs (profiles/r01_ubench_mx.txt): see 'valu'" % K,
+                        "overlaps the MFMAs only in part (about 4 vector instructions hide under one MFMA: tools/mfma_valu_overlap.hip, HISTORY.md): see 'valu'" % K,
                 "valu": {"algorithmic_laneops": pairs, "achieved": pairs / t / 1e12, "peak": VALU_PEAK_TLANEOPS,
                          "unit": "Tlaneop/s", "frac": pairs / t / 1e12 / VALU_PEAK_TLANEOPS},
                 "valu_equiv_frac": valu_equiv, "hbm": hbm}
@@ -432,7 +432,7 @@ def config_leg(name, opts, steps=20, untimed=25, packed=None):
             roof = {"bound": "mfma", "kernel": dom, "avg_launch_ms": t * 1e3, "algorithmic_flops": flops, "achieved": flops / t / 1e12,
                     "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t / 1e12 / MFMA_FP4_PEAK_TFLOPS,
                     "note": "fp4 MFMA inner product, 2 flops per code bit (K = %d) and pair; the kernel's other per-pair cost is the "
-                            "vector-ALU harvest of the accumulators (does not overlap the MFMAs on gfx950)" % (64 * W)}
+                            "vector-ALU harvest of the accumulators (hides under the MFMAs only in part on gfx950)" % (64 * W)}
         elif dom == "k_rank_dense":
             # N/8 < R <= N: k_dense_bytes wrote one byte {match, dist} per pair; one block per query streams its N bytes twice
             # (count, then place) and writes R match bits -- each row costs two LDS atomics on its thread's counter column
@@ -769,13 +769,15 @@ def main():
         # hg_map in two halves, two steps in flight: step i + 1 is enqueued before step i's results are waited for, so the GPU goes
         # from one step straight into the next; every step's verdict is checked and its APs are on the host when its map_end returns
         ctx.map_begin(R)
+        t1 = t0
         for i in range(args.steps):
-            t1 = time.perf_counter()
             if i + 1 < args.steps:
                 ctx.map_begin(R)
             a, r = ctx.map_end()
+            t2 = time.perf_counter()
+            each.append(t2 - t1)                        # (from one step's results to the next one's)
+            t1 = t2
             m = metric.mean_over_hits(a, r)
-            each.append(time.perf_counter() - t1)
     else:
         for _ in range(args.steps):
             t1 = time.perf_counter()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools/gpu_evidence_r05.sh <tag> : round 5's evidence set -- the driver-style bench line, kernel trace + PMC passes of the headline step (C2),
-# PMC passes of C5 (k_select_mx4: merged into the traffic file under _workloads.c5), kernel traces of C1 / C3 / C5, the per-rank replica timing
+# PMC passes of C5 (k_select_mx4: merged into the traffic file under _workloads.c5), kernel traces of C1 / C3 / C5, the per-rank replica timing,
+# kernel trace + counter passes of the real-valued call
 set -u
 TAG=${1:-ev5}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -15,6 +16,7 @@ python tools/pmc_traffic.py $(find gpurun_out/${TAG}_pmc_c5/pmc3 -name "*.db" | 
 bash tools/gpu_config_traces.sh ${TAG}_cfg > $OUT/cfg.log 2>&1
 cp gpurun_out/${TAG}_cfg/c1_kernel_trace_stats.txt gpurun_out/${TAG}_cfg/c3_kernel_trace_stats.txt gpurun_out/${TAG}_cfg/c5_kernel_trace_stats.txt $OUT/ 2>/dev/null
 timeout 600 python tools/replica_shard_timing.py > $OUT/replica_shard_timing.txt 2>&1
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD} bash tools/gpu_real_pmc.sh ${TAG}_real > $OUT/real_pmc.txt 2>&1
 for f in $OUT/bench_*.json; do python -c "
 import json
 d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', round(d['ms_per_step'],4), round(d['value']), d['parity_vs_reference_golden'], d['roofline']['frac'], d['roofline'].get('traffic'))"; done
