@@ -870,6 +870,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "real_cap_boost")) *value = c->real_cap_boost;
     else if (!strcmp(key, "last_optimistic")) *value = c->optimistic ? 1 : 0;
     else if (!strcmp(key, "real_attempts")) *value = c->real_attempts;
+    else if (!strcmp(key, "real_requeried")) *value = c->real_requeried;
     // how the last real-valued ranking ran: bit 0 = bf16 filter + exact rescoring, bit 1 = ranked by the LDS-resident kernel,
     // bit 2 = record lists beyond the LDS ordered group by group (k_real_group_*), bit 3 = the filter ran in IEEE half (else bfloat16)
     else if (!strcmp(key, "real_path")) *value = (c->real_filtered ? 1 : 0) | (c->real_lds_ranked ? 2 : 0) | (c->real_grouped ? 4 : 0) | (c->real_filtered && c->dbfb_half ? 8 : 0);

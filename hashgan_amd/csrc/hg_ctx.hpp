@@ -282,6 +282,7 @@ struct hg_ctx {
     i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit
     bool real_no_cut = false;     // the current real_attempt takes every row (thr = -inf)
     bool real_filtered = false;   // the last real_select left unscored candidates that k_real_rescore completed
+    i64 real_requeried = 0;       // queries that lost the first real-valued bet and were ranked again on their own (cumulative)
     i64 real_attempts = 0;        // statistics of the last real-valued ranking: attempts made (1 = the first bet held) ...
     i64 real_lds_ranked = 0;      // ... and whether the LDS-resident rank kernel produced its lists
     i64 opt_real_mfma = 2;     // "real_mfma": 2 = bf16 filter on the matrix cores + exact rescoring of the survivors, 1 = exact float32 MFMA pass, 0 = vector ALU

@@ -5,6 +5,9 @@
 #include "hg_real_mx.hpp"
 #include "hg_real_bf.hpp"
 
+constexpr double REAL_FIRST_SIGMA = 5.0;        // depth of the first cut in deviations of the sampled count: one query in ~3e5 loses it and is ranked again on its
+                                              // own (real_requery_lost).  10k x 1M x 64, R = 5000: 6 -> 5.92 ms per call, 5 -> 5.81, 4 -> 5.86, 3.5 -> 6.01 (the
+                                              // rescore's time follows its rounds, not its rows: the shallower cut mostly helps the rank stage)
 constexpr i64 REAL_SAMPLE_HITS = 64;          // the real-valued bet samples so that this many of a query's top R rows are in the sample (tools/real_sample_sweep.py: 32 .. 256 measured)
 constexpr i64 REAL_SEG_BYTES = 512 * 1024;    // bytes of feature rows per segment of the real-valued pair passes
 
@@ -413,6 +416,70 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     return HG_OK;
 }
 
+static int run_real(hg_ctx* c, int64_t R, bool with_ap);
+
+// A few queries lost the first bet (their cut kept fewer than R rows, or their rows crowd into one slice): those alone run again,
+// on a child context that borrows the database's tables, with the usual escalation; their lists and match bits go back into the
+// parent's rows and the parent evaluates all queries.  The whole call is redone only when many queries lost (run_real).  Because a
+// lost query now costs a fraction of a millisecond instead of the call, the first cut can sit shallower (REAL_FIRST_SIGMA).
+static int real_requery_lost(hg_ctx* c, int64_t R, bool with_ap, bool* handled) {
+    *handled = false;
+    if (c->is_sub || !c->real_lds_ranked || !c->real_filtered) return HG_OK;
+    const Geo g = c->geo;
+    std::vector<u32> bad((size_t)g.Q);
+    HG_HIP(hipMemcpyAsync(bad.data(), c->qbad.p, (size_t)g.Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HG_TRY(c->sync());
+    std::vector<u32> lost;
+    for (int q = 0; q < g.Q; ++q) if (bad[(size_t)q]) lost.push_back((u32)q);
+    const i64 nF = (i64)lost.size();
+    if (nF == 0 || nF * 16 > g.Q) return HG_OK;
+    if (!c->sub) {
+        c->sub = new hg_ctx();
+        c->sub->is_sub = true;
+        c->sub->device = c->device;
+        c->sub->stream = c->stream;                  // same stream: ordered with the parent's work
+    }
+    hg_ctx* s = c->sub;
+    s->N = c->N; s->b = c->b; s->C = c->C; s->n_total = c->n_total; s->NW = c->NW; s->NB = c->NB; s->LW = c->LW;
+    s->idx_base = c->idx_base; s->n_cu = c->n_cu;
+    s->target_units = c->target_units; s->min_segment = c->min_segment; s->opt_max_segments = c->opt_max_segments;
+    s->timing = 0;
+    s->bpad = c->bpad;
+    s->opt_real_mfma = c->opt_real_mfma; s->opt_real_sort_lds = c->opt_real_sort_lds; s->opt_real_groups = c->opt_real_groups;
+    s->real_cap_boost = c->real_cap_boost;
+    s->db.borrow(c->db);
+    s->dblab.borrow(c->dblab);
+    s->dbf.borrow(c->dbf); s->dbf_resident = true;
+    s->dbfb.borrow(c->dbfb); s->xmax2.borrow(c->xmax2); s->dbfb_valid = c->dbfb_valid; s->dbfb_half = c->dbfb_half;
+    s->Q = nF;
+    HG_TRY(c->flist.reserve((size_t)nF * 4));
+    HG_HIP(hipMemcpyAsync(c->flist.p, lost.data(), (size_t)nF * 4, hipMemcpyHostToDevice, c->stream));
+    HG_TRY(s->qf.reserve((size_t)nF * c->bpad * 4 + 256));
+    HG_TRY(s->qlab.reserve((size_t)nF * c->LW * 8));
+    auto move = [&](const void* src, void* dst, i64 rowbytes, int gather) {
+        hipLaunchKernelGGL(k_move_rows, dim3((unsigned)nF), dim3(256), 0, c->stream, (const u8*)src, (u8*)dst,
+                           c->flist.as<u32>(), rowbytes, gather);
+    };
+    move(c->qf.p, s->qf.p, (i64)c->bpad * 4, 1);
+    move(c->qlab.p, s->qlab.p, (i64)c->LW * 8, 1);
+    HG_TRY(c->check_launch("k_move_rows"));
+    s->qf_resident = true;
+    s->stage = ST_DB | ST_Q;
+    HG_TRY(run_real(s, R, false));
+    if (s->RW != c->RW) return fail(HG_ERR_HIP, "real-valued ranking: internal error, the requeried lists have another width");
+    move(s->mbits.p, c->mbits.p, c->RW * 8, 0);
+    move(s->out_idx.p, c->out_idx.p, R * 4, 0);
+    move(s->scores.p, c->scores.p, R * 4, 0);
+    HG_TRY(c->check_launch("k_move_rows"));
+    HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+    c->stage = ST_DB | ST_Q | ST_SELECT | ST_MATCH;
+    if (with_ap) HG_TRY(do_ap(c));
+    HG_TRY(c->sync());                               // `lost` (the H2D source) must outlive the copy
+    c->real_requeried += nF;
+    *handled = true;
+    return HG_OK;
+}
+
 static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
     if (!c->bpad || !c->dbf.p || !c->qf.p || !c->dbf_resident || !c->qf_resident)
         return fail(HG_ERR_STATE, "real-valued ranking needs the float features on the GPU: load them with hg_set_database_f32 / "
@@ -423,8 +490,11 @@ static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
     c->real_attempts = 0;
     if (R * 8 <= c->N && c->N >= 65536) {              // bet on a sampled cut; retry once deeper, then give up betting
         const double boost0 = (double)c->real_cap_boost;
-        HG_TRY(real_attempt(c, R, true, 6.0, 3.0 * boost0, with_ap, &lost));
+        HG_TRY(real_attempt(c, R, true, c->is_sub ? 6.0 : REAL_FIRST_SIGMA, 3.0 * boost0, with_ap, &lost));
         if (!lost) { c->real_lists = true; return HG_OK; }
+        bool handled = false;
+        HG_TRY(real_requery_lost(c, R, with_ap, &handled));
+        if (handled) { c->real_lists = true; return HG_OK; }
         // a deeper cut with twice the budget; then -- features that follow the labels in a database stored class by class
         // put a query's top rows into a tenth of its slices -- eight and sixty-four times the slices' capacity, kept for
         // the next calls on this database (the exhaustive mode below writes EVERY pair down: 80 GB at 10k x 1M)

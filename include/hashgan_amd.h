@@ -297,14 +297,14 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  *                 ALU), "real_sort_lds" (1: ranked by the LDS-resident kernel when the records fit), "real_groups" (1: lists beyond the LDS ordered group by group)
  *   ("probe_select" exists only in the measurement build, python -m hashgan_amd.build --probes) */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
-/* Counters and facts about the last call (21 keys): "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly),
+/* Counters and facts about the last call (22 keys): "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly),
  * "optimistic_requeried" (single queries rerun exactly after losing their bet), "optimistic_rebets" (second and widened bets), "last_optimistic",
  * "rank_leftovers" (queries the LDS-resident rank kernel left to the general one), "select_variant" (1 k_select, 2 k_select_dense, 3 k_select_mx,
  * 5 k_select_mx3, 6 k_select_mx4), "rank_variant" (1 k_rank_fused, 3 k_rank_cnt, 6 k_rank_lean, 7 k_rank_dense, 8 k_rank_dense<slices>), "ap_fused",
  * "cap_boost", "crowding_x100", "segments", "records_kept" (records the last bet's select left in the slices: a download, not part of a step),
  * "device_bytes", "graph_replays", "map_async_steps" / "map_async_redone" (hg_map_begin: steps enqueued blind / of those, run again by hg_map_end);
  * "cut_beyond_planes" (1: the last hg_guess_finish met a query whose cut lies beyond the b/2 + 2 planes the owner-routed exchange carries -- its bet
- * cannot be won by wider slices; a download); real-valued path: "real_attempts", "real_cap_boost", "real_path" (bit 0 filter + rescoring, bit 1 ranked in LDS,
+ * cannot be won by wider slices; a download); real-valued path: "real_attempts", "real_requeried" (queries that lost the first cut and were ranked again on their own, cumulative), "real_cap_boost", "real_path" (bit 0 filter + rescoring, bit 1 ranked in LDS,
  * bit 2 lists ordered group by group). */
 int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
 /* What hg_set_database_f32 (queries = 0) / hg_set_queries_f32 (queries = 1) found in the float table: out[0] entries outside

@@ -133,6 +133,40 @@ def test_features_that_follow_the_labels_in_a_class_sorted_database():
         c.close()
 
 
+def test_a_few_lost_queries_are_ranked_again_on_their_own():
+    """Two of 240 queries have their whole top R in one stretch of the database (near-copies of themselves stored together): their
+    slices overflow whatever the cut -- and those long rows crowd a few other queries' lists too --, the rest win their bet.
+    Only the losers run again (a child context on the same tables, stat "real_requeried"), the call itself stays at one
+    attempt, and every list and AP is the oracle's bit for bit."""
+    rng = np.random.default_rng(17)
+    Q, N, b, R, C = 240, 150000, 32, 1500, 7
+    dbf = np.tanh(rng.standard_normal((N, b))).astype(np.float32)
+    qf = np.tanh(rng.standard_normal((Q, b))).astype(np.float32)
+    for k, (q, at) in enumerate(((3, 20000), (29, 90000))):
+        v = np.sign(rng.standard_normal(b)).astype(np.float32) * 0.9
+        qf[q] = v
+        dbf[at:at + 2500] = np.tanh(0.75 * np.sign(v) + 0.3 * rng.standard_normal((2500, b))).astype(np.float32)
+    dl = (rng.random((N, C)) < 0.25).astype(np.int64)
+    ql = (rng.random((Q, C)) < 0.25).astype(np.int64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, ap_ref, idx_ref, score_ref = RM.map_from_features(qf, dbf, ql, dl, R)
+    c = _native.Context(0)
+    try:
+        c.set_database_f32(dbf, dl)
+        c.set_queries_f32(qf, ql)
+        n0 = c.get_stat("real_requeried")
+        ap, rel = c.map_real(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        n1 = c.get_stat("real_requeried") - n0
+        assert c.get_stat("real_attempts") == 1 and 2 <= n1 <= 15, (c.get_stat("real_attempts"), n1)
+        idx, score = c.topr_real(R)
+        assert np.array_equal(idx, idx_ref) and np.array_equal(score.view(np.uint32), score_ref.view(np.uint32))
+        assert c.get_stat("real_requeried") - n0 == 2 * n1
+    finally:
+        c.close()
+
+
 def test_python_surface_ranks_real_features_like_the_reference():
     """MAPs(R).get_maps_by_feature on tanh-like features = the reference's own semantics."""
     from hashgan_amd import MAPs, MAP
