@@ -278,6 +278,7 @@ struct hg_ctx {
     DevBuf sampx;              // float features of the sampled rows in MFMA A-fragment order (k_real_sample_mx), rebuilt per call
     DevBuf dbfb, thr2, xmax2;  // filter + rescore path (hg_real_bf.hpp): bf16 image of the database, lowered cuts, max row norm^2
     bool dbfb_valid = false;
+    double real_expect = 0.0;  // rows per query the current real-valued attempt expects its cut to keep (real_attempt; picks the rescore's slices per wavefront)
     bool dbfb_half = false;    // ... in IEEE half instead of bfloat16 (no feature of the database can overflow it: real_launch_select_bf)
     i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit
     bool real_no_cut = false;     // the current real_attempt takes every row (thr = -inf)

@@ -121,9 +121,11 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
 #undef HG_FILTER
     c->t_end();
     HG_TRY(c->check_launch("k_real_select_bf"));
-    // slices per wavefront of the rescoring pass: about one round of 64 kept rows (the filter keeps ~2 R per query)
-    const double per_slice = 2.0 * (double)c->R / (double)g.S;
-    const int SG = per_slice * 8 <= 60 ? 8 : per_slice * 4 <= 60 ? 4 : per_slice * 3 <= 60 ? 3 : per_slice * 2 <= 60 ? 2 : 1;
+    // slices per wavefront of the rescoring pass: the kernel's time follows its ROUNDS of 64 rows (2 slices 2.41 ms, 3 2.07, 4 2.12, 8 2.07,
+    // 1 4.04 at 10k x 1M x 64, R = 5000: 17 rows per slice), so as many slices as still fit one round most of the time -- the rows a
+    // query is expected to keep (the rank its cut was guessed at, scaled back from the sample; every row without a cut) over its slices
+    const double per_slice = 1.03 * c->real_expect / (double)g.S;
+    const int SG = per_slice * 8 <= 56 ? 8 : per_slice * 6 <= 56 ? 6 : per_slice * 4 <= 56 ? 4 : per_slice * 3 <= 56 ? 3 : per_slice * 2 <= 56 ? 2 : 1;
     const i64 waves = (i64)((g.S + SG - 1) / SG) * g.Q;
     c->t_begin(KI_REAL_RESCORE);
 #define HG_RESCORE(sg)                                                                                                                   \
@@ -132,7 +134,7 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
                            c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(),               \
                            c->sl_cnt.as<u32>(), KP, g);                                                                                  \
         break;
-    switch (SG) { HG_RESCORE(8) HG_RESCORE(4) HG_RESCORE(3) HG_RESCORE(2) HG_RESCORE(1) }
+    switch (SG) { HG_RESCORE(8) HG_RESCORE(6) HG_RESCORE(4) HG_RESCORE(3) HG_RESCORE(2) HG_RESCORE(1) }
 #undef HG_RESCORE
     c->t_end();
     c->real_filtered = true;
@@ -256,6 +258,7 @@ extern "C" {
 // one attempt; *lost = some query came up short of R records or overflowed a slice (bet mode only)
 static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double budget, bool with_ap, int* lost) {
     ++c->real_attempts;
+    c->real_expect = bet ? (double)R * (1.0 + sigma / std::sqrt((double)REAL_SAMPLE_HITS)) : (double)c->N;
     c->real_lds_ranked = 0;
     c->real_no_cut = !bet;
     make_geometry(c);
