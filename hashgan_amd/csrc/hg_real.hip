@@ -121,11 +121,33 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
 #undef HG_FILTER
     c->t_end();
     HG_TRY(c->check_launch("k_real_select_bf"));
-    // slices per wavefront of the rescoring pass: the kernel's time follows its ROUNDS of 64 rows (2 slices 2.41 ms, 3 2.07, 4 2.12, 8 2.07,
-    // 1 4.04 at 10k x 1M x 64, R = 5000: 17 rows per slice), so as many slices as still fit one round most of the time -- the rows a
-    // query is expected to keep (the rank its cut was guessed at, scaled back from the sample; every row without a cut) over its slices
+    // slices per wavefront of the rescoring pass.  The kernel's time follows its ROUNDS of 64 rows and its wavefronts, hardly its rows
+    // (10k x 1M x 64, R = 5000, 17 rows per slice: 1 slice 4.04 ms, 2 2.41, 3 2.06, 4 2.12, 5 2.05, 6 1.90, 7 1.92, 8 2.07, 11 2.20), so
+    // the count that fills its rounds best: expected rounds of a wavefront (the rows a query is expected to keep -- the rank its cut was
+    // guessed at, scaled back from the sample; every row without a cut -- over its slices, Poisson-ish) plus half a round of fixed cost,
+    // a little more per round the more slices the lane-to-slice search walks, per slice
     const double per_slice = 1.03 * c->real_expect / (double)g.S;
-    const int SG = per_slice * 8 <= 56 ? 8 : per_slice * 6 <= 56 ? 6 : per_slice * 4 <= 56 ? 4 : per_slice * 3 <= 56 ? 3 : per_slice * 2 <= 56 ? 2 : 1;
+#ifdef HG_RS_FORCE
+    const int SG = HG_RS_FORCE;
+    (void)per_slice;
+#else
+    int SG = 1;
+    {
+        double best = 1e300;
+        for (const int sg : {1, 2, 3, 4, 6, 8}) {
+            if (per_slice >= 64.0 && sg > 2) break;          // (slices of full rounds: nothing to pack, keep the rows' L2 footprint small)
+            const double m = per_slice * sg, sd = std::sqrt(m > 1.0 ? m : 1.0);
+            double rounds = 1.0;
+            for (int k = 1; k <= 64; ++k) {
+                const double p = 0.5 * std::erfc((64.0 * k - m) / sd * 0.7071067811865476);
+                rounds += p;
+                if (p < 1e-6) break;
+            }
+            const double cost = (0.5 + rounds * (1.0 + 0.03 * sg)) / sg;
+            if (cost < best) { best = cost; SG = sg; }
+        }
+    }
+#endif
     const i64 waves = (i64)((g.S + SG - 1) / SG) * g.Q;
     c->t_begin(KI_REAL_RESCORE);
 #define HG_RESCORE(sg)                                                                                                                   \
@@ -134,7 +156,11 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
                            c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(),               \
                            c->sl_cnt.as<u32>(), KP, g);                                                                                  \
         break;
+#ifdef HG_RS_FORCE
+    switch (SG) { HG_RESCORE(HG_RS_FORCE) }
+#else
     switch (SG) { HG_RESCORE(8) HG_RESCORE(6) HG_RESCORE(4) HG_RESCORE(3) HG_RESCORE(2) HG_RESCORE(1) }
+#endif
 #undef HG_RESCORE
     c->t_end();
     c->real_filtered = true;
