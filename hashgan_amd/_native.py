@@ -343,12 +343,16 @@ class Context:
         """First half of map(): enqueue a step and return (at most two in flight; see hg_map_begin in include/hashgan_amd.h)."""
         check(self._lib.hg_map_begin(self._h, int(R)))
         self.R = int(R)
+        self._in_flight = getattr(self, "_in_flight", []) + [self.Q]      # (a step's results have the length of ITS query table)
 
     def map_end(self):
         """Second half of map(): wait for the oldest step in flight, return its (ap, rel)."""
-        ap = np.empty(self.Q, dtype=np.float64)
-        rel = np.empty(self.Q, dtype=np.int64)
+        pending = getattr(self, "_in_flight", [])
+        nq = pending[0] if pending else self.Q
+        ap = np.empty(nq, dtype=np.float64)
+        rel = np.empty(nq, dtype=np.int64)
         check(self._lib.hg_map_end(self._h, _ptr(ap), _ptr(rel)))
+        self._in_flight = pending[1:]
         return ap, rel
 
     # -- real-valued features ---------------------------------------------------

@@ -1619,7 +1619,7 @@ int hg_map_end(hg_ctx* c, double* host_ap, int64_t* host_rel) {
     }
     HG_HIP(hipEventSynchronize(m.ev));
     const u32* w = (const u32*)m.pin;                      // [verdict][queries the fused rank kernel declined] ...
-    if (w[0] == 0 && w[1] == 0 && (i64)Q == c->Q) {
+    if (w[0] == 0 && w[1] == 0) {                          // (won: the results are this step's whatever the tables hold by now)
         const char* pb = (const char*)m.pin;
         if (host_ap) memcpy(host_ap, pb + 16, Q * 8);
         if (host_rel) {

@@ -358,6 +358,14 @@ def test_map_in_two_halves_equals_map(case_cache):
         for _ in range(2):
             ap, rel = ctx.map_end()
             assert np.array_equal(ap, g["ap"][::-1], equal_nan=True)
+        # a step in flight while the queries are replaced by fewer: its results are its own (and of its own length)
+        ctx.map_begin(R)
+        ctx.set_queries(metric.pack_codes(c["qbits"][:40].copy()), metric.pack_labels(c["qlab"][:40].copy()))
+        ap, rel = ctx.map_end()
+        assert ap.shape[0] == c["qbits"].shape[0] and np.array_equal(ap, g["ap"][::-1], equal_nan=True)
+        ap, rel = ctx.map(R)
+        assert np.array_equal(ap, g["ap"][:40], equal_nan=True)
+        ctx.set_queries(metric.pack_codes(c["qbits"][::-1].copy()), metric.pack_labels(c["qlab"][::-1].copy()))
         # another R in flight next to the first
         ap_half, rel_half = ctx.map(R // 2)
         ctx.map_begin(R // 2)
