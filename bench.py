@@ -879,6 +879,9 @@ def main():
         out["value_definition"] = "Q queries ranked against the WHOLE %d-row database per step / step time (max over ranks)" % N
         out["weak_scaling_equivalent"] = {"definition": "query x per-GPU-shard evaluations per second = value * n_gpus",
                                           "value": Q * world / per_step}
+        out["scaling_note"] = ("strong scaling of ONE %d-row database over the GPUs (BASELINE config 4).  The --gpus 1 line times C2 (N = 1M, the "
+                               "configuration the metric is quoted on), so value(--gpus 1) is NOT this curve's one-GPU point: that is "
+                               "`scaling_reference_c4_one_gpu` in the --gpus 1 line (the same %d rows on one GPU, ~4.8 ms per step, ~2.1 M queries/s)" % (N, N))
     if timing:
         span = timing.pop("step_gpu_span", None)
         rec_bytes = 8 if any(kv.replace(" ", "") == "compact_records=0" for kv in args.opt) else 1
