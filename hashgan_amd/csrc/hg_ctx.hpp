@@ -194,6 +194,7 @@ struct hg_ctx {
     i64 cap_boost = 1;         // slice capacity multiplier a lost bet escalated to on this database (run_oneshot); 1 after every load
     i64 opt_rank_dense = 1;    // "rank_dense": N/8 < R <= N on one shard through the byte matrix (k_dense_bytes + k_rank_dense, hg_rank_dense.hpp; codes of <= 126 bits, <= 128 classes); 0: off
     bool leftovers_expected = false;   // the last fused step on this context left queries to the general kernel
+    bool last_leftovers_inline = false;   // (the last finished step did: finish_leftovers)
     bool leftovers_inline = false;     // ... and this step ranked its own within the stream (launch_rank_slices with the flags)
     i64 opt_inline_leftovers = 1;      // "inline_leftovers"
     i64 opt_rank_slices = 7000;    // "rank_slices": a bet's one-byte records with R >= this are ranked by k_rank_dense<slices>; 0: off (k_rank_cnt's tiles).
@@ -253,6 +254,7 @@ struct hg_ctx {
     struct MapSlot {
         void* pin = nullptr; size_t cap = 0; hipEvent_t ev = nullptr;
         bool async = false;            // enqueued only (else: ran synchronously, results in ap / rel)
+        bool inline_ok = false;        // the step ranked its fused kernel's leftovers itself
         i64 R = 0, Q = 0;
         std::vector<double> ap; std::vector<int64_t> rel;
     } mslot[2];

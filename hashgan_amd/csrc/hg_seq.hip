@@ -1371,6 +1371,7 @@ static int finish_leftovers(hg_ctx* c, int* flag) {
     if ((nleft != 0) != c->leftovers_expected) { c->leftovers_expected = nleft != 0; c->cfg_epoch++; }
     if (!nleft) return HG_OK;
     c->opt_leftover += nleft;
+    c->last_leftovers_inline = c->leftovers_inline;
     if (c->leftovers_inline) { c->leftovers_inline = false; return HG_OK; }     // k_rank_dense<slices> ranked them within the step
     const size_t Q = (size_t)c->geo.Q;
     int nbits = 1;
@@ -1549,10 +1550,12 @@ int hg_topr(hg_ctx* c, int64_t R) {
 int hg_map(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
     HG_TRY(need(c, ST_DB | ST_Q, "hg_map", "hg_set_database + hg_set_queries"));
     const i64 fails0 = c->opt_fallbacks + c->opt_requeried + c->opt_rebets, left0 = c->opt_leftover;
+    c->last_leftovers_inline = false;
     HG_TRY(run_oneshot(c, R, false, true));
     HG_TRY(hg_get_ap(c, host_ap, host_rel));
     // what hg_map_begin may enqueue without looking back: this very step, when it just won its bet outright
-    if (c->optimistic && c->opt_fallbacks + c->opt_requeried + c->opt_rebets == fails0 && c->opt_leftover == left0 && !c->is_sub) {
+    // (queries the fused rank kernel declines are fine when the step ranks them itself within the stream: leftovers_inline)
+    if (c->optimistic && c->opt_fallbacks + c->opt_requeried + c->opt_rebets == fails0 && (c->opt_leftover == left0 || c->last_leftovers_inline) && !c->is_sub) {
         c->map_warm_cfg = c->cfg_epoch; c->map_warm_epoch = g_alloc_epoch; c->map_warm_R = R;
     } else {
         c->map_warm_R = -1;
@@ -1593,6 +1596,8 @@ int hg_map_begin(hg_ctx* c, int64_t R) {
         c->opt_runs++;
         HG_TRY(enqueue_bet_with_ap(c, R, stride, need_cnt, m.pin));
         HG_HIP(hipEventRecord(m.ev, c->stream));
+        m.inline_ok = c->leftovers_inline;               // the step ranks what its fused kernel declines within the stream
+        c->leftovers_inline = false;
         c->ap_staged = false;
         m.async = true;
         c->map_async_steps++;
@@ -1619,7 +1624,7 @@ int hg_map_end(hg_ctx* c, double* host_ap, int64_t* host_rel) {
     }
     HG_HIP(hipEventSynchronize(m.ev));
     const u32* w = (const u32*)m.pin;                      // [verdict][queries the fused rank kernel declined] ...
-    if (w[0] == 0 && w[1] == 0) {                          // (won: the results are this step's whatever the tables hold by now)
+    if (w[0] == 0 && (w[1] == 0 || m.inline_ok)) {         // (won: the results are this step's whatever the tables hold by now)
         const char* pb = (const char*)m.pin;
         if (host_ap) memcpy(host_ap, pb + 16, Q * 8);
         if (host_rel) {

@@ -1037,9 +1037,20 @@ def test_fused_step_hands_wide_lists_to_the_general_kernel(ctx):
         ap1, rel1 = ctx.map(R)
         assert ctx.get_stat("ap_fused") == 1 and ctx.get_stat("rank_leftovers") - l1 >= 2
         assert np.array_equal(ap1, ap, equal_nan=True) and np.array_equal(rel1, rel)
+        # ... and so do steps enqueued blind (hg_map_begin): leftovers ranked within the step are no reason to run it again
+        n0, r0 = ctx.get_stat("map_async_steps"), ctx.get_stat("map_async_redone")
+        ctx.map_begin(R)
+        ctx.map_begin(R)
+        for _ in range(2):
+            apb, relb = ctx.map_end()
+            assert np.array_equal(apb, ap, equal_nan=True) and np.array_equal(relb, rel)
+        assert ctx.get_stat("map_async_steps") - n0 == 2 and ctx.get_stat("map_async_redone") == r0
         ctx.set_option("inline_leftovers", 0)
         ap1, rel1 = ctx.map(R)
         assert ctx.get_stat("ap_fused") == 0
+        ctx.map_begin(R)                                  # leftovers the step does not rank itself: never blind
+        apb, relb = ctx.map_end()
+        assert np.array_equal(apb, ap, equal_nan=True) and ctx.get_stat("map_async_steps") - n0 == 2
         assert np.array_equal(ap1, ap, equal_nan=True) and np.array_equal(rel1, rel)
         ctx.set_option("inline_leftovers", 1)
         ctx.set_option("max_segments", 2048)
