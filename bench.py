@@ -700,6 +700,19 @@ def main():
         sys.exit(2)
     force = os.environ.get("HG_BENCH_FORCE_SHARDED") == "1"
     sharded_leg = world > 1 or force
+    if world > 1:
+        # a rank that waits for ever inside a collective (a peer died, a mismatched exchange) must not hold the launcher for ever:
+        # after HG_BENCH_WATCHDOG seconds (default 900) rank 0 prints the line with an `error` key and every rank leaves
+        import threading
+
+        def _give_up():
+            if rank == 0:
+                print(error_line("no result after %s s (HG_BENCH_WATCHDOG): a collective of the sharded step did not return" %
+                                 os.environ.get("HG_BENCH_WATCHDOG", "900"), world, args.steps, args.warmup), flush=True)
+            os._exit(5)
+        wd = threading.Timer(float(os.environ.get("HG_BENCH_WATCHDOG", "900")), _give_up)
+        wd.daemon = True
+        wd.start()
     wl = args.workload or ("c4" if world > 1 else "c2")
     spec = WORKLOADS[wl]
 
