@@ -886,7 +886,9 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
         *value = total;
     }
 #ifdef HG_RANK_PROFILE
+#ifdef HG_RANK_PROFILE                        // (tools/rank_phase_profile.py: where k_rank_cnt left its phase timestamps)
     else if (!strcmp(key, "dbg_hwq_ptr")) *value = (int64_t)(uintptr_t)c->hwq.p;
+#endif
 #endif
     else if (!strcmp(key, "graph_replays")) *value = c->graph_replays;
     else if (!strcmp(key, "cut_beyond_planes")) {      // a download: asked for after a lost owner-routed bet only
