@@ -2,7 +2,8 @@ import numpy as np, sys
 sys.path.insert(0,"/root/repo")
 from hashgan_amd import _native
 rng=np.random.default_rng(0)
-Q,N,b,R=10000,1000000,64,5000
+import os
+Q,N,b,R=10000,1000000,64,int(os.environ.get("HG_PROF_R","5000"))
 dbf=np.tanh(rng.standard_normal((N,b))).astype(np.float32); qf=np.tanh(rng.standard_normal((Q,b))).astype(np.float32)
 dl=np.zeros((N,10),np.int64); dl[np.arange(N),rng.integers(0,10,N)]=1
 ql=np.zeros((Q,10),np.int64); ql[np.arange(Q),rng.integers(0,10,Q)]=1
