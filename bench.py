@@ -280,6 +280,67 @@ def h2d_inclusive(spec, packed, reps=10):
             "map_equal_to_resident_path": bool(val == val2)}, float(val)
 
 
+def drop_in_literal(spec, packed, reps=12):
+    """main.py:164 LITERALLY: `MAPs(cfg.DATA.MAP_R).get_maps_by_feature(db, test)` -- a NEW MAPs object per evaluation, never closed,
+    host arrays as forward_all() returns them.  `reps` calls per shape, each on a fresh object, NONE discarded (the first one pays
+    whatever a process pays once: the pooled context's creation, its allocations, the packing threads).  Shapes: the timed
+    workload on +-1 codes; the reference's own CIFAR-10 evaluation on tanh features (config/cifar_evaluation.yaml:9-12: TEST_SIZE
+    1000, DB_SIZE 54000, MAP_R 54000, HASH_DIM 64 of lib/config.py:10); its NUS-WIDE setting (config/nuswide_step_1.yaml:10-13:
+    5000 x 168692, MAP_R 5000, 81 labels) on tanh features.  Never `value`."""
+    import gc
+    import types
+    from hashgan_amd import MAPs, pool_stats, _native
+    qw, ql, dw, dl = packed
+    b, C, R = spec["b"], spec["C"], spec["R"]
+    rng = np.random.default_rng(0xD1)
+
+    def tanh_case(Q, N, bb, CC, multi):
+        if multi:
+            lab = (rng.random((N, CC)) < 0.03).astype(np.int64)
+            lab[np.arange(N), rng.integers(0, CC, N)] = 1
+            qlab = (rng.random((Q, CC)) < 0.03).astype(np.int64)
+            qlab[np.arange(Q), rng.integers(0, CC, Q)] = 1
+        else:
+            eye = np.eye(CC, dtype=np.int64)
+            lab, qlab = eye[rng.integers(0, CC, N)], eye[rng.integers(0, CC, Q)]
+        return (types.SimpleNamespace(output=np.tanh(rng.standard_normal((N, bb), dtype=np.float32)), label=lab),
+                types.SimpleNamespace(output=np.tanh(rng.standard_normal((Q, bb), dtype=np.float32)), label=qlab))
+    shapes = {
+        "c2_pm1_codes": (R, types.SimpleNamespace(output=unpack_bits(dw, b).astype(np.float32) * 2 - 1, label=unpack_bits(dl, C).astype(np.int64)),
+                         types.SimpleNamespace(output=unpack_bits(qw, b).astype(np.float32) * 2 - 1, label=unpack_bits(ql, C).astype(np.int64))),
+        "cifar10_tanh": (54000,) + tanh_case(1000, 54000, 64, 10, False),
+        "nuswide81_tanh": (5000,) + tanh_case(5000, 168692, 64, 81, True),
+    }
+    out = {"call": "MAPs(R).get_maps_by_feature(database, query): a NEW MAPs object per call, never closed (main.py:164), host float32 / int64 arrays; "
+                   "%d calls per shape, none discarded" % reps}
+    probe = _native.Context(0)
+    try:
+        for name, (r_, db, q) in shapes.items():
+            gc.collect()
+            p0, h0 = pool_stats(), _native.host_phase_timers(probe)
+            each, vals = [], []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                v = MAPs(r_).get_maps_by_feature(db, q)      # the object is collected with the statement: its context goes back to the pool
+                each.append(time.perf_counter() - t0)
+                vals.append(v)
+            p1, h1 = pool_stats(), _native.host_phase_timers(probe)
+            ms = [round(x * 1e3, 3) for x in each]
+            out[name] = {"shape": "Q=%d N=%d b=%d R=%d C=%d" % (q.output.shape[0], db.output.shape[0], db.output.shape[1], r_, db.label.shape[1]),
+                         "ms_each_call": ms, "min_ms": min(ms), "median_ms": float(np.median(ms)), "max_ms": max(ms),
+                         "max_over_median": round(max(ms) / float(np.median(ms)), 3),
+                         "max_over_median_after_first": round(max(ms[1:]) / float(np.median(ms)), 3),
+                         "same_result_every_call": bool(all(v == vals[0] for v in vals)), "map": float(vals[0]),
+                         "contexts_created": p1["contexts_created"] - p0["contexts_created"], "contexts_recycled": p1["contexts_recycled"] - p0["contexts_recycled"],
+                         "host_phase_ms": {k: round(h1[k][0] - h0[k][0], 3) for k in h0 if h1[k][0] - h0[k][0] > 0.0005},
+                         "host_phase_calls": {k: h1[k][1] - h0[k][1] for k in h0 if h1[k][1] - h0[k][1] > 0},
+                         "host_array_bytes": int(db.output.nbytes + db.label.nbytes + q.output.nbytes + q.label.nbytes)}
+        out["pool"] = pool_stats()
+    finally:
+        probe.close()
+    return out
+
+
 def real_valued(spec, reps=5):
     """The caller's REAL input: main.py:157,164 hands tanh outputs (lib/architecture.py:147,192,384-389), not codes, to the
     metric, which ranks them by float32 inner product (metric.py:13-14 as written).  The same call on such features at
@@ -672,6 +733,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive MAPs(...) timing")
     ap.add_argument("--no-sorted", action="store_true", help="skip the class-sorted database timing")
+    ap.add_argument("--no-literal", action="store_true", help="skip the literal drop-in leg (a new MAPs object per call, main.py:164)")
     ap.add_argument("--no-large-r", action="store_true", help="skip the large-R legs (R = N/20, R = N/2 on the timed workload's arrays)")
     ap.add_argument("--no-real", action="store_true", help="skip the real-valued (tanh features) call timing")
     ap.add_argument("--no-c4-ref", action="store_true", help="skip the one-GPU C4 point of the scaling curve")
@@ -928,6 +990,8 @@ def main():
             return d
         if not args.no_h2d:
             side("h2d_inclusive", h2d)
+        if not args.no_literal:
+            side("drop_in_literal", lambda: drop_in_literal(spec, packed))
         if not args.no_sorted and spec["kind"] == "planted":
             side("class_sorted_database", lambda: class_sorted(spec, packed))
         if not args.no_real:

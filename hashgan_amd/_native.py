@@ -160,6 +160,7 @@ class Context:
         self._h = h
         self.device = int(device)
         self.Q = self.N = self.R = self.b = self.C = None
+        self.options_touched = set()       # keys set through set_option (metric's engine pool only recycles contexts on their defaults)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -461,9 +462,11 @@ class Context:
     def set_stream(self, stream_handle):
         """Run on the caller's HIP stream (an int handle: a hipStream_t); None = back to a private one."""
         check(self._lib.hg_set_stream(self._h, _p(stream_handle) if stream_handle else None))
+        self.options_touched.add("stream")
 
     def set_option(self, key, value):
         check(self._lib.hg_set_option(self._h, key.encode(), int(value)))
+        self.options_touched.add(key)
 
     def trim(self):
         """Free the work buffers (they only grow); the loaded tables stay."""
@@ -496,6 +499,15 @@ class Context:
         n = C.c_int()
         check(self._lib.hg_timing_read(self._h, cap, names, ms, cnt, C.byref(n)))
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+
+def host_phase_timers(ctx):
+    """Process-wide host-side cost of what a context does outside its kernels (hg_ctx.hpp, HostPhase): {phase: (total ms, calls,
+    longest call ms)} for init, devmalloc, devfree, hostmalloc, hostfree, destroy, stream, event."""
+    out = {}
+    for ph in ("init", "devmalloc", "devfree", "hostmalloc", "hostfree", "destroy", "stream", "event"):
+        out[ph] = (ctx.get_stat("host_us_" + ph) / 1e3, ctx.get_stat("host_n_" + ph), ctx.get_stat("host_max_us_" + ph) / 1e3)
+    return out
 
 
 def comm_unique_id():

@@ -65,6 +65,8 @@ void build_shape(int n, ApShape& sh) {
 
 
 std::atomic<unsigned long long> g_alloc_epoch{1};
+const char* const kHostPhaseNames[HP_COUNT] = {"init", "devmalloc", "devfree", "hostmalloc", "hostfree", "destroy", "stream", "event"};
+std::atomic<long long> g_host_ns[HP_COUNT], g_host_calls[HP_COUNT], g_host_max_ns[HP_COUNT];
 
 int need(hg_ctx* c, unsigned st, const char* who, const char* what) {
     if (!c) return fail(HG_ERR_ARG, "%s: null context", who);
@@ -119,9 +121,9 @@ int ensure_out_block(hg_ctx* c) {
 
 int ensure_pin(hg_ctx* c, size_t need_b) {
     if (c->pin_cap >= need_b) return HG_OK;
-    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin) (void)host_timed(HP_HOSTFREE, [&] { return hipHostFree(c->pin); });
     c->pin = nullptr; c->pin_cap = 0;
-    HG_HIP(hipHostMalloc(&c->pin, need_b, hipHostMallocDefault));
+    HG_HIP(host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(&c->pin, need_b, hipHostMallocDefault); }));
     c->pin_cap = need_b;
     ++g_alloc_epoch;                                   // captured downloads point into the old block
     return HG_OK;
@@ -143,6 +145,7 @@ int hg_device_count(int* count) {
 int hg_init(int device, hg_ctx** out) {
     if (!out) return fail(HG_ERR_ARG, "hg_init: null pointer");
     *out = nullptr;
+    HostTimer t_init(HP_INIT);
     int n = 0;
     HG_HIP(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(HG_ERR_ARG, "hg_init: device %d out of range (%d visible)", device, n);
@@ -154,7 +157,7 @@ int hg_init(int device, hg_ctx** out) {
     c->device = device;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cu = cus;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = host_timed(HP_STREAM, [&] { return hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); });
     if (e != hipSuccess) { delete c; return fail(HG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = c;
     return HG_OK;
@@ -162,6 +165,7 @@ int hg_init(int device, hg_ctx** out) {
 
 int hg_destroy(hg_ctx* c) {
     if (!c) return HG_OK;
+    HostTimer t_destroy(HP_DESTROY);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->t_collect();
@@ -171,7 +175,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part, &c->dbytes, &c->outblk};
+                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part, &c->dbytes, &c->outblk, &c->beyond};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -179,10 +183,14 @@ int hg_destroy(hg_ctx* c) {
     c->obuf[0].release(); c->obuf[1].release();
     comm_release(c);
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
-    if (c->pin) (void)hipHostFree(c->pin);
-    for (auto& m : c->mslot) { if (m.pin) (void)hipHostFree(m.pin); if (m.ev) (void)hipEventDestroy(m.ev); m.pin = nullptr; m.ev = nullptr; }
-    if (c->hpk) (void)hipHostFree(c->hpk);
-    if (c->fstage) (void)hipHostFree(c->fstage);
+    {
+        HostTimer t_hf(HP_HOSTFREE);
+        if (c->pin) (void)hipHostFree(c->pin);
+        for (auto& m : c->mslot) { if (m.pin) (void)hipHostFree(m.pin); if (m.ev) (void)hipEventDestroy(m.ev); m.pin = nullptr; m.ev = nullptr; }
+        if (c->hpk) (void)hipHostFree(c->hpk);
+        if (c->fstage) (void)hipHostFree(c->fstage);
+        for (auto& q : c->qstage) { if (q.pin) (void)hipHostFree(q.pin); if (q.ev) (void)hipEventDestroy(q.ev); q.pin = nullptr; q.ev = nullptr; }
+    }
     if (c->stream2_ev) (void)hipEventDestroy(c->stream2_ev);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     for (auto& e : c->fstage_ev) if (e) (void)hipEventDestroy(e);
@@ -234,6 +242,7 @@ int hg_set_database(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, in
     c->cap_boost = c->real_cap_boost = 1;
     c->crowd_probed = false;
     c->cfg_epoch++;
+    c->db_gen++;
     return HG_OK;
 }
 
@@ -284,7 +293,7 @@ static int stage_floats(hg_ctx* c, const float* x, i64 n, int b, int bpad, DevBu
     constexpr int NSL = 4;
     const size_t CH = (size_t)16 << 20;
     if (!c->fstage) {
-        HG_HIP(hipHostMalloc(&c->fstage, CH * NSL, hipHostMallocDefault));
+        HG_HIP(host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(&c->fstage, CH * NSL, hipHostMallocDefault); }));
         for (int k = 0; k < NSL; ++k) HG_HIP(hipEventCreateWithFlags(&c->fstage_ev[k], hipEventDisableTiming));
     }
     const i64 rows_per = (i64)(CH / ((size_t)bpad * 4));
@@ -313,9 +322,9 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
     const size_t need_b = ((cb + 63) & ~(size_t)63) + lbytes;
     if (c->hpk_cap < need_b) {
         HG_TRY(c->sync());
-        if (c->hpk) (void)hipHostFree(c->hpk);
+        if (c->hpk) (void)host_timed(HP_HOSTFREE, [&] { return hipHostFree(c->hpk); });
         c->hpk = nullptr; c->hpk_cap = 0;
-        HG_HIP(hipHostMalloc(&c->hpk, need_b, hipHostMallocDefault));
+        HG_HIP(host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(&c->hpk, need_b, hipHostMallocDefault); }));
         c->hpk_cap = need_b;
     }
     u32* hc = (u32*)c->hpk;
@@ -354,7 +363,7 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
     std::string stage_msg;                               // (the error text is thread-local: carried over by hand)
     std::thread stager;
     if (early) {
-        if (!c->stream2) HG_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        if (!c->stream2) HG_HIP(host_timed(HP_STREAM, [&] { return hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking); }));
         if (!c->stream2_ev) HG_HIP(hipEventCreateWithFlags(&c->stream2_ev, hipEventDisableTiming));
         HG_TRY(feats.reserve(fb_f + 256));
         try {
@@ -437,7 +446,18 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     c->cap_boost = c->real_cap_boost = 1;
     c->crowd_probed = false;
     c->cfg_epoch++;
+    c->db_gen++;
     return HG_OK;
+}
+
+// A new query table of the SAME size on an unchanged database and configuration keeps hg_map_begin's licence to enqueue blind:
+// every buffer of the step is sized by Q, nothing about the bet depends on what the queries are (its verdict is checked on the
+// GPU either way), so a caller that hands over batch after batch keeps two steps in flight.
+static void queries_replaced(hg_ctx* c, i64 old_q, bool had_q) {
+    const bool carry = had_q && old_q == c->Q && c->map_warm_R >= 0 && c->map_warm_cfg == c->cfg_epoch;
+    c->cfg_epoch++;
+    c->q_gen++;
+    if (carry) c->map_warm_cfg = c->cfg_epoch;
 }
 
 int hg_set_queries_f32(hg_ctx* c, const float* host_x, const int64_t* host_labels, int64_t Q, int64_t* bad_codes,
@@ -445,6 +465,8 @@ int hg_set_queries_f32(hg_ctx* c, const float* host_x, const int64_t* host_label
     HG_TRY(need(c, ST_DB, "hg_set_queries_f32", "hg_set_database"));
     if (Q < 1 || !host_x || !host_labels) return fail(HG_ERR_ARG, "hg_set_queries_f32: need Q >= 1 and data");
     if (Q > 0x7FFFFFC0ll) return fail(HG_ERR_ARG, "hg_set_queries_f32: Q too large");
+    const i64 old_q = c->Q;
+    const bool had_q = (c->stage & ST_Q) != 0;
     c->Q = Q;
     if (c->opt_host_pack) {
         // the query table is small: its floats follow whenever the database's are there (the inner-product ranking needs both)
@@ -458,7 +480,7 @@ int hg_set_queries_f32(hg_ctx* c, const float* host_x, const int64_t* host_label
     }
     c->stage = ST_DB | ST_Q;
     c->qx_valid = false;
-    c->cfg_epoch++;
+    queries_replaced(c, old_q, had_q);
     return HG_OK;
 }
 
@@ -477,15 +499,36 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     HG_TRY(need(c, ST_DB, "hg_set_queries", "hg_set_database"));
     if (Q < 1 || !codes || !labels) return fail(HG_ERR_ARG, "hg_set_queries: need Q >= 1 and data");
     if (Q > 0x7FFFFFC0ll) return fail(HG_ERR_ARG, "hg_set_queries: Q too large");
+    const i64 old_q = c->Q;
+    const bool had_q = (c->stage & ST_Q) != 0;
     c->Q = Q;
-    HG_TRY(upload_codes(c, c->qc, codes, Q, (c->b + 63) / 64, c->NW));
-    HG_TRY(c->qlab.reserve((size_t)Q * c->LW * 8));
-    HG_HIP(hipMemcpyAsync(c->qlab.p, labels, (size_t)Q * c->LW * 8, hipMemcpyHostToDevice, c->stream));
-    HG_TRY(c->sync());
+    // through a pinned block of the context's own (two, alternating), copied from there by the stream: the call returns without
+    // waiting for whatever the stream still holds -- a step of hg_map_begin on the previous batch -- and the caller's arrays
+    // are free the moment it does
+    const int W = (c->b + 63) / 64;
+    const size_t cb = (size_t)Q * W * 8, lb = (size_t)Q * c->LW * 8;
+    hg_ctx::QStage& qs = c->qstage[c->qstage_next];
+    c->qstage_next ^= 1;
+    if (qs.used) HG_HIP(hipEventSynchronize(qs.ev));   // (the copy out of this block two loads ago)
+    if (qs.cap < cb + lb) {
+        if (qs.pin) (void)host_timed(HP_HOSTFREE, [&] { return hipHostFree(qs.pin); });
+        qs.pin = nullptr; qs.cap = 0;
+        const size_t want = cb + lb < 4096 ? 4096 : cb + lb;
+        HG_HIP(host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(&qs.pin, want, hipHostMallocDefault); }));
+        qs.cap = want;
+    }
+    if (!qs.ev) HG_HIP(hipEventCreateWithFlags(&qs.ev, hipEventDisableTiming));
+    memcpy(qs.pin, codes, cb);
+    memcpy((char*)qs.pin + cb, labels, lb);
+    HG_TRY(upload_codes(c, c->qc, (const uint64_t*)qs.pin, Q, W, c->NW));
+    HG_TRY(c->qlab.reserve(lb));
+    HG_HIP(hipMemcpyAsync(c->qlab.p, (const char*)qs.pin + cb, lb, hipMemcpyHostToDevice, c->stream));
+    HG_HIP(hipEventRecord(qs.ev, c->stream));
+    qs.used = true;
     c->stage = ST_DB | ST_Q;
     c->qx_valid = false;
     c->qf_resident = false;                            // packed input: no float table
-    c->cfg_epoch++;
+    queries_replaced(c, old_q, had_q);
     return HG_OK;
 }
 
@@ -731,6 +774,11 @@ int hg_set_stream(hg_ctx* c, void* stream) {
 
 int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return fail(HG_ERR_ARG, "hg_set_option: null argument");
+    if (!strcmp(key, "handicap_next_bet")) {           // test hook: not a configuration change (a blind hg_map_begin stays blind -- and loses)
+        if (value < 0 || value > 64) return fail(HG_ERR_ARG, "handicap_next_bet must be 0..64");
+        c->handicap_next = value;
+        return HG_OK;
+    }
     c->cfg_epoch++;                                    // whatever changes: a captured step is rebuilt
     if (!strcmp(key, "step_graph")) { c->opt_graph = value != 0; return HG_OK; }
     if (!strcmp(key, "stage_sync")) { c->stage_sync = value != 0; return HG_OK; }
@@ -880,9 +928,12 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
                          &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->mbits2,
-                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part};
+                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part, &c->dbytes, &c->outblk, &c->beyond,
+                         &c->comm_tmp, &c->gath_idx, &c->gath_dist, &c->obuf[0], &c->obuf[1]};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;
+        for (auto& d : c->gathered) if (!d.borrowed) total += (i64)d.cap;
+        for (auto& d : c->scratch) if (!d.borrowed) total += (i64)d.cap;
         *value = total;
     }
 #ifdef HG_RANK_PROFILE
@@ -890,6 +941,17 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "dbg_hwq_ptr")) *value = (int64_t)(uintptr_t)c->hwq.p;
 #endif
 #endif
+    else if (!strncmp(key, "host_", 5)) {              // process-wide host-side phase timers (hg_ctx.hpp, HostPhase)
+        const char* rest = key + 5;
+        int kind = -1;                                 // 0 total us, 1 calls, 2 longest call us
+        if (!strncmp(rest, "us_", 3)) { kind = 0; rest += 3; }
+        else if (!strncmp(rest, "n_", 2)) { kind = 1; rest += 2; }
+        else if (!strncmp(rest, "max_us_", 7)) { kind = 2; rest += 7; }
+        int ph = -1;
+        for (int i = 0; i < HP_COUNT; ++i) if (!strcmp(rest, kHostPhaseNames[i])) ph = i;
+        if (kind < 0 || ph < 0) return fail(HG_ERR_ARG, "hg_get_stat: unknown key '%s'", key);
+        *value = kind == 0 ? g_host_ns[ph].load() / 1000 : kind == 1 ? g_host_calls[ph].load() : g_host_max_ns[ph].load() / 1000;
+    }
     else if (!strcmp(key, "graph_replays")) *value = c->graph_replays;
     else if (!strcmp(key, "cut_beyond_planes")) {      // a download: asked for after a lost owner-routed bet only
         u32 v = 0;

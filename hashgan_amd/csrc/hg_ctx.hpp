@@ -18,6 +18,7 @@
 
 #include <rccl/rccl.h>     // types and enums only: the library itself is dlopen'ed by hg_comm_init (573 MB, not every process needs it)
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -48,6 +49,26 @@ int fail(int code, const char* fmt, ...);       // sets g_err, returns code
 
 // Bumped whenever a device buffer moves: captured graphs hold raw addresses and die with the epoch they were built in.
 extern std::atomic<unsigned long long> g_alloc_epoch;   // bumped by every context's buffers (one MAPs object per thread is supported): atomic
+
+// Host-side cost of the runtime calls a context makes outside its kernels -- creating it, device and pinned allocations and
+// their release -- accumulated process-wide (hg_get_stat "host_us_<phase>", "host_n_<phase>", "host_max_us_<phase>"): what a
+// caller that builds a context per evaluation (main.py:164 builds a MAPs per evaluation) pays before any kernel runs.
+enum HostPhase { HP_INIT = 0, HP_DEVMALLOC, HP_DEVFREE, HP_HOSTMALLOC, HP_HOSTFREE, HP_DESTROY, HP_STREAM, HP_EVENT, HP_COUNT };
+extern const char* const kHostPhaseNames[HP_COUNT];
+extern std::atomic<long long> g_host_ns[HP_COUNT], g_host_calls[HP_COUNT], g_host_max_ns[HP_COUNT];
+struct HostTimer {
+    int id;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(int i) : id(i), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() {
+        const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        g_host_ns[id] += ns;
+        g_host_calls[id] += 1;
+        long long m = g_host_max_ns[id].load();
+        while (ns > m && !g_host_max_ns[id].compare_exchange_weak(m, ns)) {}
+    }
+};
+template <class F> inline auto host_timed(int id, F&& f) { HostTimer t_(id); return f(); }
 
 // HG_EFENCE=1 (debugging): every device buffer ends 64..127 bytes before an UNMAPPED 2 MiB page of its own virtual range
 // (hipMemAddressReserve / hipMemMap), so a kernel reading or writing past a buffer -- beyond the 64 bytes of slack the
@@ -105,7 +126,7 @@ struct DevBuf {
     bool borrowed = false;      // points into another context's allocation
     Fence fence;                // HG_EFENCE: the buffer's own virtual range
     void drop() {
-        if (p && !borrowed) { if (fence.va) fence_free(fence); else (void)hipFree(p); }
+        if (p && !borrowed) { HostTimer t_(HP_DEVFREE); if (fence.va) fence_free(fence); else (void)hipFree(p); }
     }
     int reserve(size_t bytes) {
         if (bytes <= cap) return HG_OK;
@@ -121,7 +142,7 @@ struct DevBuf {
             HG_HIP(hipMemset(p, 0xCB, bytes + 64));
             HG_HIP(hipDeviceSynchronize());
         } else {
-            HG_HIP(hipMalloc(&p, bytes + 64));
+            HG_HIP(host_timed(HP_DEVMALLOC, [&] { return hipMalloc(&p, bytes + 64); }));
         }
         cap = bytes;
         ++g_alloc_epoch;
@@ -256,12 +277,19 @@ struct hg_ctx {
         bool async = false;            // enqueued only (else: ran synchronously, results in ap / rel)
         bool inline_ok = false;        // the step ranked its fused kernel's leftovers itself
         i64 R = 0, Q = 0;
+        unsigned long long q_gen = 0, db_gen = 0;   // the tables the step was enqueued on (hg_map_end redoes a lost step only on those)
         std::vector<double> ap; std::vector<int64_t> rel;
     } mslot[2];
     int ms_head = 0, ms_n = 0;
     unsigned long long map_warm_cfg = 0, map_warm_epoch = 0;   // configuration of the last synchronous hg_map that won its bet outright
     i64 map_warm_R = -1;
     i64 map_async_steps = 0, map_async_redone = 0;
+    unsigned long long q_gen = 0, db_gen = 0;      // bumped by every (re)load of the query / database tables
+    i64 handicap_next = 0;     // test hook "handicap_next_bet": the NEXT bet's guess sits this many deviations BELOW the expected count (it loses), once
+    // hg_set_queries stages the packed tables through two alternating pinned blocks and does not wait for the stream: a new batch
+    // can be handed over while a step on the previous one is still in flight (hg_map_begin / hg_map_end, batch after batch)
+    struct QStage { void* pin = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } qstage[2];
+    int qstage_next = 0;
     bool ap_staged = false;
     DevBuf hist, hown, posbase, seglt, segtie;
     DevBuf t, tguess, sstar, cnt_lt, quota, tie_before, n_lt, err;
@@ -341,7 +369,7 @@ struct hg_ctx {
     hipEvent_t get_event() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
-        (void)hipEventCreate(&e);
+        (void)host_timed(HP_EVENT, [&] { return hipEventCreate(&e); });
         return e;
     }
     bool t_wanted(int id) const {

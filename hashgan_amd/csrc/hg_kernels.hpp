@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_guess_direct(const u32* __restrict__ hs
     const bool live = q < g.Q;
     const int qq = live ? q : 0;                       // dead lanes follow query 0 (shuffles need every lane)
     const double fr = (double)g.R * (double)sampled / (double)n_total;
-    const u64 need = (u64)ceil(fr + sigma * sqrt(fr) + 1.0);
+    const u64 need = (u64)ceil(fmax(1.0, fr + sigma * sqrt(fr) + 1.0));     // (sigma < 0: the "handicap_next_bet" test hook)
     const i64 plane = (i64)g.NB * g.Qpad;
     const int per = (Sh + PARTS - 1) / PARTS;          // part p sums segments [p * per, (p + 1) * per)
     const int s0 = part * per < Sh ? part * per : Sh, s1 = s0 + per < Sh ? s0 + per : Sh;

@@ -1171,9 +1171,11 @@ static int enqueue_optimistic(hg_ctx* c, int64_t R, int stride, u32 need_cnt) {
     {   // lanes per query by the number of sampled segments each has to sum
         const int ratio = (int)(gh.L / g.L);
         const u32 srows = (u32)sampled_rows(c, stride);
+        double sigma = (double)c->opt_sigma;
+        if (c->handicap_next && !c->capturing) { sigma = -(double)c->handicap_next; c->handicap_next = 0; }   // (test hook: this bet is meant to lose)
 #define HG_GUESS(P)                                                                                                     \
         hipLaunchKernelGGL(k_guess_direct<P>, dim3(grid_for(g.Qpad, WPB * (64 / P))), dim3(256), 0, c->stream,          \
-                           c->hist.as<u32>(), gh.S, ratio, (double)c->opt_sigma, (i64)c->n_total, srows,                \
+                           c->hist.as<u32>(), gh.S, ratio, sigma, (i64)c->n_total, srows,                \
                            c->tguess.as<int>(), c->sstar.as<int>(), c->failq.as<u32>(), c->err.as<int>(), crowd, g)
         // (more lanes per query shorten a lane's share of a plane but scatter a wavefront's loads over more lines: with 64
         // lanes for every query that the chip has room for, Q = 1000 went 0.068 -> 0.090 ms, C3 0.032 -> 0.061)
@@ -1575,6 +1577,7 @@ int hg_map_begin(hg_ctx* c, int64_t R) {
     if (c->ms_n == 2) return fail(HG_ERR_STATE, "hg_map_begin: two steps are in flight already (hg_map_end takes the oldest)");
     hg_ctx::MapSlot& m = c->mslot[(c->ms_head + c->ms_n) & 1];
     m.R = R; m.Q = c->Q;
+    m.q_gen = c->q_gen; m.db_gen = c->db_gen;
     int stride = 0;
     u32 need_cnt = 0;
     bool blind = c->map_warm_R == R && c->map_warm_cfg == c->cfg_epoch && c->map_warm_epoch == g_alloc_epoch && !c->is_sub;
@@ -1587,9 +1590,9 @@ int hg_map_begin(hg_ctx* c, int64_t R) {
     if (blind) {
         const size_t need_b = (size_t)c->Q * 12 + 16;
         if (m.cap < need_b) {
-            if (m.pin) (void)hipHostFree(m.pin);
+            if (m.pin) (void)host_timed(HP_HOSTFREE, [&] { return hipHostFree(m.pin); });
             m.pin = nullptr; m.cap = 0;
-            HG_HIP(hipHostMalloc(&m.pin, need_b, hipHostMallocDefault));
+            HG_HIP(host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(&m.pin, need_b, hipHostMallocDefault); }));
             m.cap = need_b;
         }
         if (!m.ev) HG_HIP(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
@@ -1635,9 +1638,11 @@ int hg_map_end(hg_ctx* c, double* host_ap, int64_t* host_rel) {
     }
     // the bet was lost (or queries were left over): the synchronous call sorts that out -- reruns, deeper bets, wider slices -- on
     // the same tables; a younger step in flight keeps its own verdict in its own block
-    c->map_async_redone++;
     c->map_warm_R = -1;
-    if ((i64)Q != c->Q) return fail(HG_ERR_STATE, "hg_map_end: the queries were replaced while a step that lost its bet was in flight");
+    if (m.q_gen != c->q_gen || m.db_gen != c->db_gen || (i64)Q != c->Q)
+        return fail(HG_ERR_STATE, "hg_map_end: the %s replaced while a step that lost its bet was in flight: its tables are gone, "
+                                  "load them again and call hg_map", m.db_gen != c->db_gen ? "database was" : "queries were");
+    c->map_async_redone++;
     return hg_map(c, m.R, host_ap, host_rel);
 }
 

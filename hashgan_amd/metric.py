@@ -64,6 +64,11 @@ class RetrievalEngine:
     def close(self):
         self.ctx.close()
 
+    def forget(self):
+        """Before the engine goes back to the pool: nothing of the last owner's tables may be taken for resident."""
+        self.b = self.C = self.N = self.db_kind = self.db_src = None
+        self.resident = None
+
     def set_database(self, codes, labels, idx_base=0, n_total=None, packed=False):
         if packed:
             cw, lw, b, C_ = codes
@@ -108,9 +113,76 @@ def mean_over_hits(ap, rel):
 
 
 # ------------------------------------------------------------------ engines
+class _Pool:
+    """Process-wide pool of GPU contexts for MAPs objects.  main.py:164 writes `MAPs(cfg.DATA.MAP_R).get_maps_by_feature(...)`:
+    a NEW object per evaluation, never closed.  A context of its own per object would mean a stream, ~0.3 GB of device buffers
+    and the pinned staging blocks created and torn down around every call (hipMalloc / hipHostMalloc / hipFree: tens of
+    milliseconds, and now and then a stall of a second -- bench.py's `drop_in_literal` leg).  So an object BORROWS a context on
+    first use and hands it back when it is closed or collected; the context keeps its buffers (they only grow), the next
+    object's tables are loaded into them.  An object that is alive keeps its context to itself (no two objects ever share
+    device state at the same time); a context whose engine options were changed by its borrower is destroyed instead of
+    recycled; at most `max_idle` contexts per device wait in the pool."""
+    lock = threading.Lock()
+    idle = {}
+    max_idle = 2
+    created = 0
+    recycled = 0
+    closed = 0
+
+    @classmethod
+    def acquire(cls, device):
+        with cls.lock:
+            lst = cls.idle.get(device)
+            if lst:
+                cls.recycled += 1
+                return lst.pop()
+            cls.created += 1
+        return RetrievalEngine(device)
+
+    @classmethod
+    def release(cls, eng):
+        keep = False
+        try:
+            touched = eng.ctx.options_touched - {"keep_floats"}         # (set by every load)
+            pending = getattr(eng.ctx, "_in_flight", None)
+            if not touched and not pending and eng.ctx._h and not getattr(eng, "poisoned", False):
+                eng.forget()
+                with cls.lock:
+                    lst = cls.idle.setdefault(eng.ctx.device, [])
+                    if len(lst) < cls.max_idle:
+                        lst.append(eng)
+                        keep = True
+        finally:
+            if not keep:
+                with cls.lock:
+                    cls.closed += 1
+                eng.close()
+
+    @classmethod
+    def close_all(cls):
+        with cls.lock:
+            engines = [e for lst in cls.idle.values() for e in lst]
+            cls.idle.clear()
+            cls.closed += len(engines)
+        for e in engines:
+            e.close()
+
+    @classmethod
+    def stats(cls):
+        with cls.lock:
+            idle = [e for lst in cls.idle.values() for e in lst]
+            return {"contexts_created": cls.created, "contexts_recycled": cls.recycled, "contexts_closed": cls.closed,
+                    "contexts_idle": len(idle), "idle_device_bytes": sum(e.ctx.get_stat("device_bytes") for e in idle)}
+
+
+def pool_stats():
+    """Counters of the MAPs context pool: contexts created / recycled / closed / idle, device bytes the idle ones hold."""
+    return _Pool.stats()
+
+
 class _Shared:
     """One lazily created engine per device for the function spellings (MAP, calc_map, extra_metrics): a context
-    is not thread safe, so every use holds its lock.  MAPs objects own private engines instead."""
+    is not thread safe, so every use holds its lock.  MAPs objects borrow theirs from _Pool instead."""
     lock = threading.Lock()
     engines = {}
 
@@ -132,8 +204,9 @@ class _Shared:
 
 
 def release_engines():
-    """Free the GPU contexts (and their device memory) behind MAP / calc_map / extra_metrics."""
+    """Free the GPU contexts (and their device memory) behind MAP / calc_map / extra_metrics and the idle ones of MAPs' pool."""
     _Shared.close_all()
+    _Pool.close_all()
 
 
 def _check_shapes(q_codes, db_codes, q_labels, db_labels, R):
@@ -235,8 +308,10 @@ def _evaluate(q_codes, db_codes, q_labels, db_labels, R, device, mode):
 class MAPs:
     """Same constructor and method as lib/metric.py:4-24.
 
-    The object owns one GPU context (created on first use, freed by close() / garbage collection) and a lock, so
-    several MAPs objects -- different R, different threads -- never share device state.  main.py:237-240 evaluates
+    The object holds one GPU context from first use to close() / garbage collection -- borrowed from a process-wide pool
+    (_Pool: main.py:164 builds a new MAPs per evaluation, and a context of its own each time would cost allocations worth
+    many times the evaluation) -- and a lock, so several live MAPs objects -- different R, different threads -- never share
+    device state.  main.py:237-240 evaluates
     the same database against fresh queries again and again; `set_database` keeps it packed on the GPU between
     calls (explicit), and a database whose arrays are the SAME read-only objects as last time is reused
     automatically (a writable array may have changed in place, so it is uploaded again)."""
@@ -256,15 +331,15 @@ class MAPs:
 
     def _engine(self):
         if self._eng is None:
-            self._eng = RetrievalEngine(self.device)
+            self._eng = _Pool.acquire(self.device)
         return self._eng
 
     def close(self):
         with self._lock:
             if self._eng is not None:
-                self._eng.close()
-                self._eng = None
+                eng, self._eng = self._eng, None
                 self._resident = None
+                _Pool.release(eng)
 
     def __del__(self):
         try:
@@ -280,8 +355,17 @@ class MAPs:
             raise ValueError("database.output must be [N, b] and database.label [N, C]")
         with self._lock:
             self._resident = None                      # a failed load leaves NO database (never the previous one half replaced)
-            _load_database(self._engine(), out, lab, "sign" if self.binarize else "reference")
+            self._guard(_load_database, self._engine(), out, lab, "sign" if self.binarize else "reference")
             self._resident = ("explicit", database)
+
+    def _guard(self, fn, *args):
+        """A HIP-level failure (a fault, out of memory) may leave the context unusable: it is destroyed, not recycled."""
+        try:
+            return fn(*args)
+        except _native.HashganNativeError as e:
+            if e.code in (_native.HG_ERR_HIP, _native.HG_ERR_NOMEM) and self._eng is not None:
+                self._eng.poisoned = True
+            raise
 
     def _ensure_database(self, database):
         if database is None:
@@ -297,7 +381,7 @@ class MAPs:
         if out.ndim != 2 or lab.ndim != 2 or out.shape[0] != lab.shape[0]:
             raise ValueError("database.output must be [N, b] and database.label [N, C]")
         self._resident = None                          # a failed load leaves NO database
-        _load_database(self._engine(), out, lab, "sign" if self.binarize else "reference")
+        self._guard(_load_database, self._engine(), out, lab, "sign" if self.binarize else "reference")
         self._resident = ("auto", out, lab)
 
     def get_maps_by_feature(self, database, query):
@@ -316,7 +400,7 @@ class MAPs:
             R = int(self.R)
             if not 1 <= R <= eng.N:
                 raise ValueError("R=%d must be in 1..N (N=%d database rows)" % (R, eng.N))
-            ap, rel = _rank(eng, q_codes, q_labels, R, "sign" if self.binarize else "reference")
+            ap, rel = self._guard(_rank, eng, q_codes, q_labels, R, "sign" if self.binarize else "reference")
         return mean_over_hits(ap, rel)
 
 

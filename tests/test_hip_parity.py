@@ -130,6 +130,60 @@ def test_python_surface_matches_golden(case_cache):
         MAP(c["qbits"], c["dbbits"], c["qlab"], c["dblab"], c["dbbits"].shape[0] + 1)
 
 
+def test_a_new_maps_object_per_evaluation_recycles_one_context(case_cache):
+    """main.py:164 as written -- `MAPs(R).get_maps_by_feature(database, query)`, a NEW object per evaluation, never closed: fifty of
+    them, alternating between two shapes and between +-1 codes and real-valued features, all draw the same pooled context (one
+    created, the rest recycled), every result equals the golden / the first call's, and the device memory the pool holds stops
+    growing after the first round of shapes (buffers only grow: what the largest evaluation needed is the floor)."""
+    import gc
+    import types
+    from hashgan_amd import MAPs, pool_stats, release_engines
+    ca, cb = case_cache("e_ragged"), case_cache("e_b100")
+    ga, gb = cases.load_golden("e_ragged"), cases.load_golden("e_b100")
+
+    def ns(c, k, real=False):
+        out = c[k + "bits"].astype(np.float32) * 2 - 1
+        if real:
+            out = np.tanh(out * (1.0 + 0.25 * np.arange(out.shape[1], dtype=np.float32)))
+        return types.SimpleNamespace(output=out, label=c[k + "lab"].astype(np.int64))
+    release_engines()
+    gc.collect()
+    s0 = pool_stats()
+    assert s0["contexts_idle"] == 0
+    jobs = [(ca["R"], ns(ca, "db"), ns(ca, "q"), ga["map"]), (cb["R"], ns(cb, "db"), ns(cb, "q"), gb["map"]),
+            (ca["R"], ns(ca, "db", True), ns(ca, "q", True), None)]
+    floor = None
+    first_real = None
+    for i in range(51):
+        R, db, q, want = jobs[i % 3]
+        got = MAPs(R).get_maps_by_feature(db, q)           # the object dies with the statement
+        if want is None:
+            first_real = got if first_real is None else first_real
+            want = first_real
+        assert got == want, (i, got, want)
+        st = pool_stats()
+        assert st["contexts_idle"] == 1, st
+        if i == 5:
+            floor = st["idle_device_bytes"]
+        if i > 5:
+            assert st["idle_device_bytes"] == floor, (i, st, floor)
+    st = pool_stats()
+    assert st["contexts_created"] - s0["contexts_created"] == 1 and st["contexts_recycled"] - s0["contexts_recycled"] == 50
+    # a borrower that changed engine options does not hand its context back; one alive keeps its context to itself
+    m = MAPs(ca["R"])
+    m.get_maps_by_feature(jobs[0][1], jobs[0][2])
+    m2 = MAPs(ca["R"])
+    assert m2.get_maps_by_feature(jobs[0][1], jobs[0][2]) == ga["map"] and m2._eng is not m._eng
+    m._eng.ctx.set_option("guess_sigma", 7)
+    closed0 = pool_stats()["contexts_closed"]
+    m.close()
+    assert pool_stats()["contexts_closed"] == closed0 + 1
+    m2.close()
+    assert pool_stats()["contexts_idle"] == 1
+    release_engines()
+    assert pool_stats()["contexts_idle"] == 0 and pool_stats()["idle_device_bytes"] == 0
+
+
 def test_maps_objects_are_independent_and_keep_a_resident_database(case_cache):
     """Two MAPs objects (own contexts) interleaved, from two threads; set_database / read-only arrays skip the
     re-upload (main.py:237-240 evaluates the same database again and again)."""
@@ -324,8 +378,9 @@ def test_step_graph_replays_equal_eager_steps(case_cache):
 
 def test_map_in_two_halves_equals_map(case_cache):
     """hg_map_begin / hg_map_end: the same AP and hit counts as hg_map, bit for bit -- the first begin runs the call itself, the
-    following ones enqueue blind with two steps in flight; a third begin is refused; new queries make the next begin synchronous
-    again; a blind step that loses its bet (slices squeezed by an option between the halves' warm-up and the step) is redone."""
+    following ones enqueue blind with two steps in flight; a third begin is refused; a new query table of the same size keeps
+    the licence to enqueue blind (batch after batch), one of another size makes the next begin synchronous again.  (A blind
+    step that loses its bet: test_a_blind_step_that_loses_is_redone_on_its_own_tables.)"""
     c = case_cache("c2_q64")
     g = cases.load_golden("c2_q64")
     ctx = _native.Context(0)
@@ -349,15 +404,33 @@ def test_map_in_two_halves_equals_map(case_cache):
             ctx.map_end()
         if ctx.get_stat("last_optimistic"):
             assert ctx.get_stat("map_async_steps") >= 6 and ctx.get_stat("map_async_redone") == 0
-        # other queries: the next begin runs synchronously (nothing is known about their bet), the ones after it blind
+        # other queries, as many as before: the next begin is blind too (a caller that hands over batch after batch keeps two
+        # steps in flight) -- and the batch may be replaced while the step on the previous one is still in flight
+        warm = bool(ctx.get_stat("last_optimistic"))
         ctx.set_queries(metric.pack_codes(c["qbits"][::-1].copy()), metric.pack_labels(c["qlab"][::-1].copy()))
         n0 = ctx.get_stat("map_async_steps")
         ctx.map_begin(R)
-        assert ctx.get_stat("map_async_steps") == n0
+        assert ctx.get_stat("map_async_steps") == n0 + (1 if warm else 0)
+        ctx.set_queries(metric.pack_codes(c["qbits"]), metric.pack_labels(c["qlab"]))
         ctx.map_begin(R)
-        for _ in range(2):
-            ap, rel = ctx.map_end()
-            assert np.array_equal(ap, g["ap"][::-1], equal_nan=True)
+        ap, rel = ctx.map_end()
+        assert np.array_equal(ap, g["ap"][::-1], equal_nan=True)
+        ctx.set_queries(metric.pack_codes(c["qbits"][::-1].copy()), metric.pack_labels(c["qlab"][::-1].copy()))
+        ctx.map_begin(R)
+        ap, rel = ctx.map_end()
+        assert np.array_equal(ap, g["ap"], equal_nan=True) and np.array_equal(rel, rel0)
+        ap, rel = ctx.map_end()
+        assert np.array_equal(ap, g["ap"][::-1], equal_nan=True)
+        assert ctx.get_stat("map_async_redone") == 0
+        # a table of another size: nothing is known about buffers of that size -- the next begin runs the call itself
+        ctx.set_queries(metric.pack_codes(c["qbits"][:50].copy()), metric.pack_labels(c["qlab"][:50].copy()))
+        n0 = ctx.get_stat("map_async_steps")
+        ctx.map_begin(R)
+        assert ctx.get_stat("map_async_steps") == n0
+        ap, rel = ctx.map_end()
+        assert np.array_equal(ap, g["ap"][:50], equal_nan=True)
+        ctx.set_queries(metric.pack_codes(c["qbits"][::-1].copy()), metric.pack_labels(c["qlab"][::-1].copy()))
+        ap, rel = ctx.map(R)
         # a step in flight while the queries are replaced by fewer: its results are its own (and of its own length)
         ctx.map_begin(R)
         ctx.set_queries(metric.pack_codes(c["qbits"][:40].copy()), metric.pack_labels(c["qlab"][:40].copy()))
@@ -374,6 +447,98 @@ def test_map_in_two_halves_equals_map(case_cache):
         assert np.array_equal(a, ap_half, equal_nan=True) and np.array_equal(r, rel_half)
         a, r = ctx.map_end()
         assert np.array_equal(a, g["ap"][::-1], equal_nan=True)
+    finally:
+        ctx.close()
+
+
+def test_a_blind_step_that_loses_is_redone_on_its_own_tables(case_cache):
+    """The branch of hg_map_end that identical inputs never reach: a step enqueued blind (hg_map_begin after a won hg_map) LOSES its
+    bet -- forced by the test hook "handicap_next_bet", which puts the next guess far below the expected count without touching the
+    configuration -- and hg_map_end runs it again on the same tables: stat map_async_redone == 1, results == the reference's golden.
+    If the queries (same count!) or the database were replaced in between, the lost step's tables are gone: HG_ERR_STATE, never the
+    new batch's results under the old step's name (include/hashgan_amd.h, hg_map_begin)."""
+    c = case_cache("c2_q64")
+    g = cases.load_golden("c2_q64")
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, c)
+        R = c["R"]
+        ap0, rel0 = ctx.map(R)
+        assert np.array_equal(ap0, g["ap"], equal_nan=True)
+        if not ctx.get_stat("last_optimistic"):
+            pytest.skip("the bet does not apply to this shape")
+        # 1. lost, tables untouched: redone
+        ctx.set_option("handicap_next_bet", 12)
+        n0 = ctx.get_stat("map_async_steps")
+        ctx.map_begin(R)
+        assert ctx.get_stat("map_async_steps") == n0 + 1, "the hook must not end the licence to enqueue blind"
+        ap, rel = ctx.map_end()
+        assert ctx.get_stat("map_async_redone") == 1
+        assert np.array_equal(ap, g["ap"], equal_nan=True) and np.array_equal(rel, rel0)
+        # (the redo was a synchronous hg_map that won: the next begin is blind again, and wins)
+        ctx.map_begin(R)
+        assert ctx.get_stat("map_async_steps") == n0 + 2
+        ap, rel = ctx.map_end()
+        assert ctx.get_stat("map_async_redone") == 1 and np.array_equal(ap, g["ap"], equal_nan=True)
+        # 2. lost, and the queries replaced by ANOTHER table of the same count before the second half
+        ctx.set_option("handicap_next_bet", 12)
+        ctx.map_begin(R)
+        ctx.set_queries(metric.pack_codes(c["qbits"][::-1].copy()), metric.pack_labels(c["qlab"][::-1].copy()))
+        with pytest.raises(_native.HashganNativeError) as ei:
+            ctx.map_end()
+        assert ei.value.code == _native.HG_ERR_STATE and "queries were replaced" in str(ei.value)
+        assert ctx.get_stat("map_async_redone") == 1
+        ap, rel = ctx.map(R)                               # the context is fine: the tables it holds now
+        assert np.array_equal(ap, g["ap"][::-1], equal_nan=True)
+        # 3. lost, and the database reloaded
+        ctx.set_option("handicap_next_bet", 12)
+        ctx.map_begin(R)
+        _load(ctx, c)
+        with pytest.raises(_native.HashganNativeError) as ei:
+            ctx.map_end()
+        assert ei.value.code == _native.HG_ERR_STATE and "database was replaced" in str(ei.value)
+        ap, rel = ctx.map(R)
+        assert np.array_equal(ap, g["ap"], equal_nan=True)
+        # 4. a lost step with a younger one behind it: the redo answers the old step, the younger keeps its own block
+        ctx.set_option("handicap_next_bet", 12)
+        ctx.map_begin(R)
+        ctx.map_begin(R)
+        a1, r1 = ctx.map_end()
+        a2, r2 = ctx.map_end()
+        assert np.array_equal(a1, g["ap"], equal_nan=True) and np.array_equal(a2, g["ap"], equal_nan=True) and np.array_equal(r2, rel0)
+        assert ctx.get_stat("map_async_redone") == 2
+    finally:
+        ctx.close()
+
+
+def test_batch_after_batch_keeps_two_steps_in_flight(case_cache):
+    """What a caller with a fresh query batch per step does (lib/metric.py once per batch): hg_set_queries -- which no longer waits
+    for the stream -- then hg_map_begin, the previous batch's hg_map_end afterwards.  Every step after the first is enqueued blind
+    and every batch's APs equal the golden's rows of that batch."""
+    c = case_cache("c2_q64")
+    g = cases.load_golden("c2_q64")
+    Q = c["qbits"].shape[0]
+    rng = np.random.default_rng(11)
+    perms = [rng.permutation(Q) for _ in range(7)]
+    packed = [(metric.pack_codes(c["qbits"][p]), metric.pack_labels(c["qlab"][p])) for p in perms]
+    ctx = _native.Context(0)
+    try:
+        _load(ctx, c)
+        R = c["R"]
+        ctx.map(R)
+        if not ctx.get_stat("last_optimistic"):
+            pytest.skip("the bet does not apply to this shape")
+        n0 = ctx.get_stat("map_async_steps")
+        ctx.set_queries(*packed[0])
+        ctx.map_begin(R)
+        for i in range(1, len(perms)):
+            ctx.set_queries(*packed[i])                    # while step i - 1 is in flight
+            ctx.map_begin(R)
+            ap, rel = ctx.map_end()
+            assert np.array_equal(ap, g["ap"][perms[i - 1]], equal_nan=True), i
+        ap, rel = ctx.map_end()
+        assert np.array_equal(ap, g["ap"][perms[-1]], equal_nan=True)
+        assert ctx.get_stat("map_async_steps") == n0 + len(perms) and ctx.get_stat("map_async_redone") == 0
     finally:
         ctx.close()
 
