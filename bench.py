@@ -651,7 +651,20 @@ def query_split_leg(args, spec, rank, world, local_rank, dry_dir, comm, qw, ql):
         from tests import cases
         g = cases.load_golden(spec["golden"])
         k = g["ap"].shape[0]
-        return {"decomposition": "whole database (%d rows, %d MB packed) on each of %d GPUs; queries split %s; the only exchange "
+        # the curve's ORIGIN, measured in this very run: the same workload unsharded on one GPU (this rank's own -- every rank
+        # holds the whole database for this leg; all ranks run it at once, rank 0 reports its own)
+        ctx2.set_queries(qw, ql)
+        for _ in range(2):
+            a1, r1 = ctx2.map(R)
+        ctx2.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a1, r1 = ctx2.map(R)
+        ctx2.synchronize()
+        one_gpu = (time.perf_counter() - t0) / steps
+        comm.barrier()
+        return {"one_gpu_ms": one_gpu * 1e3, "one_gpu_parity": bool(np.array_equal(a1[:k], g["ap"], equal_nan=True)),
+                "decomposition": "whole database (%d rows, %d MB packed) on each of %d GPUs; queries split %s; the only exchange "
                                  "is the all-gather of 16 bytes per query" % (N, N * 16 // 1000000, world,
                                                                             [n for _, n in sharded.shard_bounds(spec["Q"], world)]),
                 "steps": steps, "ms_per_step": dt * 1e3, "value": spec["Q"] / dt, "unit": "queries/s", "map": float(m),
@@ -950,6 +963,19 @@ def main():
         out["exchange"] = exchange
     if qsplit is not None:
         out["query_split"] = qsplit
+        if "one_gpu_ms" in qsplit:
+            # one record that explains itself: the SAME workload (C4 unless --workload says otherwise) on one GPU of this run, on the
+            # database-sharded form (`value`) and on the query-split form -- nobody has to join a --gpus 1 line of another workload
+            one = qsplit.pop("one_gpu_ms")
+            sh_ms, qs_ms = per_step * 1e3, qsplit["ms_per_step"]
+            out["strong_scaling"] = {
+                "workload": out["config"]["workload"], "n_gpus": world,
+                "one_gpu_ms": round(one, 5), "one_gpu_parity_vs_reference_golden": qsplit.pop("one_gpu_parity"),
+                "database_sharded": {"ms_per_step": round(sh_ms, 5), "speedup": round(one / sh_ms, 4), "efficiency": round(one / sh_ms / world, 4)},
+                "query_split": {"ms_per_step": round(qs_ms, 5), "speedup": round(one / qs_ms, 4), "efficiency": round(one / qs_ms / world, 4)},
+                "recommended": "query_split for databases that fit one GPU (16 bytes per row: 160 MB at N = 10M) -- no data-path collective, modelled "
+                               "~7.5x at 8 GPUs; database_sharded (the north star's form, `value`) when the database does not fit or must stay partitioned -- "
+                               "modelled ~5x at 8 GPUs before the wire (DESIGN.md section 6)"}
     if sharded_leg:
         out["value_definition"] = "Q queries ranked against the WHOLE %d-row database per step / step time (max over ranks)" % N
         out["weak_scaling_equivalent"] = {"definition": "query x per-GPU-shard evaluations per second = value * n_gpus",

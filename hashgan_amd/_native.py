@@ -91,6 +91,7 @@ _SIGNATURES = {
     "hg_get_census": [_p, C.c_int, C.POINTER(_i64)],
     "hg_shard_step": [_p, _i64, C.c_int, _p, _p, C.POINTER(C.c_int)],
     "hg_trim": [_p],
+    "hg_release_cache": [],
     "hg_timing_enable": [_p, C.c_int],
     "hg_timing_reset": [_p],
     "hg_timing_read": [_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_int)],
@@ -508,6 +509,11 @@ def host_phase_timers(ctx):
     for ph in ("init", "devmalloc", "devfree", "hostmalloc", "hostfree", "destroy", "stream", "event"):
         out[ph] = (ctx.get_stat("host_us_" + ph) / 1e3, ctx.get_stat("host_n_" + ph), ctx.get_stat("host_max_us_" + ph) / 1e3)
     return out
+
+
+def release_cache():
+    """Return the process-wide cache of device / pinned blocks and streams to the HIP runtime (hg_release_cache)."""
+    check(load().hg_release_cache())
 
 
 def comm_unique_id():

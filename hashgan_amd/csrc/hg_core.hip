@@ -4,6 +4,8 @@
 #include "hg_host_pack.hpp"
 
 #include <exception>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 
@@ -68,6 +70,112 @@ std::atomic<unsigned long long> g_alloc_epoch{1};
 const char* const kHostPhaseNames[HP_COUNT] = {"init", "devmalloc", "devfree", "hostmalloc", "hostfree", "destroy", "stream", "event"};
 std::atomic<long long> g_host_ns[HP_COUNT], g_host_calls[HP_COUNT], g_host_max_ns[HP_COUNT];
 
+// ---- the process-wide cache of device blocks, pinned blocks and streams (hg_ctx.hpp) ----------------------------------
+namespace {
+struct BlockCache {
+    std::mutex m;
+    std::multimap<std::pair<int, size_t>, void*> blocks;   // (device, bytes) -> block; pinned blocks: device -1
+    size_t dev_bytes = 0, pin_bytes = 0;
+    std::multimap<int, hipStream_t> streams;
+    long long hits = 0, misses = 0;
+    static size_t limit(const char* env, size_t dflt_mb) {
+        const char* v = getenv(env);
+        return (size_t)(v ? atoll(v) : (long long)dflt_mb) << 20;
+    }
+    void* take(int device, size_t want, size_t* got) {
+        std::lock_guard<std::mutex> lk(m);
+        auto it = blocks.lower_bound({device, want});
+        if (it == blocks.end() || it->first.first != device || it->first.second > 2 * want + ((size_t)1 << 20)) { ++misses; return nullptr; }
+        void* p = it->second;
+        *got = it->first.second;
+        (device < 0 ? pin_bytes : dev_bytes) -= *got;
+        blocks.erase(it);
+        ++hits;
+        return p;
+    }
+    static void free_block(int device, void* p) {
+        if (device < 0) { HostTimer t_(HP_HOSTFREE); (void)hipHostFree(p); }
+        else { HostTimer t_(HP_DEVFREE); (void)hipFree(p); }
+    }
+    void give(int device, void* p, size_t bytes) {
+        static const size_t dev_limit = limit("HG_CACHE_MB", 8192), pin_limit = limit("HG_PIN_CACHE_MB", 512);
+        const size_t lim = device < 0 ? pin_limit : dev_limit;
+        // (hipFree waits for the device; a cached block must be just as free of readers and writers before anybody else takes it)
+        (void)hipDeviceSynchronize();
+        if (bytes > lim) { free_block(device, p); return; }
+        std::vector<std::pair<int, void*>> evict;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            blocks.insert({{device, bytes}, p});
+            size_t& total = device < 0 ? pin_bytes : dev_bytes;
+            total += bytes;
+            while (total > lim) {                              // the largest block of this kind goes first
+                auto hi = blocks.upper_bound({device, ~(size_t)0});
+                if (hi == blocks.begin()) break;
+                --hi;
+                if ((hi->first.first < 0) != (device < 0)) break;
+                total -= hi->first.second;
+                evict.push_back({hi->first.first, hi->second});
+                blocks.erase(hi);
+            }
+        }
+        for (auto& e : evict) free_block(e.first, e.second);
+    }
+    void release_all() {
+        std::vector<std::pair<int, void*>> all;
+        std::vector<std::pair<int, hipStream_t>> st;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (auto& b : blocks) all.push_back({b.first.first, b.second});
+            blocks.clear();
+            dev_bytes = pin_bytes = 0;
+            for (auto& x : streams) st.push_back({x.first, x.second});
+            streams.clear();
+        }
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (auto& b : all) { if (b.first >= 0) (void)hipSetDevice(b.first); free_block(b.first, b.second); }
+        for (auto& x : st) { (void)hipSetDevice(x.first); (void)hipStreamDestroy(x.second); }
+        (void)hipSetDevice(cur);
+    }
+};
+BlockCache& cache() { static BlockCache* c = new BlockCache(); return *c; }      // (never destroyed: contexts may outlive static destructors)
+}  // namespace
+
+void* cache_take_dev(int device, size_t want, size_t* got) { return cache().take(device, want, got); }
+void cache_give_dev(int device, void* p, size_t bytes) { cache().give(device, p, bytes); }
+void* cache_take_pin(size_t want, size_t* got) { return cache().take(-1, want, got); }
+void cache_give_pin(void* p, size_t bytes) { cache().give(-1, p, bytes); }
+hipStream_t cache_take_stream(int device) {
+    BlockCache& c = cache();
+    std::lock_guard<std::mutex> lk(c.m);
+    auto it = c.streams.find(device);
+    if (it == c.streams.end()) return nullptr;
+    hipStream_t s = it->second;
+    c.streams.erase(it);
+    return s;
+}
+void cache_give_stream(int device, hipStream_t s) {
+    BlockCache& c = cache();
+    {
+        std::lock_guard<std::mutex> lk(c.m);
+        if (c.streams.count(device) < 8) { c.streams.insert({device, s}); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+void cache_release_all() { cache().release_all(); }
+static long long cache_stat(int which) {
+    BlockCache& c = cache();
+    std::lock_guard<std::mutex> lk(c.m);
+    return which == 0 ? (long long)c.dev_bytes : which == 1 ? (long long)c.pin_bytes : which == 2 ? c.hits : which == 3 ? c.misses : (long long)c.streams.size();
+}
+static int stream_create(int device, hipStream_t* out) {
+    *out = cache_take_stream(device);
+    if (*out) return HG_OK;
+    HG_HIP(host_timed(HP_STREAM, [&] { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }));
+    return HG_OK;
+}
+
 int need(hg_ctx* c, unsigned st, const char* who, const char* what) {
     if (!c) return fail(HG_ERR_ARG, "%s: null context", who);
     if ((c->stage & st) != st) return fail(HG_ERR_STATE, "%s called before %s", who, what);
@@ -121,10 +229,9 @@ int ensure_out_block(hg_ctx* c) {
 
 int ensure_pin(hg_ctx* c, size_t need_b) {
     if (c->pin_cap >= need_b) return HG_OK;
-    if (c->pin) (void)host_timed(HP_HOSTFREE, [&] { return hipHostFree(c->pin); });
+    pin_free(c->pin, c->pin_cap);
     c->pin = nullptr; c->pin_cap = 0;
-    HG_HIP(host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(&c->pin, need_b, hipHostMallocDefault); }));
-    c->pin_cap = need_b;
+    HG_HIP(pin_alloc(&c->pin, need_b, &c->pin_cap));
     ++g_alloc_epoch;                                   // captured downloads point into the old block
     return HG_OK;
 }
@@ -157,8 +264,8 @@ int hg_init(int device, hg_ctx** out) {
     c->device = device;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cu = cus;
-    hipError_t e = host_timed(HP_STREAM, [&] { return hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); });
-    if (e != hipSuccess) { delete c; return fail(HG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    const int rc_s = stream_create(device, &c->stream);
+    if (rc_s != HG_OK) { delete c; return rc_s; }
     *out = c;
     return HG_OK;
 }
@@ -183,18 +290,15 @@ int hg_destroy(hg_ctx* c) {
     c->obuf[0].release(); c->obuf[1].release();
     comm_release(c);
     if (c->sub) { hg_ctx* s = c->sub; c->sub = nullptr; (void)hg_destroy(s); }
-    {
-        HostTimer t_hf(HP_HOSTFREE);
-        if (c->pin) (void)hipHostFree(c->pin);
-        for (auto& m : c->mslot) { if (m.pin) (void)hipHostFree(m.pin); if (m.ev) (void)hipEventDestroy(m.ev); m.pin = nullptr; m.ev = nullptr; }
-        if (c->hpk) (void)hipHostFree(c->hpk);
-        if (c->fstage) (void)hipHostFree(c->fstage);
-        for (auto& q : c->qstage) { if (q.pin) (void)hipHostFree(q.pin); if (q.ev) (void)hipEventDestroy(q.ev); q.pin = nullptr; q.ev = nullptr; }
-    }
+    pin_free(c->pin, c->pin_cap);
+    for (auto& m : c->mslot) { pin_free(m.pin, m.cap); if (m.ev) (void)hipEventDestroy(m.ev); m.pin = nullptr; m.ev = nullptr; }
+    pin_free(c->hpk, c->hpk_cap);
+    pin_free(c->fstage, c->fstage_cap);
+    for (auto& q : c->qstage) { pin_free(q.pin, q.cap); if (q.ev) (void)hipEventDestroy(q.ev); q.pin = nullptr; q.ev = nullptr; }
     if (c->stream2_ev) (void)hipEventDestroy(c->stream2_ev);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); cache_give_stream(c->device, c->stream2); }
     for (auto& e : c->fstage_ev) if (e) (void)hipEventDestroy(e);
-    if (c->stream && c->own_stream && !c->is_sub) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->own_stream && !c->is_sub) cache_give_stream(c->device, c->stream);   // (synchronised above)
     delete c;
     return HG_OK;
 }
@@ -293,7 +397,7 @@ static int stage_floats(hg_ctx* c, const float* x, i64 n, int b, int bpad, DevBu
     constexpr int NSL = 4;
     const size_t CH = (size_t)16 << 20;
     if (!c->fstage) {
-        HG_HIP(host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(&c->fstage, CH * NSL, hipHostMallocDefault); }));
+        HG_HIP(pin_alloc(&c->fstage, CH * NSL, &c->fstage_cap));
         for (int k = 0; k < NSL; ++k) HG_HIP(hipEventCreateWithFlags(&c->fstage_ev[k], hipEventDisableTiming));
     }
     const i64 rows_per = (i64)(CH / ((size_t)bpad * 4));
@@ -322,10 +426,9 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
     const size_t need_b = ((cb + 63) & ~(size_t)63) + lbytes;
     if (c->hpk_cap < need_b) {
         HG_TRY(c->sync());
-        if (c->hpk) (void)host_timed(HP_HOSTFREE, [&] { return hipHostFree(c->hpk); });
+        pin_free(c->hpk, c->hpk_cap);
         c->hpk = nullptr; c->hpk_cap = 0;
-        HG_HIP(host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(&c->hpk, need_b, hipHostMallocDefault); }));
-        c->hpk_cap = need_b;
+        HG_HIP(pin_alloc(&c->hpk, need_b, &c->hpk_cap));
     }
     u32* hc = (u32*)c->hpk;
     u64* hl = (u64*)((char*)c->hpk + ((cb + 63) & ~(size_t)63));
@@ -363,7 +466,7 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
     std::string stage_msg;                               // (the error text is thread-local: carried over by hand)
     std::thread stager;
     if (early) {
-        if (!c->stream2) HG_HIP(host_timed(HP_STREAM, [&] { return hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking); }));
+        if (!c->stream2) HG_TRY(stream_create(c->device, &c->stream2));
         if (!c->stream2_ev) HG_HIP(hipEventCreateWithFlags(&c->stream2_ev, hipEventDisableTiming));
         HG_TRY(feats.reserve(fb_f + 256));
         try {
@@ -511,11 +614,9 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     c->qstage_next ^= 1;
     if (qs.used) HG_HIP(hipEventSynchronize(qs.ev));   // (the copy out of this block two loads ago)
     if (qs.cap < cb + lb) {
-        if (qs.pin) (void)host_timed(HP_HOSTFREE, [&] { return hipHostFree(qs.pin); });
+        pin_free(qs.pin, qs.cap);
         qs.pin = nullptr; qs.cap = 0;
-        const size_t want = cb + lb < 4096 ? 4096 : cb + lb;
-        HG_HIP(host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(&qs.pin, want, hipHostMallocDefault); }));
-        qs.cap = want;
+        HG_HIP(pin_alloc(&qs.pin, cb + lb, &qs.cap));
     }
     if (!qs.ev) HG_HIP(hipEventCreateWithFlags(&qs.ev, hipEventDisableTiming));
     memcpy(qs.pin, codes, cb);
@@ -760,12 +861,12 @@ int hg_set_stream(hg_ctx* c, void* stream) {
     HG_TRY(c->sync());                               // drain the old stream first
     c->drop_graph();
     c->cfg_epoch++;
-    if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->own_stream) cache_give_stream(c->device, c->stream);
     if (stream) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
     } else {
-        HG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HG_TRY(stream_create(c->device, &c->stream));
         c->own_stream = true;
     }
     if (c->sub) c->sub->stream = c->stream;
@@ -903,6 +1004,11 @@ int hg_trim(hg_ctx* c) {
     return HG_OK;
 }
 
+int hg_release_cache(void) {
+    cache_release_all();
+    return HG_OK;
+}
+
 int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     if (!c || !key || !value) return fail(HG_ERR_ARG, "hg_get_stat: null argument");
     if (!strcmp(key, "optimistic_runs")) *value = c->opt_runs;
@@ -941,6 +1047,11 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
     else if (!strcmp(key, "dbg_hwq_ptr")) *value = (int64_t)(uintptr_t)c->hwq.p;
 #endif
 #endif
+    else if (!strcmp(key, "cache_device_bytes")) *value = cache_stat(0);      // the process-wide block cache (hg_ctx.hpp)
+    else if (!strcmp(key, "cache_pinned_bytes")) *value = cache_stat(1);
+    else if (!strcmp(key, "cache_hits")) *value = cache_stat(2);
+    else if (!strcmp(key, "cache_misses")) *value = cache_stat(3);
+    else if (!strcmp(key, "cache_streams")) *value = cache_stat(4);
     else if (!strncmp(key, "host_", 5)) {              // process-wide host-side phase timers (hg_ctx.hpp, HostPhase)
         const char* rest = key + 5;
         int kind = -1;                                 // 0 total us, 1 calls, 2 longest call us

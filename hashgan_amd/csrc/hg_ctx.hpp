@@ -119,14 +119,50 @@ inline void fence_free(Fence& f) {
     f = Fence{};
 }
 
+// Process-wide cache of what a context allocates and a destroyed (or trimmed) context gives back: device blocks, pinned host
+// blocks, streams.  hipMalloc on this stack takes 0.03 - 0.4 ms -- and now and then SECONDS (3.5 s measured for one call among
+// a few hundred: tools/new_context_probe.py, profiles/r06_new_context_probe.txt), hipStreamCreate 1.5 - 18 ms, a 64 MB
+// hipHostMalloc 9 ms, hg_destroy's frees 3.7 ms: a caller that builds a context per evaluation paid all of that per call.  A
+// block goes back to the cache instead of the runtime and the next request of a similar size takes it (best fit, at most twice
+// the size asked for); the cache holds at most HG_CACHE_MB (default 8192) of device and HG_PIN_CACHE_MB (default 512) of pinned
+// memory -- the largest blocks go first when it is full -- and hg_release_cache() empties it.  HG_EFENCE builds bypass it.
+void* cache_take_dev(int device, size_t want, size_t* got);           // nullptr: nothing suitable cached
+void cache_give_dev(int device, void* p, size_t bytes);              // (frees it if the cache is full)
+void* cache_take_pin(size_t want, size_t* got);
+void cache_give_pin(void* p, size_t bytes);
+hipStream_t cache_take_stream(int device);                           // nullptr: none cached
+void cache_give_stream(int device, hipStream_t s);
+void cache_release_all();
+inline size_t cache_round(size_t bytes) {                            // sizes a later request can match: 4 KB up to 1 MB, then 1 MB
+    const size_t g = bytes < ((size_t)1 << 20) ? 4096 : (size_t)1 << 20;
+    return (bytes + g - 1) / g * g;
+}
+// pinned host block through the cache (*cap = what the block really holds)
+inline hipError_t pin_alloc(void** p, size_t want, size_t* cap) {
+    *p = cache_take_pin(want, cap);
+    if (*p) return hipSuccess;
+    const size_t sz = cache_round(want);
+    const hipError_t e = host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(p, sz, hipHostMallocDefault); });
+    if (e == hipSuccess) *cap = sz;
+    return e;
+}
+inline void pin_free(void* p, size_t cap) { if (p) cache_give_pin(p, cap); }
+
 // A device buffer that only ever grows.
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    size_t blk = 0;             // bytes of the allocation behind p (0: borrowed, or a fenced one)
+    int dev = 0;
     bool borrowed = false;      // points into another context's allocation
     Fence fence;                // HG_EFENCE: the buffer's own virtual range
     void drop() {
-        if (p && !borrowed) { HostTimer t_(HP_DEVFREE); if (fence.va) fence_free(fence); else (void)hipFree(p); }
+        if (p && !borrowed) {
+            if (fence.va) { HostTimer t_(HP_DEVFREE); fence_free(fence); }
+            else if (blk) cache_give_dev(dev, p, blk);
+            else { HostTimer t_(HP_DEVFREE); (void)hipFree(p); }
+        }
+        blk = 0;
     }
     int reserve(size_t bytes) {
         if (bytes <= cap) return HG_OK;
@@ -142,7 +178,13 @@ struct DevBuf {
             HG_HIP(hipMemset(p, 0xCB, bytes + 64));
             HG_HIP(hipDeviceSynchronize());
         } else {
-            HG_HIP(host_timed(HP_DEVMALLOC, [&] { return hipMalloc(&p, bytes + 64); }));
+            HG_HIP(hipGetDevice(&dev));
+            p = cache_take_dev(dev, bytes + 64, &blk);
+            if (!p) {
+                const size_t sz = cache_round(bytes + 64);
+                HG_HIP(host_timed(HP_DEVMALLOC, [&] { return hipMalloc(&p, sz); }));
+                blk = sz;
+            }
         }
         cap = bytes;
         ++g_alloc_epoch;
@@ -324,6 +366,7 @@ struct hg_ctx {
     i64 opt_keep_floats = 2;   // "keep_floats": database float table on the GPU -- 0 never, 1 always, 2 only if it is not a +-1 code
     hipStream_t stream2 = nullptr;   // the float table's uploads while the packing pool works (pack_on_host)
     hipEvent_t stream2_ev = nullptr;
+    size_t fstage_cap = 0;
     void* fstage = nullptr;    // 4 x 16 MB of pinned staging for float tables on their way to the GPU (pack_on_host)
     hipEvent_t fstage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void* hpk = nullptr;       // pinned staging for the packed tables

@@ -1590,10 +1590,9 @@ int hg_map_begin(hg_ctx* c, int64_t R) {
     if (blind) {
         const size_t need_b = (size_t)c->Q * 12 + 16;
         if (m.cap < need_b) {
-            if (m.pin) (void)host_timed(HP_HOSTFREE, [&] { return hipHostFree(m.pin); });
+            pin_free(m.pin, m.cap);
             m.pin = nullptr; m.cap = 0;
-            HG_HIP(host_timed(HP_HOSTMALLOC, [&] { return hipHostMalloc(&m.pin, need_b, hipHostMallocDefault); }));
-            m.cap = need_b;
+            HG_HIP(pin_alloc(&m.pin, need_b, &m.cap));
         }
         if (!m.ev) HG_HIP(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
         c->opt_runs++;

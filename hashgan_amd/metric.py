@@ -204,9 +204,11 @@ class _Shared:
 
 
 def release_engines():
-    """Free the GPU contexts (and their device memory) behind MAP / calc_map / extra_metrics and the idle ones of MAPs' pool."""
+    """Free the GPU contexts (and their device memory) behind MAP / calc_map / extra_metrics and the idle ones of MAPs' pool,
+    and hand the library's cache of device and pinned blocks back to the HIP runtime."""
     _Shared.close_all()
     _Pool.close_all()
+    _native.release_cache()
 
 
 def _check_shapes(q_codes, db_codes, q_labels, db_labels, R):

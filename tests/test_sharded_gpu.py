@@ -279,6 +279,13 @@ def test_bench_multi_rank_control_flow(world, workload, tmp_path):
     assert abs(d["value"] - 2100 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # raw queries per second
     assert d["optimistic_runs"] == (3 if world == 2 else 0) and d["optimistic_fallbacks"] == 0
     assert "dry_run_not_a_measurement" in d and "cpu_baseline" not in d
+    # the line explains its own scaling: the same workload on one GPU of this run, and both decompositions against it
+    ss = d["strong_scaling"]
+    assert ss["n_gpus"] == world and ss["one_gpu_parity_vs_reference_golden"] is True and ss["one_gpu_ms"] > 0
+    for form in ("database_sharded", "query_split"):
+        assert abs(ss[form]["speedup"] - ss["one_gpu_ms"] / ss[form]["ms_per_step"]) < 1e-3 * ss[form]["speedup"] + 1e-3
+        assert abs(ss[form]["efficiency"] * world - ss[form]["speedup"]) < 1e-3 * ss[form]["speedup"] + 1e-3
+    assert d["query_split"]["parity_vs_reference_golden"] is True
 
 
 @pytest.mark.parametrize("G", [1, 3])
