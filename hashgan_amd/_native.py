@@ -92,6 +92,7 @@ _SIGNATURES = {
     "hg_shard_step": [_p, _i64, C.c_int, _p, _p, C.POINTER(C.c_int)],
     "hg_trim": [_p],
     "hg_release_cache": [],
+    "hg_preload": [_p],
     "hg_timing_enable": [_p, C.c_int],
     "hg_timing_reset": [_p],
     "hg_timing_read": [_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_int)],
@@ -468,6 +469,10 @@ class Context:
     def set_option(self, key, value):
         check(self._lib.hg_set_option(self._h, key.encode(), int(value)))
         self.options_touched.add(key)
+
+    def preload(self):
+        """One-time costs of every path now instead of on first use (hg_preload)."""
+        check(self._lib.hg_preload(self._h))
 
     def trim(self):
         """Free the work buffers (they only grow); the loaded tables stay."""

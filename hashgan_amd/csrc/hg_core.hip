@@ -84,8 +84,14 @@ struct BlockCache {
     }
     void* take(int device, size_t want, size_t* got) {
         std::lock_guard<std::mutex> lk(m);
+        static const bool trace = getenv("HG_CACHE_TRACE") != nullptr;
         auto it = blocks.lower_bound({device, want});
-        if (it == blocks.end() || it->first.first != device || it->first.second > 2 * want + ((size_t)1 << 20)) { ++misses; return nullptr; }
+        if (it == blocks.end() || it->first.first != device || it->first.second > 2 * want + ((size_t)1 << 20)) {
+            ++misses;
+            if (trace) fprintf(stderr, "[hg cache] miss: %s block of %zu bytes (cached: %zu device, %zu pinned bytes in %zu blocks)\n",
+                               device < 0 ? "pinned" : "device", want, dev_bytes, pin_bytes, blocks.size());
+            return nullptr;
+        }
         void* p = it->second;
         *got = it->first.second;
         (device < 0 ? pin_bytes : dev_bytes) -= *got;
@@ -98,7 +104,7 @@ struct BlockCache {
         else { HostTimer t_(HP_DEVFREE); (void)hipFree(p); }
     }
     void give(int device, void* p, size_t bytes) {
-        static const size_t dev_limit = limit("HG_CACHE_MB", 8192), pin_limit = limit("HG_PIN_CACHE_MB", 512);
+        static const size_t dev_limit = limit("HG_CACHE_MB", 49152), pin_limit = limit("HG_PIN_CACHE_MB", 512);
         const size_t lim = device < 0 ? pin_limit : dev_limit;
         // (hipFree waits for the device; a cached block must be just as free of readers and writers before anybody else takes it)
         (void)hipDeviceSynchronize();
@@ -393,13 +399,24 @@ static int pack_on_device(hg_ctx* c, const float* x, const int64_t* lab, i64 n, 
 // A big float table (256 MB at 1M x 64) on its way to the GPU: the runtime stages a pageable source at ~25 GB/s.  Host
 // threads copy 16 MB chunks (rows padded on the way) into four pinned buffers instead, each chunk's DMA runs while the next
 // is copied.  Enqueues on `stream`; which_pool: the host pool that copies (1 while pool 0 packs).
-static int stage_floats(hg_ctx* c, const float* x, i64 n, int b, int bpad, DevBuf& feats, hipStream_t stream, int which_pool) {
+static int ensure_fstage(hg_ctx* c) {
     constexpr int NSL = 4;
     const size_t CH = (size_t)16 << 20;
     if (!c->fstage) {
         HG_HIP(pin_alloc(&c->fstage, CH * NSL, &c->fstage_cap));
         for (int k = 0; k < NSL; ++k) HG_HIP(hipEventCreateWithFlags(&c->fstage_ev[k], hipEventDisableTiming));
     }
+    return HG_OK;
+}
+static int ensure_stream2(hg_ctx* c) {
+    if (!c->stream2) HG_TRY(stream_create(c->device, &c->stream2));
+    if (!c->stream2_ev) HG_HIP(hipEventCreateWithFlags(&c->stream2_ev, hipEventDisableTiming));
+    return HG_OK;
+}
+static int stage_floats(hg_ctx* c, const float* x, i64 n, int b, int bpad, DevBuf& feats, hipStream_t stream, int which_pool) {
+    constexpr int NSL = 4;
+    const size_t CH = (size_t)16 << 20;
+    HG_TRY(ensure_fstage(c));
     const i64 rows_per = (i64)(CH / ((size_t)bpad * 4));
     int slot = 0;
     bool used[NSL] = {false, false, false, false};
@@ -466,8 +483,7 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
     std::string stage_msg;                               // (the error text is thread-local: carried over by hand)
     std::thread stager;
     if (early) {
-        if (!c->stream2) HG_TRY(stream_create(c->device, &c->stream2));
-        if (!c->stream2_ev) HG_HIP(hipEventCreateWithFlags(&c->stream2_ev, hipEventDisableTiming));
+        HG_TRY(ensure_stream2(c));
         HG_TRY(feats.reserve(fb_f + 256));
         try {
             stager = std::thread([&] {
@@ -1001,6 +1017,19 @@ int hg_trim(hg_ctx* c) {
     c->stage &= (ST_DB | ST_Q);
     c->lists_valid = false;
     c->real_lists = false;
+    return HG_OK;
+}
+
+int hg_preload(hg_ctx* c) {
+    if (!c) return fail(HG_ERR_ARG, "hg_preload: null context");
+    HG_TRY(c->use());
+    HG_TRY(ensure_stream2(c));
+    HG_TRY(ensure_fstage(c));
+    HG_TRY(ensure_pin(c, (size_t)1 << 20));
+    hipFuncAttributes a;
+    HG_HIP(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ap)));
+    HG_TRY(preload_seq()); HG_TRY(preload_valu()); HG_TRY(preload_mx()); HG_TRY(preload_mx1()); HG_TRY(preload_real());
+    host_pack_warm();
     return HG_OK;
 }
 

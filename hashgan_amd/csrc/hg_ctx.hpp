@@ -124,7 +124,7 @@ inline void fence_free(Fence& f) {
 // a few hundred: tools/new_context_probe.py, profiles/r06_new_context_probe.txt), hipStreamCreate 1.5 - 18 ms, a 64 MB
 // hipHostMalloc 9 ms, hg_destroy's frees 3.7 ms: a caller that builds a context per evaluation paid all of that per call.  A
 // block goes back to the cache instead of the runtime and the next request of a similar size takes it (best fit, at most twice
-// the size asked for); the cache holds at most HG_CACHE_MB (default 8192) of device and HG_PIN_CACHE_MB (default 512) of pinned
+// the size asked for); the cache holds at most HG_CACHE_MB (default 49152 -- a class-sorted C2 database's widened record slices alone are 14.9 GB) of device and HG_PIN_CACHE_MB (default 512) of pinned
 // memory -- the largest blocks go first when it is full -- and hg_release_cache() empties it.  HG_EFENCE builds bypass it.
 void* cache_take_dev(int device, size_t want, size_t* got);           // nullptr: nothing suitable cached
 void cache_give_dev(int device, void* p, size_t bytes);              // (frees it if the cache is full)
@@ -521,6 +521,7 @@ int launch_hist_mx(hg_ctx* c);                   // k_hist_i8 / k_hist_mx
 int launch_select_mx(hg_ctx* c, int lw);         // k_select_mx<NW, LW, QT, COMPACT>
 int launch_select_mx3(hg_ctx* c, int lw);        // k_select_mx3 (codes of <= 64 bits, one-byte records)
 int launch_select_mx4(hg_ctx* c, int lw);        // k_select_mx4 (codes of 65..128 bits, one-byte records)
+int preload_valu(); int preload_mx(); int preload_mx1(); int preload_real(); int preload_seq();   // one per translation unit with kernels (hg_preload)
 // hg_comm.hip
 void comm_release(hg_ctx* c);                    // destroys the context's communicator, if any
 

@@ -25,6 +25,7 @@ void host_pack_ship(const float* x, const int64_t* lab, long long n, int b, int 
 // rows [r0, r1) of x [n][b] copied to dst [r1 - r0][bpad] (pad columns zeroed) by the pool's threads: how the float table
 // reaches pinned staging memory at memory speed before it crosses PCIe (a pageable source is staged by the runtime at ~25 GB/s)
 void host_copy_rows(const float* x, long long r0, long long r1, int b, int bpad, float* dst, int threads, int which_pool = 0);
+void host_pack_warm();      // start the pools' threads now (hg_preload)
 
 }  // namespace hg
 
@@ -316,6 +317,16 @@ inline void host_copy_rows(const float* x, long long r0, long long r1, int b, in
     };
     if (threads == 1 || !hostpack::pool(which_pool).run(threads, work))  // (a busy pool: this thread alone)
         for (int t = 0; t < threads; ++t) work(t);
+}
+
+// hg_preload: the pools' threads start with the first job that wants them (a few milliseconds for the packing pool's 4 x 64):
+// an empty job of the largest shape starts them now
+inline void host_pack_warm() {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int threads = hw <= 64 ? (int)std::min<unsigned>(hw ? hw : 1u, 32u) : (int)std::min<unsigned>(hw / 4, 64u);
+    auto nop = [](int) {};
+    if (threads > 1) (void)hostpack::pool(0).run_progress(threads * 4, nop, [](int) {});
+    (void)hostpack::pool(1).run(std::min(threads, 16), nop);
 }
 
 inline void host_pack(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,

@@ -203,3 +203,11 @@ int launch_select_mx3(hg_ctx* c, int lw) {           // codes of <= 64 bits, one
     if (c->NW == 1) return lw == 1 ? launch_select_mx3_t<1, 1>(c) : launch_select_mx3_t<1, 2>(c);
     return lw == 1 ? launch_select_mx3_t<2, 1>(c) : launch_select_mx3_t<2, 2>(c);
 }
+
+// hg_preload: the runtime loads a translation unit's code object when one of its kernels is first needed (milliseconds);
+// asking for a kernel's attributes does that now
+int preload_mx() {
+    hipFuncAttributes a;
+    HG_HIP(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_select_mx3<2, 1>)));
+    return HG_OK;
+}

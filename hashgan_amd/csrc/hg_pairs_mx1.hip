@@ -51,3 +51,10 @@ template <int NW> int select_mx_nw(hg_ctx* c, int lw) {
 
 int launch_select_mx(hg_ctx* c, int lw) { HG_DISPATCH_NW(select_mx_nw, c, lw) }
 
+// hg_preload: the runtime loads a translation unit's code object when one of its kernels is first needed (milliseconds);
+// asking for a kernel's attributes does that now
+int preload_mx1() {
+    hipFuncAttributes a;
+    HG_HIP(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_select_mx<2, 1, 2, true>)));
+    return HG_OK;
+}

@@ -69,3 +69,11 @@ template <int NW> int select_dense_nw(hg_ctx* c, int lw) {
 int launch_hist(hg_ctx* c) { HG_DISPATCH_NW(launch_hist_t, c) }
 int launch_select_valu(hg_ctx* c, int lw, bool optimistic) { HG_DISPATCH_NW(select_valu_nw, c, lw, optimistic) }
 int launch_select_dense(hg_ctx* c, int lw) { HG_DISPATCH_NW(select_dense_nw, c, lw) }
+
+// hg_preload: the runtime loads a translation unit's code object when one of its kernels is first needed (milliseconds);
+// asking for a kernel's attributes does that now
+int preload_valu() {
+    hipFuncAttributes a;
+    HG_HIP(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_hist<2>)));
+    return HG_OK;
+}

@@ -559,3 +559,11 @@ int hg_map_real(hg_ctx* c, int64_t R, double* host_ap, int64_t* host_rel) {
 }
 
 }  // extern "C"
+
+// hg_preload: the runtime loads a translation unit's code object when one of its kernels is first needed (milliseconds);
+// asking for a kernel's attributes does that now
+int preload_real() {
+    hipFuncAttributes a;
+    HG_HIP(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_real_thr2)));
+    return HG_OK;
+}

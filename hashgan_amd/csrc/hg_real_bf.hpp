@@ -497,6 +497,9 @@ static __global__ __launch_bounds__(256) void k_real_sample_any(const float* __r
 //   5  the ranked list: idx and score of A[P[k]], and the label-match bit of every rank (k_match's gather).
 // A query whose records exceed NA sets bit 1 of *err (the host then ranks with the global-memory passes); one whose
 // cut was too high or whose slices overflowed sets bit 0 (a lost bet).
+constexpr u32 RG_PILE = 96;                                 // a fine bucket this full is still ranked by counting (its records compare against each other: 96^2 per
+                                                             // bucket at worst); beyond, the scores sit on a grid and the radix passes take over.  (24 until round 6: one
+                                                             // bucket of 26 among a CIFAR-sized call's 10^4 groups sent the whole call to the radix passes, 1.8 -> 5.4 ms.)
 constexpr int RK_SMAX = 4096;                                // slices per query the offsets array takes
 constexpr int RK_RMAX = 6144;                                // ranked-list length the position arrays take
 template <int NA> constexpr size_t real_rank_lds_bytes() { return (size_t)NA * 8 + (size_t)RK_RMAX * 4 + (RK_SMAX + 1) * 4; }
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
             const u32 bstar = s_prefix, cend = s_need;        // boundary bucket, records in the buckets up to it
             u32 big = cend > (u32)RK_RMAX ? 1u : 0u;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) big |= (4u * tid + x <= bstar && c4[x] > 24u) ? 1u : 0u;
+            for (int x = 0; x < 4; ++x) big |= (4u * tid + x <= bstar && c4[x] > RG_PILE) ? 1u : 0u;
             if (!__syncthreads_or((int)big)) {
                 u32 run = ex;
 #pragma unroll
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
                 __syncthreads();
                 u32 c4[4], sum = 0, big = 0;
 #pragma unroll
-                for (int x = 0; x < 4; ++x) { c4[x] = hw[4 * tid + x]; sum += c4[x]; big |= c4[x] > 24u ? 1u : 0u; }
+                for (int x = 0; x < 4; ++x) { c4[x] = hw[4 * tid + x]; sum += c4[x]; big |= c4[x] > RG_PILE ? 1u : 0u; }
                 const bool piled = __syncthreads_or((int)big) != 0;
                 if (!piled) {
                     u32 tot;
@@ -866,7 +869,6 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
 constexpr int RG_CAP = 6144;                                 // records per group: 48 KB + positions + counters, two blocks per CU
 constexpr int RG_MAXG = 32;
 constexpr int RG_COARSE = 1024;
-constexpr u32 RG_PILE = 24;
 // score of a record key (= mono_inv(~key), spelt without a select: with the select form this compiler's instruction selection
 // died in a float -> bucket computation)
 __device__ __forceinline__ float rg_score(const u32 key) {

@@ -1646,3 +1646,11 @@ int hg_map_end(hg_ctx* c, double* host_ap, int64_t* host_rel) {
 }
 
 }  // extern "C"
+
+// hg_preload: the runtime loads a translation unit's code object when one of its kernels is first needed (milliseconds);
+// asking for a kernel's attributes does that now
+int preload_seq() {
+    hipFuncAttributes a;
+    HG_HIP(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_copy_out)));
+    return HG_OK;
+}

@@ -137,7 +137,9 @@ class _Pool:
                 cls.recycled += 1
                 return lst.pop()
             cls.created += 1
-        return RetrievalEngine(device)
+        eng = RetrievalEngine(device)
+        eng.ctx.preload()          # (the process's first evaluation pays for every path's first use: no later one does)
+        return eng
 
     @classmethod
     def release(cls, eng):

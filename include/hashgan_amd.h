@@ -317,12 +317,17 @@ int hg_trim(hg_ctx* ctx);
 /* Device blocks, pinned host blocks and streams that a destroyed or trimmed context gives up go to a process-wide cache and the
  * next context takes them from there instead of the HIP runtime (hipMalloc now and then stalls for SECONDS on this stack, a
  * stream costs 1.5 - 18 ms to create: a caller that builds a context per evaluation -- main.py:164 builds a MAPs object per
- * evaluation -- would pay that per call).  At most HG_CACHE_MB (8192) of device and HG_PIN_CACHE_MB (512) of pinned memory are
+ * evaluation -- would pay that per call).  At most HG_CACHE_MB (49152: a sixth of the part's 288 GB) of device and HG_PIN_CACHE_MB (512) of pinned memory are
  * held; hg_release_cache returns all of it to the runtime.  Stats (any context): "cache_device_bytes", "cache_pinned_bytes",
  * "cache_hits", "cache_misses", "cache_streams"; "host_us_<phase>" / "host_n_<phase>" / "host_max_us_<phase>" with phase one of
  * init, devmalloc, devfree, hostmalloc, hostfree, destroy, stream, event: what the process has spent in those runtime calls.
  * The reference has no counterpart (lib/metric.py allocates NumPy arrays per call). */
 int hg_release_cache(void);
+/* Pay now what a context otherwise pays on first use of each path: the second stream and the pinned staging of the float
+ * tables' uploads (hg_set_database_f32), the result block, the code objects of every translation unit (the runtime loads one
+ * when a kernel of it is first launched), the host packing threads.  ~30 ms; hashgan_amd's MAPs pool calls it once per context
+ * it creates, so that the first evaluation of ANOTHER shape or path in a process costs what the later ones do. */
+int hg_preload(hg_ctx* ctx);
 /* HIP-event timing of the kernels launched on the context's stream.  on = 2: every kernel; 1: only the
  * select pass over the query x database pairs (k_select, k_select_mx*: the roofline kernel) -- two events per launch keep
  * consecutive kernels from being dispatched back to back, ~4 us each; 0: off.  Levels 1 and 2 also time the

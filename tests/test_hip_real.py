@@ -97,6 +97,43 @@ def test_every_row_ranked_group_by_group(kind):
         c.close()
 
 
+def test_a_fine_bucket_of_26_records_stays_with_the_groups():
+    """bench.py's CIFAR-shaped leg of round 6 (tanh features, Q = 1000, N = R = 54000, seed 0xD1): query 711's first group holds a
+    fine score bucket of 26 records.  The pile guard (then 24) sent the WHOLE call to the four radix passes -- 5.4 ms per call
+    instead of 1.8; a bucket of that size is simply ranked by counting (RG_PILE = 96).  The oracle's lists and APs, bit for bit,
+    with the groups (stat real_path bit 2) and, for comparison, with the radix passes."""
+    rng = np.random.default_rng(0xD1)
+    N, Qall, b, C = 54000, 1000, 64, 10
+    eye = np.eye(C, dtype=np.int64)
+    dl, ql = eye[rng.integers(0, C, N)], eye[rng.integers(0, C, Qall)]
+    dbf = np.tanh(rng.standard_normal((N, b), dtype=np.float32))
+    qf = np.tanh(rng.standard_normal((Qall, b), dtype=np.float32))
+    sl = slice(709, 714)
+    qf, ql = np.ascontiguousarray(qf[sl]), np.ascontiguousarray(ql[sl])
+    # (the premise, checked on the host: 4096 equal-width buckets over the scores of query 711's first ~6000 rows hold one of > 24)
+    s = np.sort((qf[2:3] @ dbf.T)[0])[::-1][:5986]
+    fb = np.minimum(((s[0] - s) * (np.float32(4096.0) / (s[0] - s[-1]))).astype(np.int64), 4095)
+    assert np.bincount(fb).max() > 24
+    R = N
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, ap_ref, idx_ref, score_ref = RM.map_from_features(qf, dbf, ql.astype(np.int8), dl.astype(np.int8), R)
+    c = _native.Context(0)
+    try:
+        c.set_database_f32(dbf, dl)
+        c.set_queries_f32(qf, ql)
+        idx, score = c.topr_real(R)
+        assert (c.get_stat("real_path") >> 2) & 1, "the call left the groups for the radix passes"
+        assert np.array_equal(idx, idx_ref) and np.array_equal(score.view(np.uint32), score_ref.view(np.uint32))
+        ap, rel = c.map_real(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        c.set_option("real_groups", 0)
+        idx2, _ = c.topr_real(R)
+        assert ((c.get_stat("real_path") >> 2) & 1) == 0 and np.array_equal(idx2, idx_ref)
+    finally:
+        c.close()
+
+
 def test_features_that_follow_the_labels_in_a_class_sorted_database():
     """What a trained network hands over when the database is stored class by class: a query's top rows all sit in its
     class's tenth of the segments.  Both sampled cuts lose on slice capacity, the slices are widened (real_cap_boost) and

@@ -17,7 +17,7 @@ SHAPES = {"cifar": (1000, 54000, 64, 54000, 10, False), "nus": (5000, 168692, 64
 
 
 def main():
-    for name in (sys.argv[1:] or ["cifar", "nus"]):
+    for name in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["cifar", "nus"]):
         Q, N, b, R, C, multi = SHAPES[name]
         rng = np.random.default_rng(7)
         if multi:
@@ -67,5 +67,40 @@ def main():
         ctx.close()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--after-c2" not in sys.argv:
     main()
+
+
+def after_c2():
+    """bench.py's drop_in_literal order: the pooled context serves the C2 +-1 shape first, then the CIFAR tanh shape."""
+    import types
+    from hashgan_amd import MAPs
+    rng = np.random.default_rng(3)
+    eye = np.eye(10, dtype=np.int64)
+
+    def case(Q, N, real):
+        x = rng.standard_normal((N, 64), dtype=np.float32)
+        y = rng.standard_normal((Q, 64), dtype=np.float32)
+        f = (lambda a: np.tanh(a)) if real else (lambda a: np.where(a > 0, 1.0, -1.0).astype(np.float32))
+        return (types.SimpleNamespace(output=f(x), label=eye[rng.integers(0, 10, N)]), types.SimpleNamespace(output=f(y), label=eye[rng.integers(0, 10, Q)]))
+    big = case(10000, 1000000, False)
+    cif = case(1000, 54000, True)
+    for rnd in range(2):
+        for name, (db, q), R in (("c2 +-1", big, 5000), ("cifar tanh", cif, 54000)):
+            m = MAPs(R)
+            each = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                m.get_maps_by_feature(db, q)
+                each.append(round((time.perf_counter() - t0) * 1e3, 3))
+            ctx = m._eng.ctx
+            t0 = time.perf_counter(); metric._load_database(m._eng, db.output, db.label, "reference"); t1 = time.perf_counter()
+            ctx.set_queries_f32(q.output, q.label); t2 = time.perf_counter()
+            print("  ", name, "calls", each, "| load db %.3f  queries %.3f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3), "real_path", ctx.get_stat("real_path"),
+                  "device_bytes", ctx.get_stat("device_bytes"), flush=True)
+            m._resident = None
+            m.close()
+
+
+if "--after-c2" in sys.argv:
+    after_c2()
