@@ -348,6 +348,7 @@ struct hg_ctx {
     DevBuf dbfx;               // float features of the database in MFMA A-fragment order (k_real_select_mx), built on first use
     bool dbfx_valid = false;
     DevBuf sampx;              // float features of the sampled rows in MFMA A-fragment order (k_real_sample_mx), rebuilt per call
+    DevBuf cntq;               // real-valued path: the slices' record counts after the rescore, query-major [Q][S] (k_real_rank_lds reads a query's row in one piece)
     DevBuf dbfb, thr2, xmax2;  // filter + rescore path (hg_real_bf.hpp): bf16 image of the database, lowered cuts, max row norm^2
     bool dbfb_valid = false;
     double real_expect = 0.0;  // rows per query the current real-valued attempt expects its cut to keep (real_attempt; picks the rescore's slices per wavefront)
@@ -508,6 +509,7 @@ int ensure_out_block(hg_ctx* c);                   // err / ap / rel as views of
 int read_plan_flag(hg_ctx* c, int* flag);        // *err back to the host (synchronises)
 int launch_min_topr(hg_ctx* c, const u32* idx_all, const u8* dist_all, i64 n, int G);
 // hg_seq.hip
+int stage_ap_download(hg_ctx* c, void* dst = nullptr);   // {verdict, AP, hit counts} into pinned host memory behind everything enqueued so far (no synchronisation)
 void make_geometry(hg_ctx* c);
 Geo hist_geometry(const hg_ctx* c);
 int set_R(hg_ctx* c, int64_t R, int G, int rank);

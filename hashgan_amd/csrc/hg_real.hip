@@ -115,7 +115,9 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
                            c->qf.as<float>(), c->dbfb.as<u8>(), c->thr2.as<float>(), a, c->cand.as<u64>(), gs);                              \
     } while (0)
     // (a wavefront's 64 record rows within 4 GB: 32-bit cursors -- every bet; beyond, e.g. every row a record of a 10M-row database, 64-bit ones)
-    const bool far_rows = (unsigned long long)c->crow * 8ull * 64ull >= (1ull << 32);
+    // (a 32-bit cursor keeps counting past a full slice -- by up to a segment's rows -- so that the hits it dropped are known: the
+    // furthest it can get is the wavefront's 64 record rows plus one segment)
+    const bool far_rows = (64ull * (unsigned long long)c->crow + (unsigned long long)g.L) * 8ull >= (1ull << 32);
     if (c->dbfb_half) { if (far_rows) HG_FILTER(true, true); else HG_FILTER(true, false); }
     else { if (far_rows) HG_FILTER(false, true); else HG_FILTER(false, false); }
 #undef HG_FILTER
@@ -149,12 +151,13 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     }
 #endif
     const i64 waves = (i64)((g.S + SG - 1) / SG) * g.Q;
+    HG_TRY(c->cntq.reserve((size_t)g.Q * g.S * 4));
     c->t_begin(KI_REAL_RESCORE);
 #define HG_RESCORE(sg)                                                                                                                   \
     case sg:                                                                                                                             \
         hipLaunchKernelGGL((k_real_rescore<(KP <= 128 ? KP : 0), sg>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(),  \
                            c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(),               \
-                           c->sl_cnt.as<u32>(), KP, g);                                                                                  \
+                           c->sl_cnt.as<u32>(), c->cntq.as<u32>(), KP, g);                                                               \
         break;
 #ifdef HG_RS_FORCE
     switch (SG) { HG_RESCORE(HG_RS_FORCE) }
@@ -356,21 +359,33 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
                                    (int)real_rank_lds_bytes<NA>()));
         c->t_begin(KI_RADIX);
         hipLaunchKernelGGL(k_real_rank_lds<NA>, dim3(g.Q), dim3(1024), real_rank_lds_bytes<NA>(), c->stream, c->cand.as<u64>(), c->crow, c->cap,
-                           c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->thr.as<float>(), c->out_idx.as<u32>(), c->scores.as<float>(),
+                           c->cntq.as<u32>(), c->failq.as<u32>(), c->thr.as<float>(), c->out_idx.as<u32>(), c->scores.as<float>(),
                            c->dblab.as<u64>(), c->qlab.as<u64>(), c->mbits.as<u64>(), c->RW, c->err.as<int>(), c->qbad.as<u32>(), g);
         c->t_end();
         HG_TRY(c->check_launch("k_real_rank_lds"));
         int flag = 0;
-        HG_TRY(read_plan_flag(c, &flag));
+        if (with_ap) {
+            // the usual case holds its bet: AP and the download of {verdict, AP, hit counts} ride behind the rank kernel and the call
+            // synchronises ONCE (round 5: verdict, wait, AP, wait, two copies, wait); a lost bet's APs are simply not used
+            c->stage = ST_DB | ST_Q | ST_SELECT | ST_MATCH;
+            HG_TRY(do_ap(c));
+            HG_TRY(stage_ap_download(c));
+            HG_TRY(c->sync());
+            flag = *(const int*)c->pin;
+            c->stage = ST_DB | ST_Q | ST_SELECT;
+        } else {
+            HG_TRY(read_plan_flag(c, &flag));
+        }
         if (!(flag & 2)) {
             c->real_lds_ranked = 1;
             *lost = flag & 1;
             c->stage = ST_DB | ST_Q | ST_SELECT;
             if (*lost) return HG_OK;
             c->stage |= ST_MATCH;                          // the rank kernel left the match bits too
-            if (with_ap) HG_TRY(do_ap(c));
-            return c->sync();
+            if (with_ap) { c->stage |= ST_AP; c->ap_staged = true; }
+            return HG_OK;
         }
+        c->stage = ST_DB | ST_Q | ST_SELECT;
         HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));    // some query's records exceed the LDS: the global-memory passes rank them all
     }
     if (rows * 3 > (size_t)200 << 30) {
@@ -416,7 +431,14 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     c->real_grouped = grouped ? 1 : 0;
     if (grouped) {
         c->stage = ST_DB | ST_Q | ST_SELECT | ST_MATCH;
-        if (with_ap) HG_TRY(do_ap(c));
+        if (with_ap) {                                     // AP + one download + one synchronisation (as above)
+            HG_TRY(do_ap(c));
+            HG_TRY(stage_ap_download(c));
+            HG_TRY(c->sync());
+            *lost = *(const int*)c->pin;
+            c->ap_staged = *lost == 0;
+            return HG_OK;
+        }
         HG_TRY(read_plan_flag(c, lost));
         return HG_OK;
     }
@@ -517,6 +539,7 @@ static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
     if (R < 1 || R > c->N) return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->N);
     int lost = 0;
     c->real_attempts = 0;
+    if (with_ap && !c->is_sub) HG_TRY(ensure_out_block(c));      // verdict, APs and hit counts side by side: one download
     if (R * 8 <= c->N && c->N >= 65536) {              // bet on a sampled cut; retry once deeper, then give up betting
         const double boost0 = (double)c->real_cap_boost;
         HG_TRY(real_attempt(c, R, true, c->is_sub ? 6.0 : REAL_FIRST_SIGMA, 3.0 * boost0, with_ap, &lost));

@@ -161,8 +161,14 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
                 const float4 x = f[0], y = f[1];
                 w[0] = pack_h2<HALF>(-x.x, -x.y); w[1] = pack_h2<HALF>(-x.z, -x.w);
                 w[2] = pack_h2<HALF>(-y.x, -y.y); w[3] = pack_h2<HALF>(-y.z, -y.w);
-                if (HALF) big = fmaxf(big, fmaxf(fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))),
-                                                 fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)))));
+                if (HALF) {
+                    big = fmaxf(big, fmaxf(fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))),
+                                           fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)))));
+                    // (fmaxf drops a NaN operand: a NaN feature is found by the sum instead -- NaN in, NaN out; inf - inf too, and
+                    // an infinite feature is beyond 2^15 anyway)
+                    const float sm = ((x.x + x.y) + (x.z + x.w)) + ((y.x + y.y) + (y.z + y.w));
+                    if (sm != sm) big = __uint_as_float(0x7F800000u);
+                }
             }
             bq[t][m] = *(const hx8*)w;
         }
@@ -303,7 +309,7 @@ constexpr int rescore_lds_bytes() { return WPB * 64 * RS_ROWB; }
 template <int KPT, int SG>          // KPT: the (padded) feature count, 0 = taken at run time (kp_rt; beyond 128 features)
 __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ qf, const float* __restrict__ dbf, const u32* sl_cnt,
                                                       u64* __restrict__ cand, u32 cap, i64 crow, const float* __restrict__ thr,
-                                                      u32* sl_cnt_out, const int kp_rt, const Geo g) {      // (sl_cnt_out may be sl_cnt)
+                                                      u32* sl_cnt_out, u32* __restrict__ cnt_by_query, const int kp_rt, const Geo g) {      // (sl_cnt_out may be sl_cnt; cnt_by_query: the same counts [Q][S])
     const int KP = KPT ? KPT : kp_rt;
     extern __shared__ __attribute__((aligned(16))) u8 rlds[];
     const int lane = threadIdx.x & 63;
@@ -421,7 +427,10 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
     }
 #pragma unroll
     for (int x = 0; x < SG; ++x)
-        if (lane == x && s0 + x < g.S) sl_cnt_out[(i64)(s0 + x) * g.Qpad + q] = kept[x];
+        if (lane == x && s0 + x < g.S) {
+            sl_cnt_out[(i64)(s0 + x) * g.Qpad + q] = kept[x];
+            cnt_by_query[(i64)q * g.S + s0 + x] = kept[x];       // the rank kernel reads a query's counts as one run (its block met S cache lines for S counts)
+        }
 }
 
 // Sample pass for any feature count (k_real_sample keeps a query's features in registers: up to 128): wavefront =
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
     u32 n = 0;
     for (int sb = 0; sb < g.S; sb += 1024) {
         const int s = sb + tid;
-        const u32 c = s < g.S ? sl_cnt[(i64)s * g.Qpad + q] : 0u;
+        const u32 c = s < g.S ? sl_cnt[(i64)q * g.S + s] : 0u;       // (query-major: k_real_rescore's cnt_by_query)
         u32 tot;
         const u32 ex = block_excl_scan_1024(c, s_w, tot);
         if (s < g.S) off[s] = n + ex;

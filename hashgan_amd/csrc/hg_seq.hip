@@ -1295,7 +1295,7 @@ static __global__ __launch_bounds__(256) void k_copy_out(const uint4* __restrict
     if (i < tail_dwords) ((u32*)(dst + n16))[i] = ((const u32*)(src + n16))[i];
 }
 
-static int stage_ap_download(hg_ctx* c, void* dst = nullptr) {      // dst: a pinned block of its own (hg_map_begin), else the context's
+extern "C++" int stage_ap_download(hg_ctx* c, void* dst) {      // dst: a pinned block of its own (hg_map_begin), else (nullptr) the context's
     const size_t Q = (size_t)c->geo.Q;
     if (!dst) HG_TRY(ensure_pin(c, Q * 12 + 16));
     char* pb = (char*)(dst ? dst : c->pin);    // [flag: 16 B][ap Q x 8][rel Q x 4]
