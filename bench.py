@@ -888,6 +888,66 @@ def main():
         fence()
         pipe = {"steps_in_flight": 2, "api": "hg_map_begin / hg_map_end", "sync_ms_per_step": (time.perf_counter() - ts) / ns * 1e3,
                 "sync_steps_timed": ns, "blind_steps": ctx.get_stat("map_async_steps"), "blind_steps_redone": ctx.get_stat("map_async_redone")}
+        try:
+            # what a caller with a FRESH query batch per step gets (lib/metric.py once per batch): hg_set_queries -- which does not wait
+            # for the stream -- then hg_map_begin, the previous batch's hg_map_end after it; two alternating query tables, every
+            # step's APs checked against the table it was enqueued on
+            qw2, ql2 = np.ascontiguousarray(qw[::-1]), np.ascontiguousarray(ql[::-1])
+            tabs = [(qw, ql), (qw2, ql2)]
+            ctx.set_queries(*tabs[1])
+            ref1, _ = ctx.map(R)
+            ctx.set_queries(*tabs[0])
+            ref0, _ = ctx.map(R)
+            refs = [ref0, ref1]
+            n0 = ctx.get_stat("map_async_steps")
+            fence()
+            ts = time.perf_counter()
+            ctx.set_queries(*tabs[0])
+            ctx.map_begin(R)
+            ok = True
+            for i in range(ns):
+                if i + 1 < ns:
+                    ctx.set_queries(*tabs[(i + 1) & 1])
+                    ctx.map_begin(R)
+                a_, r_ = ctx.map_end()
+                ok = ok and np.array_equal(a_, refs[i & 1], equal_nan=True)
+            fence()
+            pipe["fresh_queries_per_step"] = {"ms_per_step": (time.perf_counter() - ts) / ns * 1e3, "steps": ns, "blind_steps": ctx.get_stat("map_async_steps") - n0,
+                                              "every_step_equals_its_own_batch": bool(ok),
+                                              "note": "hg_set_queries (80 KB of packed codes + 80 KB of labels from host memory) + hg_map_begin per step, the previous step's hg_map_end after it"}
+            ctx.set_queries(qw, ql)
+            a, _ = ctx.map(R)
+        except Exception as e:      # noqa: BLE001 -- a side measurement must never cost the main line
+            pipe["fresh_queries_per_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            # two contexts (a stream and work buffers each) on the same tables, steps enqueued alternately: one step's tail -- rank + AP,
+            # the download -- and the next one's sampled histogram and guess run under the other stream's select.  What a caller may do
+            # with the C ABI as it is; never `value`: per-kernel times no longer add up to the step
+            ctx_b = _native.Context(0 if dry_dir else local_rank)
+            try:
+                for kv in args.opt:
+                    k_, v_ = kv.split("=")
+                    ctx_b.set_option(k_, int(v_))
+                ctx_b.set_database(dw, dl, b, C)
+                ctx_b.set_queries(qw, ql)
+                for _ in range(5):
+                    ab, _ = ctx_b.map(R)
+                pair = [ctx, ctx_b]
+                fence(); ctx_b.synchronize()
+                ns2 = max(2, ns)
+                ts = time.perf_counter()
+                pair[0].map_begin(R)
+                for i in range(ns2):
+                    if i + 1 < ns2:
+                        pair[(i + 1) & 1].map_begin(R)
+                    a_, r_ = pair[i & 1].map_end()
+                fence(); ctx_b.synchronize()
+                pipe["two_contexts_alternating"] = {"ms_per_step": (time.perf_counter() - ts) / ns2 * 1e3, "steps": ns2,
+                                                    "equal_to_one_context": bool(np.array_equal(ab, a, equal_nan=True) and np.array_equal(a_, a, equal_nan=True))}
+            finally:
+                ctx_b.close()
+        except Exception as e:      # noqa: BLE001
+            pipe["two_contexts_alternating"] = {"error": "%s: %s" % (type(e).__name__, e)}
     exchange = None
     if sharded_leg:
         # what crosses the wire per step and rank (the owner-routed form: three all-to-alls and one small all-gather), and how long the
@@ -988,6 +1048,9 @@ def main():
         rec_bytes = 8 if any(kv.replace(" ", "") == "compact_records=0" for kv in args.opt) else 1
         roof, per_kernel = kernel_rooflines(timing, spec, rows, per_step, rec_bytes, kernel_names(ctx, spec))
         roof["launches_timed"] = per_kernel[roof["timing_slot"]]["launches"]
+        if pipe is not None:       # the step one call at a time (hg_map: enqueue, wait, copy out, return): the figure comparable across rounds
+            roof["sync_ms_per_step"] = round(pipe["sync_ms_per_step"], 5)
+            roof["step_valu_equiv_frac_sync"] = round(roof["valu_equiv_frac"]["step"] * per_step * 1e3 / pipe["sync_ms_per_step"], 5)
         roof["timed"] = "HIP events around the kernel on every %s step of the timed region" % ("" if every == 1 else "%d-th" % every)
         out["roofline"] = roof
         out["kernels"] = {k_: {"avg_ms": round(v["avg_ms"], 5), "launches": v["launches"]} for k_, v in per_kernel.items()}

@@ -980,6 +980,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
     } else if (!strcmp(key, "real_mfma")) {
         if (value < 0 || value > 2) return fail(HG_ERR_ARG, "real_mfma must be 0, 1 or 2");
         c->opt_real_mfma = value;
+    } else if (!strcmp(key, "real_sample_half")) {
+        c->opt_real_sample_h = value != 0;
     } else if (!strcmp(key, "real_groups")) {
         c->opt_real_groups = value != 0;
     } else if (!strcmp(key, "real_sort_lds")) {

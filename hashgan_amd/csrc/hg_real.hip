@@ -66,8 +66,9 @@ template <int KP> int real_launch_select_mx(hg_ctx* c) {
     return c->check_launch("k_real_select_mx");
 }
 // filter + rescore (hg_real_bf.hpp): bf16 pair pass with a rigorous margin, then the exact chain for the survivors
-template <int KP> int real_launch_select_bf(hg_ctx* c) {
-    constexpr int QT = KP <= 128 ? 2 : 1;
+// the filter's 16-bit image of the database (and the choice between IEEE half and bfloat16), built on first use
+int ensure_filter_image(hg_ctx* c) {
+    const int KP = c->bpad;
     if (!c->dbfb_valid) {
         const i64 n16 = (c->N + 15) / 16 * 16;
         HG_TRY(c->dbfb.reserve((size_t)n16 * KP * 2));
@@ -84,13 +85,18 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
         // the relative term once norms fall below ~0.1; bfloat16 has float32's exponents and no such floor)
         c->dbfb_half = c->opt_real_mfma == 2 && xm >= 1.0f && xm < 1073741824.0f;         // 1 <= largest row norm^2 < 2^30 (inf and the NaN marker fail the test)
         if (c->dbfb_half) hipLaunchKernelGGL(k_expand_dbf_bf16<true>, dim3(grid_for(n16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
-                                             c->dbfb.as<uint4>(), (i64)c->N, n16, KP);
+                                             c->dbfb.as<uint4>(), (i64)c->N, n16, KP, (i64)1);
         else hipLaunchKernelGGL(k_expand_dbf_bf16<false>, dim3(grid_for(n16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
-                                c->dbfb.as<uint4>(), (i64)c->N, n16, KP);
+                                c->dbfb.as<uint4>(), (i64)c->N, n16, KP, (i64)1);
         c->t_end();
         HG_TRY(c->check_launch("k_expand_dbf_bf16"));
         c->dbfb_valid = true;
     }
+    return HG_OK;
+}
+template <int KP> int real_launch_select_bf(hg_ctx* c) {
+    constexpr int QT = KP <= 128 ? 2 : 1;
+    HG_TRY(ensure_filter_image(c));
     Geo g = c->geo;
     HG_TRY(c->thr2.reserve((size_t)g.Qpad * 4));
     c->t_begin(KI_REAL_GUESS);
@@ -240,6 +246,47 @@ template <int KP> int real_launch_sample_mx(hg_ctx* c, i64 M, i64 stride, i64 ms
     c->t_end();
     return c->check_launch("k_real_sample_mx");
 }
+// sample pass in the filter's 16-bit arithmetic (k_real_sample_h): the sampled rows' image rebuilt per call (1.6 MB at 10k x 1M), ~32 segments
+template <int KP> int real_launch_sample_h(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
+    HG_TRY(ensure_filter_image(c));                      // (decides half / bfloat16 for this database)
+    const i64 m16 = (M + 15) / 16 * 16;
+    HG_TRY(c->sampx.reserve((size_t)m16 * KP * 2));
+    c->t_begin(KI_REAL_SAMPLE);
+    if (c->dbfb_half) hipLaunchKernelGGL(k_expand_dbf_bf16<true>, dim3(grid_for(m16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
+                                         c->sampx.as<uint4>(), M, m16, KP, stride);
+    else hipLaunchKernelGGL(k_expand_dbf_bf16<false>, dim3(grid_for(m16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
+                            c->sampx.as<uint4>(), M, m16, KP, stride);
+    Geo g = c->geo;
+    g.N = M;
+    i64 L = (M + 31) / 32;                               // ~32 segments (16 pairs) of a multiple of 16 rows
+    L = (L + 15) / 16 * 16;
+    g.L = L;
+    g.S = (int)((M + L - 1) / L);
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + WPB * 64 - 1) / (WPB * 64);
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    if (c->dbfb_half) hipLaunchKernelGGL((k_real_sample_h<KP, true>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
+                                         c->samp.as<float>(), mstride, g);
+    else hipLaunchKernelGGL((k_real_sample_h<KP, false>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
+                            c->samp.as<float>(), mstride, g);
+    c->t_end();
+    return c->check_launch("k_real_sample_h");
+}
+int real_sample_h(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
+    switch (c->bpad) {
+        case 16: return real_launch_sample_h<16>(c, M, stride, mstride);
+        case 32: return real_launch_sample_h<32>(c, M, stride, mstride);
+        case 48: return real_launch_sample_h<48>(c, M, stride, mstride);
+        case 64: return real_launch_sample_h<64>(c, M, stride, mstride);
+        case 80: return real_launch_sample_h<80>(c, M, stride, mstride);
+        case 96: return real_launch_sample_h<96>(c, M, stride, mstride);
+        case 112: return real_launch_sample_h<112>(c, M, stride, mstride);
+        default: return real_launch_sample_h<128>(c, M, stride, mstride);
+    }
+}
 int real_sample_mx(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
     switch (c->bpad) {
         case 16: return real_launch_sample_mx<16>(c, M, stride, mstride);
@@ -253,6 +300,8 @@ int real_sample_mx(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
     }
 }
 int real_sample(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
+    // with the 16-bit filter behind it the sample runs in the same arithmetic (its scores only place the cut); "real_mfma" 1 keeps the exact chains
+    if (c->bpad <= 128 && c->opt_real_mfma == 2 && c->opt_real_sample_h && c->geo.L % 16 == 0) return real_sample_h(c, M, stride, mstride);
     if (c->bpad <= 128 && c->opt_real_mfma) return real_sample_mx(c, M, stride, mstride);
     if (c->bpad > 128) {                                 // k_real_sample keeps the query in registers: the staged form beyond
         const Geo& g = c->geo;

@@ -52,8 +52,9 @@ template <bool HALF> __device__ __forceinline__ u32 pack_h2(float lo, float hi) 
 // Database image in A-fragment order of v_mfma_f32_32x32x16_bf16: groups of 16 rows; chunk (group G, MFMA m, k-half
 // hh, row r) = 16 bytes at (((G * (KP/16) + m) * 2 + hh) * 16 + r) * 16 holding bf16 features 16 m + 8 hh .. + 7 of
 // row 16 G + r.
+// (rstride > 1: image row i is table row i * rstride -- the sample pass's image of every rstride-th row, N = the sampled rows)
 template <bool HALF>
-static __global__ __launch_bounds__(256) void k_expand_dbf_bf16(const float* __restrict__ dbf, uint4* __restrict__ img, i64 N, i64 n16, int KP) {
+static __global__ __launch_bounds__(256) void k_expand_dbf_bf16(const float* __restrict__ dbf, uint4* __restrict__ img, i64 N, i64 n16, int KP, i64 rstride) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     const int per_row = KP / 8;
     if (i >= n16 * per_row) return;
@@ -61,7 +62,7 @@ static __global__ __launch_bounds__(256) void k_expand_dbf_bf16(const float* __r
     const int c = (int)(i - row * per_row), m = c >> 1, hh = c & 1;
     uint4 v = {0u, 0u, 0u, 0u};
     if (row < N) {
-        const float4* f = (const float4*)(dbf + row * KP + 16 * m + 8 * hh);
+        const float4* f = (const float4*)(dbf + row * rstride * KP + 16 * m + 8 * hh);
         const float4 a = f[0], b = f[1];
         v.x = pack_h2<HALF>(a.x, a.y); v.y = pack_h2<HALF>(a.z, a.w);
         v.z = pack_h2<HALF>(b.x, b.y); v.w = pack_h2<HALF>(b.z, b.w);
@@ -291,6 +292,108 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
             }
             a.sl_cnt[(i64)s * g.Qpad + q] = live ? cnt[t] : 0u;
             if (dropped[t] && live) a.fail[q] = 1u;
+        }
+    }
+}
+
+// Sample pass in the filter's 16-bit arithmetic (round 6; k_real_sample_mx ran the exact float32 chains at the vector fma rate:
+// 0.35 ms of a 5.4 ms call for scores that only place a cut).  The cut is the rank_s-th largest SAMPLED score and may be any
+// number: the filter keeps every pair that can score above it and the rank stage verifies that R rows do (else the bet is lost
+// and retried), so approximate sample scores -- off by the filter's own margin at most -- move it by a hair and change nothing
+// that is returned.  k_real_sample_mx's mapping (lane = query column j and 16 rows per tile, 16 consecutive samples of its query
+// stored as they lie in the accumulator) on k_real_select_bf's fragments: the sampled rows' image is k_expand_dbf_bf16's with a
+// row stride, B = +q in half / bfloat16.  A query feature half cannot hold scores 0 everywhere (its cut is void: the filter keeps
+// every row of that query anyway).
+template <int KP, bool HALF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void k_real_sample_h(const float* __restrict__ qf, const u8* __restrict__ img, float* __restrict__ samp, i64 mstride, const Geo g) {
+    constexpr int QT = 2, WQ = 32 * QT;
+    constexpr int NM = KP / 16;
+    typedef typename std::conditional<HALF, f16x8, bf16x8>::type hx8;
+    const int lb = logical_block(g.nBlk);
+    if (lb < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nQB = g.nQT;
+    const int sp = lb / nQB, qb = lb - sp * nQB;
+    const int h = lane >> 5, j = lane & 31;
+    const int s = 2 * sp + h;
+    const i64 lo0 = (i64)(2 * sp) * g.L, lo1 = lo0 + g.L;
+    const i64 len0 = lo0 >= g.N ? 0 : (lo0 + g.L < g.N ? g.L : g.N - lo0);
+    const i64 len1 = lo1 >= g.N ? 0 : (lo1 + g.L < g.N ? g.L : g.N - lo1);
+    const i64 mylen = h ? len1 : len0;
+    const i64 ntile = ((len0 > len1 ? len0 : len1) + 15) / 16;
+    const i64 NG = (g.N + 15) >> 4;
+    const int q0w = (qb * WPB + wave) * WQ;
+    hx8 bq[QT][NM];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = q0w + t * 32 + j;
+        float big = 0.0f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            u32 w[4] = {0u, 0u, 0u, 0u};
+            if (q < g.Q) {
+                const float4* f = (const float4*)(qf + (i64)q * KP + 16 * m + 8 * h);
+                const float4 x = f[0], y = f[1];
+                w[0] = pack_h2<HALF>(x.x, x.y); w[1] = pack_h2<HALF>(x.z, x.w);
+                w[2] = pack_h2<HALF>(y.x, y.y); w[3] = pack_h2<HALF>(y.z, y.w);
+                if (HALF) {
+                    big = fmaxf(big, fmaxf(fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))),
+                                           fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)))));
+                    const float sm = ((x.x + x.y) + (x.z + x.w)) + ((y.x + y.y) + (y.z + y.w));
+                    if (sm != sm) big = __uint_as_float(0x7F800000u);
+                }
+            }
+            bq[t][m] = *(const hx8*)w;
+        }
+        if (HALF) {
+            const bool mine = !(big < 32768.0f);
+            const bool theirs = __shfl_xor((int)mine, 32) != 0;     // (every lane asks)
+            if (mine || theirs) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) { const u32 z[4] = {0u, 0u, 0u, 0u}; bq[t][m] = *(const hx8*)z; }
+            }
+        }
+    }
+    const int ah = (j >> 2) & 1;
+    const int ar = (j & 3) + 4 * (j >> 3);
+    const i64 ag0 = (ah ? lo1 : lo0) >> 4;
+    auto chunk = [&](const i64 T, const int m) -> hx8 {
+        i64 G = ag0 + T;
+        G = G < NG ? G : NG - 1;                             // past the end: any valid group (never stored)
+        return *(const hx8*)(img + ((((G * NM + m) * 2 + h) * 16 + ar) * 16));
+    };
+    hx8 av[NM];
+    if (ntile > 0) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) av[m] = chunk(0, m);
+    }
+    for (i64 T = 0; T < ntile; ++T) {
+        const i64 left = mylen - T * 16;
+        const i64 Tn = T + 1 < ntile ? T + 1 : T;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                acc = real_filter_mfma(av[m], bq[t][m], acc);
+                if (t == QT - 1) av[m] = chunk(Tn, m);
+            }
+            const int q = q0w + t * 32 + j;
+            if (q < g.Q && left > 0) {
+                float* out = samp + (i64)q * mstride + (i64)s * g.L + T * 16;       // 64-byte aligned: L and mstride are multiples of 16
+                if (left >= 16) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        ((float4*)out)[r4] = float4{acc[4 * r4] + 0.0f, acc[4 * r4 + 1] + 0.0f, acc[4 * r4 + 2] + 0.0f, acc[4 * r4 + 3] + 0.0f};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) if (r < left) out[r] = acc[r] + 0.0f;
+                }
+            }
         }
     }
 }

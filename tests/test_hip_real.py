@@ -317,9 +317,10 @@ def test_filter_and_rescore_equals_the_exact_passes(kind, Q, N, b, R, ctx):
     ctx.set_database_f32(dbf, dl.astype(np.int64))
     ctx.set_queries_f32(qf, ql.astype(np.int64))
     try:
-        for mode, lds in ((2, 1), (2, 0), (1, 1), (0, 1)):
+        for mode, lds, half_sample in ((2, 1, 1), (2, 1, 0), (2, 0, 1), (1, 1, 1), (0, 1, 1)):
             ctx.set_option("real_mfma", mode)
             ctx.set_option("real_sort_lds", lds)
+            ctx.set_option("real_sample_half", half_sample)      # the cut from 16-bit sample scores (round 6) or from exact chains: the same lists
             idx, score = ctx.topr_real(R)
             assert np.array_equal(score.view(np.uint32), score_ref.view(np.uint32)), (kind, mode, lds)
             assert np.array_equal(idx, idx_ref), (kind, mode, lds)
@@ -335,6 +336,7 @@ def test_filter_and_rescore_equals_the_exact_passes(kind, Q, N, b, R, ctx):
     finally:
         ctx.set_option("real_mfma", 2)
         ctx.set_option("real_sort_lds", 1)
+        ctx.set_option("real_sample_half", 1)
 
 
 def test_real_valued_ranking_vs_np_dot_envelope(ctx):
