@@ -268,10 +268,11 @@ template <int KP> int real_launch_sample_h(hg_ctx* c, i64 M, i64 stride, i64 mst
     g.nUnits = (i64)nSP * nQB;
     g.wpb = WPB;
     g.nBlk = (int)g.nUnits;
-    if (c->dbfb_half) hipLaunchKernelGGL((k_real_sample_h<KP, true>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
-                                         c->samp.as<float>(), mstride, g);
-    else hipLaunchKernelGGL((k_real_sample_h<KP, false>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
-                            c->samp.as<float>(), mstride, g);
+#define HG_SAMPLE_H(HALF_, O16_) hipLaunchKernelGGL((k_real_sample_h<KP, HALF_, O16_>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), \
+                                                     c->sampx.as<u8>(), c->samp.as<float>(), mstride, g)
+    if (c->dbfb_half) { if (c->samp16) HG_SAMPLE_H(true, true); else HG_SAMPLE_H(true, false); }
+    else { if (c->samp16) HG_SAMPLE_H(false, true); else HG_SAMPLE_H(false, false); }
+#undef HG_SAMPLE_H
     c->t_end();
     return c->check_launch("k_real_sample_h");
 }
@@ -370,9 +371,12 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         // samp[q][mstride]: the matrix-core sample pass stores 16 samples at a time (rows 64-byte aligned), the vector kernels M densely
         const i64 mstride = c->bpad <= 128 && c->opt_real_mfma ? (M + 15) / 16 * 16 : M;
         HG_TRY(c->samp.reserve((size_t)g.Q * mstride * 4));
+        // 16-bit sample scores when both ends take them: k_real_sample_h writes, k_real_guess_lds reads
+        c->samp16 = M <= RG_MMAX && c->bpad <= 128 && c->opt_real_mfma == 2 && c->opt_real_sample_h && c->geo.L % 16 == 0;
         HG_TRY(real_sample(c, M, stride, mstride));
         c->t_begin(KI_REAL_GUESS);
-        if (M <= RG_MMAX) hipLaunchKernelGGL(k_real_guess_lds, dim3(g.Q), dim3(1024), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
+        if (M <= RG_MMAX && c->samp16) hipLaunchKernelGGL(k_real_guess_lds<true>, dim3(g.Q), dim3(1024), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
+        else if (M <= RG_MMAX) hipLaunchKernelGGL(k_real_guess_lds<false>, dim3(g.Q), dim3(1024), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
         else hipLaunchKernelGGL(k_real_guess, dim3(g.Q), dim3(256), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
         c->t_end();
         HG_TRY(c->check_launch("k_real_guess"));

@@ -304,7 +304,9 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
 // stored as they lie in the accumulator) on k_real_select_bf's fragments: the sampled rows' image is k_expand_dbf_bf16's with a
 // row stride, B = +q in half / bfloat16.  A query feature half cannot hold scores 0 everywhere (its cut is void: the filter keeps
 // every row of that query anyway).
-template <int KP, bool HALF>
+// OUT16: the scores leave as bfloat16 (round to nearest even: monotone, so the rank_s-th largest of the rounded scores is the
+// rounded rank_s-th largest; half the bytes for the pass that is bound by them and for k_real_guess_lds, which reads them all)
+template <int KP, bool HALF, bool OUT16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
 void k_real_sample_h(const float* __restrict__ qf, const u8* __restrict__ img, float* __restrict__ samp, i64 mstride, const Geo g) {
     constexpr int QT = 2, WQ = 32 * QT;
@@ -384,14 +386,27 @@ void k_real_sample_h(const float* __restrict__ qf, const u8* __restrict__ img, f
             }
             const int q = q0w + t * 32 + j;
             if (q < g.Q && left > 0) {
-                float* out = samp + (i64)q * mstride + (i64)s * g.L + T * 16;       // 64-byte aligned: L and mstride are multiples of 16
-                if (left >= 16) {
+                if (OUT16) {
+                    u16* out = (u16*)samp + (i64)q * mstride + (i64)s * g.L + T * 16;   // 32-byte aligned
+                    if (left >= 16) {
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4)
-                        ((float4*)out)[r4] = float4{acc[4 * r4] + 0.0f, acc[4 * r4 + 1] + 0.0f, acc[4 * r4 + 2] + 0.0f, acc[4 * r4 + 3] + 0.0f};
+                        for (int r8 = 0; r8 < 2; ++r8)
+                            ((uint4*)out)[r8] = uint4{pack_bf16x2(acc[8 * r8] + 0.0f, acc[8 * r8 + 1] + 0.0f), pack_bf16x2(acc[8 * r8 + 2] + 0.0f, acc[8 * r8 + 3] + 0.0f),
+                                                      pack_bf16x2(acc[8 * r8 + 4] + 0.0f, acc[8 * r8 + 5] + 0.0f), pack_bf16x2(acc[8 * r8 + 6] + 0.0f, acc[8 * r8 + 7] + 0.0f)};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) if (r < left) out[r] = (u16)(pack_bf16x2(acc[r] + 0.0f, 0.0f) & 0xFFFFu);
+                    }
                 } else {
+                    float* out = samp + (i64)q * mstride + (i64)s * g.L + T * 16;       // 64-byte aligned: L and mstride are multiples of 16
+                    if (left >= 16) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) if (r < left) out[r] = acc[r] + 0.0f;
+                        for (int r4 = 0; r4 < 4; ++r4)
+                            ((float4*)out)[r4] = float4{acc[4 * r4] + 0.0f, acc[4 * r4 + 1] + 0.0f, acc[4 * r4 + 2] + 0.0f, acc[4 * r4 + 3] + 0.0f};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) if (r < left) out[r] = acc[r] + 0.0f;
+                    }
                 }
             }
         }
@@ -1192,6 +1207,7 @@ static __global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __re
 // 1024 threads copy the query's samples (as order-preserving keys) once, then the same 11 + 11 + 10 bit radix select of
 // the rank_s-th largest runs out of LDS.  M <= RG_MMAX.
 constexpr int RG_MMAX = 16384;
+template <bool IN16>            // IN16: the samples are bfloat16 (k_real_sample_h<.., OUT16>): the float32 with those upper 16 bits
 static __global__ __launch_bounds__(1024) void k_real_guess_lds(const float* __restrict__ samp, i64 M, i64 mstride, u32 rank_s,
                                                          float* __restrict__ thr) {
     __shared__ u32 keys[RG_MMAX];
@@ -1204,7 +1220,12 @@ static __global__ __launch_bounds__(1024) void k_real_guess_lds(const float* __r
         if (tid == 0) thr[q] = __uint_as_float(0xFF800000u);  // -inf: everything qualifies
         return;
     }
-    for (i64 i = tid; i < M; i += 1024) keys[i] = mono_key(col[i]);
+    if (IN16) {
+        const u16* __restrict__ col16 = (const u16*)samp + (i64)q * mstride;
+        for (i64 i = tid; i < M; i += 1024) keys[i] = mono_key(__uint_as_float((u32)col16[i] << 16));
+    } else {
+        for (i64 i = tid; i < M; i += 1024) keys[i] = mono_key(col[i]);
+    }
     if (tid == 0) { s_prefix = 0; s_rank = rank_s; }
     u32 mask = 0;
     const int shifts[3] = {21, 10, 0};
