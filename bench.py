@@ -747,6 +747,9 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive MAPs(...) timing")
     ap.add_argument("--no-sorted", action="store_true", help="skip the class-sorted database timing")
     ap.add_argument("--no-literal", action="store_true", help="skip the literal drop-in leg (a new MAPs object per call, main.py:164)")
+    ap.add_argument("--no-pipeline-extras", action="store_true",
+                    help="skip the pipeline's side legs (a fresh query table per step; two contexts alternating): a profiled run "
+                         "(rocprofv3) should hold the headline step's launches only")
     ap.add_argument("--no-large-r", action="store_true", help="skip the large-R legs (R = N/20, R = N/2 on the timed workload's arrays)")
     ap.add_argument("--no-real", action="store_true", help="skip the real-valued (tanh features) call timing")
     ap.add_argument("--no-c4-ref", action="store_true", help="skip the one-GPU C4 point of the scaling curve")
@@ -889,6 +892,8 @@ def main():
         pipe = {"steps_in_flight": 2, "api": "hg_map_begin / hg_map_end", "sync_ms_per_step": (time.perf_counter() - ts) / ns * 1e3,
                 "sync_steps_timed": ns, "blind_steps": ctx.get_stat("map_async_steps"), "blind_steps_redone": ctx.get_stat("map_async_redone")}
         try:
+            if args.no_pipeline_extras:
+                raise StopIteration
             # what a caller with a FRESH query batch per step gets (lib/metric.py once per batch): hg_set_queries -- which does not wait
             # for the stream -- then hg_map_begin, the previous batch's hg_map_end after it; two alternating query tables, every
             # step's APs checked against the table it was enqueued on
@@ -917,9 +922,13 @@ def main():
                                               "note": "hg_set_queries (80 KB of packed codes + 80 KB of labels from host memory) + hg_map_begin per step, the previous step's hg_map_end after it"}
             ctx.set_queries(qw, ql)
             a, _ = ctx.map(R)
+        except StopIteration:
+            pass
         except Exception as e:      # noqa: BLE001 -- a side measurement must never cost the main line
             pipe["fresh_queries_per_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
+            if args.no_pipeline_extras:
+                raise StopIteration
             # two contexts (a stream and work buffers each) on the same tables, steps enqueued alternately: one step's tail -- rank + AP,
             # the download -- and the next one's sampled histogram and guess run under the other stream's select.  What a caller may do
             # with the C ABI as it is; never `value`: per-kernel times no longer add up to the step
@@ -946,6 +955,8 @@ def main():
                                                     "equal_to_one_context": bool(np.array_equal(ab, a, equal_nan=True) and np.array_equal(a_, a, equal_nan=True))}
             finally:
                 ctx_b.close()
+        except StopIteration:
+            pass
         except Exception as e:      # noqa: BLE001
             pipe["two_contexts_alternating"] = {"error": "%s: %s" % (type(e).__name__, e)}
     exchange = None

@@ -5,7 +5,7 @@ TAG=${1:-cfg}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for wl in c1 c3 c5; do
-  B="python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-large-r --no-c4-ref --no-configs --no-literal --kernel-timing none"
+  B="python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-large-r --no-c4-ref --no-configs --no-literal --no-pipeline-extras --kernel-timing none"
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_$wl -o t -- $B > $OUT/trace_$wl.log 2>&1
   ( echo "# rocprofv3 --kernel-trace --stats -- bench.py --workload $wl --steps 20 --warmup 5 --kernel-timing none (side legs off)"; grep "^{" $OUT/trace_$wl.log | tail -1 | python3 -c "
 import json,sys

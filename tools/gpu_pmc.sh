@@ -5,7 +5,7 @@ TAG=${1:-pmc}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-B0="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-large-r --no-c4-ref --no-configs --kernel-timing none $*"
+B0="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --no-real --no-sorted --no-large-r --no-c4-ref --no-configs --no-literal --no-pipeline-extras --kernel-timing none $*"
 if [ -n "$HG_PMC_CMD" ]; then B=$(echo "$HG_PMC_CMD" | sed "s#python tools/#python $GRAFT_REPO_ROOT/tools/#"); else B=$B0; fi
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1
 i=0
