@@ -117,7 +117,13 @@ def cpu_baseline(spec, packed, budget_s=12.0, chunk=128):
         blas = [(p.get("internal_api"), p.get("num_threads")) for p in threadpoolctl.threadpool_info()]
     except Exception:      # noqa: BLE001
         blas = None
-    return {"value": done / dt, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+    quota = None
+    try:                                             # the box may cap the process far below its core count (cgroup v2 cpu.max: "<quota> <period>")
+        qs, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if qs == "max" else float(qs) / float(per)
+    except (OSError, ValueError):
+        pass
+    return {"value": done / dt, "unit": "queries/s", "cores": os.cpu_count(), "cgroup_cpu_quota": quota, "kind": "port",
             "sample": "%d of %d queries (chunks of %d) x full N=%d database in %.1f s; float32 +-1 features; np.dot on "
                       "BLAS threads %s, np.argsort and the per-query loop on 1 core; numpy %s"
                       % (done, Q, chunk, dbf.shape[0], dt, blas, np.__version__)}

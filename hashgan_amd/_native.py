@@ -509,9 +509,10 @@ class Context:
 
 def host_phase_timers(ctx):
     """Process-wide host-side cost of what a context does outside its kernels (hg_ctx.hpp, HostPhase): {phase: (total ms, calls,
-    longest call ms)} for init, devmalloc, devfree, hostmalloc, hostfree, destroy, stream, event."""
+    longest call ms)} for init, devmalloc, devfree, hostmalloc, hostfree, destroy, stream, event, sync (waiting for the GPU), pack (the host
+    packing pass) and thread (starting the float table's staging thread)."""
     out = {}
-    for ph in ("init", "devmalloc", "devfree", "hostmalloc", "hostfree", "destroy", "stream", "event"):
+    for ph in ("init", "devmalloc", "devfree", "hostmalloc", "hostfree", "destroy", "stream", "event", "sync", "pack", "thread"):
         out[ph] = (ctx.get_stat("host_us_" + ph) / 1e3, ctx.get_stat("host_n_" + ph), ctx.get_stat("host_max_us_" + ph) / 1e3)
     return out
 

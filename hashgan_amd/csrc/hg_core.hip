@@ -67,7 +67,7 @@ void build_shape(int n, ApShape& sh) {
 
 
 std::atomic<unsigned long long> g_alloc_epoch{1};
-const char* const kHostPhaseNames[HP_COUNT] = {"init", "devmalloc", "devfree", "hostmalloc", "hostfree", "destroy", "stream", "event"};
+const char* const kHostPhaseNames[HP_COUNT] = {"init", "devmalloc", "devfree", "hostmalloc", "hostfree", "destroy", "stream", "event", "sync", "pack", "thread"};
 std::atomic<long long> g_host_ns[HP_COUNT], g_host_calls[HP_COUNT], g_host_max_ns[HP_COUNT];
 
 // ---- the process-wide cache of device blocks, pinned blocks and streams (hg_ctx.hpp) ----------------------------------
@@ -486,6 +486,7 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
         HG_TRY(ensure_stream2(c));
         HG_TRY(feats.reserve(fb_f + 256));
         try {
+            HostTimer t_thr(HP_THREAD);                  // ("thread": starting the staging thread)
             stager = std::thread([&] {
                 if (hipSetDevice(c->device) != hipSuccess) { stage_rc = HG_ERR_HIP; stage_msg = "hipSetDevice failed in the staging thread"; return; }
                 stage_rc = stage_floats(c, x, n, b, bpad_f, feats, c->stream2, 1);
@@ -497,6 +498,7 @@ static int pack_on_host(hg_ctx* c, const float* x, const int64_t* lab, i64 n, De
     }
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{stager};
     try {
+        HostTimer t_pack(HP_PACK);                       // ("pack": the packing pool's pass over the arrays, prefixes shipped meanwhile)
         host_pack_ship(x, lab, n, b, C, hc, hl, &cs, 0,
                        +[](void* f, long long rows) { (*static_cast<decltype(ship)*>(f))(rows); }, &ship);
     } catch (const std::exception& e) {               // no exception crosses the C ABI (thread creation can fail)
@@ -569,6 +571,15 @@ int hg_set_database_f32(hg_ctx* c, const float* host_x, const int64_t* host_labe
     return HG_OK;
 }
 
+// hg_set_queries: dst_a[i] = src_a[(i / dw) * sw + i % dw] (packed code rows: the unused upper half of an odd row's last 64-bit word is dropped),
+// dst_b[j] = src_b[j] (label words) -- sources in pinned host memory
+static __global__ __launch_bounds__(256) void k_copy_in(const u32* __restrict__ src_a, u32* __restrict__ dst_a, const i64 na, const int sw, const int dw,
+                                                        const u32* __restrict__ src_b, u32* __restrict__ dst_b, const i64 nb) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < na) { const i64 r = i / dw; dst_a[i] = src_a[r * sw + (i - r * dw)]; }
+    else if (i - na < nb) dst_b[i - na] = src_b[i - na];
+}
+
 // A new query table of the SAME size on an unchanged database and configuration keeps hg_map_begin's licence to enqueue blind:
 // every buffer of the step is sized by Q, nothing about the bet depends on what the queries are (its verdict is checked on the
 // GPU either way), so a caller that hands over batch after batch keeps two steps in flight.
@@ -637,9 +648,20 @@ int hg_set_queries(hg_ctx* c, const uint64_t* codes, const uint64_t* labels, int
     if (!qs.ev) HG_HIP(hipEventCreateWithFlags(&qs.ev, hipEventDisableTiming));
     memcpy(qs.pin, codes, cb);
     memcpy((char*)qs.pin + cb, labels, lb);
-    HG_TRY(upload_codes(c, c->qc, (const uint64_t*)qs.pin, Q, W, c->NW));
+    HG_TRY(c->qc.reserve((size_t)Q * c->NW * 4 + 64 * 4));
     HG_TRY(c->qlab.reserve(lb));
-    HG_HIP(hipMemcpyAsync(c->qlab.p, (const char*)qs.pin + cb, lb, hipMemcpyHostToDevice, c->stream));
+    // fetched by a KERNEL out of the pinned block (it is device-addressable: loads over the link), like k_copy_out the other way: a
+    // copy-engine transfer of these 160 KB sits ~20 us on the stream behind a cross-queue barrier -- per step, for a caller that hands
+    // over a new batch per step (a small table only: a big one is the copy engines' work)
+    if (cb + lb <= ((size_t)4 << 20)) {
+        const i64 nc = (i64)Q * c->NW, nl = (i64)Q * c->LW * 2;
+        hipLaunchKernelGGL(k_copy_in, dim3(grid_for(nc + nl)), dim3(256), 0, c->stream, (const u32*)qs.pin, c->qc.as<u32>(), nc, 2 * W, c->NW,
+                           (const u32*)((const char*)qs.pin + cb), c->qlab.as<u32>(), nl);
+        HG_TRY(c->check_launch("k_copy_in"));
+    } else {
+        HG_TRY(upload_codes(c, c->qc, (const uint64_t*)qs.pin, Q, W, c->NW));
+        HG_HIP(hipMemcpyAsync(c->qlab.p, (const char*)qs.pin + cb, lb, hipMemcpyHostToDevice, c->stream));
+    }
     HG_HIP(hipEventRecord(qs.ev, c->stream));
     qs.used = true;
     c->stage = ST_DB | ST_Q;

@@ -53,7 +53,7 @@ extern std::atomic<unsigned long long> g_alloc_epoch;   // bumped by every conte
 // Host-side cost of the runtime calls a context makes outside its kernels -- creating it, device and pinned allocations and
 // their release -- accumulated process-wide (hg_get_stat "host_us_<phase>", "host_n_<phase>", "host_max_us_<phase>"): what a
 // caller that builds a context per evaluation (main.py:164 builds a MAPs per evaluation) pays before any kernel runs.
-enum HostPhase { HP_INIT = 0, HP_DEVMALLOC, HP_DEVFREE, HP_HOSTMALLOC, HP_HOSTFREE, HP_DESTROY, HP_STREAM, HP_EVENT, HP_COUNT };
+enum HostPhase { HP_INIT = 0, HP_DEVMALLOC, HP_DEVFREE, HP_HOSTMALLOC, HP_HOSTFREE, HP_DESTROY, HP_STREAM, HP_EVENT, HP_SYNC, HP_PACK, HP_THREAD, HP_COUNT };
 extern const char* const kHostPhaseNames[HP_COUNT];
 extern std::atomic<long long> g_host_ns[HP_COUNT], g_host_calls[HP_COUNT], g_host_max_ns[HP_COUNT];
 struct HostTimer {
@@ -480,7 +480,7 @@ struct hg_ctx {
         pending.clear();
     }
     int sync() {
-        HG_HIP(hipStreamSynchronize(stream));
+        HG_HIP(host_timed(HP_SYNC, [&] { return hipStreamSynchronize(stream); }));     // ("sync": waiting for the GPU -- kernels and copies included)
         if (pending.size() > 4096) t_collect();       // otherwise the elapsed times are read when somebody asks for them
         return HG_OK;
     }

@@ -33,7 +33,10 @@ void host_pack_warm();      // start the pools' threads now (hg_preload)
 #include <immintrin.h>
 #include <linux/futex.h>
 #include <pthread.h>
+#include <sched.h>
 #include <sys/syscall.h>
+#include <cstdio>
+#include <cstdlib>
 #include <unistd.h>
 #include <algorithm>
 #include <cstring>
@@ -152,17 +155,23 @@ public:
     // f(0) .. f(parts - 1); the caller takes parts too unless `caller_waits` hands it another duty: then it runs
     // on_progress(done_parts) in a loop (done_parts: how many of the LOWEST-numbered parts are complete, monotone) until all
     // are -- parts are claimed in ascending order, so a caller can ship finished prefixes while the rest is in the works.
-    template <class F> bool run(int parts, const F& f) { return run_impl(parts, f, (void (*)(void*, int))nullptr, nullptr); }
-    template <class F, class P> bool run_progress(int parts, const F& f, const P& on_progress) {
+    // max_helpers: worker threads that may take parts (0: one per part).  With a shipping caller the parts outnumber the threads
+    // meant to work on them (four per thread, so that prefixes complete early): until round 6 every PART got a thread -- 256 of
+    // them on the GPU box's 256 hardware threads, next to the caller, the staging thread and its pool -- and one call in fifteen
+    // waited 20 - 70 ms for a worker that had claimed a part and lost its processor (tools/literal_outliers.py).
+    template <class F> bool run(int parts, const F& f, int max_helpers = 0) { return run_impl(parts, f, (void (*)(void*, int))nullptr, nullptr, max_helpers); }
+    template <class F, class P> bool run_progress(int parts, const F& f, const P& on_progress, int max_helpers = 0) {
         struct PC { const P* p; } pc{&on_progress};
-        return run_impl(parts, f, +[](void* c, int done) { (*static_cast<PC*>(c)->p)(done); }, &pc);
+        return run_impl(parts, f, +[](void* c, int done) { (*static_cast<PC*>(c)->p)(done); }, &pc, max_helpers);
     }
 private:
     struct Job { void (*call)(void*, int) = nullptr; void* arg = nullptr; int parts = 0; };
-    template <class F> bool run_impl(int parts, const F& f, void (*progress)(void*, int), void* parg) {
+    template <class F> bool run_impl(int parts, const F& f, void (*progress)(void*, int), void* parg, int max_helpers) {
         std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
         if (!job.owns_lock()) return false;
-        const int helpers = progress ? parts : parts - 1;                // (a caller that ships prefixes packs nothing itself)
+        int helpers = progress ? parts : parts - 1;                      // (a caller that ships prefixes packs nothing itself)
+        if (max_helpers > 0 && helpers > max_helpers) helpers = max_helpers;
+        if (progress && helpers < 1) helpers = 1;
         while ((int)th_.size() < helpers) {
             const uint32_t seen = gen_.load();
             th_.emplace_back([this, seen] { worker(seen); });
@@ -244,23 +253,56 @@ inline Pool& pool(int which = 0) {
 
 }  // namespace hostpack
 
+// Threads a pool may put to work at once.  Two limits beyond the hardware's count: the process's affinity mask, and the cgroup's CPU
+// quota -- the GPU box gives a 256-hardware-thread machine a quota of 16 CPUs (cpu.max "1600000 100000"): 64 packing threads in
+// back-to-back calls ran it dry and one call in twenty stood still for 20 - 70 ms until the next period (tools/literal_outliers.py;
+// with 32 threads none did, and the median call was faster too).  Twice the quota: a call's burst is a millisecond or two.
+inline int default_pack_threads() {
+    static const int cached = [] {
+        unsigned hw = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0 && (unsigned)n < hw) hw = (unsigned)n; }
+        int threads = hw <= 64 ? (int)std::min<unsigned>(hw ? hw : 1u, 32u) : (int)std::min<unsigned>(hw / 4, 64u);
+        double quota = 0.0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                      // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            long long per = 0;
+            if (fscanf(f, "%31s %lld", q, &per) == 2 && per > 0 && strcmp(q, "max") != 0) quota = (double)atoll(q) / (double)per;
+            fclose(f);
+        } else {                                                                  // cgroup v1
+            long long q = -1, per = 0;
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
+            if (q > 0 && per > 0) quota = (double)q / (double)per;
+        }
+        if (quota > 0.0) {
+            const int lim = std::max(2, (int)(2.0 * quota + 0.5));
+            if (threads > lim) threads = lim;
+        }
+        if (const char* e = getenv("HG_PACK_THREADS")) { const int v = atoi(e); if (v > 0) threads = v; }
+        return threads;
+    }();
+    return cached;
+}
+
 // on_rows(rows_done): optional; called from the CALLING thread, with a growing count, whenever another prefix of the rows
 // is packed (the caller then packs nothing itself: it ships those rows -- hipMemcpyAsync -- while the workers go on).
 inline void host_pack_ship(const float* x, const int64_t* lab, long long n, int b, int C, uint32_t* codes, uint64_t* labels,
                            HostPackCensus* census, int threads, void (*on_rows)(void*, long long), void* on_rows_arg) {
     const bool wide = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
     if (threads <= 0) {
-        const unsigned hw = std::thread::hardware_concurrency();
         // the pass is memory bound: on the GPU box (2 x 64 cores, 256 hardware threads) hg_set_database_f32 at C2 takes
         // 1.67 ms with 32 threads, 1.38 with 64, 1.39 with 96, 1.59 with 128, 1.86 with 192 (tools/h2d_split.py, round 3:
         // futex wake-up, four parts per thread claimed in order, prefixes shipped while the rest packs; with the
         // condition-variable pool and one part per thread it was 2.8 / 2.2 / 2.0 / 1.65 / 1.66)
-        threads = hw <= 64 ? (int)std::min<unsigned>(hw ? hw : 1u, 32u) : (int)std::min<unsigned>(hw / 4, 64u);
+        // (round 6: and never more than twice the cgroup's CPU quota: default_pack_threads)
+        threads = default_pack_threads();
     }
     const long long bytes = n * ((long long)(x ? b * 4 : 0) + (lab ? C * 8 : 0));
     threads = (int)std::max<long long>(1, std::min<long long>(threads, bytes >> 20));    // at least ~1 MB of input per thread
-    // with a shipping caller: four parts per thread, claimed in ascending order, so prefixes complete early
-    const int parts = on_rows && threads > 1 ? threads * 4 : threads;
+    // with a shipping caller: eight parts per thread, claimed in ascending order, so prefixes complete early (round 6: 32 threads x 8 parts
+    // measured 2.64 - 2.76 ms per C2 call against 2.88 - 3.30 with x 4: finer prefixes to ship, an evener finish)
+    const int parts = on_rows && threads > 1 ? threads * 8 : threads;
     std::vector<HostPackCensus> part((size_t)parts);
     auto work = [&](int t) {
         const long long r0 = n * t / parts, r1 = n * (t + 1) / parts;
@@ -272,7 +314,8 @@ inline void host_pack_ship(const float* x, const int64_t* lab, long long n, int 
         work(0);
         ran = true;
     } else if (on_rows) {
-        ran = hostpack::pool().run_progress(parts, work, [&](int done) { on_rows(on_rows_arg, n * done / parts); });
+        static const int cap = getenv("HG_PACK_HELPERS") ? atoi(getenv("HG_PACK_HELPERS")) : 0;      // (experiments)
+        ran = hostpack::pool().run_progress(parts, work, [&](int done) { on_rows(on_rows_arg, n * done / parts); }, cap > 0 ? cap : threads);
     } else {
         ran = hostpack::pool().run(parts, work);
     }
@@ -296,10 +339,7 @@ inline void host_pack_ship(const float* x, const int64_t* lab, long long n, int 
 inline void host_copy_rows(const float* x, long long r0, long long r1, int b, int bpad, float* dst, int threads, int which_pool) {
     const long long rows = r1 - r0;
     if (rows <= 0) return;
-    if (threads <= 0) {
-        const unsigned hw = std::thread::hardware_concurrency();
-        threads = hw <= 64 ? (int)std::min<unsigned>(hw ? hw : 1u, 32u) : (int)std::min<unsigned>(hw / 4, 64u);
-    }
+    if (threads <= 0) threads = default_pack_threads();
     // a 16 MB chunk per call: sixteen threads copy it faster than PCIe takes it (the next chunk's copy runs under this one's
     // DMA); waking 64 for 256 KB each was slower -- 1M x 64 floats: 8.8 ms per hg_set_database_f32 against 7.0
     const long long bytes = rows * (long long)bpad * 4;
@@ -322,10 +362,9 @@ inline void host_copy_rows(const float* x, long long r0, long long r1, int b, in
 // hg_preload: the pools' threads start with the first job that wants them (a few milliseconds for the packing pool's 4 x 64):
 // an empty job of the largest shape starts them now
 inline void host_pack_warm() {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int threads = hw <= 64 ? (int)std::min<unsigned>(hw ? hw : 1u, 32u) : (int)std::min<unsigned>(hw / 4, 64u);
+    const int threads = default_pack_threads();
     auto nop = [](int) {};
-    if (threads > 1) (void)hostpack::pool(0).run_progress(threads * 4, nop, [](int) {});
+    if (threads > 1) (void)hostpack::pool(0).run_progress(threads * 8, nop, [](int) {}, threads);
     (void)hostpack::pool(1).run(std::min(threads, 16), nop);
 }
 

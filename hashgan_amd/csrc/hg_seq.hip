@@ -97,12 +97,23 @@ bool hist_mx_applies(const hg_ctx* c, int stride, bool pairs_ok) {
 }
 
 // The record pass of the current sequence: which kernel takes it (the launchers live in hg_pairs_valu.hip / hg_pairs_mx.hip).
+// one-byte records {match, dist} (no index): only the matrix-core kernels of the bet produce them, and only when nobody wants the lists
+static bool select_takes_mx(const hg_ctx* c) { return c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS); }
+static bool records_are_bytes(const hg_ctx* c) {
+    return select_takes_mx(c) && c->opt_compact && !c->want_lists && c->LW <= 2 && c->cap % 16 == 0 && c->crow * 64 < (1ll << 31);
+}
+// the record rows of the coming select: Q x crow slots of one byte or eight.  (Until round 6 eight bytes were reserved either way:
+// 2 GB at C2 for 0.25 GB of records -- and 14.9 GB once a class-sorted database had widened the slices, a hipMalloc that took
+// between 0.4 ms and 3.5 s.)
+static int reserve_records(hg_ctx* c) {
+    return c->cand.reserve((size_t)c->geo.Q * (size_t)c->crow * (records_are_bytes(c) ? 1 : 8) + 64);
+}
+
 int launch_select(hg_ctx* c) {
     const int NW = c->NW;
     const int lw = c->LW <= 2 ? c->LW : 0;           // > 128 classes: match bits come from k_match
-    // one-byte records (no index): only the matrix-core kernels of the bet produce them, and only when nobody wants the lists
-    const bool mx = c->optimistic && c->opt_select_mfma && c->cap < (1u << MX_POS_BITS);
-    c->rec8 = mx && c->opt_compact && !c->want_lists && c->LW <= 2 && c->cap % 16 == 0 && c->crow * 64 < (1ll << 31);
+    const bool mx = select_takes_mx(c);
+    c->rec8 = records_are_bytes(c);
     if (!c->optimistic && c->R * 4 >= c->n_total) { c->last_select = 2; return launch_select_dense(c, lw); }   // dense regime: most pairs are selected
     // three rows per accumulator + batched drain: codes of <= 64 bits, one-byte records (<= 128 classes).  (For <= 32 bits the
     // second k-half of every MFMA is empty, and it still beat round 2's two-rows-per-accumulator kernel: 0.69 vs 0.85 ms at b = 32.)
@@ -574,7 +585,7 @@ static int do_select(hg_ctx* c) {
     const Geo& g = c->geo;
     const size_t slots = (size_t)g.Q * g.R;
     if (c->LW > 2) c->want_lists = true;                  // k_match gathers through the idx list
-    HG_TRY(c->cand.reserve((size_t)g.Q * c->crow * 8));
+    HG_TRY(reserve_records(c));
     HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
     HG_TRY(c->out_idx.reserve(c->want_lists ? slots * 4 : 16));
     HG_TRY(c->out_dist.reserve(c->want_lists ? slots : 16));
@@ -695,7 +706,7 @@ int hg_select_candidates(hg_ctx* c) {
     if (!c->optimistic) return fail(HG_ERR_STATE, "hg_select_candidates: no guess in force (use hg_select after hg_plan)");
     const Geo& g = c->geo;
     c->want_lists = c->staged_lists != 0 || c->LW > 2;  // decides the record format (hg_rank places them)
-    HG_TRY(c->cand.reserve((size_t)g.Q * c->crow * 8));
+    HG_TRY(reserve_records(c));
     HG_TRY(launch_select(c));
     const size_t plane = (size_t)g.NB * g.Qpad * 4;
     HG_HIP(hipMemsetAsync(c->hown.as<char>() + plane, 0, TAIL_WORDS * 4, c->stream));
@@ -718,7 +729,7 @@ int hg_select_ranked(hg_ctx* c) {
     const bool wide = c->LW > 2;
     c->want_lists = wide;
     const size_t slots = (size_t)g.Q * g.R;
-    HG_TRY(c->cand.reserve((size_t)g.Q * c->crow * 8));
+    HG_TRY(reserve_records(c));
     HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
     HG_TRY(c->out_idx.reserve(wide ? slots * 4 : 16)); HG_TRY(c->out_dist.reserve(wide ? slots : 16));
     if (wide) HG_HIP(hipMemsetAsync(c->out_idx.p, 0xFF, slots * 4, c->stream));    // slots past the shard's own records: IDX_NONE

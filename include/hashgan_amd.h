@@ -320,7 +320,8 @@ int hg_trim(hg_ctx* ctx);
  * evaluation -- would pay that per call).  At most HG_CACHE_MB (49152: a sixth of the part's 288 GB) of device and HG_PIN_CACHE_MB (512) of pinned memory are
  * held; hg_release_cache returns all of it to the runtime.  Stats (any context): "cache_device_bytes", "cache_pinned_bytes",
  * "cache_hits", "cache_misses", "cache_streams"; "host_us_<phase>" / "host_n_<phase>" / "host_max_us_<phase>" with phase one of
- * init, devmalloc, devfree, hostmalloc, hostfree, destroy, stream, event: what the process has spent in those runtime calls.
+ * init, devmalloc, devfree, hostmalloc, hostfree, destroy, stream, event, sync (waiting for the GPU), pack (host packing pass), thread
+ * (starting the float table's staging thread): what the process has spent there.
  * The reference has no counterpart (lib/metric.py allocates NumPy arrays per call). */
 int hg_release_cache(void);
 /* Pay now what a context otherwise pays on first use of each path: the second stream and the pinned staging of the float
