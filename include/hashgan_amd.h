@@ -194,8 +194,13 @@ int hg_map(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel);
  * two steps may be in flight (a third hg_map_begin is HG_ERR_STATE), so the GPU starts one step the moment the previous one
  * ends.  A step is only enqueued blind when the last synchronous hg_map on the same tables, options and R won its bet
  * outright; otherwise hg_map_begin runs the whole call itself.  A blind step that loses its bet is run again by hg_map_end.
- * Replacing the tables between the two halves is allowed only for steps that won (else HG_ERR_STATE).
- * Stats "map_async_steps" / "map_async_redone". */
+ * Replacing the tables between the two halves is allowed only for steps that won: hg_map_end on a LOST step whose query or database
+ * table has been loaded again since its hg_map_begin (whatever the new table's size) returns HG_ERR_STATE -- never the new batch's
+ * results under the old step's name.  A new query table of the SAME size on an unchanged database and configuration keeps the licence
+ * to enqueue blind, and hg_set_queries does not wait for the stream (the tables travel through a pinned block of the context's own):
+ * a caller that hands over batch after batch -- hg_set_queries, hg_map_begin, the previous batch's hg_map_end -- keeps two steps in
+ * flight.  Stats "map_async_steps" / "map_async_redone".  Test hook: option "handicap_next_bet" (0..64; not a configuration change)
+ * puts the NEXT bet's guess that many deviations below the expected count, once: the bet loses. */
 int hg_map_begin(hg_ctx* ctx, int64_t R);
 int hg_map_end(hg_ctx* ctx, double* host_ap, int64_t* host_rel);
 
@@ -297,7 +302,7 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  *                 ALU), "real_sample_half" (1: the sampled cut's scores in the filter's 16-bit arithmetic -- they only place the cut; 0: exact float32 chains), "real_sort_lds" (1: ranked by the LDS-resident kernel when the records fit), "real_groups" (1: lists beyond the LDS ordered group by group)
  *   ("probe_select" exists only in the measurement build, python -m hashgan_amd.build --probes) */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
-/* Counters and facts about the last call (22 keys): "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly),
+/* Counters and facts about the last call (22 keys; the process-wide "cache_*" and "host_*" keys are listed at hg_release_cache): "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly),
  * "optimistic_requeried" (single queries rerun exactly after losing their bet), "optimistic_rebets" (second and widened bets), "last_optimistic",
  * "rank_leftovers" (queries the LDS-resident rank kernel left to the general one), "select_variant" (1 k_select, 2 k_select_dense, 3 k_select_mx,
  * 5 k_select_mx3, 6 k_select_mx4), "rank_variant" (1 k_rank_fused, 3 k_rank_cnt, 6 k_rank_lean, 7 k_rank_dense, 8 k_rank_dense<slices>), "ap_fused",
