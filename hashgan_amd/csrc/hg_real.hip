@@ -163,7 +163,7 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     case sg:                                                                                                                             \
         hipLaunchKernelGGL((k_real_rescore<(KP <= 128 ? KP : 0), sg>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(),  \
                            c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(),               \
-                           c->sl_cnt.as<u32>(), c->cntq.as<u32>(), KP, g);                                                               \
+                           c->sl_cnt.as<u32>(), c->cntq.as<u32>(), c->dblab.as<u64>(), c->qlab.as<u64>(), c->real_no_cut ? 0 : 1, KP, g);                         \
         break;
 #ifdef HG_RS_FORCE
     switch (SG) { HG_RESCORE(HG_RS_FORCE) }
@@ -590,6 +590,7 @@ static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
                                   "hg_set_queries_f32 (option keep_floats = 1 if the database is a +-1 code)");
     if (c->n_total != c->N) return fail(HG_ERR_STATE, "real-valued ranking is single-shard");
     if (R < 1 || R > c->N) return fail(HG_ERR_ARG, "R=%lld outside 1..N (N=%lld rows in the database)", (long long)R, (long long)c->N);
+    if (c->N > 0x7FFFFFFFll) return fail(HG_ERR_ARG, "real-valued ranking takes up to 2^31 - 1 rows (have %lld)", (long long)c->N);   // (bit 31 of a record's index half is its match bit)
     int lost = 0;
     c->real_attempts = 0;
     if (with_ap && !c->is_sub) HG_TRY(ensure_out_block(c));      // verdict, APs and hit counts side by side: one download

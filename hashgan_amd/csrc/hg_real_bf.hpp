@@ -427,7 +427,8 @@ constexpr int rescore_lds_bytes() { return WPB * 64 * RS_ROWB; }
 template <int KPT, int SG>          // KPT: the (padded) feature count, 0 = taken at run time (kp_rt; beyond 128 features)
 __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ qf, const float* __restrict__ dbf, const u32* sl_cnt,
                                                       u64* __restrict__ cand, u32 cap, i64 crow, const float* __restrict__ thr,
-                                                      u32* sl_cnt_out, u32* __restrict__ cnt_by_query, const int kp_rt, const Geo g) {      // (sl_cnt_out may be sl_cnt; cnt_by_query: the same counts [Q][S])
+                                                      u32* sl_cnt_out, u32* __restrict__ cnt_by_query, const u64* __restrict__ dblab, const u64* __restrict__ qlab,
+                                                      const int embed_match, const int kp_rt, const Geo g) {      // (sl_cnt_out may be sl_cnt; cnt_by_query: the same counts [Q][S])
     const int KP = KPT ? KPT : kp_rt;
     extern __shared__ __attribute__((aligned(16))) u8 rlds[];
     const int lane = threadIdx.x & 63;
@@ -482,6 +483,10 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
             idx_next = (u32)rows[(i64)kn * cap + offn];
         }
         const u32 local = idx - g.idx_base;
+        // the row's label words travel with its features (round 6): the record takes its label-match bit (metric.py:17-19) along as bit 31 of
+        // the index half (a float table has fewer than 2^31 rows: run_real), and k_real_rank_lds no longer gathers 8 bytes per RANK out of the
+        // label table -- 2.3 GB of fetches per call at 10k x 1M for 0.6 GB of records, its list phase a quarter of its time
+        const u64 lab0 = dblab[(i64)local * g.LW];
         u32 ridx[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) ridx[e] = (u32)__shfl((int)local, 8 * e + pr);
@@ -541,7 +546,12 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
             if (k == x) { mine = m; before = kept[x]; }
             kept[x] += (u32)__popcll(bal & m);
         }
-        if (pass) rows[(i64)k * cap + before + (u32)__popcll(bal & mine & below)] = ((u64)(~mono_key(ipv)) << 32) | (u64)idx;
+        if (pass) {
+            u64 any = lab0 & qlab[(i64)q * g.LW];
+            for (int w = 1; w < g.LW; ++w) any |= dblab[(i64)local * g.LW + w] & qlab[(i64)q * g.LW + w];
+            // (embed_match = 0: the records go to kernels that order by the whole 64 bits -- every row a record, > 128 features)
+            rows[(i64)k * cap + before + (u32)__popcll(bal & mine & below)] = ((u64)(~mono_key(ipv)) << 32) | (u64)(idx | (any && embed_match ? 0x80000000u : 0u));
+        }
     }
 #pragma unroll
     for (int x = 0; x < SG; ++x)
@@ -960,18 +970,14 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
         }   // !ordered
         if (!bad) {
             // ---- 5: the ranked list, and its label-match bits (metric.py:17-19; k_match's gather, one launch saved) ----
-            const u64* __restrict__ ql = qlab + (i64)q * g.LW;
+            (void)dblab; (void)qlab;
             for (u32 k = tid; k < (u32)RW * 64u; k += 1024) {
                 bool m = false;
                 if (k < R) {
                     const u64 rec = A[Pfin[k]];
-                    const u32 gi = (u32)rec;
-                    out_idx[(i64)q * g.R + k] = gi;
+                    out_idx[(i64)q * g.R + k] = (u32)rec & 0x7FFFFFFFu;
                     if (scores) scores[(i64)q * g.R + k] = mono_inv(~(u32)(rec >> 32));
-                    const u64* __restrict__ dl = dblab + (i64)(gi - g.idx_base) * g.LW;
-                    u64 any = 0;
-                    for (int w = 0; w < g.LW; ++w) any |= dl[w] & ql[w];
-                    m = any != 0;
+                    m = ((u32)rec >> 31) != 0u;               // the match bit k_real_rescore left in the record
                 }
                 const u64 word = __ballot(m);
                 if (lane == 0) mbits[(i64)q * RW + (k >> 6)] = word;

@@ -330,7 +330,7 @@ static __global__ __launch_bounds__(256) void k_real_finish(const u64* __restric
     if (k == 0) { qbad[q] = bad ? 1u : 0u; if (bad) atomicExch(err, 1); }
     if (bad || k >= g.R) return;
     const u64 rec = sorted[(i64)q * crow + k];
-    out_idx[(i64)q * g.R + k] = (u32)rec;
+    out_idx[(i64)q * g.R + k] = thr ? (u32)rec & 0x7FFFFFFFu : (u32)rec;      // (filtered records carry their match bit as bit 31: k_real_rescore)
     if (scores) scores[(i64)q * g.R + k] = mono_inv(~(u32)(rec >> 32));
 }
 
