@@ -34,6 +34,7 @@ void host_pack_warm();      // start the pools' threads now (hg_preload)
 #include <linux/futex.h>
 #include <pthread.h>
 #include <sched.h>
+#include <stdint.h>
 #include <sys/syscall.h>
 #include <cstdio>
 #include <cstdlib>
@@ -142,6 +143,52 @@ inline long futex(std::atomic<uint32_t>* addr, int op, uint32_t val) {
     return syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), op | FUTEX_PRIVATE_FLAG, val, nullptr, nullptr, 0);
 }
 
+// NUMA: which node holds a host array, and which processors belong to a node.  On the GPU box (two sockets) a packing pass whose threads
+// sit on the OTHER node than the caller's arrays takes 3.4 - 3.6 ms instead of 1.5 - 1.7 at C2 (tools/numa_probe.py) -- and where the
+// scheduler puts a pool's threads is luck: whole boxes measured 4.5 ms per literal call where others measured 2.6.  A pool's workers are
+// therefore confined to the node of the array they are about to read (the process's own affinity mask permitting).
+inline int node_of_address(const void* p) {
+    int node = -1;
+    const long r = syscall(SYS_get_mempolicy, &node, nullptr, 0ul, (unsigned long)(uintptr_t)p, 3ul /* MPOL_F_NODE | MPOL_F_ADDR */);
+    return r == 0 ? node : -2;                                           // -2: the call is not available (seccomp): ask where the caller runs
+}
+inline int node_of_range(const void* base, size_t bytes, size_t min_bytes = (size_t)32 << 20) {   // -1: mixed or unknown (no confinement); -3: no opinion
+    if (!base || bytes < min_bytes) return -3;                           // small arrays: not worth moving threads for -- the pool stays where it is
+    int node = -1;
+    for (int k = 0; k < 5; ++k) {
+        const int n = node_of_address((const char*)base + (bytes - 1) / 4 * k);
+        if (n == -2) {                                                   // the caller's own node: where its arrays were most likely first touched
+            unsigned cpu = 0, nd = 0;
+            return syscall(SYS_getcpu, &cpu, &nd, nullptr) == 0 ? (int)nd : -1;
+        }
+        if (n < 0) return -1;
+        if (k == 0) node = n; else if (n != node) return -1;
+    }
+    return node;
+}
+inline bool node_cpus(int node, cpu_set_t* out) {                        // the node's processors that this process may use
+    CPU_ZERO(out);
+    char path[64];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char buf[1024] = {0};
+    const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!ok) return false;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    int n = 0;
+    for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int got = sscanf(tok, "%d-%d", &a, &b);
+        if (got < 1) continue;
+        if (got == 1) b = a;
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed)) { CPU_SET(c, out); ++n; }
+    }
+    return n >= 8;                                                       // (a handful of processors would be worse than the wrong node)
+}
+
 // Workers that outlive a call: starting and joining 31 threads cost 0.5 ms of a 4 ms call at C2 (17 us each on the GPU
 // box's EPYC).  One job at a time (a second caller in another thread finds the pool busy and starts threads of its own,
 // as every call did before).
@@ -159,6 +206,19 @@ public:
     // meant to work on them (four per thread, so that prefixes complete early): until round 6 every PART got a thread -- 256 of
     // them on the GPU box's 256 hardware threads, next to the caller, the staging thread and its pool -- and one call in fifteen
     // waited 20 - 70 ms for a worker that had claimed a part and lost its processor (tools/literal_outliers.py).
+    // confine the workers to `node`'s processors (-1: wherever the process may run) from the next job on; a busy pool keeps what it has
+    void set_node(int node) {
+        std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
+        if (!job.owns_lock() || node == node_) return;
+        cpu_set_t mask;
+        if (node >= 0) { if (!node_cpus(node, &mask)) return; }
+        else if (sched_getaffinity(0, sizeof mask, &mask) != 0) return;
+        int failed = 0;
+        for (auto& t : th_) failed += pthread_setaffinity_np(t.native_handle(), sizeof mask, &mask) != 0;
+        static const bool trace = getenv("HG_PACK_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[hg pack] pool %p: %zu workers -> node %d (%d processors; %d refused)\n", (void*)this, th_.size(), node, CPU_COUNT(&mask), failed);
+        mask_ = mask; node_ = node;
+    }
     template <class F> bool run(int parts, const F& f, int max_helpers = 0) { return run_impl(parts, f, (void (*)(void*, int))nullptr, nullptr, max_helpers); }
     template <class F, class P> bool run_progress(int parts, const F& f, const P& on_progress, int max_helpers = 0) {
         struct PC { const P* p; } pc{&on_progress};
@@ -175,6 +235,7 @@ private:
         while ((int)th_.size() < helpers) {
             const uint32_t seen = gen_.load();
             th_.emplace_back([this, seen] { worker(seen); });
+            if (node_ >= 0) (void)pthread_setaffinity_np(th_.back().native_handle(), sizeof mask_, &mask_);
         }
         struct Ctx { const F* f; } ctx{&f};
         if ((int)flags_.size() < parts) flags_ = std::vector<std::atomic<unsigned char>>((size_t)parts);
@@ -228,6 +289,8 @@ private:
         }
     }
     std::mutex job_mu_;
+    int node_ = -1;                                                        // the node the workers are confined to (set_node)
+    cpu_set_t mask_;
     std::vector<std::thread> th_;
     Job jobs_[2];
     std::vector<std::atomic<unsigned char>> flags_;                       // part i done (only resized under job_mu_, between jobs)
@@ -310,6 +373,13 @@ inline void host_pack_ship(const float* x, const int64_t* lab, long long n, int 
         else hostpack::rows_scalar(x, lab, r0, r1, b, C, codes, labels, part[(size_t)t]);
     };
     bool ran = false;
+    if (parts > 1) {
+        static const bool pin = !getenv("HG_PACK_NO_NUMA");
+        if (pin) {
+            const int node = x ? hostpack::node_of_range(x, (size_t)n * b * 4) : hostpack::node_of_range(lab, (size_t)n * C * 8);
+            if (node != -3) hostpack::pool().set_node(node);
+        }
+    }
     if (parts == 1) {
         work(0);
         ran = true;
@@ -355,6 +425,13 @@ inline void host_copy_rows(const float* x, long long r0, long long r1, int b, in
             }
         }
     };
+    if (threads > 1) {
+        static const bool pin = !getenv("HG_PACK_NO_NUMA");
+        if (pin) {
+            const int node = hostpack::node_of_range(x + r0 * b, (size_t)rows * b * 4, (size_t)4 << 20);
+            if (node != -3) hostpack::pool(which_pool).set_node(node);
+        }
+    }
     if (threads == 1 || !hostpack::pool(which_pool).run(threads, work))  // (a busy pool: this thread alone)
         for (int t = 0; t < threads; ++t) work(t);
 }
