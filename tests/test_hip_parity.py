@@ -184,6 +184,38 @@ def test_a_new_maps_object_per_evaluation_recycles_one_context(case_cache):
     assert pool_stats()["contexts_idle"] == 0 and pool_stats()["idle_device_bytes"] == 0
 
 
+def test_block_cache_serves_new_contexts(case_cache):
+    """hg_init / hg_destroy as a caller without the Python pool would use them (a context per evaluation): after the first context
+    has come and gone, a new one takes its device blocks, pinned blocks and stream from the library's process-wide cache -- no
+    hipMalloc, no hipHostMalloc, no hipStreamCreate (host-phase counters) -- and hg_release_cache hands everything back."""
+    c = case_cache("c2_q64")
+    g = cases.load_golden("c2_q64")
+
+    def cycle():
+        ctx = _native.Context(0)
+        try:
+            _load(ctx, c)
+            ap, _ = ctx.map(c["R"])
+            assert np.array_equal(ap, g["ap"], equal_nan=True)
+            return {k: ctx.get_stat(k) for k in ("host_n_devmalloc", "host_n_hostmalloc", "host_n_stream", "cache_hits", "cache_misses")}
+        finally:
+            ctx.close()
+    cycle()                                                # (whatever earlier tests left in the cache: this cycle completes it)
+    first = cycle()
+    for _ in range(4):
+        st = cycle()
+    for k in ("host_n_devmalloc", "host_n_hostmalloc", "host_n_stream", "cache_misses"):
+        assert st[k] == first[k], (k, first, st)
+    assert st["cache_hits"] > first["cache_hits"]
+    probe = _native.Context(0)
+    try:
+        assert probe.get_stat("cache_device_bytes") > 0
+        _native.release_cache()
+        assert probe.get_stat("cache_device_bytes") == 0 and probe.get_stat("cache_pinned_bytes") == 0 and probe.get_stat("cache_streams") == 0
+    finally:
+        probe.close()
+
+
 def test_maps_objects_are_independent_and_keep_a_resident_database(case_cache):
     """Two MAPs objects (own contexts) interleaved, from two threads; set_database / read-only arrays skip the
     re-upload (main.py:237-240 evaluates the same database again and again)."""
