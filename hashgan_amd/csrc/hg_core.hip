@@ -1041,6 +1041,7 @@ int hg_trim(hg_ctx* c) {
     c->stage &= (ST_DB | ST_Q);
     c->lists_valid = false;
     c->real_lists = false;
+    cache_release_all();                               // (a caller that trims wants the memory back at the RUNTIME -- another framework in the process -- not in this library's cache)
     return HG_OK;
 }
 

@@ -317,7 +317,8 @@ int hg_get_stat(hg_ctx* ctx, const char* key, int64_t* value);
  * tells +-1 codes (ranked by Hamming distance), {0,1} bits and real-valued features (ranked by inner product, metric.py:13) apart. */
 int hg_get_census(hg_ctx* ctx, int queries, int64_t out[4]);
 /* Work buffers only grow; hg_trim frees everything except the resident code/label/feature tables
- * (stat "device_bytes" reports what the context holds). */
+ * (stat "device_bytes" reports what the context holds) and empties the process-wide block cache (hg_release_cache): the memory
+ * goes back to the HIP runtime, e.g. for another framework in the same process. */
 int hg_trim(hg_ctx* ctx);
 /* Device blocks, pinned host blocks and streams that a destroyed or trimmed context gives up go to a process-wide cache and the
  * next context takes them from there instead of the HIP runtime (hipMalloc now and then stalls for SECONDS on this stack, a
