@@ -179,7 +179,8 @@ inline bool node_cpus(int node, cpu_set_t* out) {                        // the 
     cpu_set_t allowed;
     if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
     int n = 0;
-    for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    char* save = nullptr;                                                // (two pools may ask at once: the packing pool and the staging thread's)
+    for (char* tok = strtok_r(buf, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {
         int a = 0, b = 0;
         const int got = sscanf(tok, "%d-%d", &a, &b);
         if (got < 1) continue;
