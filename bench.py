@@ -123,7 +123,8 @@ def cpu_baseline(spec, packed, budget_s=12.0, chunk=128):
         quota = None if qs == "max" else float(qs) / float(per)
     except (OSError, ValueError):
         pass
-    return {"value": done / dt, "unit": "queries/s", "cores": os.cpu_count(), "cgroup_cpu_quota": quota, "kind": "port",
+    used = max([n for _, n in (blas or []) if isinstance(n, int)] or [os.cpu_count() or 1])      # threads the run really used: np.dot's BLAS pool (argsort and the loop: one)
+    return {"value": done / dt, "unit": "queries/s", "cores": used, "host_hardware_threads": os.cpu_count(), "cgroup_cpu_quota": quota, "kind": "port",
             "sample": "%d of %d queries (chunks of %d) x full N=%d database in %.1f s; float32 +-1 features; np.dot on "
                       "BLAS threads %s, np.argsort and the per-query loop on 1 core; numpy %s"
                       % (done, Q, chunk, dbf.shape[0], dt, blas, np.__version__)}
