@@ -9,6 +9,7 @@ constexpr double REAL_FIRST_SIGMA = 5.0;        // depth of the first cut in dev
                                               // own (real_requery_lost).  10k x 1M x 64, R = 5000: 6 -> 5.92 ms per call, 5 -> 5.81, 4 -> 5.86, 3.5 -> 6.01 (the
                                               // rescore's time follows its rounds, not its rows: the shallower cut mostly helps the rank stage)
 constexpr i64 REAL_SAMPLE_HITS = 64;          // the real-valued bet samples so that this many of a query's top R rows are in the sample (tools/real_sample_sweep.py: 32 .. 256 measured)
+constexpr i64 REAL_SECOND_SAMPLE = 4;         // the second, counting sample takes every (stride / 4)-th row: 256 expected hits
 constexpr i64 REAL_SEG_BYTES = 512 * 1024;    // bytes of feature rows per segment of the real-valued pair passes
 
 namespace {
@@ -288,6 +289,52 @@ int real_sample_h(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
         default: return real_launch_sample_h<128>(c, M, stride, mstride);
     }
 }
+// the second, counting sample (k_real_sample_count + k_real_guess2): thr[q] moves up to the deepest cut a four times larger sample supports
+template <int KP> int real_launch_sample_count(hg_ctx* c, i64 M2, i64 stride2, u32 need2) {
+    const Geo& g0 = c->geo;
+    const i64 m16 = (M2 + 15) / 16 * 16;
+    HG_TRY(c->sampx.reserve((size_t)m16 * KP * 2));     // (sized for this pass before the first one ran: real_attempt)
+    c->t_begin(KI_REAL_SAMPLE);
+    if (c->dbfb_half) hipLaunchKernelGGL(k_expand_dbf_bf16<true>, dim3(grid_for(m16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
+                                         c->sampx.as<uint4>(), M2, m16, KP, stride2);
+    else hipLaunchKernelGGL(k_expand_dbf_bf16<false>, dim3(grid_for(m16 * (KP / 8))), dim3(256), 0, c->stream, c->dbf.as<float>(),
+                            c->sampx.as<uint4>(), M2, m16, KP, stride2);
+    Geo g = g0;
+    g.N = M2;
+    i64 L = (M2 + 63) / 64;                              // ~64 segments (32 pairs) of a multiple of 16 rows
+    L = (L + 15) / 16 * 16;
+    g.L = L;
+    g.S = (int)((M2 + L - 1) / L);
+    const int nSP = (g.S + 1) / 2;
+    const int nQB = (g.Q + WPB * 64 - 1) / (WPB * 64);
+    g.nQT = nQB;
+    g.nUnits = (i64)nSP * nQB;
+    g.wpb = WPB;
+    g.nBlk = (int)g.nUnits;
+    HG_TRY(c->hist2.reserve((size_t)nSP * g.Qpad * RC_BINS * 4 + (size_t)WPB * 64 * RC_BINS * 4));      // [segment pair][Qpad][bin], every word written (+ a block's overhang past Qpad)
+    if (c->dbfb_half) hipLaunchKernelGGL((k_real_sample_count<KP, true>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
+                                         c->thr.as<float>(), c->hist2.as<u32>(), g);
+    else hipLaunchKernelGGL((k_real_sample_count<KP, false>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
+                            c->thr.as<float>(), c->hist2.as<u32>(), g);
+    c->t_end();
+    HG_TRY(c->check_launch("k_real_sample_count"));
+    c->t_begin(KI_REAL_GUESS);
+    hipLaunchKernelGGL(k_real_guess2, dim3(grid_for(g0.Q, 8)), dim3(256), 0, c->stream, c->hist2.as<u32>(), c->thr.as<float>(), g0.Q, (i64)g0.Qpad, nSP, need2);
+    c->t_end();
+    return c->check_launch("k_real_guess2");
+}
+int real_sample_count(hg_ctx* c, i64 M2, i64 stride2, u32 need2) {
+    switch (c->bpad) {
+        case 16: return real_launch_sample_count<16>(c, M2, stride2, need2);
+        case 32: return real_launch_sample_count<32>(c, M2, stride2, need2);
+        case 48: return real_launch_sample_count<48>(c, M2, stride2, need2);
+        case 64: return real_launch_sample_count<64>(c, M2, stride2, need2);
+        case 80: return real_launch_sample_count<80>(c, M2, stride2, need2);
+        case 96: return real_launch_sample_count<96>(c, M2, stride2, need2);
+        case 112: return real_launch_sample_count<112>(c, M2, stride2, need2);
+        default: return real_launch_sample_count<128>(c, M2, stride2, need2);
+    }
+}
 int real_sample_mx(hg_ctx* c, i64 M, i64 stride, i64 mstride) {
     switch (c->bpad) {
         case 16: return real_launch_sample_mx<16>(c, M, stride, mstride);
@@ -337,7 +384,7 @@ extern "C" {
 // one attempt; *lost = some query came up short of R records or overflowed a slice (bet mode only)
 static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double budget, bool with_ap, int* lost) {
     ++c->real_attempts;
-    c->real_expect = bet ? (double)R * (1.0 + sigma / std::sqrt((double)REAL_SAMPLE_HITS)) : (double)c->N;
+    c->real_expect = bet ? (double)R * (1.0 + sigma / std::sqrt((double)REAL_SAMPLE_HITS)) : (double)c->N;      // (a second sample lowers it: below)
     c->real_lds_ranked = 0;
     c->real_no_cut = !bet;
     make_geometry(c);
@@ -373,6 +420,11 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         HG_TRY(c->samp.reserve((size_t)g.Q * mstride * 4));
         // 16-bit sample scores when both ends take them: k_real_sample_h writes, k_real_guess_lds reads
         c->samp16 = M <= RG_MMAX && c->bpad <= 128 && c->opt_real_mfma == 2 && c->opt_real_sample_h && c->geo.L % 16 == 0;
+        // ... and then a second, counting sample four times as large tightens the cut (k_real_sample_count)
+        const i64 stride2 = stride / REAL_SECOND_SAMPLE;
+        const bool second = c->samp16 && c->opt_real_second && stride2 >= 1 && stride >= 2 * REAL_SECOND_SAMPLE;
+        const i64 M2 = second ? (c->N + stride2 - 1) / stride2 : 0;
+        if (second) HG_TRY(c->sampx.reserve((size_t)((M2 + 15) / 16 * 16) * c->bpad * 2));      // (before the first pass reads it: no move between the two)
         HG_TRY(real_sample(c, M, stride, mstride));
         c->t_begin(KI_REAL_GUESS);
         if (M <= RG_MMAX && c->samp16) hipLaunchKernelGGL(k_real_guess_lds<true>, dim3(g.Q), dim3(1024), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
@@ -380,6 +432,12 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         else hipLaunchKernelGGL(k_real_guess, dim3(g.Q), dim3(256), 0, c->stream, c->samp.as<float>(), M, mstride, rank_s, c->thr.as<float>());
         c->t_end();
         HG_TRY(c->check_launch("k_real_guess"));
+        if (second) {
+            const double fr2 = (double)R * (double)M2 / (double)c->N;
+            const u32 need2 = (u32)std::ceil(fr2 + sigma * std::sqrt(fr2)) + 1u;
+            HG_TRY(real_sample_count(c, M2, stride2, need2));
+            c->real_expect = (double)R * (1.0 + sigma / std::sqrt(fr2 > 1.0 ? fr2 : 1.0));
+        }
         const double mean = budget * (double)R / (double)g.S;
         u32 cap = (u32)std::ceil(mean + 6.0 * std::sqrt(mean) + 16.0);
         cap = (cap + 15u) & ~15u;                         // a multiple of the compact records' ring (16) and flush piece (8)

@@ -413,6 +413,165 @@ void k_real_sample_h(const float* __restrict__ qf, const u8* __restrict__ img, f
     }
 }
 
+// A second, COUNTING sample (round 6).  The first sample places the cut `sigma` deviations of ITS count deep -- 64 expected hits: 5 sigma
+// = 62 % more rows than R reach the filter's records, the rescore and the rank stage.  This pass runs the same 16-bit products over a
+// sample four times as large and stores nothing: a score above the first cut lo[q] is counted into one of RC_BINS equal bins of
+// [lo, lo + span) (the last bin takes everything beyond), in LDS, and flushed with global atomic adds.  k_real_guess2 then moves
+// the cut up to the highest bin edge that still has `need` sampled scores at or above it (256 expected hits: 5 sigma = 31 %).  Any edge
+// is a valid cut (the rank stage verifies that R rows score above it); a query whose lo is not a positive finite number is left alone.
+constexpr int RC_BINS = 32;
+__device__ __forceinline__ float rc_span(const float lo) { return 0.16f * lo + 1.0e-6f; }      // ~0.4 standard deviations of a query's scores when lo sits 2.4 deep
+
+template <int KP, bool HALF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void k_real_sample_count(const float* __restrict__ qf, const u8* __restrict__ img, const float* __restrict__ thr, u32* __restrict__ hist, const Geo g) {
+    constexpr int QT = 2, WQ = 32 * QT;
+    constexpr int NM = KP / 16;
+    typedef typename std::conditional<HALF, f16x8, bf16x8>::type hx8;
+    __shared__ u32 lh[WPB][WQ][RC_BINS];                     // 32 KB: a wavefront's 64 queries x 32 bins
+    const int lb = logical_block(g.nBlk);
+    if (lb < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nQB = g.nQT;
+    const int sp = lb / nQB, qb = lb - sp * nQB;
+    const int h = lane >> 5, j = lane & 31;
+    const i64 lo0 = (i64)(2 * sp) * g.L, lo1 = lo0 + g.L;
+    const i64 len0 = lo0 >= g.N ? 0 : (lo0 + g.L < g.N ? g.L : g.N - lo0);
+    const i64 len1 = lo1 >= g.N ? 0 : (lo1 + g.L < g.N ? g.L : g.N - lo1);
+    const i64 mylen = h ? len1 : len0;
+    const i64 ntile = ((len0 > len1 ? len0 : len1) + 15) / 16;
+    const i64 NG = (g.N + 15) >> 4;
+    const int q0w = (qb * WPB + wave) * WQ;
+    for (int e = lane; e < WQ * RC_BINS; e += 64) (&lh[wave][0][0])[e] = 0u;
+    hx8 bq[QT][NM];
+    float nlo[QT], invw[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = q0w + t * 32 + j;
+        float big = 0.0f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            u32 w[4] = {0u, 0u, 0u, 0u};
+            if (q < g.Q) {
+                const float4* f = (const float4*)(qf + (i64)q * KP + 16 * m + 8 * h);
+                const float4 x = f[0], y = f[1];
+                w[0] = pack_h2<HALF>(x.x, x.y); w[1] = pack_h2<HALF>(x.z, x.w);
+                w[2] = pack_h2<HALF>(y.x, y.y); w[3] = pack_h2<HALF>(y.z, y.w);
+                if (HALF) {
+                    big = fmaxf(big, fmaxf(fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))),
+                                           fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)))));
+                    const float sm = ((x.x + x.y) + (x.z + x.w)) + ((y.x + y.y) + (y.z + y.w));
+                    if (sm != sm) big = __uint_as_float(0x7F800000u);
+                }
+            }
+            bq[t][m] = *(const hx8*)w;
+        }
+        bool wild = false;
+        if (HALF) {
+            const bool mine = !(big < 32768.0f);
+            const bool theirs = __shfl_xor((int)mine, 32) != 0;     // (every lane asks)
+            wild = mine || theirs;
+        }
+        const float lo = q < g.Q ? thr[q] : 0.0f;
+        const bool ok = q < g.Q && !wild && lo > 0.0f && lo < 3.0e38f;                 // (else: nothing is counted for this query, its cut stays)
+        // B = -q and C = lo: acc = lo - approx, a score above the cut is a set sign bit (the filter's harvest); +inf: never
+        nlo[t] = ok ? lo : __uint_as_float(0x7F800000u);
+        invw[t] = ok ? -(float)RC_BINS / rc_span(lo) : 0.0f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            u32 w[4];
+            *(hx8*)w = bq[t][m];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] ^= 0x80008000u;                            // negate both 16-bit halves
+            bq[t][m] = *(const hx8*)w;
+        }
+    }
+    const int ah = (j >> 2) & 1;
+    const int ar = (j & 3) + 4 * (j >> 3);
+    const i64 ag0 = (ah ? lo1 : lo0) >> 4;
+    auto chunk = [&](const i64 T, const int m) -> hx8 {
+        i64 G = ag0 + T;
+        G = G < NG ? G : NG - 1;
+        return *(const hx8*)(img + ((((G * NM + m) * 2 + h) * 16 + ar) * 16));
+    };
+    hx8 av[NM];
+    if (ntile > 0) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) av[m] = chunk(0, m);
+    }
+    wave_lds_sync();
+    for (i64 T = 0; T < ntile; ++T) {
+        const int left = (int)(mylen - T * 16);
+        const i64 Tn = T + 1 < ntile ? T + 1 : T;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = nlo[t];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                acc = real_filter_mfma(av[m], bq[t][m], acc);
+                if (t == QT - 1) av[m] = chunk(Tn, m);
+            }
+            u32* mine = &lh[wave][t * 32 + j][0];
+            const u32 keep = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : (1u << left) - 1u);
+            u32 mask = 0;
+#pragma unroll
+            for (int r = 15; r >= 0; --r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(acc[r]), 31);
+            mask &= keep;
+            while (__any(mask != 0u)) {                       // (a lane meets a score above the cut in one tile of four: a round or two)
+                if (mask != 0u) {
+                    const int r = __builtin_ctz(mask);
+                    mask &= mask - 1u;
+                    float v8[8], v4[4], v2[2];                // acc[r] by a binary tree of selects on the bits of r
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v8[k] = (r & 8) ? acc[8 + k] : acc[k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v4[k] = (r & 4) ? v8[4 + k] : v8[k];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) v2[k] = (r & 2) ? v4[2 + k] : v4[k];
+                    const float d = (r & 1) ? v2[1] : v2[0];  // lo - approx < 0
+                    const int bk = (int)(d * invw[t]);
+                    atomicAdd(&mine[bk < RC_BINS - 1 ? bk : RC_BINS - 1], 1u);
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+    // this segment pair's counts, plain stores of the wavefront's 8 KB (k_real_guess2 adds the pairs up: ten million global atomic adds
+    // -- nearly every counter of every block is non-zero -- were half of this pass's time)
+    u32* __restrict__ out = hist + ((i64)sp * g.Qpad + q0w) * RC_BINS;
+    for (int e = lane; e < WQ * RC_BINS; e += 64)
+        if (q0w + e / RC_BINS < g.Qpad) out[e] = (&lh[wave][0][0])[e];
+}
+
+// thr[q] <- the highest edge of k_real_sample_count's bins that still has `need` sampled scores at or above it (never below thr[q])
+// (one wavefront-lane per (query, bin): lane k of a group of 32 sums bin k over the nSP segment pairs, the group scans from the top)
+static __global__ __launch_bounds__(256) void k_real_guess2(const u32* __restrict__ hist, float* __restrict__ thr, const int Q, const i64 Qpad, const int nSP,
+                                                     const u32 need) {
+    const int q = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
+    const bool live = q < Q;
+    u32 c = 0;
+    if (live) for (int sp = 0; sp < nSP; ++sp) c += hist[((i64)sp * Qpad + q) * RC_BINS + k];
+    // suffix sums inside the group of 32 lanes: cum[k] = c[k] + c[k + 1] + ... + c[31]
+    u32 cum = c;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const u32 t = (u32)__shfl_down((int)cum, o, 32); if (k + o < 32) cum += t; }
+    const u64 ok = __ballot(live && k >= 1 && cum >= need);
+    const u32 mine = (u32)(ok >> (threadIdx.x & 32));          // this group's 32 flags
+    if (!live || k != 0 || mine == 0u) return;
+    const float lo = thr[q];
+    if (!(lo > 0.0f && lo < 3.0e38f)) return;
+    const float w = rc_span(lo) / (float)RC_BINS;
+    const int edge = 31 - __builtin_clz(mine);                 // the highest bin that still has `need` scores at or above it
+    {
+        // a score in bin k is >= lo + k w up to the rounding of (score - lo) * (1 / w): a few units in the last place of slack
+        const float e = lo + (float)edge * w;
+        thr[q] = e - 4.0f * 1.1920929e-07f * fabsf(e) - w * 1.0e-3f;
+    }
+}
+
 // Rescore: wavefront = (group of SG consecutive slices, query); lane = one kept row.  The query's features are
 // wave-uniform (scalar loads); consecutive wavefronts take consecutive queries of the SAME segment group, whose rows
 // (SG x real_segment_bytes) stay in the L2 while all queries pass.  The 64 rows of a round are fetched COALESCED, 32

@@ -317,26 +317,28 @@ def test_filter_and_rescore_equals_the_exact_passes(kind, Q, N, b, R, ctx):
     ctx.set_database_f32(dbf, dl.astype(np.int64))
     ctx.set_queries_f32(qf, ql.astype(np.int64))
     try:
-        for mode, lds, half_sample in ((2, 1, 1), (2, 1, 0), (2, 0, 1), (1, 1, 1), (0, 1, 1)):
+        for mode, lds, half_sample, second in ((2, 1, 1, 1), (2, 1, 1, 0), (2, 1, 0, 1), (2, 0, 1, 1), (1, 1, 1, 1), (0, 1, 1, 1)):
             ctx.set_option("real_mfma", mode)
             ctx.set_option("real_sort_lds", lds)
             ctx.set_option("real_sample_half", half_sample)      # the cut from 16-bit sample scores (round 6) or from exact chains: the same lists
+            ctx.set_option("real_second_sample", second)         # ... tightened by the second, counting sample, or not: the same lists
             idx, score = ctx.topr_real(R)
-            assert np.array_equal(score.view(np.uint32), score_ref.view(np.uint32)), (kind, mode, lds)
-            assert np.array_equal(idx, idx_ref), (kind, mode, lds)
+            assert np.array_equal(score.view(np.uint32), score_ref.view(np.uint32)), (kind, mode, lds, half_sample, second)
+            assert np.array_equal(idx, idx_ref), (kind, mode, lds, half_sample, second)
             if kind not in ("bits", "wildq"):   # (a cut inside a tie group of thousands overflows the slices: deeper attempts, same lists)
-                assert ctx.get_stat("real_attempts") == 1, (kind, mode, lds)
+                assert ctx.get_stat("real_attempts") == 1, (kind, mode, lds, half_sample, second)
             assert (ctx.get_stat("real_path") & 1) == (1 if mode == 2 else 0)
             if mode == 2:               # the filter's format: IEEE half unless a database feature could overflow it
                 assert ((ctx.get_stat("real_path") >> 3) & 1) == (0 if kind in ("huge", "tiny") else 1), kind
             if ctx.get_stat("real_attempts") == 1 and kind not in ("bits", "wildq"):   # (tie groups can exceed the LDS: the global passes take over)
                 assert ((ctx.get_stat("real_path") >> 1) & 1) == (1 if mode == 2 and lds and R <= 6144 else 0)
             ap, rel = ctx.map_real(R)
-            assert np.array_equal(ap, ap_ref, equal_nan=True), (kind, mode, lds)
+            assert np.array_equal(ap, ap_ref, equal_nan=True), (kind, mode, lds, half_sample, second)
     finally:
         ctx.set_option("real_mfma", 2)
         ctx.set_option("real_sort_lds", 1)
         ctx.set_option("real_sample_half", 1)
+        ctx.set_option("real_second_sample", 1)
 
 
 def test_real_valued_ranking_vs_np_dot_envelope(ctx):
