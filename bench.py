@@ -387,7 +387,7 @@ def real_valued(spec, reps=5):
             ctx.timing_enable(False)
             timing.pop("step_gpu_span", None)
             real_names = {"k_real_select": "k_real_select_bf (bf16 MFMA filter)", "k_radix_pass": "k_real_rank_lds (select R-th key + order, in LDS)",
-                          "k_real_sample": "k_real_sample_h (16-bit sample scores)", "k_real_guess": "k_real_guess_lds + k_real_thr2"}
+                          "k_real_sample": "k_real_sample_h + k_real_sample_count (16-bit sample scores; the second, counting sample)", "k_real_guess": "k_real_guess_lds + k_real_guess2 + k_real_thr2"}
             kern = {real_names.get(k_, k_): round(ms / max(cnt, 1) * (cnt / 3.0), 5) for k_, (ms, cnt) in timing.items()}    # ms per call
             flops = 2.0 * Q * N * b
             filt = timing.get("k_real_select", (0.0, 1))
