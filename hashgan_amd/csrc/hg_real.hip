@@ -9,7 +9,9 @@ constexpr double REAL_FIRST_SIGMA = 5.0;        // depth of the first cut in dev
                                               // own (real_requery_lost).  10k x 1M x 64, R = 5000: 6 -> 5.92 ms per call, 5 -> 5.81, 4 -> 5.86, 3.5 -> 6.01 (the
                                               // rescore's time follows its rounds, not its rows: the shallower cut mostly helps the rank stage)
 constexpr i64 REAL_SAMPLE_HITS = 64;          // the real-valued bet samples so that this many of a query's top R rows are in the sample (tools/real_sample_sweep.py: 32 .. 256 measured)
-constexpr i64 REAL_SECOND_SAMPLE = 4;         // the second, counting sample takes every (stride / 4)-th row: 256 expected hits
+constexpr i64 REAL_SECOND_SAMPLE = 4;         // the second, counting sample expects four times REAL_SAMPLE_HITS of a query's top R rows: 256
+constexpr i64 REAL_FIRST_HITS_BRACKET = 24;   // ... and the first sample, when a second one follows, this many (10k x 1M x 64, R = 5000, call: 64 -> 4.86 ms, 48 -> 4.76, 32 -> 4.72,
+                                              // 24 -> 4.68, 16 -> 4.65, 12 -> 4.70, 8 -> 4.80 -- below 16 the bins of the second sample no longer reach the cut; 6: lists beyond the LDS)
 constexpr i64 REAL_SEG_BYTES = 512 * 1024;    // bytes of feature rows per segment of the real-valued pair passes
 
 namespace {
@@ -409,8 +411,14 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     HG_HIP(hipMemsetAsync(c->failq.p, 0, qb, c->stream));
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     if (bet) {
-        // sample so that about 64 of a query's top R rows are in it; guess the cut `sigma` deviations deep
-        i64 stride = (i64)((double)R / (double)REAL_SAMPLE_HITS);
+        // sample so that about 64 of a query's top R rows are in it; guess the cut `sigma` deviations deep.  With a second, counting sample
+        // behind it (256 expected hits) the first one only has to bracket the cut from below: half the rows do (REAL_FIRST_HITS_BRACKET)
+        const bool can16 = c->bpad <= 128 && c->opt_real_mfma == 2 && c->opt_real_sample_h && c->geo.L % 16 == 0;
+        const i64 hits_b = REAL_FIRST_HITS_BRACKET;
+        const i64 stride2 = (i64)((double)R / (double)(REAL_SAMPLE_HITS * REAL_SECOND_SAMPLE));
+        i64 stride = (i64)((double)R / (double)hits_b);
+        bool second = can16 && c->opt_real_second && stride2 >= 1 && stride >= 2 * stride2 && (c->N + stride - 1) / stride <= RG_MMAX;
+        if (!second) stride = (i64)((double)R / (double)REAL_SAMPLE_HITS);
         if (stride < 1) stride = 1;
         const i64 M = (c->N + stride - 1) / stride;
         const double fr = (double)R * (double)M / (double)c->N;
@@ -419,10 +427,8 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         const i64 mstride = c->bpad <= 128 && c->opt_real_mfma ? (M + 15) / 16 * 16 : M;
         HG_TRY(c->samp.reserve((size_t)g.Q * mstride * 4));
         // 16-bit sample scores when both ends take them: k_real_sample_h writes, k_real_guess_lds reads
-        c->samp16 = M <= RG_MMAX && c->bpad <= 128 && c->opt_real_mfma == 2 && c->opt_real_sample_h && c->geo.L % 16 == 0;
-        // ... and then a second, counting sample four times as large tightens the cut (k_real_sample_count)
-        const i64 stride2 = stride / REAL_SECOND_SAMPLE;
-        const bool second = c->samp16 && c->opt_real_second && stride2 >= 1 && stride >= 2 * REAL_SECOND_SAMPLE;
+        c->samp16 = M <= RG_MMAX && can16;
+        // ... and then the second, counting sample tightens the cut (k_real_sample_count)
         const i64 M2 = second ? (c->N + stride2 - 1) / stride2 : 0;
         if (second) HG_TRY(c->sampx.reserve((size_t)((M2 + 15) / 16 * 16) * c->bpad * 2));      // (before the first pass reads it: no move between the two)
         HG_TRY(real_sample(c, M, stride, mstride));
