@@ -314,10 +314,16 @@ template <int KP> int real_launch_sample_count(hg_ctx* c, i64 M2, i64 stride2, u
     g.wpb = WPB;
     g.nBlk = (int)g.nUnits;
     HG_TRY(c->hist2.reserve((size_t)nSP * g.Qpad * RC_BINS * 4 + (size_t)WPB * 64 * RC_BINS * 4));      // [segment pair][Qpad][bin], every word written (+ a block's overhang past Qpad)
-    if (c->dbfb_half) hipLaunchKernelGGL((k_real_sample_count<KP, true>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
-                                         c->thr.as<float>(), c->hist2.as<u32>(), g);
-    else hipLaunchKernelGGL((k_real_sample_count<KP, false>), dim3(padded_grid(g.nBlk)), dim3(256), 0, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
-                            c->thr.as<float>(), c->hist2.as<u32>(), g);
+    constexpr int lds = real_count_lds_bytes(KP);
+    if (c->dbfb_half) {
+        if (lds > 64 * 1024) HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_sample_count<KP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((k_real_sample_count<KP, true>), dim3(padded_grid(g.nBlk)), dim3(256), lds, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
+                           c->thr.as<float>(), c->hist2.as<u32>(), g);
+    } else {
+        if (lds > 64 * 1024) HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_sample_count<KP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((k_real_sample_count<KP, false>), dim3(padded_grid(g.nBlk)), dim3(256), lds, c->stream, c->qf.as<float>(), c->sampx.as<u8>(),
+                           c->thr.as<float>(), c->hist2.as<u32>(), g);
+    }
     c->t_end();
     HG_TRY(c->check_launch("k_real_sample_count"));
     c->t_begin(KI_REAL_GUESS);

@@ -422,17 +422,24 @@ void k_real_sample_h(const float* __restrict__ qf, const u8* __restrict__ img, f
 constexpr int RC_BINS = 32;
 __device__ __forceinline__ float rc_span(const float lo) { return 0.16f * lo + 1.0e-6f; }      // ~0.4 standard deviations of a query's scores when lo sits 2.4 deep
 
+// LDS: the filter's double-buffered windows of RB_WT row tiles (one copy of the fragments for the block's four wavefronts: straight out of
+// the L2 every wavefront fetched its own -- 1 GB per pass, the pass's time), then per wavefront 64 queries x 32 bins of 16-bit counts, two to
+// a dword (a block meets at most 2 x L < 65 536 rows).
+constexpr int real_count_lds_bytes(int KP) { return real_bf_lds_bytes(KP) + WPB * 64 * RC_BINS * 2; }
+
 template <int KP, bool HALF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
 void k_real_sample_count(const float* __restrict__ qf, const u8* __restrict__ img, const float* __restrict__ thr, u32* __restrict__ hist, const Geo g) {
+    extern __shared__ __attribute__((aligned(16))) u8 clds[];
     constexpr int QT = 2, WQ = 32 * QT;
     constexpr int NM = KP / 16;
+    constexpr int STAGE = RB_WT * NM * 1024;
     typedef typename std::conditional<HALF, f16x8, bf16x8>::type hx8;
-    __shared__ u32 lh[WPB][WQ][RC_BINS];                     // 32 KB: a wavefront's 64 queries x 32 bins
     const int lb = logical_block(g.nBlk);
     if (lb < 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32* lh = (u32*)(clds + 2 * STAGE) + wave * (WQ * RC_BINS / 2);        // [64 queries][16 dwords]: bin k of query x in half (k & 1) of dword x * 16 + k / 2
     const int nQB = g.nQT;
     const int sp = lb / nQB, qb = lb - sp * nQB;
     const int h = lane >> 5, j = lane & 31;
@@ -443,7 +450,7 @@ void k_real_sample_count(const float* __restrict__ qf, const u8* __restrict__ im
     const i64 ntile = ((len0 > len1 ? len0 : len1) + 15) / 16;
     const i64 NG = (g.N + 15) >> 4;
     const int q0w = (qb * WPB + wave) * WQ;
-    for (int e = lane; e < WQ * RC_BINS; e += 64) (&lh[wave][0][0])[e] = 0u;
+    for (int e = lane; e < WQ * RC_BINS / 2; e += 64) lh[e] = 0u;
     hx8 bq[QT][NM];
     float nlo[QT], invw[QT];
 #pragma unroll
@@ -456,8 +463,8 @@ void k_real_sample_count(const float* __restrict__ qf, const u8* __restrict__ im
             if (q < g.Q) {
                 const float4* f = (const float4*)(qf + (i64)q * KP + 16 * m + 8 * h);
                 const float4 x = f[0], y = f[1];
-                w[0] = pack_h2<HALF>(x.x, x.y); w[1] = pack_h2<HALF>(x.z, x.w);
-                w[2] = pack_h2<HALF>(y.x, y.y); w[3] = pack_h2<HALF>(y.z, y.w);
+                w[0] = pack_h2<HALF>(-x.x, -x.y); w[1] = pack_h2<HALF>(-x.z, -x.w);        // B = -q (acc = lo - approx: the filter's sign test)
+                w[2] = pack_h2<HALF>(-y.x, -y.y); w[3] = pack_h2<HALF>(-y.z, -y.w);
                 if (HALF) {
                     big = fmaxf(big, fmaxf(fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))),
                                            fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)))));
@@ -475,75 +482,78 @@ void k_real_sample_count(const float* __restrict__ qf, const u8* __restrict__ im
         }
         const float lo = q < g.Q ? thr[q] : 0.0f;
         const bool ok = q < g.Q && !wild && lo > 0.0f && lo < 3.0e38f;                 // (else: nothing is counted for this query, its cut stays)
-        // B = -q and C = lo: acc = lo - approx, a score above the cut is a set sign bit (the filter's harvest); +inf: never
-        nlo[t] = ok ? lo : __uint_as_float(0x7F800000u);
+        nlo[t] = ok ? lo : __uint_as_float(0x7F800000u);                                // C = lo: acc = lo - approx; +inf: never below zero
         invw[t] = ok ? -(float)RC_BINS / rc_span(lo) : 0.0f;
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            u32 w[4];
-            *(hx8*)w = bq[t][m];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] ^= 0x80008000u;                            // negate both 16-bit halves
-            bq[t][m] = *(const hx8*)w;
-        }
     }
-    const int ah = (j >> 2) & 1;
-    const int ar = (j & 3) + 4 * (j >> 3);
+    const int ah = (j >> 2) & 1;                             // lane-half (segment) that A row j feeds
+    const int ar = (j & 3) + 4 * (j >> 3);                   // its row inside that half's 16
     const i64 ag0 = (ah ? lo1 : lo0) >> 4;
-    auto chunk = [&](const i64 T, const int m) -> hx8 {
-        i64 G = ag0 + T;
-        G = G < NG ? G : NG - 1;
-        return *(const hx8*)(img + ((((G * NM + m) * 2 + h) * 16 + ar) * 16));
+    const i64 nwin = (ntile + RB_WT - 1) / RB_WT;
+    auto stage_window = [&](const i64 win, const int buf) {
+        for (int c = wave; c < RB_WT * NM; c += WPB) {
+            const int T = c / NM, m = c - T * NM;
+            i64 G = ag0 + win * RB_WT + T;
+            G = G < NG ? G : NG - 1;                         // past the end: any valid group (masked by `left`)
+            HG_GLDS16(img + ((((G * NM + m) * 2 + h) * 16 + ar) * 16), clds + buf * STAGE + c * 1024);
+        }
     };
-    hx8 av[NM];
-    if (ntile > 0) {
-#pragma unroll
-        for (int m = 0; m < NM; ++m) av[m] = chunk(0, m);
-    }
-    wave_lds_sync();
-    for (i64 T = 0; T < ntile; ++T) {
-        const int left = (int)(mylen - T * 16);
-        const i64 Tn = T + 1 < ntile ? T + 1 : T;
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = nlo[t];
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                acc = real_filter_mfma(av[m], bq[t][m], acc);
-                if (t == QT - 1) av[m] = chunk(Tn, m);
-            }
-            u32* mine = &lh[wave][t * 32 + j][0];
+    if (nwin > 0) stage_window(0, 0);
+    for (i64 win = 0; win < nwin; ++win) {
+        const int buf = (int)(win & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my copies have landed; after the barrier everybody's have
+        __syncthreads();                                     // ... and nobody still reads the other buffer (nor zeroes its counters)
+        if (win + 1 < nwin) stage_window(win + 1, buf ^ 1);
+        const u8* st = clds + buf * STAGE;
+#pragma unroll 1
+        for (int Tw = 0; Tw < RB_WT; ++Tw) {
+            const i64 T = win * RB_WT + Tw;
+            if (T >= ntile) break;
+            const int left = (int)(mylen - T * 16);
             const u32 keep = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : (1u << left) - 1u);
-            u32 mask = 0;
+            hx8 av[NM];
 #pragma unroll
-            for (int r = 15; r >= 0; --r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(acc[r]), 31);
-            mask &= keep;
-            while (__any(mask != 0u)) {                       // (a lane meets a score above the cut in one tile of four: a round or two)
-                if (mask != 0u) {
-                    const int r = __builtin_ctz(mask);
-                    mask &= mask - 1u;
-                    float v8[8], v4[4], v2[2];                // acc[r] by a binary tree of selects on the bits of r
+            for (int m = 0; m < NM; ++m) av[m] = *(const hx8*)(st + ((Tw * NM + m) * 64 + lane) * 16);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v8[k] = (r & 8) ? acc[8 + k] : acc[k];
+            for (int t = 0; t < QT; ++t) {
+                f32x16 acc;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v4[k] = (r & 4) ? v8[4 + k] : v8[k];
+                for (int r = 0; r < 16; ++r) acc[r] = nlo[t];
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) v2[k] = (r & 2) ? v4[2 + k] : v4[k];
-                    const float d = (r & 1) ? v2[1] : v2[0];  // lo - approx < 0
-                    const int bk = (int)(d * invw[t]);
-                    atomicAdd(&mine[bk < RC_BINS - 1 ? bk : RC_BINS - 1], 1u);
+                for (int m = 0; m < NM; ++m) acc = real_filter_mfma(av[m], bq[t][m], acc);
+                u32 mask = 0;
+#pragma unroll
+                for (int r = 15; r >= 0; --r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(acc[r]), 31);
+                mask &= keep;
+                // a lane meets a score above the cut in one tile of four: a round or two per tile, the lane's row picked out of its sixteen
+                // accumulators by four levels of bit-field inserts (sixteen tests and branches per tile -- some lane always has a hit --
+                // were 3/4 of this pass's instructions; selects on the bits of r the compiler turns into an indexed trip through memory)
+                u32* mine = lh + (t * 32 + j) * (RC_BINS / 2);
+                while (__any(mask != 0u)) {
+                    if (mask != 0u) {
+                        const u32 r = (u32)__builtin_ctz(mask);
+                        mask &= mask - 1u;
+                        const u32 m3 = 0u - ((r >> 3) & 1u), m2 = 0u - ((r >> 2) & 1u), m1 = 0u - ((r >> 1) & 1u), m0 = 0u - (r & 1u);
+                        u32 a8[8], a4[4], a2[2];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) a8[k] = (__float_as_uint(acc[8 + k]) & m3) | (__float_as_uint(acc[k]) & ~m3);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a4[k] = (a8[4 + k] & m2) | (a8[k] & ~m2);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) a2[k] = (a4[2 + k] & m1) | (a4[k] & ~m1);
+                        const float d = __uint_as_float((a2[1] & m0) | (a2[0] & ~m0));        // lo - approx < 0
+                        const int bk0 = (int)(d * invw[t]);
+                        const int bk = bk0 < RC_BINS - 1 ? bk0 : RC_BINS - 1;
+                        atomicAdd(&mine[bk >> 1], 1u << (16 * (bk & 1)));
+                    }
                 }
             }
         }
     }
-    wave_lds_sync();
-    // this segment pair's counts, plain stores of the wavefront's 8 KB (k_real_guess2 adds the pairs up: ten million global atomic adds
-    // -- nearly every counter of every block is non-zero -- were half of this pass's time)
+    __syncthreads();                                         // (a block without windows still zeroed its counters above)
+    // this segment pair's counts, plain stores (k_real_guess2 adds the pairs up): [sp][q][bin] u32, unpacked on the way out
     u32* __restrict__ out = hist + ((i64)sp * g.Qpad + q0w) * RC_BINS;
     for (int e = lane; e < WQ * RC_BINS; e += 64)
-        if (q0w + e / RC_BINS < g.Qpad) out[e] = (&lh[wave][0][0])[e];
+        if (q0w + e / RC_BINS < g.Qpad) out[e] = (lh[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
 }
 
 // thr[q] <- the highest edge of k_real_sample_count's bins that still has `need` sampled scores at or above it (never below thr[q])
