@@ -457,9 +457,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         c->cap = cap < whole ? cap : whole;
     } else {
         // no bet: every row becomes a record (thr = -inf), slices are whole segments
-        std::vector<float> ninf((size_t)g.Q, -INFINITY);
-        HG_HIP(hipMemcpyAsync(c->thr.p, ninf.data(), (size_t)g.Q * 4, hipMemcpyHostToDevice, c->stream));
-        HG_HIP(hipStreamSynchronize(c->stream));
+        HG_HIP(hipMemsetD32Async((hipDeviceptr_t)c->thr.p, (int)0xFF800000u, (size_t)g.Q, c->stream));     // (a fill on the stream: no host vector, no wait)
         c->cap = (u32)g.L;
     }
     c->crow = (i64)g.S * c->cap;
