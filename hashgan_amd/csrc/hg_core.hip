@@ -288,7 +288,7 @@ int hg_destroy(hg_ctx* c) {
                      &c->t, &c->tguess, &c->sstar, &c->cnt_lt, &c->quota, &c->tie_before, &c->n_lt, &c->err, &c->sl_start,
                      &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist, &c->mbits,
                      &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq, &c->dbf, &c->qf, &c->samp, &c->thr,
-                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part, &c->dbytes, &c->outblk, &c->beyond, &c->cntq, &c->hist2};
+                     &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->mbits2, &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part, &c->dbytes, &c->outblk, &c->beyond, &c->cntq, &c->hist2, &c->krows};
     for (auto* d : all) d->release();
     for (auto& d : c->gathered) d.release();
     for (auto& d : c->scratch) d.release();
@@ -1006,6 +1006,9 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_real_sample_h = value != 0;
     } else if (!strcmp(key, "real_second_sample")) {
         c->opt_real_second = value != 0;
+    } else if (!strcmp(key, "real_whole_rounds")) {
+        if (value < 0 || value > 8) return fail(HG_ERR_ARG, "real_whole_rounds must be 0 .. 8");
+        c->opt_real_rounds = value;
     } else if (!strcmp(key, "real_groups")) {
         c->opt_real_groups = value != 0;
     } else if (!strcmp(key, "real_sort_lds")) {
@@ -1090,7 +1093,7 @@ int hg_get_stat(hg_ctx* c, const char* key, int64_t* value) {
                          &c->sl_start, &c->sl_tie, &c->sl_cnt, &c->tot, &c->failq, &c->cand, &c->out_idx, &c->out_dist,
                          &c->mbits, &c->shapes, &c->ap, &c->rel, &c->stage_in, &c->badcnt, &c->qbad, &c->flist, &c->hwq,
                          &c->dbf, &c->qf, &c->samp, &c->thr, &c->sortA, &c->sortB, &c->gtab, &c->scores, &c->dbx, &c->qx, &c->bigq, &c->mbits2,
-                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part, &c->dbytes, &c->outblk, &c->beyond, &c->cntq, &c->hist2,
+                         &c->dbfx, &c->dbfb, &c->thr2, &c->xmax2, &c->dbx8, &c->dbx3, &c->dbx4, &c->sampx, &c->ap_recip, &c->part, &c->dbytes, &c->outblk, &c->beyond, &c->cntq, &c->hist2, &c->krows,
                          &c->comm_tmp, &c->gath_idx, &c->gath_dist, &c->obuf[0], &c->obuf[1]};
         i64 total = 0;
         for (auto* d : all) if (!d->borrowed) total += (i64)d->cap;

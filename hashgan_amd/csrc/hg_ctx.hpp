@@ -349,12 +349,14 @@ struct hg_ctx {
     bool dbfx_valid = false;
     DevBuf sampx;              // float features of the sampled rows in MFMA A-fragment order (k_real_sample_mx), rebuilt per call
     DevBuf cntq;               // real-valued path: the slices' record counts after the rescore, query-major [Q][S] (k_real_rank_lds reads a query's row in one piece)
+    DevBuf krows;              // real-valued path: the rows the filter kept, 4-byte row numbers [Q][S][cap] (k_real_select_bf writes, k_real_rescore reads)
     DevBuf dbfb, thr2, xmax2;  // filter + rescore path (hg_real_bf.hpp): bf16 image of the database, lowered cuts, max row norm^2
     bool dbfb_valid = false;
     double real_expect = 0.0;  // rows per query the current real-valued attempt expects its cut to keep (real_attempt; picks the rescore's slices per wavefront)
     bool dbfb_half = false;    // ... in IEEE half instead of bfloat16 (no feature of the database can overflow it: real_launch_select_bf)
     DevBuf hist2;              // the second sample's counts [Q][RC_BINS] (k_real_sample_count)
     i64 opt_real_second = 1;   // "real_second_sample": a second, counting sample four times as large tightens the sampled cut
+    i64 opt_real_rounds = 3;   // "real_whole_rounds": the no-cut float32 MFMA pass (k_real_select_mx) cuts the database so that its blocks fill whole rounds of this many per CU; 0: the plain geometry
     bool samp16 = false;       // the current attempt's sample scores are bfloat16 (k_real_sample_h -> k_real_guess_lds)
     i64 opt_real_sample_h = 1; // "real_sample_half": the sampled cut's scores in the filter's 16-bit arithmetic (k_real_sample_h) instead of exact float32 chains
     i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit

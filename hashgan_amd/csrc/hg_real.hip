@@ -115,18 +115,19 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
     gs.wpb = WPB;
     gs.nBlk = (int)gs.nUnits;
     RealSelArgs a{c->thr.as<float>(), c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->cap, c->crow};
+    HG_TRY(c->krows.reserve((size_t)g.Q * c->crow * 4));     // the kept rows' numbers: the filter writes, the rescore reads
     c->t_begin(KI_REAL_SELECT);
 #define HG_FILTER(HALF_, FAR_)                                                                                                               \
     do {                                                                                                                                     \
         if (real_bf_lds_bytes(KP) > 64 * 1024)                                                                                               \
             HG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_real_select_bf<KP, QT, HALF_, FAR_>), hipFuncAttributeMaxDynamicSharedMemorySize, real_bf_lds_bytes(KP))); \
         hipLaunchKernelGGL((k_real_select_bf<KP, QT, HALF_, FAR_>), dim3(padded_grid(gs.nBlk)), dim3(256), real_bf_lds_bytes(KP), c->stream, \
-                           c->qf.as<float>(), c->dbfb.as<u8>(), c->thr2.as<float>(), a, c->cand.as<u64>(), gs);                              \
+                           c->qf.as<float>(), c->dbfb.as<u8>(), c->thr2.as<float>(), a, c->krows.as<u32>(), gs);                            \
     } while (0)
     // (a wavefront's 64 record rows within 4 GB: 32-bit cursors -- every bet; beyond, e.g. every row a record of a 10M-row database, 64-bit ones)
     // (a 32-bit cursor keeps counting past a full slice -- by up to a segment's rows -- so that the hits it dropped are known: the
     // furthest it can get is the wavefront's 64 record rows plus one segment)
-    const bool far_rows = (64ull * (unsigned long long)c->crow + (unsigned long long)g.L) * 8ull >= (1ull << 32);
+    const bool far_rows = (64ull * (unsigned long long)c->crow + (unsigned long long)g.L) * 4ull >= (1ull << 32);
     if (c->dbfb_half) { if (far_rows) HG_FILTER(true, true); else HG_FILTER(true, false); }
     else { if (far_rows) HG_FILTER(false, true); else HG_FILTER(false, false); }
 #undef HG_FILTER
@@ -165,7 +166,7 @@ template <int KP> int real_launch_select_bf(hg_ctx* c) {
 #define HG_RESCORE(sg)                                                                                                                   \
     case sg:                                                                                                                             \
         hipLaunchKernelGGL((k_real_rescore<(KP <= 128 ? KP : 0), sg>), dim3(grid_for(waves, WPB)), dim3(256), rescore_lds_bytes(), c->stream, c->qf.as<float>(),  \
-                           c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(),               \
+                           c->dbf.as<float>(), c->sl_cnt.as<u32>(), c->krows.as<u32>(), c->cand.as<u64>(), c->cap, c->crow, c->thr.as<float>(), \
                            c->sl_cnt.as<u32>(), c->cntq.as<u32>(), c->dblab.as<u64>(), c->qlab.as<u64>(), c->real_no_cut ? 0 : 1, KP, g);                         \
         break;
 #ifdef HG_RS_FORCE
@@ -409,6 +410,30 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
             gg.nBlk = (int)((gg.nUnits + WPB - 1) / WPB);
         }
     }
+    if (!bet && c->bpad <= 128 && c->opt_real_mfma && c->opt_real_rounds > 0) {
+        // Every row a record through k_real_select_mx: blocks = (pairs of segments) x (256 queries), four wavefronts each, up to
+        // three resident per CU (two beyond 64 features).  The plain geometry gave the CIFAR evaluation (1000 x 54 000) 376 blocks
+        // for 256 CUs -- half the CUs with two, half with one; cut the database so that the blocks fill whole rounds instead.
+        Geo& gg = c->geo;
+        const i64 nQB = (gg.Q + WPB * 32 * RMX_QT - 1) / (WPB * 32 * RMX_QT);
+        const i64 per_cu = c->bpad <= 64 ? std::min<i64>(c->opt_real_rounds, 3) : std::min<i64>(c->opt_real_rounds, 2);
+        const i64 slots = (i64)c->n_cu * per_cu;
+        const i64 nSP0 = (gg.S + 1) / 2;
+        i64 k = (nSP0 * nQB + slots - 1) / slots;          // rounds the plain geometry touches
+        if (k < 1) k = 1;
+        const i64 nSP = slots * k / nQB;
+        if (nSP >= 1) {
+            i64 L = (gg.N + 2 * nSP - 1) / (2 * nSP);
+            L = (L + 15) / 16 * 16;
+            if (L < 64) L = 64;
+            if (L <= gg.L) {
+                gg.L = L;
+                gg.S = (int)((gg.N + L - 1) / L);
+                gg.nUnits = (i64)gg.S * gg.nQT;
+                gg.nBlk = (int)((gg.nUnits + WPB - 1) / WPB);
+            }
+        }
+    }
     HG_TRY(set_R(c, R, 1, 0));
     const Geo& g = c->geo;
     const size_t qb = (size_t)g.Qpad * 4;
@@ -545,24 +570,29 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         c->t_end();
         HG_TRY(c->check_launch("k_real_group_sort"));
         int flag = 0;
-        HG_TRY(read_plan_flag(c, &flag));
-        if (flag & 4) HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
-        else grouped = true;
-    }
-    c->real_grouped = grouped ? 1 : 0;
-    if (grouped) {
-        c->stage = ST_DB | ST_Q | ST_SELECT | ST_MATCH;
-        if (with_ap) {                                     // AP + one download + one synchronisation (as above)
+        if (with_ap) {
+            // the usual case has no pile: AP and the download of {flag, AP, hit counts} ride behind the sort and the call synchronises
+            // ONCE (as above; a piled-up query's APs are simply not used -- the bitmaps they are read from are zeroed, defined memory)
+            c->stage = ST_DB | ST_Q | ST_SELECT | ST_MATCH;
             HG_TRY(do_ap(c));
             HG_TRY(stage_ap_download(c));
             HG_TRY(c->sync());
-            *lost = *(const int*)c->pin;
-            c->ap_staged = *lost == 0;
+            flag = *(const int*)c->pin;
+            c->stage = ST_DB | ST_Q | ST_SELECT;
+        } else {
+            HG_TRY(read_plan_flag(c, &flag));
+        }
+        if (flag & 4) {
+            HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
+        } else {
+            c->real_grouped = 1;
+            c->stage = ST_DB | ST_Q | ST_SELECT | ST_MATCH;
+            *lost = flag;
+            if (with_ap) { c->stage |= ST_AP; c->ap_staged = flag == 0; }
             return HG_OK;
         }
-        HG_TRY(read_plan_flag(c, lost));
-        return HG_OK;
     }
+    c->real_grouped = 0;
     for (int pass = 0; pass < 4 && !grouped; ++pass) {
         RadixArgs ra{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, c->crow, pass == 0, 32 + 8 * pass};
         u64* out = bufs[pass & 1];

@@ -121,7 +121,7 @@ template <int KP, int QT, bool HALF, bool FAR>          // QT query tiles (of 32
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KP <= 64 ? HG_RB_WAVES : 2, KP <= 64 ? HG_RB_WAVES : 2)))
 void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, const float* __restrict__ thr2, const RealSelArgs a,
-                      u64* __restrict__ cand, const Geo g) {
+                      u32* __restrict__ krows, const Geo g) {
     extern __shared__ __attribute__((aligned(16))) u8 blds[];
     constexpr int WQ = 32 * QT;
     constexpr int NM = KP / 16;                              // MFMAs (and 16-byte A chunks per lane) per tile
@@ -148,7 +148,8 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
     hx8 bq[QT][NM];
     float cut[QT];
     u32 cnt[QT], room[QT], dropped[QT], woff[QT], wbeg[QT], wend[QT];
-    u64* wp[QT];
+    u32 hold[QT];                                            // the first row number of a pair: two leave in one 8-byte store
+    u32* wp[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int q = q0w + t * 32 + j;
@@ -186,16 +187,16 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
                 if (live) cut[t] = __uint_as_float(0xFF800000u);
             }
         }
-        cnt[t] = 0; room[t] = live ? a.cap : 0u; dropped[t] = 0;
-        wp[t] = cand + (i64)(q < g.Q ? q : 0) * a.crow + (i64)(seg_ok ? s : 0) * a.cap;
-        // !FAR: the lane's cursor is a 32-bit byte offset from the wavefront's first record row (the store takes a scalar base and a
-        // vector offset: no 64-bit address arithmetic per hit), and a hit beyond the slice's capacity lands on its last slot -- the
-        // query is flagged and redone anyway -- so the hit costs no branch on the room left
-        woff[t] = (u32)((((i64)(t * 32 + j)) * a.crow + (i64)(seg_ok ? s : 0) * a.cap) * 8);
+        cnt[t] = 0; room[t] = live ? a.cap : 0u; dropped[t] = 0; hold[t] = 0;
+        wp[t] = krows + (i64)(q < g.Q ? q : 0) * a.crow + (i64)(seg_ok ? s : 0) * a.cap;
+        // !FAR: the lane's cursor is a 32-bit byte offset from the wavefront's first row of kept rows (the store takes a scalar base
+        // and a vector offset: no 64-bit address arithmetic per hit), and a pair beyond the slice's capacity lands on its last pair
+        // of slots -- the query is flagged and redone anyway -- so the hit costs no branch on the room left
+        woff[t] = (u32)((((i64)(t * 32 + j)) * a.crow + (i64)(seg_ok ? s : 0) * a.cap) * 4);
         wbeg[t] = woff[t];
-        wend[t] = woff[t] + (a.cap - 1u) * 8u;                    // (the slice's last slot)
+        wend[t] = woff[t] + (a.cap - 2u) * 4u;                    // (the slice's last pair of slots; cap is a multiple of 16)
     }
-    const char* wbase = (const char*)(cand + (i64)q0w * a.crow);
+    const char* wbase = (const char*)(krows + (i64)q0w * a.crow);
 
     // ---- A fragments: windows of RB_WT tiles staged global -> LDS (k_select_mx's scheme), shared by the four
     // wavefronts of the block -- every wavefront copies a quarter of a window and reads all of it, lane-linear, so a
@@ -261,18 +262,27 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
                     if (mask[t] != 0u) {
                         const int r = __builtin_ctz(mask[t]);
                         mask[t] &= mask[t] - 1u;
+                        // Row numbers are four bytes and leave two at a time: the first of a pair waits in a register.  (8-byte
+                        // records one by one -- {row, 0}, the score filled in by the rescore -- were 70 M stores of 8 bytes into as
+                        // many different lines per call at 10k x 1M: WRITE_SIZE 2.06 GB for 0.56 GB of records.)
+                        const u32 row = row0 + (u32)r;
                         if (FAR) {
                             if (room[t]) {
-                                wp[t][cnt[t]] = (u64)(row0 + (u32)r);
+                                if (cnt[t] & 1u) *(u64*)(wp[t] + (cnt[t] - 1u)) = (u64)hold[t] | ((u64)row << 32);
+                                else hold[t] = row;
                                 ++cnt[t];
                                 --room[t];
                             } else {
                                 ++dropped[t];
                             }
                         } else {
-                            const u32 at = woff[t] < wend[t] ? woff[t] : wend[t];
-                            *(u64*)(wbase + at) = (u64)(row0 + (u32)r);
-                            woff[t] += 8u;
+                            if (woff[t] & 4u) {
+                                const u32 at = woff[t] - 4u < wend[t] ? woff[t] - 4u : wend[t];
+                                *(u64*)(wbase + at) = (u64)hold[t] | ((u64)row << 32);
+                            } else {
+                                hold[t] = row;
+                            }
+                            woff[t] += 4u;
                         }
                     }
                     any_mask |= mask[t];
@@ -286,10 +296,11 @@ void k_real_select_bf(const float* __restrict__ qf, const u8* __restrict__ img, 
         if (seg_ok && q < g.Qpad) {
             const bool live = q < g.Q;
             if (!FAR) {
-                const u32 hits = (woff[t] - wbeg[t]) >> 3;
+                const u32 hits = (woff[t] - wbeg[t]) >> 2;
                 cnt[t] = hits < a.cap ? hits : a.cap;
                 dropped[t] = hits - cnt[t];
             }
+            if (live && (cnt[t] & 1u) && !dropped[t]) wp[t][cnt[t] - 1u] = hold[t];      // an odd count: the last row number on its own
             a.sl_cnt[(i64)s * g.Qpad + q] = live ? cnt[t] : 0u;
             if (dropped[t] && live) a.fail[q] = 1u;
         }
@@ -595,7 +606,7 @@ constexpr int rescore_lds_bytes() { return WPB * 64 * RS_ROWB; }
 
 template <int KPT, int SG>          // KPT: the (padded) feature count, 0 = taken at run time (kp_rt; beyond 128 features)
 __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ qf, const float* __restrict__ dbf, const u32* sl_cnt,
-                                                      u64* __restrict__ cand, u32 cap, i64 crow, const float* __restrict__ thr,
+                                                      const u32* __restrict__ krows, u64* __restrict__ cand, u32 cap, i64 crow, const float* __restrict__ thr,
                                                       u32* sl_cnt_out, u32* __restrict__ cnt_by_query, const u64* __restrict__ dblab, const u64* __restrict__ qlab,
                                                       const int embed_match, const int kp_rt, const Geo g) {      // (sl_cnt_out may be sl_cnt; cnt_by_query: the same counts [Q][S])
     const int KP = KPT ? KPT : kp_rt;
@@ -615,7 +626,8 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
     const u32 total = pre[SG];
     const float* __restrict__ qrow = qf + (i64)q * KP;
     const float cutq = thr[q];
-    u64* __restrict__ rows = cand + (i64)q * crow + (i64)s0 * cap;
+    u64* __restrict__ rows = cand + (i64)q * crow + (i64)s0 * cap;                  // the records it leaves, slice by slice
+    const u32* __restrict__ kept_rows = krows + (i64)q * crow + (i64)s0 * cap;      // the row numbers the filter kept, the same slices
     u8* st = rlds + wave * 64 * RS_ROWB;
     u32 kept[SG];                                            // records of each slice that score above the cut, so far
 #pragma unroll
@@ -637,7 +649,7 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
     {
         int k0; u32 off0;
         locate((u32)lane, k0, off0);
-        if ((u32)lane < total) idx_next = (u32)rows[(i64)k0 * cap + off0];
+        if ((u32)lane < total) idx_next = kept_rows[(i64)k0 * cap + off0];
     }
     for (u32 base = 0; base < total; base += 64) {
         const u32 i = base + lane;
@@ -646,10 +658,10 @@ __global__ __launch_bounds__(256) void k_real_rescore(const float* __restrict__ 
         locate(i, k, off);
         const u32 idx = idx_next;                                               // (idle lanes: any valid row)
         idx_next = g.idx_base;
-        if (i + 64 < total) {                                                   // (this round's write-back lands at or before slot `off` of ITS slices:
-            int kn; u32 offn;                                                   //  a record never moves to the right, so the next round's slots are still intact)
+        if (i + 64 < total) {
+            int kn; u32 offn;
             locate(i + 64, kn, offn);
-            idx_next = (u32)rows[(i64)kn * cap + offn];
+            idx_next = kept_rows[(i64)kn * cap + offn];
         }
         const u32 local = idx - g.idx_base;
         // the row's label words travel with its features (round 6): the record takes its label-match bit (metric.py:17-19) along as bit 31 of

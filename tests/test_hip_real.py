@@ -97,6 +97,34 @@ def test_every_row_ranked_group_by_group(kind):
         c.close()
 
 
+@pytest.mark.parametrize("Q,N,b", [(70, 20011, 64), (33, 9000, 128), (100, 4999, 20)])
+def test_every_row_a_record_leaves_in_whole_lines(Q, N, b):
+    """No cut (R = N, metric.py:14 with MAP_R = DB_SIZE): k_real_select_mx turns a tile's records through LDS and stores whole
+    128-byte runs; a wavefront with lanes past Q, the last segment's partial tile and a database that ends inside a segment pair
+    take the lane-by-lane paths beside it.  The oracle's lists, scores and APs bit for bit -- on the geometry cut to whole rounds
+    of blocks (option real_whole_rounds, default 3) and on the plain one."""
+    rng = np.random.default_rng(Q + N)
+    C, R = 10, N
+    dbf, qf = np.tanh(rng.standard_normal((N, b))).astype(np.float32), np.tanh(rng.standard_normal((Q, b))).astype(np.float32)
+    dl = (rng.random((N, C)) < 0.2).astype(np.int64)
+    ql = (rng.random((Q, C)) < 0.2).astype(np.int64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, ap_ref, idx_ref, score_ref = RM.map_from_features(qf, dbf, ql.astype(np.int8), dl.astype(np.int8), R)
+    c = _native.Context(0)
+    try:
+        c.set_database_f32(dbf, dl)
+        c.set_queries_f32(qf, ql)
+        for rounds in (3, 0, 1):
+            c.set_option("real_whole_rounds", rounds)
+            idx, score = c.topr_real(R)
+            assert np.array_equal(idx, idx_ref) and np.array_equal(score.view(np.uint32), score_ref.view(np.uint32)), rounds
+            ap, rel = c.map_real(R)
+            assert np.array_equal(ap, ap_ref, equal_nan=True), rounds
+    finally:
+        c.close()
+
+
 def test_a_fine_bucket_of_26_records_stays_with_the_groups():
     """bench.py's CIFAR-shaped leg of round 6 (tanh features, Q = 1000, N = R = 54000, seed 0xD1): query 711's first group holds a
     fine score bucket of 26 records.  The pile guard (then 24) sent the WHOLE call to the four radix passes -- 5.4 ms per call

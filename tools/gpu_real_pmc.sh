@@ -16,4 +16,4 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
 done
 cd $GRAFT_REPO_ROOT
 for f in $(find $OUT -name "*.db" | sort); do python tools/prof_summary.py $f; done > $OUT/summary.txt 2>&1
-grep -E "k_real_|== " $OUT/summary.txt | head -400
+grep -E "k_real_|k_ap|== " $OUT/summary.txt | head -400
