@@ -788,7 +788,8 @@ int hg_merge_topr(hg_ctx* c, const uint32_t* dev_idx_all, const uint8_t* dev_dis
 
 int hg_get_topr_real(hg_ctx* c, uint32_t* host_idx, float* host_scores) {
     HG_TRY(need(c, ST_SELECT, "hg_get_topr_real", "hg_topr_real / hg_map_real"));
-    if (!c->real_lists) return fail(HG_ERR_STATE, "hg_get_topr_real: the last ranking was not a real-valued one");
+    if (!c->real_lists) return fail(HG_ERR_STATE, "hg_get_topr_real: no real-valued ranked lists (the last ranking was not real-valued, or it was an hg_map_real, "
+                                                  "which skips them: use hg_topr_real, or option real_map_lists = 1)");
     const size_t slots = (size_t)c->geo.Q * c->geo.R;
     if (host_idx) HG_HIP(hipMemcpyAsync(host_idx, c->out_idx.p, slots * 4, hipMemcpyDeviceToHost, c->stream));
     if (host_scores) HG_HIP(hipMemcpyAsync(host_scores, c->scores.p, slots * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1006,6 +1007,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_real_sample_h = value != 0;
     } else if (!strcmp(key, "real_second_sample")) {
         c->opt_real_second = value != 0;
+    } else if (!strcmp(key, "real_map_lists")) {
+        c->opt_real_map_lists = value != 0;
     } else if (!strcmp(key, "real_whole_rounds")) {
         if (value < 0 || value > 8) return fail(HG_ERR_ARG, "real_whole_rounds must be 0 .. 8");
         c->opt_real_rounds = value;

@@ -357,6 +357,7 @@ struct hg_ctx {
     DevBuf hist2;              // the second sample's counts [Q][RC_BINS] (k_real_sample_count)
     i64 opt_real_second = 1;   // "real_second_sample": a second, counting sample four times as large tightens the sampled cut
     i64 opt_real_rounds = 3;   // "real_whole_rounds": the no-cut float32 MFMA pass (k_real_select_mx) cuts the database so that its blocks fill whole rounds of this many per CU; 0: the plain geometry
+    i64 opt_real_map_lists = 0;   // "real_map_lists": hg_map_real also writes the ranked idx / score lists (hg_get_topr_real after it); 0: match bits and APs only, like hg_map
     bool samp16 = false;       // the current attempt's sample scores are bfloat16 (k_real_sample_h -> k_real_guess_lds)
     i64 opt_real_sample_h = 1; // "real_sample_half": the sampled cut's scores in the filter's 16-bit arithmetic (k_real_sample_h) instead of exact float32 chains
     i64 opt_real_sort_lds = 1; // "real_sort_lds": sort + finish of the filter path in one LDS-resident kernel when the records fit
@@ -380,6 +381,7 @@ struct hg_ctx {
     size_t hpk_cap = 0;
     bool dbf_resident = false, qf_resident = false;   // float tables as loaded: entries outside {-1,0,+1}, zeros, minus ones
     bool real_lists = false;
+    bool real_lists_made = false;   // ... by the last attempt (hg_map_real skips them on the paths that rank in LDS)
     i64 shapes_for_R = -1;
     i64 recip_for_R = -1;      // ap_recip holds RN(1 / k) for k = 1 .. this
     i64 opt_ap_recip = 1;      // "ap_recip": k_ap divides through the table of reciprocals (bit for bit the division; 0: divide)

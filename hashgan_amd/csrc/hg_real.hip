@@ -498,6 +498,10 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     HG_TRY(c->out_idx.reserve(slots * 4));
     HG_TRY(c->scores.reserve(slots * 4));
     HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
+    // hg_map_real wants match bits and APs: the kernels that rank in LDS skip the idx / score lists then (Q x R x 8 bytes of stores: 0.4 GB at
+    // 10k x R = 5000 and at the CIFAR evaluation alike); the global-memory passes gather the labels THROUGH the idx list and always write it
+    const bool skip_lists = with_ap && !c->opt_real_map_lists && !c->is_sub;
+    c->real_lists_made = true;
     if (c->real_filtered && bet && c->opt_real_sort_lds && g.S <= RK_SMAX && R <= RK_RMAX) {
         // a query's records fit the LDS of one workgroup: copy + select + counting passes + ranked list in one kernel
         constexpr int NA = 14336;
@@ -505,7 +509,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
                                    (int)real_rank_lds_bytes<NA>()));
         c->t_begin(KI_RADIX);
         hipLaunchKernelGGL(k_real_rank_lds<NA>, dim3(g.Q), dim3(1024), real_rank_lds_bytes<NA>(), c->stream, c->cand.as<u64>(), c->crow, c->cap,
-                           c->cntq.as<u32>(), c->failq.as<u32>(), c->thr.as<float>(), c->out_idx.as<u32>(), c->scores.as<float>(),
+                           c->cntq.as<u32>(), c->failq.as<u32>(), c->thr.as<float>(), skip_lists ? nullptr : c->out_idx.as<u32>(), skip_lists ? nullptr : c->scores.as<float>(),
                            c->dblab.as<u64>(), c->qlab.as<u64>(), c->mbits.as<u64>(), c->RW, c->err.as<int>(), c->qbad.as<u32>(), g);
         c->t_end();
         HG_TRY(c->check_launch("k_real_rank_lds"));
@@ -524,6 +528,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         }
         if (!(flag & 2)) {
             c->real_lds_ranked = 1;
+            c->real_lists_made = !skip_lists;
             *lost = flag & 1;
             c->stage = ST_DB | ST_Q | ST_SELECT;
             if (*lost) return HG_OK;
@@ -563,7 +568,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         // the sort writes the ranked lists and the match bits itself (k_real_finish and k_match are for the radix passes)
         HG_HIP(hipMemsetAsync(c->mbits.p, 0, (size_t)g.Q * c->RW * 8, c->stream));
         HG_HIP(hipMemsetAsync(c->qbad.p, 0, (size_t)g.Qpad * 4, c->stream));
-        const GroupOut go{c->out_idx.as<u32>(), c->scores.as<float>(), c->mbits.as<u32>(), c->dblab.as<u64>(), c->qlab.as<u64>(), c->RW, g.R, g.LW, g.idx_base};
+        const GroupOut go{skip_lists ? nullptr : c->out_idx.as<u32>(), skip_lists ? nullptr : c->scores.as<float>(), c->mbits.as<u32>(), c->dblab.as<u64>(), c->qlab.as<u64>(), c->RW, g.R, g.LW, g.idx_base};
         c->t_begin(KI_RADIX);
         hipLaunchKernelGGL(k_real_group_sort, dim3(g.Q, maxg), dim3(1024), real_group_sort_lds(), c->stream, c->sortA.as<u64>(), c->gtab.as<u32>(),
                            go, c->crow, c->err.as<int>());
@@ -586,6 +591,7 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
             HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
         } else {
             c->real_grouped = 1;
+            c->real_lists_made = !skip_lists;
             c->stage = ST_DB | ST_Q | ST_SELECT | ST_MATCH;
             *lost = flag;
             if (with_ap) { c->stage |= ST_AP; c->ap_staged = flag == 0; }
@@ -670,8 +676,10 @@ static int real_requery_lost(hg_ctx* c, int64_t R, bool with_ap, bool* handled) 
     HG_TRY(run_real(s, R, false));
     if (s->RW != c->RW) return fail(HG_ERR_HIP, "real-valued ranking: internal error, the requeried lists have another width");
     move(s->mbits.p, c->mbits.p, c->RW * 8, 0);
-    move(s->out_idx.p, c->out_idx.p, R * 4, 0);
-    move(s->scores.p, c->scores.p, R * 4, 0);
+    if (c->real_lists_made) {
+        move(s->out_idx.p, c->out_idx.p, R * 4, 0);
+        move(s->scores.p, c->scores.p, R * 4, 0);
+    }
     HG_TRY(c->check_launch("k_move_rows"));
     HG_HIP(hipMemsetAsync(c->err.p, 0, 4, c->stream));
     c->stage = ST_DB | ST_Q | ST_SELECT | ST_MATCH;
@@ -695,10 +703,10 @@ static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
     if (R * 8 <= c->N && c->N >= 65536) {              // bet on a sampled cut; retry once deeper, then give up betting
         const double boost0 = (double)c->real_cap_boost;
         HG_TRY(real_attempt(c, R, true, c->is_sub ? 6.0 : REAL_FIRST_SIGMA, 3.0 * boost0, with_ap, &lost));
-        if (!lost) { c->real_lists = true; return HG_OK; }
+        if (!lost) { c->real_lists = c->real_lists_made; return HG_OK; }
         bool handled = false;
         HG_TRY(real_requery_lost(c, R, with_ap, &handled));
-        if (handled) { c->real_lists = true; return HG_OK; }
+        if (handled) { c->real_lists = c->real_lists_made; return HG_OK; }
         // a deeper cut with twice the budget; then -- features that follow the labels in a database stored class by class
         // put a query's top rows into a tenth of its slices -- eight and sixty-four times the slices' capacity, kept for
         // the next calls on this database (the exhaustive mode below writes EVERY pair down: 80 GB at 10k x 1M)
@@ -710,7 +718,7 @@ static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
             HG_TRY(real_attempt(c, R, true, 16.0, 6.0 * (double)c->real_cap_boost, with_ap, &lost));
             if (!lost) {
                 if (attempt > 0 && c->real_cap_boost < 4096) c->real_cap_boost *= 2;     // (the budget that held: 6 = 2 x 3; a held plain retry changes nothing)
-                c->real_lists = true;
+                c->real_lists = c->real_lists_made;
                 return HG_OK;
             }
         }
@@ -718,7 +726,7 @@ static int run_real(hg_ctx* c, int64_t R, bool with_ap) {
     }
     HG_TRY(real_attempt(c, R, false, 0.0, 0.0, with_ap, &lost));
     if (lost) return fail(HG_ERR_HIP, "real-valued ranking: internal error, exhaustive pass came up short");
-    c->real_lists = true;
+    c->real_lists = c->real_lists_made;
     return HG_OK;
 }
 

@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
                 bool m = false;
                 if (k < R) {
                     const u64 rec = A[Pfin[k]];
-                    out_idx[(i64)q * g.R + k] = (u32)rec & 0x7FFFFFFFu;
+                    if (out_idx) out_idx[(i64)q * g.R + k] = (u32)rec & 0x7FFFFFFFu;       // (null: hg_map_real -- match bits only)
                     if (scores) scores[(i64)q * g.R + k] = mono_inv(~(u32)(rec >> 32));
                     m = ((u32)rec >> 31) != 0u;               // the match bit k_real_rescore left in the record
                 }
@@ -1375,7 +1375,7 @@ static __global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __re
         const u32 rk = lo + b0 + before;                     // the record's rank in the query's list
         if ((i64)rk < o.R) {
             const u32 gi = (u32)rec;
-            o.out_idx[(i64)q * o.R + rk] = gi;
+            if (o.out_idx) o.out_idx[(i64)q * o.R + rk] = gi;          // (null: hg_map_real -- match bits only)
             if (o.scores) o.scores[(i64)q * o.R + rk] = rg_score((u32)(rec >> 32));
             const u64* __restrict__ dl = o.dblab + (i64)(gi - o.idx_base) * o.LW;
             u64 any = 0;

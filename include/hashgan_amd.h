@@ -211,7 +211,9 @@ int hg_map_end(hg_ctx* ctx, double* host_ap, int64_t* host_rel);
  * database index ascending.  The product's summation order is fixed (one float32 fma chain in feature
  * order: what the chained v_mfma_f32_32x32x2_f32 computes) and restated exactly by oracle/real_map.py; it equals the reference's
  * np.dot wherever float32 rounding does not reorder near-equal products, exactly so on inputs
- * whose arithmetic is exact.  hg_map_real = ranking + label match + AP; hg_topr_real = ranking only. */
+ * whose arithmetic is exact.  hg_map_real = ranking + label match + AP; hg_topr_real = ranking only.
+ * hg_get_topr_real copies the ranked lists of the last hg_topr_real; hg_map_real leaves them unwritten where it ranks in LDS (as hg_map
+ * does for codes: the lists are Q x R x 8 bytes of stores the APs do not need) -- HG_ERR_STATE then, unless option "real_map_lists" is 1. */
 int hg_map_real(hg_ctx* ctx, int64_t R, double* host_ap, int64_t* host_rel);
 int hg_topr_real(hg_ctx* ctx, int64_t R);
 int hg_get_topr_real(hg_ctx* ctx, uint32_t* host_idx, float* host_scores);   /* [Q][R] each */
@@ -299,7 +301,7 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  *   loading       "host_pack" (1: hg_set_*_f32 pack on the host's cores before the upload), "keep_floats" (hg_set_*_f32: 0 never / 1 always / 2 = only
  *                 if not a +-1 code: keep the float table on the device)
  *   real-valued   "real_mfma" (2: bf16 matrix-core filter + exact float32 rescoring; 1: every pair on the float32 matrix-core instruction; 0: vector
- *                 ALU), "real_sample_half" (1: the sampled cut's scores in the filter's 16-bit arithmetic -- they only place the cut; 0: exact float32 chains), "real_second_sample" (1: a second, counting sample four times as large tightens that cut), "real_sort_lds" (1: ranked by the LDS-resident kernel when the records fit), "real_groups" (1: lists beyond the LDS ordered group by group), "real_whole_rounds" (3: without a cut -- R = N -- the database is cut so that k_real_select_mx's blocks fill whole rounds of that many per CU; 0: the plain geometry)
+ *                 ALU), "real_sample_half" (1: the sampled cut's scores in the filter's 16-bit arithmetic -- they only place the cut; 0: exact float32 chains), "real_second_sample" (1: a second, counting sample four times as large tightens that cut), "real_sort_lds" (1: ranked by the LDS-resident kernel when the records fit), "real_groups" (1: lists beyond the LDS ordered group by group), "real_map_lists" (0; 1: hg_map_real also writes the ranked idx / score lists), "real_whole_rounds" (3: without a cut -- R = N -- the database is cut so that k_real_select_mx's blocks fill whole rounds of that many per CU; 0: the plain geometry)
  *   ("probe_select" exists only in the measurement build, python -m hashgan_amd.build --probes) */
 int hg_set_option(hg_ctx* ctx, const char* key, int64_t value);
 /* Counters and facts about the last call (22 keys; the process-wide "cache_*" and "host_*" keys are listed at hg_release_cache): "optimistic_runs", "optimistic_fallbacks" (all queries rerun exactly),

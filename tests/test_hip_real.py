@@ -125,6 +125,40 @@ def test_every_row_a_record_leaves_in_whole_lines(Q, N, b):
         c.close()
 
 
+@pytest.mark.parametrize("Q,N,b,R", [(40, 70000, 64, 700), (12, 20000, 32, 20000)])
+def test_map_real_skips_the_ranked_lists_unless_asked(Q, N, b, R):
+    """hg_map_real wants label matches and APs (metric.py:17-23): the kernels that rank in LDS leave the idx / score lists
+    unwritten then, as hg_map does for codes -- hg_get_topr_real after it is a state error that says so; with option
+    real_map_lists = 1 the lists are there and equal hg_topr_real's.  The APs are the oracle's either way."""
+    rng = np.random.default_rng(Q * N)
+    C = 10
+    dbf, qf = np.tanh(rng.standard_normal((N, b))).astype(np.float32), np.tanh(rng.standard_normal((Q, b))).astype(np.float32)
+    dl = (rng.random((N, C)) < 0.2).astype(np.int64)
+    ql = (rng.random((Q, C)) < 0.2).astype(np.int64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, ap_ref, idx_ref, score_ref = RM.map_from_features(qf, dbf, ql.astype(np.int8), dl.astype(np.int8), R)
+    c = _native.Context(0)
+    try:
+        c.set_database_f32(dbf, dl)
+        c.set_queries_f32(qf, ql)
+        ap, rel = c.map_real(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        idx = np.empty((Q, R), np.uint32)
+        score = np.empty((Q, R), np.float32)
+        rc = c._lib.hg_get_topr_real(c._h, _native._ptr(idx), _native._ptr(score))
+        assert rc == _native.HG_ERR_STATE and b"real_map_lists" in _native.load().hg_last_error()
+        c.set_option("real_map_lists", 1)
+        ap, rel = c.map_real(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
+        _native.check(c._lib.hg_get_topr_real(c._h, _native._ptr(idx), _native._ptr(score)))
+        assert np.array_equal(idx, idx_ref) and np.array_equal(score.view(np.uint32), score_ref.view(np.uint32))
+        idx2, score2 = c.topr_real(R)
+        assert np.array_equal(idx2, idx_ref) and np.array_equal(score2.view(np.uint32), score_ref.view(np.uint32))
+    finally:
+        c.close()
+
+
 def test_a_fine_bucket_of_26_records_stays_with_the_groups():
     """bench.py's CIFAR-shaped leg of round 6 (tanh features, Q = 1000, N = R = 54000, seed 0xD1): query 711's first group holds a
     fine score bucket of 26 records.  The pile guard (then 24) sent the WHOLE call to the four radix passes -- 5.4 ms per call
