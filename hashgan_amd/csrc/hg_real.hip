@@ -495,12 +495,13 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
     HG_TRY(c->cand.reserve(rows));
     HG_TRY(real_select(c));
     const size_t slots = (size_t)g.Q * g.R;
-    HG_TRY(c->out_idx.reserve(slots * 4));
-    HG_TRY(c->scores.reserve(slots * 4));
     HG_TRY(c->mbits.reserve((size_t)g.Q * c->RW * 8));
     // hg_map_real wants match bits and APs: the kernels that rank in LDS skip the idx / score lists then (Q x R x 8 bytes of stores: 0.4 GB at
     // 10k x R = 5000 and at the CIFAR evaluation alike); the global-memory passes gather the labels THROUGH the idx list and always write it
+    // -- and only they reserve the lists then (and the second sort buffer: 0.43 GB each at the CIFAR evaluation, where a recycled context's
+    // first call at the shape meets hipMalloc for whatever the block cache cannot serve)
     const bool skip_lists = with_ap && !c->opt_real_map_lists && !c->is_sub;
+    if (!skip_lists) { HG_TRY(c->out_idx.reserve(slots * 4)); HG_TRY(c->scores.reserve(slots * 4)); }
     c->real_lists_made = true;
     if (c->real_filtered && bet && c->opt_real_sort_lds && g.S <= RK_SMAX && R <= RK_RMAX) {
         // a query's records fit the LDS of one workgroup: copy + select + counting passes + ranked list in one kernel
@@ -543,10 +544,9 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         if (bet) { *lost = 1; return HG_OK; }
         return fail(HG_ERR_NOMEM, "real-valued ranking: %zu GB of records needed (Q=%d, %lld per query)", rows * 3 >> 30, g.Q, (long long)c->crow);
     }
-    HG_TRY(c->sortA.reserve(rows)); HG_TRY(c->sortB.reserve(rows));
+    HG_TRY(c->sortA.reserve(rows));
     const int nwav = c->crow >= 16384 ? 16 : 4;
     const size_t lds = (size_t)(nwav + 1) * 256 * 4;
-    u64* bufs[2] = {c->sortA.as<u64>(), c->sortB.as<u64>()};
     const u64* in = c->cand.as<u64>();
     bool grouped = false;
     if (c->opt_real_groups && g.S <= 8192 && !bet && c->crow <= (i64)RG_MAXG * RG_CAP) {
@@ -599,6 +599,10 @@ static int real_attempt(hg_ctx* c, int64_t R, bool bet, double sigma, double bud
         }
     }
     c->real_grouped = 0;
+    // the global-memory passes: two sort buffers, and the ranked lists whoever asked (k_match gathers the labels through them)
+    HG_TRY(c->sortB.reserve(rows));
+    HG_TRY(c->out_idx.reserve(slots * 4)); HG_TRY(c->scores.reserve(slots * 4));
+    u64* bufs[2] = {c->sortA.as<u64>(), c->sortB.as<u64>()};
     for (int pass = 0; pass < 4 && !grouped; ++pass) {
         RadixArgs ra{c->sl_cnt.as<u32>(), c->failq.as<u32>(), c->tot.as<u32>(), c->cap, c->crow, c->crow, pass == 0, 32 + 8 * pass};
         u64* out = bufs[pass & 1];
