@@ -748,8 +748,14 @@ extern "C++" int do_ap_range(hg_ctx* c, i64 q0, i64 nq, const u32* only) {      
     bool use_recip = false;
     HG_TRY(ensure_ap_tables(c, &use_recip));
     c->t_begin(KI_AP);
-    if (nq > 0)
-        hipLaunchKernelGGL(k_ap, dim3((unsigned)nq), dim3(AP_THREADS), 0, c->stream, c->mbits.as<u64>() + (size_t)q0 * c->RW, c->RW, g.R,
+    // few queries with long lists: four times the threads per query (see k_ap)
+    const bool wide = nq * 2 < (i64)c->n_cu * 8 && g.R > 2 * AP_CHUNK && c->opt_ap_wide;
+    if (nq > 0 && wide)
+        hipLaunchKernelGGL(k_ap<512>, dim3((unsigned)nq), dim3(512), 0, c->stream, c->mbits.as<u64>() + (size_t)q0 * c->RW, c->RW, g.R,
+                           c->shapes.as<ApShape>(), use_recip ? c->ap_recip.as<double>() : (const double*)nullptr,
+                           c->ap.as<double>() + q0, c->rel.as<u32>() + q0, only ? only + q0 : (const u32*)nullptr);
+    else if (nq > 0)
+        hipLaunchKernelGGL(k_ap<AP_THREADS>, dim3((unsigned)nq), dim3(AP_THREADS), 0, c->stream, c->mbits.as<u64>() + (size_t)q0 * c->RW, c->RW, g.R,
                            c->shapes.as<ApShape>(), use_recip ? c->ap_recip.as<double>() : (const double*)nullptr,
                            c->ap.as<double>() + q0, c->rel.as<u32>() + q0, only ? only + q0 : (const u32*)nullptr);
     c->t_end();
@@ -1007,6 +1013,8 @@ int hg_set_option(hg_ctx* c, const char* key, int64_t value) {
         c->opt_real_sample_h = value != 0;
     } else if (!strcmp(key, "real_second_sample")) {
         c->opt_real_second = value != 0;
+    } else if (!strcmp(key, "ap_wide")) {
+        c->opt_ap_wide = value != 0;
     } else if (!strcmp(key, "real_map_lists")) {
         c->opt_real_map_lists = value != 0;
     } else if (!strcmp(key, "real_whole_rounds")) {
@@ -1060,7 +1068,7 @@ int hg_preload(hg_ctx* c) {
     HG_TRY(ensure_fstage(c));
     HG_TRY(ensure_pin(c, (size_t)1 << 20));
     hipFuncAttributes a;
-    HG_HIP(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ap)));
+    HG_HIP(hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ap<AP_THREADS>)));
     HG_TRY(preload_seq()); HG_TRY(preload_valu()); HG_TRY(preload_mx()); HG_TRY(preload_mx1()); HG_TRY(preload_real());
     host_pack_warm();
     return HG_OK;

@@ -385,6 +385,7 @@ struct hg_ctx {
     i64 shapes_for_R = -1;
     i64 recip_for_R = -1;      // ap_recip holds RN(1 / k) for k = 1 .. this
     i64 opt_ap_recip = 1;      // "ap_recip": k_ap divides through the table of reciprocals (bit for bit the division; 0: divide)
+    i64 opt_ap_wide = 1;       // "ap_wide": k_ap with 512 threads per query when the queries are few and their lists long (0: always 128)
 
     // collectives (RCCL over xGMI), one communicator per context; gathered[] are the landing zones of hg_allgather
     ncclComm_t comm = nullptr;

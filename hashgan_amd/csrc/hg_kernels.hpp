@@ -1703,15 +1703,20 @@ __device__ __forceinline__ void ap_eval2(const WordFn& word_at, const i64 RW, co
 }
 
 // only: optional [Q] -- evaluate just the flagged queries (the rest got their AP from k_rank_cnt's epilogue)
-static __global__ __launch_bounds__(AP_THREADS) void k_ap(const u64* __restrict__ mbits, i64 RW, i64 R,
+// NT threads per block: 128 when the queries alone fill the GPU; 512 for few queries with long lists (the reference's CIFAR-10 evaluation:
+// 1000 queries x 54 000 ranks -- at 128 threads that is two wavefronts per SIMD walking seven chunks one after the other)
+template <int NT>
+static __global__ __launch_bounds__(NT) void k_ap(const u64* __restrict__ mbits, i64 RW, i64 R,
                                                    const ApShape* __restrict__ shapes,  // [0] full chunk, [1] last chunk
-                                                   const double* __restrict__ recip,    // [R + 1] or null
+                                                   const double* __restrict__ recip,    // [R + 1 + AP_RECIP_SLACK] or null
                                                    double* __restrict__ ap, u32* __restrict__ rel, const u32* __restrict__ only) {
     __shared__ __attribute__((aligned(8))) u8 aplds[AP_LDS_BYTES];
     const int q = blockIdx.x;
     if (only && !only[q]) return;
     const u64* __restrict__ row = mbits + (i64)q * RW;
-    ap_eval<AP_THREADS>([&](const i64 w) { return row[w]; }, RW, R, shapes, recip, ap_lds_at(aplds), (int)threadIdx.x, ap + q, rel + q);
+    // with the table of reciprocals: the rank kernels' epilogue (ap_eval2: the same additions in the same order, a third of the instructions)
+    if (recip) ap_eval2<NT>([&](const i64 w) { return row[w]; }, RW, R, shapes, recip, ap_lds_at(aplds), (int)threadIdx.x, ap + q, rel + q);
+    else ap_eval<NT>([&](const i64 w) { return row[w]; }, RW, R, shapes, recip, ap_lds_at(aplds), (int)threadIdx.x, ap + q, rel + q);
 }
 
 // ----------------------------------------------------------------------------

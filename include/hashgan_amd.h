@@ -294,7 +294,7 @@ int hg_set_stream(hg_ctx* ctx, void* hip_stream);
  *                 bet is ranked by k_rank_dense<slices>; 0: off), "rank_dense" (1: N/8 < R <= N through the byte matrix), "rank_dense_gbm" (-1: auto; 1 / 0:
  *                 its bitmap in global memory / LDS), "dense_budget_mb" (16384), "all_rows_shortcut" (1: R = N needs no histogram and no plan),
  *                 "fuse_ap" (1: the AP leaves from the rank kernel's epilogue), "inline_leftovers" (1: queries the rank kernel declined are ranked within
- *                 the next step's stream), "ap_recip" (1: the AP's division as three multiply-adds against correctly rounded reciprocals -- the same bits)
+ *                 the next step's stream), "ap_recip" (1: the AP's division as three multiply-adds against correctly rounded reciprocals -- the same bits), "ap_wide" (1: k_ap with 512 threads per query when the queries are few and their lists long)
  *   staging       "stage_sync" (1; 0: staged calls and collectives only enqueue, see hg_set_stream), "defer_verdict" (0; 1: hg_rank does not wait for the
  *                 bet's verdict), "staged_lists" (1: the staged hg_select materialises the idx / dist lists), "step_graph" (0; 1: hg_map replays its
  *                 sequence as a hipGraph), "timing_every" (1: kernel timing brackets every n-th step)

@@ -121,6 +121,10 @@ def test_every_row_a_record_leaves_in_whole_lines(Q, N, b):
             assert np.array_equal(idx, idx_ref) and np.array_equal(score.view(np.uint32), score_ref.view(np.uint32)), rounds
             ap, rel = c.map_real(R)
             assert np.array_equal(ap, ap_ref, equal_nan=True), rounds
+        # few queries with long lists: k_ap took 512 threads per query above (option ap_wide, default 1); with 128 the same bits
+        c.set_option("ap_wide", 0)
+        ap, rel = c.map_real(R)
+        assert np.array_equal(ap, ap_ref, equal_nan=True)
     finally:
         c.close()
 
