@@ -1190,8 +1190,10 @@ __device__ __forceinline__ float rg_score(const u32 key) {
     return __uint_as_float((k & m & 0x7FFFFFFFu) | (~k & ~m));
 }
 __device__ __forceinline__ u32 rg_bucket(const u32 key, const float smax, const float scale, const int nb) {
-    const int bk = (int)((smax - rg_score(key)) * scale);                       // (>= 0: smax is the largest score)
-    return (u32)(bk < nb ? bk : nb - 1);
+    // (monotone in the score whatever smax is: a score above it -- k_real_group_split places its buckets on a SAMPLE of the records --
+    // lands in bucket 0, one far below in the last)
+    const int bk = (int)((smax - rg_score(key)) * scale);
+    return (u32)(bk < 0 ? 0 : bk < nb ? bk : nb - 1);
 }
 inline size_t real_group_split_lds(int S) { return ((size_t)S + 1 + RG_COARSE + RG_COARSE / 4 + 2 * (RG_MAXG + 1)) * 4; }
 
@@ -1228,16 +1230,25 @@ static __global__ __launch_bounds__(1024) void k_real_group_split(const u64* __r
     bool dense_ok = true;
     for (int s = tid; s < g.S; s += 1024) dense_ok &= off[s] == (u32)s * cap;
     const bool dense = __syncthreads_and((int)dense_ok) != 0;
-    auto for_records = [&](auto&& body) {
+    auto for_records = [&](const u32 every, auto&& body) {    // every: 1, or > 1 to visit 64 consecutive records (512 bytes) in every 64 * every (dense runs only)
         if (dense) {
             // four loads in flight per thread: one at a time, a walk was 53 dependent trips to memory at C1 (the body's LDS
             // atomic keeps the compiler from overlapping them itself)
-            for (u32 a = tid; a < n; a += 4096) {
+            const u32 ne = every > 1u ? n / every : n;       // compact index a -> record (a / 64) * 64 * every + a % 64
+            for (u32 a = tid; a < ne; a += 4096) {
                 u64 r[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) r[k] = a + 1024u * k < n ? row[a + 1024u * k] : 0ull;
+                for (int k = 0; k < 4; ++k) {
+                    const u32 ak = a + 1024u * k;
+                    const u32 at = every > 1u ? (ak >> 6) * (64u * every) + (ak & 63u) : ak;
+                    r[k] = ak < ne && at < n ? row[at] : 0ull;
+                }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if (a + 1024u * k < n) body(r[k]);
+                for (int k = 0; k < 4; ++k) {
+                    const u32 ak = a + 1024u * k;
+                    const u32 at = every > 1u ? (ak >> 6) * (64u * every) + (ak & 63u) : ak;
+                    if (ak < ne && at < n) body(r[k]);
+                }
             }
         } else {
             for (int s = 0; s < g.S; ++s) {
@@ -1247,8 +1258,13 @@ static __global__ __launch_bounds__(1024) void k_real_group_split(const u64* __r
             }
         }
     };
+    // Where the buckets lie: the extremes of 64 consecutive records in every 512 are enough (a long dense run -- every row a record, in
+    // index order: an eighth of the rows from all over the database, whole 512-byte pieces of the run); a score beyond them joins the first or the last
+    // bucket (rg_bucket), the order of the buckets is the order of the scores either way, and a bucket that fills beyond what a group
+    // holds is caught below as it always was.  One pass over 1/8 of the records instead of one over all (three passes -> 2 1/8).
+    const u32 sample_every = dense && n >= 4u * 4096u ? 8u : 1u;
     u32 kmin = 0xFFFFFFFFu, kmax = 0u;
-    for_records([&](const u64 rec) { const u32 k = (u32)(rec >> 32); kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; });
+    for_records(sample_every, [&](const u64 rec) { const u32 k = (u32)(rec >> 32); kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; });
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const u32 v = (u32)__shfl_xor((int)kmin, o), w = (u32)__shfl_xor((int)kmax, o);
@@ -1261,7 +1277,7 @@ static __global__ __launch_bounds__(1024) void k_real_group_split(const u64* __r
     const float smax = rg_score(kmin), width = smax - rg_score(kmax);
     const bool flat = !(width > 0.0f) || !(width < 3.0e38f);                    // one score for all rows, or not finite
     const float scale = (float)RG_COARSE / width;
-    for_records([&](const u64 rec) { atomicAdd(&ch[rg_bucket((u32)(rec >> 32), smax, scale, RG_COARSE)], 1u); });
+    for_records(1u, [&](const u64 rec) { atomicAdd(&ch[rg_bucket((u32)(rec >> 32), smax, scale, RG_COARSE)], 1u); });
     __syncthreads();
     {   // consecutive coarse buckets -> groups of at most RG_CAP records, every bucket for itself: bucket b, whose records
         // start at cumulative count ex_b, goes to group ex_b / T with T = RG_CAP - (largest bucket) -- a group then spans less
@@ -1302,7 +1318,7 @@ static __global__ __launch_bounds__(1024) void k_real_group_split(const u64* __r
     if (tid <= RG_MAXG) { const u32 v = gstart[tid < ng ? tid : ng]; gcur[tid] = v; gt[tid] = v; }
     __syncthreads();
     u64* __restrict__ grp = grouped + (i64)q * crow_out;
-    for_records([&](const u64 rec) { grp[atomicAdd(&gcur[gmap[rg_bucket((u32)(rec >> 32), smax, scale, RG_COARSE)]], 1u)] = rec; });
+    for_records(1u, [&](const u64 rec) { grp[atomicAdd(&gcur[gmap[rg_bucket((u32)(rec >> 32), smax, scale, RG_COARSE)]], 1u)] = rec; });
     if (tid == 0) tot[q] = n;
 }
 

@@ -63,7 +63,7 @@ def test_generic_float_features_match_oracle_bit_for_bit(Q, N, b, R, C, ctx):
     assert np.array_equal(ap, ap_ref, equal_nan=True)
 
 
-@pytest.mark.parametrize("kind", ["tanh", "grid"])
+@pytest.mark.parametrize("kind", ["tanh", "grid", "sorted"])
 def test_every_row_ranked_group_by_group(kind):
     """R = N (the reference's CIFAR-10 setting) on real-valued features: every row is a record, far more than the LDS holds.
     Continuous scores are split by score range into LDS-sized groups and ordered group by group (k_real_group_split /
@@ -74,10 +74,19 @@ def test_every_row_ranked_group_by_group(kind):
     R = N
     if kind == "tanh":
         dbf, qf = np.tanh(rng.standard_normal((N, b))).astype(np.float32), np.tanh(rng.standard_normal((Q, b))).astype(np.float32)
-    else:
+    elif kind == "grid":
         dbf, qf = rng.integers(-1, 2, (N, b)).astype(np.float32), rng.integers(-1, 2, (Q, b)).astype(np.float32)
     dl = (rng.random((N, C)) < 0.2).astype(np.int64)
     ql = (rng.random((Q, C)) < 0.2).astype(np.int64)
+    if kind == "sorted":
+        # features that follow the class, rows stored class by class: k_real_group_split places its score buckets on an eighth of the
+        # rows -- 512-byte pieces from all over the run, so every class is in the sample -- and scores beyond the sampled extremes join
+        # the end buckets
+        cls, qcls = np.sort(rng.integers(0, C, N)), rng.integers(0, C, Q)
+        proto = rng.standard_normal((C, b)).astype(np.float32)
+        dbf = np.tanh(proto[cls] + 0.5 * rng.standard_normal((N, b))).astype(np.float32)
+        qf = np.tanh(proto[qcls] + 0.5 * rng.standard_normal((Q, b))).astype(np.float32)
+        dl, ql = np.eye(C, dtype=np.int64)[cls], np.eye(C, dtype=np.int64)[qcls]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m, ap_ref, idx_ref, score_ref = RM.map_from_features(qf, dbf, ql.astype(np.int8), dl.astype(np.int8), R)
@@ -86,7 +95,7 @@ def test_every_row_ranked_group_by_group(kind):
         c.set_database_f32(dbf, dl)
         c.set_queries_f32(qf, ql)
         idx, score = c.topr_real(R)
-        assert ((c.get_stat("real_path") >> 2) & 1) == (1 if kind == "tanh" else 0)
+        assert ((c.get_stat("real_path") >> 2) & 1) == (0 if kind == "grid" else 1)
         assert np.array_equal(idx, idx_ref) and np.array_equal(score.view(np.uint32), score_ref.view(np.uint32))
         ap, rel = c.map_real(R)
         assert np.array_equal(ap, ap_ref, equal_nan=True)
