@@ -1183,6 +1183,10 @@ __global__ __launch_bounds__(1024) void k_real_rank_lds(const u64* __restrict__ 
 constexpr int RG_CAP = 6144;                                 // records per group: 48 KB + positions + counters, two blocks per CU
 constexpr int RG_MAXG = 32;
 constexpr int RG_COARSE = 1024;
+#ifndef HG_RG_FLY
+#define HG_RG_FLY 8
+#endif
+constexpr int RG_FLY = HG_RG_FLY;                            // 8-byte loads a thread of k_real_group_split has in flight (4: 0.269 ms at the CIFAR evaluation, 8: 0.258, 16: 0.257)
 // score of a record key (= mono_inv(~key), spelt without a select: with the select form this compiler's instruction selection
 // died in a float -> bucket computation)
 __device__ __forceinline__ float rg_score(const u32 key) {
@@ -1235,16 +1239,16 @@ static __global__ __launch_bounds__(1024) void k_real_group_split(const u64* __r
             // four loads in flight per thread: one at a time, a walk was 53 dependent trips to memory at C1 (the body's LDS
             // atomic keeps the compiler from overlapping them itself)
             const u32 ne = every > 1u ? n / every : n;       // compact index a -> record (a / 64) * 64 * every + a % 64
-            for (u32 a = tid; a < ne; a += 4096) {
-                u64 r[4];
+            for (u32 a = tid; a < ne; a += 1024u * RG_FLY) {
+                u64 r[RG_FLY];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < RG_FLY; ++k) {
                     const u32 ak = a + 1024u * k;
                     const u32 at = every > 1u ? (ak >> 6) * (64u * every) + (ak & 63u) : ak;
                     r[k] = ak < ne && at < n ? row[at] : 0ull;
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < RG_FLY; ++k) {
                     const u32 ak = a + 1024u * k;
                     const u32 at = every > 1u ? (ak >> 6) * (64u * every) + (ak & 63u) : ak;
                     if (ak < ne && at < n) body(r[k]);
