@@ -1351,12 +1351,33 @@ static __global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __re
     const u32 m = hi - lo;
     if (m == 0) return;
     const u64* __restrict__ src = grouped + (i64)q * crow + lo;
+    // A thread keeps its (at most RG_PER = 6) records in registers and asks for their label words the moment it has them: six gathers in
+    // flight under the bucket passes.  (They used to be asked for one by one at the very end, each behind two dependent LDS reads: six
+    // trips to memory in a row per thread, over half a block's life.)  Each record then finds its OWN rank -- its bucket's start + the
+    // bucket's records before it -- and for hg_map_real only the records that match need one.
+    constexpr int RG_PER = RG_CAP / 1024;
+    static_assert(RG_CAP % 1024 == 0, "a whole number of records per thread");
+    const u64* __restrict__ ql = o.qlab + (i64)q * o.LW;
+    u64 myrec[RG_PER];
+    u32 anym = 0;                                            // bit k: the thread's record k matches the query's labels (metric.py:17-19)
     u32 kmin = 0xFFFFFFFFu, kmax = 0u;
-    for (u32 i = tid; i < m; i += 1024) {
-        const u64 rec = src[i];
-        A[i] = rec;
-        const u32 k = (u32)(rec >> 32);
-        kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
+#pragma unroll
+    for (int k = 0; k < RG_PER; ++k) {
+        const u32 i = tid + 1024u * k;
+        myrec[k] = i < m ? src[i] : 0xFFFFFFFFFFFFFFFFull;
+    }
+#pragma unroll
+    for (int k = 0; k < RG_PER; ++k) {
+        const u32 i = tid + 1024u * k;
+        if (i < m) {
+            A[i] = myrec[k];
+            const u32 key = (u32)(myrec[k] >> 32);
+            kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax;
+            const u64* __restrict__ dl = o.dblab + (i64)((u32)myrec[k] - o.idx_base) * o.LW;
+            u64 any = 0;
+            for (int w = 0; w < o.LW; ++w) any |= dl[w] & ql[w];
+            anym |= any ? 1u << k : 0u;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -1371,7 +1392,9 @@ static __global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __re
     const float smax = rg_score(kmin), width = smax - rg_score(kmax);
     // (one score for the whole group: every record lands in bucket 0 and the pile check below decides)
     const float scale = width > 0.0f ? 4096.0f / width : 0.0f;
-    for (u32 i = tid; i < m; i += 1024) atomicAdd(&hw[rg_bucket((u32)(A[i] >> 32), smax, scale, 4096)], 1u);
+#pragma unroll
+    for (int k = 0; k < RG_PER; ++k)
+        if (tid + 1024u * k < m) atomicAdd(&hw[rg_bucket((u32)(myrec[k] >> 32), smax, scale, 4096)], 1u);
     __syncthreads();
     u32 c4[4], sum = 0, big = 0;
 #pragma unroll
@@ -1382,25 +1405,44 @@ static __global__ __launch_bounds__(1024) void k_real_group_sort(const u64* __re
 #pragma unroll
     for (int x = 0; x < 4; ++x) { hw[4 * tid + x] = run; run += c4[x]; }
     __syncthreads();
-    for (u32 i = tid; i < m; i += 1024) P[atomicAdd(&hw[rg_bucket((u32)(A[i] >> 32), smax, scale, 4096)], 1u)] = (u16)i;
+#pragma unroll
+    for (int k = 0; k < RG_PER; ++k) {
+        const u32 i = tid + 1024u * k;
+        // (a position takes 13 bits: bit 15 carries the record's match flag to whoever meets it by position)
+        if (i < m) P[atomicAdd(&hw[rg_bucket((u32)(myrec[k] >> 32), smax, scale, 4096)], 1u)] = (u16)(i | (((anym >> k) & 1u) << 15));
+    }
     __syncthreads();
-    const u64* __restrict__ ql = o.qlab + (i64)q * o.LW;
     const u32 w0 = lo >> 5;
-    for (u32 a = tid; a < m; a += 1024) {
-        const u64 rec = A[P[a]];
-        const u32 bk = rg_bucket((u32)(rec >> 32), smax, scale, 4096);
-        const u32 b0 = bk ? hw[bk - 1] : 0u, b1 = hw[bk];    // (after the scatter hw[b] is the END of bucket b)
-        u32 before = 0;
-        for (u32 e = b0; e < b1; ++e) before += A[P[e]] < rec ? 1u : 0u;
-        const u32 rk = lo + b0 + before;                     // the record's rank in the query's list
-        if ((i64)rk < o.R) {
-            const u32 gi = (u32)rec;
-            if (o.out_idx) o.out_idx[(i64)q * o.R + rk] = gi;          // (null: hg_map_real -- match bits only)
-            if (o.scores) o.scores[(i64)q * o.R + rk] = rg_score((u32)(rec >> 32));
-            const u64* __restrict__ dl = o.dblab + (i64)(gi - o.idx_base) * o.LW;
-            u64 any = 0;
-            for (int w = 0; w < o.LW; ++w) any |= dl[w] & ql[w];
-            if (any) atomicOr(&bm[(rk >> 5) - w0], 1u << (rk & 31));
+    if (o.out_idx == nullptr && o.scores == nullptr) {
+        // hg_map_real: match bits only -- a thread ranks its own records, and only those that match
+#pragma unroll
+        for (int k = 0; k < RG_PER; ++k) {
+            const u32 i = tid + 1024u * k;
+            if (i < m && ((anym >> k) & 1u)) {
+                const u64 rec = myrec[k];
+                const u32 bk = rg_bucket((u32)(rec >> 32), smax, scale, 4096);
+                const u32 b0 = bk ? hw[bk - 1] : 0u, b1 = hw[bk];    // (after the scatter hw[b] is the END of bucket b)
+                u32 before = 0;
+                for (u32 e = b0; e < b1; ++e) before += A[P[e] & 0x7FFFu] < rec ? 1u : 0u;
+                const u32 rk = lo + b0 + before;                     // the record's rank in the query's list
+                if ((i64)rk < o.R) atomicOr(&bm[(rk >> 5) - w0], 1u << (rk & 31));
+            }
+        }
+    } else {
+        // the ranked lists too: by position, so that a wavefront's ranks -- and its stores -- lie side by side
+        for (u32 a = tid; a < m; a += 1024) {
+            const u32 pa = P[a];
+            const u64 rec = A[pa & 0x7FFFu];
+            const u32 bk = rg_bucket((u32)(rec >> 32), smax, scale, 4096);
+            const u32 b0 = bk ? hw[bk - 1] : 0u, b1 = hw[bk];
+            u32 before = 0;
+            for (u32 e = b0; e < b1; ++e) before += A[P[e] & 0x7FFFu] < rec ? 1u : 0u;
+            const u32 rk = lo + b0 + before;
+            if ((i64)rk < o.R) {
+                if (o.out_idx) o.out_idx[(i64)q * o.R + rk] = (u32)rec;
+                if (o.scores) o.scores[(i64)q * o.R + rk] = rg_score((u32)(rec >> 32));
+                if (pa >> 15) atomicOr(&bm[(rk >> 5) - w0], 1u << (rk & 31));
+            }
         }
     }
     __syncthreads();
